@@ -1,0 +1,315 @@
+/*
+ * rcv_oracle.c -- CPU restatement of the RCVPose voting path.  TEST INFRASTRUCTURE ONLY.
+ *
+ * This file is the parity oracle for the HIP kernels in rcvpose_amd/csrc.  Only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it; the product path
+ * never links, imports or calls anything in oracle/.
+ *
+ * Every function restates (in plain C, own code) the arithmetic of the reference
+ * aaronWool/rcvpose, file AccumulatorSpace.py, and cites the lines it follows.  It is pinned
+ * to the reference by tests/golden/*.npz, which were produced by running the reference's own
+ * source (tests/golden/make_golden.py): exact vote grids, exact tie lists, centres.
+ *
+ * Arithmetic contract (all IEEE-754 binary64 unless noted, no FMA contraction: build with
+ * -ffp-contract=off):
+ *   - x**2 is x*x, x**0.5 is sqrt(x) (what numba emits for AccumulatorSpace.py:337).
+ *   - np.around is round-half-to-even (rint / rintf), int() truncates toward zero.
+ *   - np.mean over a strided float64 column is numpy's pairwise summation divided by n.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define ORC_OK 0
+#define ORC_E_EMPTY -1     /* reference raises ValueError (min of an empty array), :390 */
+#define ORC_E_BADGRID -2   /* reference raises (negative dimension / max of empty grid), :401,:406 */
+
+typedef struct {
+    double mean[3];      /* x_mean_mm, y_mean_mm, z_mean_mm (voxel units), :381-383 */
+    double radius_max;   /* radial_list_mm.max() widened to double, :392 */
+    int32_t zero_boundary; /* :394 */
+    int32_t length;      /* :399 */
+    int32_t dim;         /* length + int(radius_max), :401 */
+    int32_t status;
+} orc_grid_info;
+
+/* numpy's pairwise summation (numpy/core/src/umath/loops_utils.h.src, pairwise_sum_DOUBLE):
+ * blocks of <=128 with 8 interleaved partial sums, halves split at a multiple of 8. */
+static double pw_sum(const double *a, long n, long stride)
+{
+    if (n < 8) {
+        double r = 0.;
+        for (long i = 0; i < n; i++) r += a[i * stride];
+        return r;
+    }
+    if (n <= 128) {
+        double r[8];
+        long i;
+        for (int j = 0; j < 8; j++) r[j] = a[j * stride];
+        for (i = 8; i < n - (n % 8); i += 8)
+            for (int j = 0; j < 8; j++) r[j] += a[(i + j) * stride];
+        double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (; i < n; i++) res += a[i * stride];
+        return res;
+    }
+    long n2 = n / 2;
+    n2 -= n2 % 8;
+    return pw_sum(a, n2, stride) + pw_sum(a + n2 * stride, n - n2, stride);
+}
+
+/* np.mean(a[:, c]) for a float64 column view of a C-contiguous [n,3] array: add.reduce starts
+ * from the identity 0 and feeds the strided (hence buffered) operand to the inner loop in
+ * chunks of the ufunc buffer size, 8192 elements; each chunk is pairwise-summed and added to
+ * the running total; the mean is total / n  (numpy/_core/_methods.py:_mean).  Verified
+ * bit-for-bit against numpy for n up to 1e6 in tests/test_oracle_golden.py. */
+#define NPY_BUFSIZE 8192
+double orc_mean_strided(const double *a, long n, long stride)
+{
+    double s = 0.;
+    for (long off = 0; off < n; off += NPY_BUFSIZE) {
+        long len = n - off < NPY_BUFSIZE ? n - off : NPY_BUFSIZE;
+        s = s + pw_sum(a + off * stride, len, stride);
+    }
+    return s / (double)n;
+}
+
+/* rgbd_to_point_cloud, AccumulatorSpace.py:77-85.  depth: int64 [H,W] (mm) after the mask
+ * multiply; K = {fx, fy, cx, cy}.  Output xyz_mm [n,3] in row-major pixel order. */
+long orc_backproject(const int64_t *depth, int H, int W, const double *K, double *xyz_mm)
+{
+    long n = 0;
+    for (int v = 0; v < H; v++)
+        for (int u = 0; u < W; u++) {
+            int64_t z = depth[(long)v * W + u];
+            if (z == 0) continue;
+            double zs = (double)z;
+            xyz_mm[3 * n + 0] = (((double)u - K[2]) * zs) / K[0];
+            xyz_mm[3 * n + 1] = (((double)v - K[3]) * zs) / K[1];
+            xyz_mm[3 * n + 2] = zs;
+            n++;
+        }
+    return n;
+}
+
+/* The mask / gather seam, AccumulatorSpace.py:603-610 and :619 (using_ckpts branch):
+ *   sem = where(sem>0.8,1,0); sem = where(radial<=rmax, sem, 0); depth *= sem;
+ *   xyz_mm = backproject(depth); radial_list = where(radial<=rmax, radial, 0)[sem==1]; xyz = xyz_mm/1000
+ * sem, radial: float32 [H,W]; depth uint16 [H,W]; rmax_dm is a float64 (max_radii_dm[k]), the
+ * comparison radial<=rmax therefore happens in float64.  Returns the two (possibly different,
+ * SURVEY a-4) list lengths through n_points / n_radii. */
+void orc_seam(const float *sem, const float *radial, const uint16_t *depth, int H, int W, const double *K,
+              double seg_thr, double rmax_dm, double *xyz_m, float *radial_list, long *n_points, long *n_radii)
+{
+    long np_ = 0, nr = 0;
+    for (int v = 0; v < H; v++)
+        for (int u = 0; u < W; u++) {
+            long p = (long)v * W + u;
+            /* sem>0.8: python float vs float32 array compares in float32 (weak scalar);
+             * radial<=max_radii_dm[k]: float32 array vs np.float64 scalar compares in float64
+             * (numpy >= 2 promotion, the numpy the golden vectors were generated with). */
+            int m = (sem[p] > (float)seg_thr) && ((double)radial[p] <= rmax_dm);
+            if (!m) continue;
+            radial_list[nr++] = radial[p];
+            int64_t z = (int64_t)depth[p];
+            if (z == 0) continue;
+            double zs = (double)z;
+            double xs = (((double)u - K[2]) * zs) / K[0];
+            double ys = (((double)v - K[3]) * zs) / K[1];
+            xyz_m[3 * np_ + 0] = xs / 1000.;
+            xyz_m[3 * np_ + 1] = ys / 1000.;
+            xyz_m[3 * np_ + 2] = zs / 1000.;
+            np_++;
+        }
+    *n_points = np_;
+    *n_radii = nr;
+}
+
+/* The using_ckpts=False seam, AccumulatorSpace.py:612-619: radial_est = where(est<=rmax, est, 0);
+ * sem = (radial_est != 0); depth *= sem; xyz from depth.nonzero(); radial_list = radial_est[depth.nonzero()]. */
+void orc_seam_radial_only(const float *radial_est, const uint16_t *depth, int H, int W, const double *K,
+                          double rmax_dm, double *xyz_m, float *radial_list, long *n_points)
+{
+    long n = 0;
+    for (int v = 0; v < H; v++)
+        for (int u = 0; u < W; u++) {
+            long p = (long)v * W + u;
+            float r = ((double)radial_est[p] <= rmax_dm) ? radial_est[p] : 0.f;
+            if (r == 0.f || depth[p] == 0) continue;
+            double zs = (double)depth[p];
+            xyz_m[3 * n + 0] = ((((double)u - K[2]) * zs) / K[0]) / 1000.;
+            xyz_m[3 * n + 1] = ((((double)v - K[3]) * zs) / K[1]) / 1000.;
+            xyz_m[3 * n + 2] = zs / 1000.;
+            radial_list[n] = r;
+            n++;
+        }
+    *n_points = n;
+}
+
+/* Accumulator_3D up to the call of fast_for, AccumulatorSpace.py:374-401.
+ * xyz_m [n,3] metres (not modified); radial: float32 or float64 [m] decimetres (m >= n).
+ * Outputs: points_vox [n,3] (recentred, shifted, voxel units), radius_vox[m] as double
+ * (the float32 case is computed in float32 and widened exactly), info. */
+int orc_acc_prepare(const double *xyz_m, long n, const void *radial, int radial_is_f64, long m, double acc_unit,
+                    double *points_vox, double *radius_vox, orc_grid_info *info)
+{
+    memset(info, 0, sizeof(*info));
+    if (n <= 0 || m <= 0) {
+        info->status = ORC_E_EMPTY;
+        return ORC_E_EMPTY;
+    }
+    for (long i = 0; i < 3 * n; i++) points_vox[i] = (xyz_m[i] * 1000.) / acc_unit;        /* :376 */
+    for (int c = 0; c < 3; c++) info->mean[c] = orc_mean_strided(points_vox + c, n, 3);     /* :381-383 */
+    for (long i = 0; i < n; i++)
+        for (int c = 0; c < 3; c++) points_vox[3 * i + c] -= info->mean[c];               /* :384-386 */
+    double rmax;
+    if (radial_is_f64) {                                                                   /* :388 */
+        const double *r = (const double *)radial;
+        for (long i = 0; i < m; i++) radius_vox[i] = (r[i] * 100.) / acc_unit;
+    } else {
+        const float *r = (const float *)radial;
+        float unit = (float)acc_unit; /* python int 5 is a weak scalar: float32 arithmetic */
+        for (long i = 0; i < m; i++) radius_vox[i] = (double)((r[i] * 100.f) / unit);
+    }
+    rmax = radius_vox[0];
+    for (long i = 1; i < m; i++) if (radius_vox[i] > rmax) rmax = radius_vox[i];          /* :392 */
+    double pmin = points_vox[0], pmax;
+    for (long i = 1; i < 3 * n; i++) if (points_vox[i] < pmin) pmin = points_vox[i];      /* :390 */
+    int32_t zb = (int32_t)(pmin - rmax) + 1;                                               /* :394 */
+    if (zb < 0)
+        for (long i = 0; i < 3 * n; i++) points_vox[i] -= (double)zb;                      /* :396-397 */
+    pmax = points_vox[0];
+    for (long i = 1; i < 3 * n; i++) if (points_vox[i] > pmax) pmax = points_vox[i];
+    info->radius_max = rmax;
+    info->zero_boundary = zb;
+    info->length = (int32_t)pmax;                                                          /* :399 */
+    info->dim = info->length + (int32_t)rmax;                                              /* :401 */
+    if (info->dim <= 0) {
+        info->status = ORC_E_BADGRID;
+        return ORC_E_BADGRID;
+    }
+    return ORC_OK;
+}
+
+/* round-half-even of the voxel radius then int(), AccumulatorSpace.py:332 */
+static inline long radius_int(double rv) { return (long)rint(rv); }
+
+/* fast_for, AccumulatorSpace.py:325-341: every point against every voxel.
+ * votes: uint32 [D,D,D] (C order), must be zeroed by the caller.  The reference parallelises the
+ * point loop with an unsynchronised += (a data race); the race-free result (what the
+ * sequential loop gives) is reproduced here by parallelising the i-slabs instead.  The amount
+ * of arithmetic (n*D^3 distance tests) is the reference's. */
+void orc_fast_for(const double *points_vox, const double *radius_vox, long n, int D, uint32_t *votes, int threads)
+{
+    const double factor = sqrt(3.0) / 4.0; /* (3**0.5)/4, :328 */
+#ifdef _OPENMP
+    if (threads > 0) omp_set_num_threads(threads);
+#endif
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int i = 0; i < D; i++) {
+        for (long p = 0; p < n; p++) {
+            const double x = points_vox[3 * p], y = points_vox[3 * p + 1], z = points_vox[3 * p + 2];
+            const double radius = (double)radius_int(radius_vox[p]);
+            const double dx = (double)i - x, dx2 = dx * dx;
+            for (int j = 0; j < D; j++) {
+                const double dy = (double)j - y, sxy = dx2 + dy * dy;
+                uint32_t *row = votes + ((long)i * D + j) * D;
+                for (int k = 0; k < D; k++) {
+                    const double dz = (double)k - z;
+                    const double distance = sqrt(sxy + dz * dz);
+                    const double t = radius - distance;
+                    if (t < factor && t > 0) row[k] += 1;
+                }
+            }
+        }
+    }
+}
+
+/* Same votes as orc_fast_for (proved equal on the golden/small cases by tests/test_oracle.py),
+ * but only the voxels near each shell are tested -- used to check the GPU at sizes where the
+ * brute force would take minutes.  The predicate applied to each candidate is identical. */
+void orc_fast_for_sparse(const double *points_vox, const double *radius_vox, long n, int D, uint32_t *votes, int threads)
+{
+    const double factor = sqrt(3.0) / 4.0;
+#ifdef _OPENMP
+    if (threads > 0) omp_set_num_threads(threads);
+#endif
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int i = 0; i < D; i++) {
+        for (long p = 0; p < n; p++) {
+            const double x = points_vox[3 * p], y = points_vox[3 * p + 1], z = points_vox[3 * p + 2];
+            const long ri = radius_int(radius_vox[p]);
+            if (ri <= 0) continue;
+            const double radius = (double)ri;
+            const double dx = (double)i - x, dx2 = dx * dx;
+            if (dx2 >= radius * radius + 1.0) continue;
+            int j0 = (int)floor(y - radius - 1.0), j1 = (int)ceil(y + radius + 1.0);
+            if (j0 < 0) j0 = 0;
+            if (j1 > D - 1) j1 = D - 1;
+            for (int j = j0; j <= j1; j++) {
+                const double dy = (double)j - y, sxy = dx2 + dy * dy;
+                const double hi = radius * radius - sxy;
+                if (hi < -1.0) continue;
+                const double inner = radius - factor;
+                const double lo = inner * inner - sxy;
+                const double zb_ = sqrt(hi > 0 ? hi : 0) + 1.0, za_ = lo > 0 ? sqrt(lo) - 1.0 : -1.0;
+                uint32_t *row = votes + ((long)i * D + j) * D;
+                /* candidate k ranges: [z - zb_, z - za_] and [z + za_, z + zb_] (merged when they touch) */
+                int a0 = (int)floor(z - zb_), a1 = (int)ceil(z - za_);
+                int b0 = (int)floor(z + za_), b1 = (int)ceil(z + zb_);
+                if (b0 <= a1) { a1 = b1; b0 = b1 + 1; }
+                for (int pass = 0; pass < 2; pass++) {
+                    int k0 = pass ? b0 : a0, k1 = pass ? b1 : a1;
+                    if (k0 < 0) k0 = 0;
+                    if (k1 > D - 1) k1 = D - 1;
+                    for (int k = k0; k <= k1; k++) {
+                        const double dz = (double)k - z;
+                        const double distance = sqrt(sxy + dz * dz);
+                        const double t = radius - distance;
+                        if (t < factor && t > 0) row[k] += 1;
+                    }
+                }
+            }
+        }
+    }
+}
+
+/* argwhere(V == V.max()) in C order, AccumulatorSpace.py:406.  Returns the number of maxima;
+ * writes up to cap flat indices (ascending). */
+long orc_argmax_all(const uint32_t *votes, int D, uint32_t *peak, int64_t *flat_idx, long cap)
+{
+    long total = (long)D * D * D, cnt = 0;
+    uint32_t mx = 0;
+    for (long t = 0; t < total; t++) if (votes[t] > mx) mx = votes[t];
+    for (long t = 0; t < total; t++)
+        if (votes[t] == mx) {
+            if (cnt < cap) flat_idx[cnt] = t;
+            cnt++;
+        }
+    *peak = mx;
+    return cnt;
+}
+
+/* Row 0 of the returned centre in mm, AccumulatorSpace.py:408-415 (other rows stay voxel indices
+ * shifted by zero_boundary). */
+void orc_center_row0(int64_t flat, const orc_grid_info *info, double acc_unit, double *center_mm)
+{
+    long D = info->dim;
+    double c[3] = {(double)(flat / (D * D)), (double)((flat / D) % D), (double)(flat % D)};
+    for (int a = 0; a < 3; a++) {
+        if (info->zero_boundary < 0) c[a] = c[a] + (double)info->zero_boundary;
+        center_mm[a] = (c[a] + info->mean[a] + 0.5) * acc_unit;
+    }
+}
+
+int orc_num_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}

@@ -1,0 +1,60 @@
+"""oracle/fcn_torch.py (torch-CPU restatement) against outputs of the reference's own module."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import fcn_weights
+from oracle import fcn_torch
+
+
+@pytest.fixture(scope="module")
+def state_dict(golden_dir):
+    shapes = json.load(open(os.path.join(golden_dir, "fcn_state_dict_keys.json")))
+    assert len(shapes) == 1307
+    sd = fcn_weights.make_state_dict_numpy(shapes, seed=0)
+    return {k: torch.from_numpy(v) for k, v in sd.items()}
+
+
+def test_fcn1_reduced_input(state_dict, golden_dir):
+    g = np.load(os.path.join(golden_dir, "fcn1_64x96.npz"))
+    x = torch.from_numpy(fcn_weights.make_input(int(g["input_seed"]), (1, 3, 64, 96)))
+    seg, rad, st = fcn_torch.forward(state_dict, x, return_stages=True)
+    scale = np.abs(g["radial"]).max()
+    assert np.abs(rad.numpy() - g["radial"]).max() <= 1e-6 * scale
+    assert np.abs(seg.numpy() - g["seg"]).max() <= 1e-6 * np.abs(g["seg"]).max()
+    for k in g.files:
+        if k.startswith("stage_"):
+            ref = g[k]
+            if k[6:] in ("bn1", "bn6"):  # hooked before the in-place ReLU (reference :57,:179)
+                ref = np.maximum(ref, 0)
+            got = st[k[6:]].numpy()
+            assert got.shape == ref.shape, k
+            assert np.abs(got - ref).max() <= 1e-6 * max(1.0, np.abs(ref).max()), k
+
+
+def test_fcn2_full_size_samples(state_dict, golden_dir):
+    g = np.load(os.path.join(golden_dir, "fcn2_480x640_samples.npz"))
+    x = torch.from_numpy(fcn_weights.make_input(int(g["input_seed"]), (1, 3, 480, 640)))
+    seg, rad, st = fcn_torch.forward(state_dict, x, return_stages=True)
+    pix = g["pix"]
+    assert np.abs(rad.numpy().reshape(-1)[pix] - g["radial"]).max() <= 1e-6 * float(g["radial_absmax"])
+    assert np.abs(seg.numpy().reshape(-1)[pix] - g["seg"]).max() <= 1e-6 * float(g["seg_absmax"])
+    for k in g.files:
+        if k.startswith("idx_"):
+            name = k[4:]
+            got = st[name].numpy().reshape(-1)[g[k]]
+            ref = g["val_" + name]
+            if name in ("bn1", "bn6"):
+                ref = np.maximum(ref, 0)
+            assert np.abs(got - ref).max() <= 1e-5 * max(1.0, np.abs(ref).max()), name
+
+
+def test_fcn3_backbone_preprocessing(state_dict, golden_dir):
+    g = np.load(os.path.join(golden_dir, "fcn3_backbone_64x96.npz"))
+    sem, radial = fcn_torch.backbone(state_dict, g["rgb"])
+    assert sem.dtype == np.float32 and sem.shape == (64, 96)
+    assert np.abs(sem - g["sem"]).max() <= 1e-6 * np.abs(g["sem"]).max()
+    assert np.abs(radial - g["radial"]).max() <= 1e-6 * np.abs(g["radial"]).max()

@@ -1,0 +1,104 @@
+"""The CPU oracle (oracle/) against the golden vectors produced by the reference itself.
+
+These tests pin the oracle; the GPU parity tests (tests/test_gpu_*.py) then compare the HIP path
+with the oracle.  Everything here is bit-exact: integer vote grids, tie lists, float64 centres.
+"""
+import glob
+import json
+import os
+
+import numpy as np
+import pytest
+
+ACC = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(os.path.dirname(__file__), "golden", "acc*.npz")))
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name + ".npz"))
+
+
+@pytest.mark.parametrize("name", ACC)
+def test_prepare_matches_reference(oracle, golden_dir, name):
+    g = _load(golden_dir, name)
+    pts, rv, info = oracle.prepare(g["xyz_m"], g["radial_dm"])
+    assert info.dim == g["votes"].shape[0]
+    assert np.array_equal(pts, g["points_vox"])  # bit-exact float64, incl. numpy's pairwise mean
+    assert np.array_equal(rv.astype(g["radii_vox"].dtype), g["radii_vox"])
+
+
+@pytest.mark.parametrize("name", ACC)
+@pytest.mark.parametrize("sparse", [False, True])
+def test_votes_match_reference(oracle, golden_dir, name, sparse):
+    g = _load(golden_dir, name)
+    center, votes, info, peak = oracle.accumulator_3d(g["xyz_m"], g["radial_dm"], sparse=sparse, return_all=True)
+    assert np.array_equal(votes, g["votes"].astype(np.uint32))
+    assert center.shape == g["center"].shape  # every tied maximum, C order
+    assert np.array_equal(center, g["center"])
+
+
+def test_error_cases(oracle, golden_dir):
+    idx = json.load(open(os.path.join(golden_dir, "acc_index.json")))
+    assert idx["acc_empty"]["raises"] == "ValueError"
+    with pytest.raises(ValueError):
+        oracle.accumulator_3d(np.zeros((0, 3)), np.zeros((0,), dtype=np.float32))
+    c = idx["acc7_single_point_tiny_radius"]
+    assert c["raises"] == "ValueError"
+    with pytest.raises(ValueError):
+        oracle.accumulator_3d(np.array(c["xyz_m"]), np.array(c["radial_dm"], dtype=c["radial_dtype"]))
+
+
+def test_inputs_not_mutated(oracle, golden_dir):
+    g = _load(golden_dir, "acc2_noisy_f32")
+    xyz, rad = g["xyz_m"].copy(), g["radial_dm"].copy()
+    oracle.accumulator_3d(xyz, rad)
+    assert np.array_equal(xyz, g["xyz_m"]) and np.array_equal(rad, g["radial_dm"])
+
+
+def test_sparse_equals_bruteforce_random(oracle):
+    rng = np.random.default_rng(5)
+    for trial in range(6):
+        n = int(rng.integers(5, 400))
+        xyz = rng.normal(size=(n, 3)) * rng.uniform(0.005, 0.05) + np.array([0.1, -0.2, 0.9])
+        rad = rng.uniform(-0.05, 0.9, size=n).astype(np.float32 if trial % 2 else np.float64)
+        pts, rv, info = oracle.prepare(xyz, rad)
+        if info.dim > 110:
+            continue
+        a = oracle.fast_for(pts, rv, info.dim, sparse=False)
+        b = oracle.fast_for(pts, rv, info.dim, sparse=True)
+        assert np.array_equal(a, b)
+
+
+def test_pairwise_mean_is_numpys(oracle):
+    rng = np.random.default_rng(0)
+    for n in list(range(1, 140)) + [255, 256, 257, 1000, 8191, 8192, 8193, 15000, 16385, 50007, 307200]:
+        a = rng.normal(size=(n, 3)) * 100 + 37.0
+        for c in range(3):
+            assert oracle.mean_strided(a, c) == float(np.mean(a[:, c])), (n, c)
+
+
+def test_seam_golden(oracle, golden_dir):
+    for name in ("seam1_aligned", "seam2_depth_holes"):
+        g = _load(golden_dir, name)
+        xyz, rl = oracle.seam(g["sem"], g["radial"], g["depth"], float(g["max_radius_dm"]))
+        assert np.array_equal(xyz, g["xyz_m"]), name
+        assert rl.dtype == g["radial_list"].dtype and np.array_equal(rl, g["radial_list"]), name
+    g = _load(golden_dir, "seam3_radial_npy")
+    xyz, rl = oracle.seam_radial_only(g["radial_est"], g["depth"], float(g["max_radius_dm"]))
+    assert np.array_equal(xyz, g["xyz_m"]) and np.array_equal(rl, g["radial_list"])
+
+
+def test_backproject_golden(oracle, golden_dir):
+    g = _load(golden_dir, "seam1_aligned")
+    mask = (g["sem"] > np.float32(0.8)) & (g["radial"].astype(np.float64) <= float(g["max_radius_dm"]))
+    pts = oracle.backproject(g["depth"].astype(np.int64) * mask)
+    assert np.array_equal(pts, g["xyz_mm"])
+
+
+def test_chain_golden(oracle, golden_dir):
+    """seam -> Accumulator_3D, the per-keypoint body AccumulatorSpace.py:596-654."""
+    g = _load(golden_dir, "seam4_chain")
+    xyz, rl = oracle.seam(g["sem"], g["radial"], g["depth"], float(g["max_radius_dm"]))
+    assert np.array_equal(xyz, g["xyz_m"]) and np.array_equal(rl, g["radial_list"])
+    center = oracle.accumulator_3d(xyz, rl)
+    assert np.array_equal(center, g["center"])
+    assert np.abs(center[0] - g["keypoint_m"] * 1000).max() <= 5.0  # within one 5 mm voxel of the truth
