@@ -1,0 +1,191 @@
+/*
+ * rcvpose_hip.h -- C ABI of librcvpose_hip.so, the MI355X (gfx950) implementation of the RCVPose
+ * `--mode=test` hot path: ResNet-152-FCN forward -> mask / back-project seam -> 3-D radial voting
+ * -> arg-max keypoint.
+ *
+ * The reference (aaronWool/rcvpose) is pure Python and has no FFI layer; its boundary for this
+ * path is a set of Python callables.  Each entry point below names the
+ * reference callable (file:line) it stands behind.  The Python mirrors of those callables in
+ * rcvpose_amd/ (same names, arguments and error behaviour) bind this header with ctypes; the
+ * reference-side stub a maintainer would add is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - every pointer named *_dev (and every `ws`) is a DEVICE pointer owned by the caller;
+ *     the callee never allocates on the hot path (one lazily-built constant table per device).
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it, nothing synchronises.
+ *   - return value: 0 = enqueued, negative = rcv_status; data-dependent failures that the
+ *     reference reports by raising (empty cloud, empty grid) are reported in rcv_acc_result.status.
+ *   - re-entrant across distinct workspaces / handles; a workspace or handle must not be used
+ *     by two streams at once.
+ */
+#ifndef RCVPOSE_HIP_H
+#define RCVPOSE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum rcv_status {
+    RCV_OK = 0,
+    RCV_E_INVALID = -1,       /* bad argument (null pointer, non-positive size, misaligned) */
+    RCV_E_HIP = -2,           /* a HIP runtime call failed; see rcv_last_hip_error() */
+    RCV_E_WORKSPACE = -3,     /* workspace too small */
+    RCV_E_EMPTY = -4,         /* no points / no radii: reference raises ValueError (AccumulatorSpace.py:390) */
+    RCV_E_BADGRID = -5,       /* grid dimension <= 0: reference raises ValueError (AccumulatorSpace.py:401,406) */
+    RCV_E_TOO_LARGE = -6,     /* grid dimension, radius or tile count beyond what this build supports */
+    RCV_E_GRID_BUFFER = -7,   /* vote_grid_dev given but smaller than dim^3 cells (votes still counted) */
+    RCV_E_UNSUPPORTED = -8    /* layer shape / dtype not supported by the FCN engine */
+} rcv_status;
+
+const char *rcv_strerror(int status);
+int rcv_version(void);
+/* Text of the last failing HIP call in this process (for RCV_E_HIP). */
+const char *rcv_last_hip_error(void);
+/* Builds the per-device constant tables (shell thresholds).  Called lazily by the entry points;
+ * call it once up front to keep the first timed call clean. */
+int rcv_init(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Voting path
+ * ------------------------------------------------------------------------------------------ */
+
+/* Written by the device at the end of rcv_accumulate_3d; copy it back with one 96-byte D2H. */
+typedef struct rcv_acc_result {
+    double center_mm[3];   /* row 0 of the reference's `center` (AccumulatorSpace.py:413-415) */
+    double mean_vox[3];    /* x/y/z_mean_mm, voxel units (AccumulatorSpace.py:381-383) */
+    double radius_max;     /* radial_list_mm.max() (AccumulatorSpace.py:392) */
+    int32_t peak_votes;    /* VoteMap_3D.max() */
+    int32_t n_ties;        /* rows of argwhere(VoteMap_3D == max) (AccumulatorSpace.py:406) */
+    int32_t first_idx[3];  /* voxel (i,j,k) of the first maximum in C order */
+    int32_t dim;           /* D = length + int(radius_max) (AccumulatorSpace.py:401) */
+    int32_t zero_boundary; /* AccumulatorSpace.py:394 */
+    int32_t n_points;      /* N */
+    int32_t n_radii;       /* M >= N (SURVEY a-4) */
+    int32_t status;        /* rcv_status */
+} rcv_acc_result;
+
+/* Bytes of workspace needed by rcv_seam_compact / rcv_accumulate_3d for clouds of up to
+ * max_points points (and radii). */
+size_t rcv_acc_workspace_bytes(int max_points);
+
+/*
+ * The mask / back-projection seam of the per-keypoint loop, reference AccumulatorSpace.py:603-610
+ * and :619, with rgbd_to_point_cloud (:77-85) fused in:
+ *     mask = (seg > seg_thr) & (radial <= rmax_dm);  depth *= mask
+ *     xyz  = backproject(depth.nonzero()) / 1000      (metres, row-major pixel order)
+ *     radial_list = radial[mask]                       (decimetres, row-major pixel order)
+ * mode 0: the using_ckpts branch above; radial_list may be longer than xyz when the mask covers
+ *         a depth hole (the reference's behaviour, kept).
+ * mode 1: the using_ckpts=False branch (:612-618): mask = (radial <= rmax_dm ? radial : 0) != 0,
+ *         radii gathered at depth.nonzero(); seg_dev is ignored.
+ * mode 2: rgbd_to_point_cloud(K, depth) alone (:77-85): points of depth.nonzero() in MILLIMETRES
+ *         (no /1000); seg_dev, radial_dev and radial_list_dev are ignored (may be null).
+ * seg_dev, radial_dev: float32 [H,W]; depth_dev: uint16 [H,W] (mm); K = {fx, fy, cx, cy}.
+ * Outputs: xyz_m_dev float64 [cap,3], radial_list_dev float32 [cap], counts_dev int32[2] =
+ * {n_points, n_radii}.  cap must be >= H*W unless the caller knows a tighter bound.
+ */
+int rcv_seam_compact(const float *seg_dev, const float *radial_dev, const uint16_t *depth_dev, int H, int W,
+                     const double K[4], float seg_thr, double rmax_dm, int mode, double *xyz_m_dev,
+                     float *radial_list_dev, int32_t *counts_dev, int cap, void *ws, size_t ws_bytes, void *stream);
+
+/*
+ * Accumulator_3D(xyz, radial_list) -> center, reference AccumulatorSpace.py:373-419, including
+ * fast_for (:325-341) and the arg-max (:406-415).
+ *   xyz_m_dev     float64 [n_points,3], metres (not modified)
+ *   radial_dm_dev float32 or float64 [n_radii], decimetres (radial_is_f64 selects)
+ *   counts_dev    optional int32[2] = {n_points, n_radii} living on the device (output of
+ *                 rcv_seam_compact); when non-null it overrides n_points / n_radii, which then only
+ *                 give upper bounds (cap) so that nothing has to be copied to the host first.
+ *   acc_unit_mm   voxel edge in mm (the reference hard-codes 5, AccumulatorSpace.py:374)
+ *   result_dev    rcv_acc_result on the device
+ *   vote_grid_dev optional uint32 [dim^3] copy of VoteMap_3D (tests, tie listing); may be null.
+ * The votes are integer counts accumulated in LDS sub-volumes; they are bit-identical to the
+ * sequential reference loop.
+ */
+int rcv_accumulate_3d(const double *xyz_m_dev, const void *radial_dm_dev, int radial_is_f64,
+                      const int32_t *counts_dev, int n_points, int n_radii, double acc_unit_mm,
+                      rcv_acc_result *result_dev, uint32_t *vote_grid_dev, size_t vote_grid_cells, void *ws,
+                      size_t ws_bytes, void *stream);
+
+/* argwhere(VoteMap_3D == peak) in C order over a grid produced by rcv_accumulate_3d
+ * (AccumulatorSpace.py:406): writes up to cap flat indices (ascending) and the total count. */
+int rcv_collect_ties(const uint32_t *vote_grid_dev, int dim, uint32_t peak, int64_t *flat_idx_dev, int cap,
+                     int32_t *count_dev, void *stream);
+
+/* Test hook: the recentred + shifted voxel-space points fast_for receives (AccumulatorSpace.py:403),
+ * recomputed from the workspace of the last rcv_accumulate_3d call.  points_vox_dev float64 [n,3]. */
+int rcv_acc_debug_points(const void *ws, double *points_vox_dev, int32_t *radius_int_dev, int cap, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * FCN path
+ * ------------------------------------------------------------------------------------------ */
+
+/* FCResBackbone's image preparation, reference AccumulatorSpace.py:140-151:
+ * uint8 HWC -> float64 /255, -mean, /std -> float32 CHW.  rgb_dev uint8 [B,H,W,3] -> x_dev float32 [B,3,H,W]. */
+int rcv_preprocess_rgb(const uint8_t *rgb_dev, int B, int H, int W, float *x_dev, void *stream);
+
+typedef enum rcv_dtype { RCV_F32 = 0, RCV_BF16 = 1 } rcv_dtype;
+
+typedef enum rcv_op_kind {
+    RCV_OP_STEM = 1,     /* conv1 7x7 s2 p3 (no bias) + BN + ReLU, NCHW fp32 in -> NHWC out; fcnresnet.py:54-57,123-125 */
+    RCV_OP_MAXPOOL = 2,  /* 3x3 s2 p1; fcnresnet.py:58,126 */
+    RCV_OP_CONV = 3,     /* KxK conv (+BN folded) [+ residual] [+ ReLU], one or two channel-concatenated sources */
+    RCV_OP_UPSAMPLE2 = 4,/* bilinear x2, align_corners=False; fcnresnet.py:93 */
+    RCV_OP_HEAD = 5      /* conv8 1x1 -> 2 channels, split into seg / radial planes (fp32 NCHW); fcnresnet.py:186-191 */
+} rcv_op_kind;
+
+/* One step of the layer program.  Buffers are numbered slots inside the activation workspace
+ * (slot -1 = none, slot -2 = the network input x, slot -3 = the (seg, radial) output planes). */
+typedef struct rcv_op {
+    int32_t kind;
+    int32_t src0, src1;      /* input slots (src1 = second concat source or -1) */
+    int32_t res;             /* residual slot added before the ReLU, or -1 */
+    int32_t dst;             /* output slot */
+    int32_t c0, c1;          /* channels of src0 / src1 */
+    int32_t cout;
+    int32_t hin, win;        /* input spatial size */
+    int32_t hout, wout;      /* output spatial size */
+    int32_t ksize, stride, pad;
+    int32_t relu;
+    int64_t w_off;           /* element offset of this op's weights [G][cout][k][k][c0+c1] in the weight blob */
+    int64_t b_off;           /* element offset of this op's fp32 bias [G][cout] in the bias blob */
+} rcv_op;
+
+typedef struct rcv_fcn rcv_fcn; /* opaque engine handle */
+
+/*
+ * Build an engine for `groups` networks that share one topology and one input (the reference runs
+ * one DenseFCNResNet152 per keypoint on the same image, AccumulatorSpace.py:520-530,596).
+ *   ops / n_ops      the layer program (host memory, copied)
+ *   n_slots, slot_elems[n_slots]: activation slots, sizes in elements PER GROUP AND PER IMAGE
+ *   weights_dev      packed weights, dtype `dtype`, BN folded, layout per op [G][cout][kh][kw][cin]
+ *   bias_dev         fp32 biases (BN folded), per op [G][cout]
+ * The handle only stores pointers and the program; it owns no device memory.
+ */
+int rcv_fcn_create(const rcv_op *ops, int n_ops, int n_slots, const int64_t *slot_elems, int groups, int dtype,
+                   const void *weights_dev, const float *bias_dev, rcv_fcn **out);
+void rcv_fcn_destroy(rcv_fcn *h);
+/* Activation workspace bytes for a batch of B images. */
+size_t rcv_fcn_workspace_bytes(const rcv_fcn *h, int B);
+/*
+ * DenseFCNResNet152.forward, reference models/fcnresnet.py:121-191, for all groups:
+ *   x_dev    float32 [B,3,H,W] (normalised image, shared by the groups)
+ *   seg_dev, radial_dev  float32 [G,B,1,H,W]
+ */
+int rcv_fcn_forward(rcv_fcn *h, const float *x_dev, int B, float *seg_dev, float *radial_dev, void *ws,
+                    size_t ws_bytes, void *stream);
+/* Test hook: copy activation slot `slot` of group g (as stored: NHWC, engine dtype) to out_dev as fp32. */
+int rcv_fcn_debug_slot(rcv_fcn *h, const void *ws, int B, int g, int slot, float *out_dev, void *stream);
+
+/* Name and average device time (ms, HIP events on `stream`) of the slowest op kind in the last
+ * profiled forward; used by bench.py for the roofline line.  Enable with rcv_fcn_set_profiling. */
+int rcv_fcn_set_profiling(rcv_fcn *h, int enable);
+int rcv_fcn_get_profile(rcv_fcn *h, double *conv_ms, double *other_ms, double *conv_flop);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RCVPOSE_HIP_H */

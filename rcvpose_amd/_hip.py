@@ -1,0 +1,153 @@
+"""ctypes binding of librcvpose_hip.so (C ABI: include/rcvpose_hip.h).
+
+There is no CPU fallback: if the library is missing or no MI355X is visible, every product entry
+point raises.  PyTorch is used only as plumbing (device buffers, streams).
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librcvpose_hip.so")
+
+RCV_OK = 0
+RCV_E_INVALID = -1
+RCV_E_HIP = -2
+RCV_E_WORKSPACE = -3
+RCV_E_EMPTY = -4
+RCV_E_BADGRID = -5
+RCV_E_TOO_LARGE = -6
+RCV_E_GRID_BUFFER = -7
+RCV_E_UNSUPPORTED = -8
+
+RCV_F32 = 0
+RCV_BF16 = 1
+
+OP_STEM, OP_MAXPOOL, OP_CONV, OP_UPSAMPLE2, OP_HEAD = 1, 2, 3, 4, 5
+SLOT_NONE, SLOT_INPUT, SLOT_OUTPUT = -1, -2, -3
+
+
+class AccResult(ctypes.Structure):
+    _fields_ = [
+        ("center_mm", ctypes.c_double * 3),
+        ("mean_vox", ctypes.c_double * 3),
+        ("radius_max", ctypes.c_double),
+        ("peak_votes", ctypes.c_int32),
+        ("n_ties", ctypes.c_int32),
+        ("first_idx", ctypes.c_int32 * 3),
+        ("dim", ctypes.c_int32),
+        ("zero_boundary", ctypes.c_int32),
+        ("n_points", ctypes.c_int32),
+        ("n_radii", ctypes.c_int32),
+        ("status", ctypes.c_int32),
+    ]
+
+
+class Op(ctypes.Structure):
+    _fields_ = [
+        ("kind", ctypes.c_int32),
+        ("src0", ctypes.c_int32),
+        ("src1", ctypes.c_int32),
+        ("res", ctypes.c_int32),
+        ("dst", ctypes.c_int32),
+        ("c0", ctypes.c_int32),
+        ("c1", ctypes.c_int32),
+        ("cout", ctypes.c_int32),
+        ("hin", ctypes.c_int32),
+        ("win", ctypes.c_int32),
+        ("hout", ctypes.c_int32),
+        ("wout", ctypes.c_int32),
+        ("ksize", ctypes.c_int32),
+        ("stride", ctypes.c_int32),
+        ("pad", ctypes.c_int32),
+        ("relu", ctypes.c_int32),
+        ("w_off", ctypes.c_int64),
+        ("b_off", ctypes.c_int64),
+    ]
+
+
+assert ctypes.sizeof(AccResult) == 96
+
+# every symbol include/rcvpose_hip.h declares: (name, restype, argtypes)
+_vp, _i, _d, _f, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_double, ctypes.c_float, ctypes.c_size_t
+SYMBOLS = {
+    "rcv_strerror": (ctypes.c_char_p, [_i]),
+    "rcv_version": (_i, []),
+    "rcv_last_hip_error": (ctypes.c_char_p, []),
+    "rcv_init": (_i, []),
+    "rcv_acc_workspace_bytes": (_sz, [_i]),
+    "rcv_seam_compact": (_i, [_vp, _vp, _vp, _i, _i, ctypes.POINTER(_d), _f, _d, _i, _vp, _vp, _vp, _i, _vp, _sz, _vp]),
+    "rcv_accumulate_3d": (_i, [_vp, _vp, _i, _vp, _i, _i, _d, _vp, _vp, _sz, _vp, _sz, _vp]),
+    "rcv_collect_ties": (_i, [_vp, _i, ctypes.c_uint32, _vp, _i, _vp, _vp]),
+    "rcv_acc_debug_points": (_i, [_vp, _vp, _vp, _i, _vp]),
+    "rcv_preprocess_rgb": (_i, [_vp, _i, _i, _i, _vp, _vp]),
+    "rcv_fcn_create": (_i, [ctypes.POINTER(Op), _i, _i, ctypes.POINTER(ctypes.c_int64), _i, _i, _vp, _vp,
+                             ctypes.POINTER(_vp)]),
+    "rcv_fcn_destroy": (None, [_vp]),
+    "rcv_fcn_workspace_bytes": (_sz, [_vp, _i]),
+    "rcv_fcn_forward": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _sz, _vp]),
+    "rcv_fcn_debug_slot": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
+    "rcv_fcn_set_profiling": (_i, [_vp, _i]),
+    "rcv_fcn_get_profile": (_i, [_vp, ctypes.POINTER(_d), ctypes.POINTER(_d), ctypes.POINTER(_d)]),
+}
+
+_lib = None
+
+
+class HipLibraryError(RuntimeError):
+    pass
+
+
+def load_library():
+    """dlopen librcvpose_hip.so and bind every symbol of the header (no GPU needed for this)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HipLibraryError(
+            "librcvpose_hip.so is not built (%s). Run `python -m rcvpose_amd.build` (needs hipcc); "
+            "there is no CPU fallback for the product path." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    missing = []
+    for name, (res, args) in SYMBOLS.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError:
+            missing.append(name)
+            continue
+        fn.restype = res
+        fn.argtypes = args
+    if missing:  # header and library out of sync: refuse to run anything
+        raise HipLibraryError("librcvpose_hip.so lacks symbols declared in include/rcvpose_hip.h: " + ", ".join(missing))
+    _lib = lib
+    return lib
+
+
+def lib():
+    """The bound library, for product calls: additionally requires a visible GPU."""
+    import torch
+
+    L = load_library()
+    if not torch.cuda.is_available():
+        raise HipLibraryError("no HIP device visible: the rcvpose_amd product path runs on MI355X only "
+                              "(no CPU fallback)")
+    return L
+
+
+def check(rc, what=""):
+    if rc != RCV_OK:
+        L = load_library()
+        msg = L.rcv_strerror(rc).decode()
+        if rc == RCV_E_HIP:
+            msg += ": " + L.rcv_last_hip_error().decode()
+        raise HipLibraryError("%s failed: %s (%d)" % (what or "librcvpose_hip call", msg, rc))
+
+
+def ptr(t):
+    """Device/host pointer of a torch tensor (or None)."""
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def current_stream():
+    import torch
+
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -1,0 +1,860 @@
+// accumulator.hip -- the voting half of the RCVPose hot path on MI355X (gfx950 / CDNA4).
+//
+//   rcv_seam_compact   : mask + back-projection seam      (reference AccumulatorSpace.py:603-610,619; :77-85)
+//   rcv_accumulate_3d  : Accumulator_3D + fast_for + arg-max (reference AccumulatorSpace.py:373-419, :325-341)
+//
+// Design (MI355X-first, not a translation of the reference's N x D^3 loop):
+//   * the vote grid never has to live in HBM: it is cut into column tiles (TI x TJ x TK voxels) that
+//     fit the 160 KB LDS of a CU as packed 16-bit counters; one 512-thread workgroup owns a tile,
+//     culls the point list against the tile footprint, and rasterises, per (point, column), only the
+//     few voxels of the spherical shell that cross that column.  Votes are LDS atomics; no global
+//     atomics exist anywhere on the path.
+//   * the arg-max is taken per tile straight out of LDS with a wavefront reduction on the packed key
+//     (votes << 32 | ~flat_index), so ties resolve to the first voxel in C order like np.argwhere.
+//   * exactness: the reference decides `0 < round(r) - sqrt(d2) < sqrt(3)/4` in float64.  sqrt and the
+//     subtraction are monotone, so for every integer radius the test is equivalent to
+//     T_lo[r] <= d2 < T_hi[r] with two float64 thresholds that the host finds once by bisection using
+//     the very same IEEE operations.  d2 is evaluated in float64 in the reference's operation order
+//     with FMA contraction off, hence the vote counts are bit-identical to the sequential reference.
+//   * the recentring mean reproduces numpy's chunked pairwise summation bit for bit (see k_setup).
+#pragma clang fp contract(off)
+
+#include <math.h>
+#include <string.h>
+
+#include <mutex>
+
+#include "common.hpp"
+
+namespace rcv {
+namespace {
+
+constexpr int TABLE_N = 8192;          // largest integer radius (voxels) with a threshold pair
+constexpr int MAX_TILES = 1 << 17;
+constexpr int PREP_BLOCKS = 128;
+constexpr int PREP_THREADS = 256;
+constexpr int SEAM_PIX_PER_BLOCK = 1024;
+constexpr int SEAM_MAX_BLOCKS = 4096;
+constexpr int VOTE_THREADS = 512;
+constexpr int VOTE_WAVES = VOTE_THREADS / 64;
+constexpr int CELL_BYTES = 60 * 1024;  // LDS bytes of vote counters per tile
+constexpr int SURV_CAP = 256;          // points staged per cull round
+constexpr int MAX_DIM = 1600;          // flat index must fit 32 bits
+constexpr int NPY_BUFSIZE = 8192;      // numpy ufunc buffer (elements): chunking of add.reduce
+constexpr int PW_BLOCK = 128;          // numpy pairwise-sum leaf size
+
+struct alignas(16) AccHeader {
+    double mean[3];
+    double rmax;
+    double shift;     // (double)zero_boundary when negative, else 0
+    double unit;
+    int32_t n, m;
+    int32_t zb, dim;
+    int32_t TI, TJ, TK, TKp;  // tile footprint, k-extent, padded (even) cells per column
+    int32_t nti, ntj, ntk, ntiles;
+    int32_t wide;     // 1: 32-bit counters (n >= 65536), 0: packed 16-bit
+    int32_t status;
+    uint32_t tile_counter;
+    int32_t pad_;
+};
+
+struct PrepPartial {
+    double mn[3], mx[3], rmax;
+    double pad_;
+};
+
+struct Surv {
+    double x, y, z, tlo, thi;
+    int32_t ri, pad_;
+};
+
+struct Layout {
+    size_t header, partials, seam_counts, seam_offsets, tile_best, tile_ties, P, ri, total;
+};
+
+Layout make_layout(int cap)
+{
+    Layout L;
+    size_t o = 0;
+    L.header = o;        o += 512;
+    L.partials = o;      o += align_up(sizeof(PrepPartial) * PREP_BLOCKS, 256);
+    L.seam_counts = o;   o += align_up(sizeof(int2) * SEAM_MAX_BLOCKS, 256);
+    L.seam_offsets = o;  o += align_up(sizeof(int2) * SEAM_MAX_BLOCKS, 256);
+    L.tile_best = o;     o += align_up(sizeof(uint64_t) * MAX_TILES, 256);
+    L.tile_ties = o;     o += align_up(sizeof(uint32_t) * MAX_TILES, 256);
+    L.P = o;             o += align_up(sizeof(double) * 3 * (size_t)cap, 256);
+    L.ri = o;            o += align_up(sizeof(int32_t) * (size_t)cap, 256);
+    L.total = o;
+    return L;
+}
+
+// ---------------------------------------------------------------------------------------------
+// shell thresholds (host)
+// ---------------------------------------------------------------------------------------------
+double *g_thr_dev = nullptr;  // [TABLE_N][2] = {T_lo, T_hi}
+std::mutex g_init_mutex;
+
+inline uint64_t d2u(double d) { uint64_t u; memcpy(&u, &d, 8); return u; }
+inline double u2d(uint64_t u) { double d; memcpy(&d, &u, 8); return d; }
+
+void build_thresholds(double *tab)
+{
+    // f = (3**0.5)/4, AccumulatorSpace.py:328; volatile keeps the host compiler from folding/fusing
+    volatile double three = 3.0;
+    const double f = sqrt(three) / 4.0;
+    tab[0] = 0.0;
+    tab[1] = 0.0;  // radius 0: `radius - distance > 0` is never true
+    for (int r = 1; r < TABLE_N; r++) {
+        const double R = (double)r;
+        // T_hi = min{ d : sqrt(d) >= R }  (then `R - sqrt(d) > 0`  <=>  d < T_hi)
+        double hi = R * R;
+        for (;;) {
+            double below = u2d(d2u(hi) - 1);
+            volatile double s = sqrt(below);
+            if (s >= R) hi = below; else break;
+        }
+        // T_lo = min{ d : (R - sqrt(d)) < f }  -- bisection on the (monotone) bit pattern
+        uint64_t lo_u = d2u(0.0), hi_u = d2u(R * R);  // predicate false at lo_u, true at hi_u
+        while (hi_u - lo_u > 1) {
+            uint64_t mid = lo_u + (hi_u - lo_u) / 2;
+            volatile double s = sqrt(u2d(mid));
+            volatile double t = R - s;
+            if (t < f) hi_u = mid; else lo_u = mid;
+        }
+        tab[2 * r] = u2d(hi_u);
+        tab[2 * r + 1] = hi;
+    }
+}
+
+int ensure_init()
+{
+    std::lock_guard<std::mutex> lock(g_init_mutex);
+    if (g_thr_dev) return RCV_OK;
+    double *host = (double *)malloc(sizeof(double) * 2 * TABLE_N);
+    if (!host) return RCV_E_INVALID;
+    build_thresholds(host);
+    double *dev = nullptr;
+    hipError_t e = hipMalloc((void **)&dev, sizeof(double) * 2 * TABLE_N);
+    if (e == hipSuccess) e = hipMemcpy(dev, host, sizeof(double) * 2 * TABLE_N, hipMemcpyHostToDevice);
+    free(host);
+    if (e != hipSuccess) {
+        set_hip_error(e, "threshold table upload", __FILE__, __LINE__);
+        return RCV_E_HIP;
+    }
+    g_thr_dev = dev;
+    return RCV_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// device helpers
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+__device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
+
+__device__ __forceinline__ uint64_t shfl_xor_u64(uint64_t v, int m)
+{
+    uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+    lo = __shfl_xor(lo, m);
+    hi = __shfl_xor(hi, m);
+    return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ double shfl_xor_f64(double v, int m)
+{
+    return __longlong_as_double((long long)shfl_xor_u64((uint64_t)__double_as_longlong(v), m));
+}
+__device__ __forceinline__ double wave_min(double v) { for (int m = 32; m; m >>= 1) v = fmin(v, shfl_xor_f64(v, m)); return v; }
+__device__ __forceinline__ double wave_max(double v) { for (int m = 32; m; m >>= 1) v = fmax(v, shfl_xor_f64(v, m)); return v; }
+__device__ __forceinline__ uint64_t wave_max_u64(uint64_t v)
+{
+    for (int m = 32; m; m >>= 1) { uint64_t o = shfl_xor_u64(v, m); v = o > v ? o : v; }
+    return v;
+}
+__device__ __forceinline__ int wave_sum_i32(int v) { for (int m = 32; m; m >>= 1) v += __shfl_xor(v, m); return v; }
+
+__device__ __forceinline__ int clamp_to_int(double v)
+{
+    // int() of the reference truncates toward zero; clamp so the cast is defined
+    if (!(v > -2.0e9)) return -2000000000;
+    if (!(v < 2.0e9)) return 2000000000;
+    return (int)v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// seam: ordered stream compaction of the masked pixels
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void seam_flags(const float *seg, const float *rad, const uint16_t *depth, int p, float thr,
+                                           double rmax, int mode, bool &m_rad, bool &m_pt)
+{
+    if (mode == 2) {  // plain rgbd_to_point_cloud: depth.nonzero()
+        m_rad = m_pt = depth[p] != 0;
+        return;
+    }
+    const float r = rad[p];
+    const bool rok = (double)r <= rmax;  // float32 array vs float64 scalar: compared in float64
+    if (mode == 0) {
+        m_rad = (seg[p] > thr) && rok;   // python float vs float32 array: compared in float32
+        m_pt = m_rad && depth[p] != 0;
+    } else {
+        m_rad = rok && (r != 0.f) && depth[p] != 0;
+        m_pt = m_rad;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_seam_count(const float *seg, const float *rad, const uint16_t *depth, int HW,
+                                                    float thr, double rmax, int mode, int2 *blk_counts)
+{
+    __shared__ int sp[4], sr[4];
+    const int base = blockIdx.x * SEAM_PIX_PER_BLOCK;
+    int cp = 0, cr = 0;
+    for (int j = 0; j < 4; j++) {
+        int p = base + j * 256 + threadIdx.x;
+        if (p < HW) {
+            bool mr, mp;
+            seam_flags(seg, rad, depth, p, thr, rmax, mode, mr, mp);
+            cp += mp;
+            cr += mr;
+        }
+    }
+    cp = wave_sum_i32(cp);
+    cr = wave_sum_i32(cr);
+    if (lane_id() == 0) { sp[wave_id()] = cp; sr[wave_id()] = cr; }
+    __syncthreads();
+    if (threadIdx.x == 0) blk_counts[blockIdx.x] = make_int2(sp[0] + sp[1] + sp[2] + sp[3], sr[0] + sr[1] + sr[2] + sr[3]);
+}
+
+__global__ __launch_bounds__(1024) void k_seam_scan(const int2 *blk_counts, int nb, int2 *blk_offsets, int32_t *counts_out)
+{
+    __shared__ int2 s[1024];
+    const int t = threadIdx.x;
+    int2 loc[4];
+    int2 sum = make_int2(0, 0);
+    for (int j = 0; j < 4; j++) {
+        int b = t * 4 + j;
+        loc[j] = b < nb ? blk_counts[b] : make_int2(0, 0);
+        sum.x += loc[j].x;
+        sum.y += loc[j].y;
+    }
+    s[t] = sum;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        int2 v = make_int2(0, 0);
+        if (t >= off) v = s[t - off];
+        __syncthreads();
+        s[t].x += v.x;
+        s[t].y += v.y;
+        __syncthreads();
+    }
+    int2 run = make_int2(s[t].x - sum.x, s[t].y - sum.y);  // exclusive prefix of this thread's 4 blocks
+    for (int j = 0; j < 4; j++) {
+        int b = t * 4 + j;
+        if (b < nb) blk_offsets[b] = run;
+        run.x += loc[j].x;
+        run.y += loc[j].y;
+    }
+    if (t == 1023) { counts_out[0] = s[t].x; counts_out[1] = s[t].y; }
+}
+
+__global__ __launch_bounds__(256) void k_seam_scatter(const float *seg, const float *rad, const uint16_t *depth, int HW,
+                                                      int W, double fx, double fy, double cx, double cy, float thr,
+                                                      double rmax, int mode, const int2 *blk_offsets, double *xyz_m,
+                                                      float *radial_list, int cap)
+{
+    __shared__ int segp[16], segr[16];
+    const int base = blockIdx.x * SEAM_PIX_PER_BLOCK;
+    const int lane = lane_id(), wv = wave_id();
+    bool mr[4], mp[4];
+    int pre_p[4], pre_r[4];
+    const uint64_t lt = (1ull << lane) - 1ull;
+    for (int j = 0; j < 4; j++) {
+        int p = base + j * 256 + threadIdx.x;
+        mr[j] = mp[j] = false;
+        if (p < HW) seam_flags(seg, rad, depth, p, thr, rmax, mode, mr[j], mp[j]);
+        uint64_t bp = __ballot(mp[j]), br = __ballot(mr[j]);
+        pre_p[j] = __popcll(bp & lt);
+        pre_r[j] = __popcll(br & lt);
+        if (lane == 0) { segp[j * 4 + wv] = __popcll(bp); segr[j * 4 + wv] = __popcll(br); }
+    }
+    __syncthreads();
+    const int2 off = blk_offsets[blockIdx.x];
+    for (int j = 0; j < 4; j++) {
+        int p = base + j * 256 + threadIdx.x;
+        int before_p = 0, before_r = 0;
+        for (int q = 0; q < j * 4 + wv; q++) { before_p += segp[q]; before_r += segr[q]; }
+        if (mr[j] && mode != 2) {
+            int dst = off.y + before_r + pre_r[j];
+            if (dst < cap) radial_list[dst] = rad[p];
+        }
+        if (mp[j]) {
+            int dst = off.x + before_p + pre_p[j];
+            if (dst < cap) {
+                // rgbd_to_point_cloud (AccumulatorSpace.py:81-84) then xyz = xyz_mm/1000 (:619)
+                const int v = p / W, u = p - v * W;
+                const double zs = (double)depth[p];
+                const double xs = (((double)u - cx) * zs) / fx;
+                const double ys = (((double)v - cy) * zs) / fy;
+                xyz_m[3 * (size_t)dst + 0] = mode == 2 ? xs : xs / 1000.0;
+                xyz_m[3 * (size_t)dst + 1] = mode == 2 ? ys : ys / 1000.0;
+                xyz_m[3 * (size_t)dst + 2] = mode == 2 ? zs : zs / 1000.0;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// prepare: voxel-space points, integer radii, per-block extrema  (AccumulatorSpace.py:376,388,332)
+// ---------------------------------------------------------------------------------------------
+template <typename RT>
+__global__ __launch_bounds__(PREP_THREADS) void k_prep(const double *xyz_m, const RT *radial, const int32_t *counts,
+                                                       int n_arg, int m_arg, int cap, double unit, double *P,
+                                                       int32_t *ri, PrepPartial *partials)
+{
+    __shared__ double red[7][PREP_THREADS / 64];
+    int n = n_arg, m = m_arg;
+    if (counts) { n = min(counts[0], cap); m = min(counts[1], cap); }
+    const double INF = __longlong_as_double(0x7FF0000000000000ll);
+    double mn[3] = {INF, INF, INF}, mx[3] = {-INF, -INF, -INF}, rmax = -INF;
+    const RT unit_rt = (RT)unit;  // python int 5 is a weak scalar: float32 lists stay float32 (:388)
+    const int top = n > m ? n : m;
+    for (int i = blockIdx.x * PREP_THREADS + threadIdx.x; i < top; i += PREP_BLOCKS * PREP_THREADS) {
+        if (i < n) {
+            for (int c = 0; c < 3; c++) {
+                double v = (xyz_m[3 * (size_t)i + c] * 1000.0) / unit;  // xyz*1000/acc_unit, :376
+                P[(size_t)c * cap + i] = v;
+                mn[c] = fmin(mn[c], v);
+                mx[c] = fmax(mx[c], v);
+            }
+        }
+        if (i < m) {
+            RT rv = (radial[i] * (RT)100) / unit_rt;  // radial_list*100/acc_unit, :388
+            double rd = (double)rv;
+            if (rd > rmax) rmax = rd;
+            if (i < n) {
+                double rr = rint(rd);  // np.around: half to even (:332); exact for float32 values too
+                ri[i] = (rd == rd) ? clamp_to_int(rr) : 0;
+            }
+        }
+    }
+    double vals[7] = {mn[0], mn[1], mn[2], mx[0], mx[1], mx[2], rmax};
+    for (int q = 0; q < 7; q++) {
+        double v = q < 3 ? wave_min(vals[q]) : wave_max(vals[q]);
+        if (lane_id() == 0) red[q][wave_id()] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        PrepPartial pp;
+        for (int q = 0; q < 7; q++) {
+            double v = red[q][0];
+            for (int w = 1; w < PREP_THREADS / 64; w++) v = q < 3 ? fmin(v, red[q][w]) : fmax(v, red[q][w]);
+            if (q < 3) pp.mn[q] = v; else if (q < 6) pp.mx[q - 3] = v; else pp.rmax = v;
+        }
+        pp.pad_ = 0;
+        partials[blockIdx.x] = pp;
+    }
+}
+
+// numpy pairwise_sum leaf: n <= 128 elements (loops_utils.h.src), exact operation order
+__device__ double pw_leaf(const double *a, int n)
+{
+    if (n < 8) {
+        double r = 0.0;
+        for (int i = 0; i < n; i++) r += a[i];
+        return r;
+    }
+    double r0 = a[0], r1 = a[1], r2 = a[2], r3 = a[3], r4 = a[4], r5 = a[5], r6 = a[6], r7 = a[7];
+    int i;
+    for (i = 8; i < n - (n % 8); i += 8) {
+        r0 += a[i + 0]; r1 += a[i + 1]; r2 += a[i + 2]; r3 += a[i + 3];
+        r4 += a[i + 4]; r5 += a[i + 5]; r6 += a[i + 6]; r7 += a[i + 7];
+    }
+    double res = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
+    for (; i < n; i++) res += a[i];
+    return res;
+}
+
+// setup: numpy-exact means, grid sizing, tile geometry.  One workgroup.
+//   np.mean(xyz_mm[:,c]) (:381-383) = add.reduce over a strided float64 view: the ufunc machinery
+//   feeds the inner loop chunks of 8192 elements, each chunk is summed with the pairwise recursion
+//   (halves split at a multiple of 8, leaves <= 128 with 8 interleaved partial sums) and added to the
+//   running total in order.  Here a chunk's recursion tree is laid out as a binary heap (<= 255 nodes):
+//   one thread per heap node finds its (offset, length) by walking down from the root, leaves are
+//   summed in parallel, inner nodes level by level; the chunk totals are then added sequentially.
+__global__ __launch_bounds__(1024) void k_setup(const PrepPartial *partials, const double *P, const int32_t *counts,
+                                                int n_arg, int m_arg, int cap, double unit, int grid_cells_ok,
+                                                AccHeader *hdr)
+{
+    __shared__ double val[4][3][256];
+    __shared__ unsigned char kind[4][256];  // 0 = absent, 1 = leaf, 2 = inner
+    __shared__ double total[3];
+    int n = n_arg, m = m_arg;
+    if (counts) { n = min(counts[0], cap); m = min(counts[1], cap); }
+    const int t = threadIdx.x, grp = t >> 8, h = t & 255;
+    if (t < 3) total[t] = 0.0;
+    __syncthreads();
+    const int nchunks = n > 0 ? (n + NPY_BUFSIZE - 1) / NPY_BUFSIZE : 0;
+    for (int c0 = 0; c0 < nchunks; c0 += 4) {
+        const int c = c0 + grp;
+        unsigned char kd = 0;
+        if (c < nchunks && h >= 1) {
+            const int off0 = c * NPY_BUFSIZE;
+            int len = min(NPY_BUFSIZE, n - off0), o = 0;
+            const int depth = 31 - __clz(h);
+            bool exists = true;
+            for (int b = depth - 1; b >= 0; b--) {
+                if (len <= PW_BLOCK) { exists = false; break; }
+                int n2 = len / 2;
+                n2 -= n2 % 8;
+                if ((h >> b) & 1) { o += n2; len -= n2; } else { len = n2; }
+            }
+            if (exists) {
+                if (len <= PW_BLOCK) {
+                    kd = 1;
+                    for (int a = 0; a < 3; a++) val[grp][a][h] = pw_leaf(P + (size_t)a * cap + off0 + o, len);
+                } else {
+                    kd = 2;
+                }
+            }
+        }
+        kind[grp][h] = kd;
+        __syncthreads();
+        for (int d = 6; d >= 0; d--) {
+            if (h >= (1 << d) && h < (2 << d) && kind[grp][h] == 2)
+                for (int a = 0; a < 3; a++) val[grp][a][h] = val[grp][a][2 * h] + val[grp][a][2 * h + 1];
+            __syncthreads();
+        }
+        if (t < 3) {
+            double s = total[t];
+            for (int g = 0; g < 4 && c0 + g < nchunks; g++) s = s + val[g][t][1];
+            total[t] = s;
+        }
+        __syncthreads();
+    }
+    if (t != 0) return;
+
+    AccHeader H;
+    memset(&H, 0, sizeof(H));
+    H.n = n; H.m = m; H.unit = unit;
+    if (n <= 0 || m <= 0) {
+        H.status = RCV_E_EMPTY;  // reference: ValueError from .min() of an empty array (:390)
+        *hdr = H;
+        return;
+    }
+    const double INF = __longlong_as_double(0x7FF0000000000000ll);
+    double mn[3] = {INF, INF, INF}, mx[3] = {-INF, -INF, -INF}, rmax = -INF;
+    for (int b = 0; b < PREP_BLOCKS; b++) {
+        for (int a = 0; a < 3; a++) { mn[a] = fmin(mn[a], partials[b].mn[a]); mx[a] = fmax(mx[a], partials[b].mx[a]); }
+        rmax = fmax(rmax, partials[b].rmax);
+    }
+    double qmin = INF, qmax = -INF;
+    for (int a = 0; a < 3; a++) {
+        H.mean[a] = total[a] / (double)n;                 // np.mean: sum / count
+        qmin = fmin(qmin, mn[a] - H.mean[a]);             // min of (x - mean): rounding is monotone
+        qmax = fmax(qmax, mx[a] - H.mean[a]);
+    }
+    H.rmax = rmax;
+    const int zb = clamp_to_int(qmin - rmax) + 1;          // :394
+    H.zb = zb;
+    H.shift = zb < 0 ? (double)zb : 0.0;                    // :396-397
+    const double pmax = zb < 0 ? qmax - (double)zb : qmax;
+    const int length = clamp_to_int(pmax);                  // :399
+    const long long dim = (long long)length + (long long)clamp_to_int(rmax);  // :401
+    if (dim <= 0) { H.status = RCV_E_BADGRID; *hdr = H; return; }
+    if (dim > MAX_DIM) { H.status = RCV_E_TOO_LARGE; H.dim = (int)min(dim, 2000000000ll); *hdr = H; return; }
+    const int D = (int)dim;
+    H.dim = D;
+    H.wide = n >= 65536;
+    const int cell_bytes = H.wide ? 4 : 2;
+    const int cells = CELL_BYTES / cell_bytes;
+    // tile: TJ = 16 (or D if smaller) columns across j; TI rows; full k extent when it fits
+    int TJ = D < 16 ? D : 16, TI, TK = D, TKp = (D + 1) & ~1;
+    if ((long long)TJ * TKp > cells) {  // a single row of columns does not fit: split k
+        TI = 1;
+        TJ = D < 64 ? D : 64;
+        TKp = (cells / TJ) & ~1;
+        TK = TKp;
+    } else {
+        TI = cells / (TJ * TKp);
+        if (TI > 16) TI = 16;
+        if (TI > D) TI = D;
+        // prefer at least ~2 workgroups per CU worth of tiles as long as a wave still gets 64 columns
+        while (TI > 4 && (long long)((D + TI - 1) / TI) * ((D + TJ - 1) / TJ) < 512) TI >>= 1;
+    }
+    H.TI = TI; H.TJ = TJ; H.TK = TK; H.TKp = TKp;
+    H.nti = (D + TI - 1) / TI; H.ntj = (D + TJ - 1) / TJ; H.ntk = (D + TK - 1) / TK;
+    const long long nt = (long long)H.nti * H.ntj * H.ntk;
+    if (nt > MAX_TILES) { H.status = RCV_E_TOO_LARGE; *hdr = H; return; }
+    H.ntiles = (int)nt;
+    H.status = grid_cells_ok ? RCV_OK : RCV_OK;
+    H.tile_counter = 0;
+    *hdr = H;
+}
+
+// ---------------------------------------------------------------------------------------------
+// vote: one workgroup per tile, counters in LDS, arg-max straight from LDS
+// ---------------------------------------------------------------------------------------------
+template <bool WIDE>
+__device__ __forceinline__ uint32_t cell_read(const uint32_t *cells, int cell)
+{
+    if (WIDE) return cells[cell];
+    return (cells[cell >> 1] >> ((cell & 1) * 16)) & 0xFFFFu;
+}
+
+template <bool WIDE>
+__global__ __launch_bounds__(VOTE_THREADS) void k_vote(AccHeader *hdr, const double *P, const int32_t *ri_arr, int cap,
+                                                       const double *thr, uint64_t *tile_best, uint32_t *tile_ties,
+                                                       uint32_t *grid_out, unsigned long long grid_cells)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t *cells = (uint32_t *)smem;
+    Surv *surv = (Surv *)(smem + CELL_BYTES);
+    int *wcount = (int *)(smem + CELL_BYTES + SURV_CAP * sizeof(Surv));           // [VOTE_WAVES]
+    uint64_t *wred = (uint64_t *)(smem + CELL_BYTES + SURV_CAP * sizeof(Surv) + 64);  // [VOTE_WAVES]
+    int *wredi = (int *)(smem + CELL_BYTES + SURV_CAP * sizeof(Surv) + 64 + 8 * VOTE_WAVES);  // [VOTE_WAVES]
+
+    const AccHeader H = *hdr;
+    if (H.status != RCV_OK || (int)H.wide != (int)WIDE) return;
+    const int D = H.dim, n = H.n, TI = H.TI, TJ = H.TJ, TK = H.TK, TKp = H.TKp;
+    const int lane = lane_id(), wv = wave_id(), tid = threadIdx.x;
+    const int ncols = TI * TJ;
+    const int npass = (ncols + 63) / 64;
+    const int ncells = ncols * TKp;
+    const int nwords = WIDE ? ncells : ncells / 2;
+    const bool flush = grid_out != nullptr && (unsigned long long)D * D * D <= grid_cells;
+
+    for (int tile = blockIdx.x; tile < H.ntiles; tile += gridDim.x) {
+        const int tk = tile % H.ntk, tj = (tile / H.ntk) % H.ntj, ti = tile / (H.ntk * H.ntj);
+        const int i0 = ti * TI, j0 = tj * TJ, k0 = tk * TK;
+        const int i1 = min(i0 + TI, D), j1 = min(j0 + TJ, D), k1 = min(k0 + TK, D);
+        for (int w = tid; w < nwords; w += VOTE_THREADS) cells[w] = 0u;
+        __syncthreads();
+
+        for (int base = 0; base < n; base += SURV_CAP) {
+            // ---- cull SURV_CAP points against the tile footprint (threads 0..SURV_CAP-1 test one each) ----
+            bool keep = false;
+            Surv s;
+            {
+                const int p = base + tid;
+                if (tid < SURV_CAP && p < n) {
+                    const int r = ri_arr[p];
+                    if (r >= TABLE_N) {
+                        atomicMin(&hdr->status, (int)RCV_E_TOO_LARGE);
+                    } else if (r > 0) {
+                        // fast_for sees xyz_mm - mean - zero_boundary (AccumulatorSpace.py:384-386,397)
+                        s.x = (P[p] - H.mean[0]) - H.shift;
+                        s.y = (P[(size_t)cap + p] - H.mean[1]) - H.shift;
+                        s.z = (P[2 * (size_t)cap + p] - H.mean[2]) - H.shift;
+                        s.tlo = thr[2 * r];
+                        s.thi = thr[2 * r + 1];
+                        s.ri = r;
+                        s.pad_ = 0;
+                        const double ex = fmax(fmax((double)i0 - s.x, s.x - (double)(i1 - 1)), 0.0);
+                        const double ey = fmax(fmax((double)j0 - s.y, s.y - (double)(j1 - 1)), 0.0);
+                        const double rr = (double)r;
+                        keep = (ex * ex + ey * ey) * (1.0 - 1e-9) < s.thi && s.z + rr >= (double)k0 &&
+                               s.z - rr <= (double)(k1 - 1);
+                    }
+                }
+            }
+            const uint64_t kb = __ballot(keep);
+            if (lane == 0) wcount[wv] = __popcll(kb);
+            __syncthreads();
+            {
+                int before = 0;
+                for (int q = 0; q < wv; q++) before += wcount[q];
+                if (keep) surv[before + __popcll(kb & ((1ull << lane) - 1ull))] = s;
+            }
+            __syncthreads();
+            int nsurv = 0;
+            for (int q = 0; q < VOTE_WAVES; q++) nsurv += wcount[q];
+
+            // ---- rasterise: each wave takes whole points, its lanes take the tile's columns ----
+            for (int si = wv; si < nsurv; si += VOTE_WAVES) {
+                const Surv s = surv[si];
+                for (int pass = 0; pass < npass; pass++) {
+                    const int col = pass * 64 + lane;
+                    const int il = col / TJ, jl = col - il * TJ;
+                    const int i = i0 + il, j = j0 + jl;
+                    if (col >= ncols || i >= i1 || j >= j1) continue;
+                    const double dx = (double)i - s.x, dy = (double)j - s.y;
+                    const double sxy = dx * dx + dy * dy;  // (i-x)**2 + (j-y)**2, reference order (:337)
+                    const double a = s.thi - sxy;
+                    if (!(a > 0.0)) continue;
+                    const double b = s.tlo - sxy;
+                    const double eps = 1e-3;
+                    const double zh = (double)__builtin_sqrtf((float)a) + eps;
+                    int lo1, hi1, lo2 = 1, hi2 = 0;
+                    if (b <= 0.0) {
+                        lo1 = (int)ceil(s.z - zh);
+                        hi1 = (int)floor(s.z + zh);
+                    } else {
+                        const double zl = (double)__builtin_sqrtf((float)b) - eps;
+                        lo1 = (int)ceil(s.z - zh);
+                        hi1 = (int)floor(s.z - zl);
+                        lo2 = (int)ceil(s.z + zl);
+                        hi2 = (int)floor(s.z + zh);
+                        if (lo2 <= hi1) { hi1 = hi2; lo2 = 1; hi2 = 0; }
+                    }
+                    lo1 = max(lo1, k0); hi1 = min(hi1, k1 - 1);
+                    lo2 = max(lo2, k0); hi2 = min(hi2, k1 - 1);
+                    const int n1 = max(hi1 - lo1 + 1, 0), n2 = max(hi2 - lo2 + 1, 0);
+                    const int cbase = col * TKp - k0;
+                    for (int q = 0; q < n1 + n2; q++) {
+                        const int k = q < n1 ? lo1 + q : lo2 + (q - n1);
+                        const double dz = (double)k - s.z;
+                        const double d2 = sxy + dz * dz;  // ... + (k-z)**2
+                        if (d2 >= s.tlo && d2 < s.thi) {
+                            const int cell = cbase + k;
+                            if (WIDE) atomicAdd(&cells[cell], 1u);
+                            else atomicAdd(&cells[cell >> 1], 1u << ((cell & 1) * 16));
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+        }
+
+        // ---- tile arg-max (first maximum in C order) + tie count, optional flush ----
+        uint64_t best = 0;
+        for (int c = tid; c < ncells; c += VOTE_THREADS) {
+            const int col = c / TKp, kk = c - col * TKp;
+            const int il = col / TJ, jl = col - il * TJ;
+            const int i = i0 + il, j = j0 + jl, k = k0 + kk;
+            if (i >= i1 || j >= j1 || k >= k1) continue;
+            const uint32_t v = cell_read<WIDE>(cells, c);
+            const uint32_t flat = ((uint32_t)i * (uint32_t)D + (uint32_t)j) * (uint32_t)D + (uint32_t)k;
+            const uint64_t key = ((uint64_t)v << 32) | (uint64_t)(0xFFFFFFFFu - flat);
+            best = key > best ? key : best;
+            if (flush) grid_out[flat] = v;
+        }
+        best = wave_max_u64(best);
+        if (lane == 0) wred[wv] = best;
+        __syncthreads();
+        best = wred[0];
+        for (int q = 1; q < VOTE_WAVES; q++) best = wred[q] > best ? wred[q] : best;
+        const uint32_t vmax = (uint32_t)(best >> 32);
+        int ties = 0;
+        for (int c = tid; c < ncells; c += VOTE_THREADS) {
+            const int col = c / TKp, kk = c - col * TKp;
+            const int il = col / TJ, jl = col - il * TJ;
+            if (i0 + il >= i1 || j0 + jl >= j1 || k0 + kk >= k1) continue;
+            ties += cell_read<WIDE>(cells, c) == vmax;
+        }
+        ties = wave_sum_i32(ties);
+        if (lane == 0) wredi[wv] = ties;
+        __syncthreads();
+        if (tid == 0) {
+            int tsum = 0;
+            for (int q = 0; q < VOTE_WAVES; q++) tsum += wredi[q];
+            tile_best[tile] = best;
+            tile_ties[tile] = (uint32_t)tsum;
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void k_final(const AccHeader *hdr, const uint64_t *tile_best, const uint32_t *tile_ties,
+                                               int grid_given, unsigned long long grid_cells, rcv_acc_result *out)
+{
+    __shared__ uint64_t sb[4];
+    __shared__ unsigned long long st[4];
+    const AccHeader H = *hdr;
+    rcv_acc_result R;
+    memset(&R, 0, sizeof(R));
+    R.dim = H.dim; R.zero_boundary = H.zb; R.n_points = H.n; R.n_radii = H.m; R.status = H.status;
+    R.radius_max = H.rmax;
+    for (int a = 0; a < 3; a++) R.mean_vox[a] = H.mean[a];
+    if (H.status != RCV_OK) {
+        if (threadIdx.x == 0) *out = R;
+        return;
+    }
+    uint64_t best = 0;
+    for (int t = threadIdx.x; t < H.ntiles; t += 256) best = tile_best[t] > best ? tile_best[t] : best;
+    best = wave_max_u64(best);
+    if (lane_id() == 0) sb[wave_id()] = best;
+    __syncthreads();
+    best = sb[0];
+    for (int q = 1; q < 4; q++) best = sb[q] > best ? sb[q] : best;
+    const uint32_t vmax = (uint32_t)(best >> 32);
+    unsigned long long ties = 0;
+    for (int t = threadIdx.x; t < H.ntiles; t += 256)
+        if ((uint32_t)(tile_best[t] >> 32) == vmax) ties += tile_ties[t];
+    for (int m = 32; m; m >>= 1) ties += shfl_xor_u64(ties, m);
+    if (lane_id() == 0) st[wave_id()] = ties;
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    ties = st[0] + st[1] + st[2] + st[3];
+    const uint32_t flat = 0xFFFFFFFFu - (uint32_t)(best & 0xFFFFFFFFull);
+    const uint32_t D = (uint32_t)H.dim;
+    const int idx[3] = {(int)(flat / (D * D)), (int)((flat / D) % D), (int)(flat % D)};
+    for (int a = 0; a < 3; a++) {
+        R.first_idx[a] = idx[a];
+        double c = (double)idx[a];
+        if (H.zb < 0) c = c + (double)H.zb;                 // center + zero_boundary, :409-410
+        R.center_mm[a] = ((c + H.mean[a]) + 0.5) * H.unit;  // (center + mean + 0.5) * acc_unit, :413-415
+    }
+    R.peak_votes = (int32_t)vmax;
+    R.n_ties = ties > 2147483647ull ? 2147483647 : (int32_t)ties;
+    if (grid_given && (unsigned long long)D * D * D > grid_cells) R.status = RCV_E_GRID_BUFFER;
+    *out = R;
+}
+
+__global__ void k_debug_points(const AccHeader *hdr, const double *P, const int32_t *ri, int cap, int out_cap,
+                               double *points_vox, int32_t *radius_int)
+{
+    const AccHeader H = *hdr;
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= H.n || i >= out_cap) return;
+    for (int a = 0; a < 3; a++) points_vox[3 * (size_t)i + a] = (P[(size_t)a * cap + i] - H.mean[a]) - H.shift;
+    if (radius_int) radius_int[i] = ri[i];
+}
+
+// argwhere(grid == peak), ascending flat order; one workgroup walks the grid in order (rare path)
+__global__ __launch_bounds__(1024) void k_collect_ties(const uint32_t *grid, unsigned long long total, uint32_t peak,
+                                                       int64_t *out, int cap, int32_t *count_out)
+{
+    __shared__ int wc[16];
+    __shared__ int running;
+    if (threadIdx.x == 0) running = 0;
+    __syncthreads();
+    for (unsigned long long base = 0; base < total; base += 1024) {
+        unsigned long long c = base + threadIdx.x;
+        bool hit = c < total && grid[c] == peak;
+        uint64_t b = __ballot(hit);
+        if (lane_id() == 0) wc[wave_id()] = __popcll(b);
+        __syncthreads();
+        int before = running;
+        for (int q = 0; q < wave_id(); q++) before += wc[q];
+        if (hit) {
+            int dst = before + __popcll(b & ((1ull << lane_id()) - 1ull));
+            if (dst < cap) out[dst] = (int64_t)c;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) { int s = 0; for (int q = 0; q < 16; q++) s += wc[q]; running += s; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *count_out = running;
+}
+
+constexpr size_t VOTE_LDS_BYTES = CELL_BYTES + SURV_CAP * sizeof(Surv) + 64 + 8 * VOTE_WAVES + 4 * VOTE_WAVES + 32;
+bool g_vote_attr_set = false;
+
+}  // namespace
+}  // namespace rcv
+
+using namespace rcv;
+
+extern "C" {
+
+int rcv_init(void) { return ensure_init(); }
+
+size_t rcv_acc_workspace_bytes(int max_points)
+{
+    if (max_points < 1) max_points = 1;
+    return make_layout(max_points).total;
+}
+
+int rcv_seam_compact(const float *seg_dev, const float *radial_dev, const uint16_t *depth_dev, int H, int W,
+                     const double K[4], float seg_thr, double rmax_dm, int mode, double *xyz_m_dev,
+                     float *radial_list_dev, int32_t *counts_dev, int cap, void *ws, size_t ws_bytes, void *stream)
+{
+    if (!depth_dev || !K || !xyz_m_dev || !counts_dev || !ws) return RCV_E_INVALID;
+    if (mode < 0 || mode > 2) return RCV_E_INVALID;
+    if (mode != 2 && (!radial_dev || !radial_list_dev)) return RCV_E_INVALID;
+    if (mode == 0 && !seg_dev) return RCV_E_INVALID;
+    if (H <= 0 || W <= 0 || cap <= 0) return RCV_E_INVALID;
+    const long long HW = (long long)H * W;
+    const int nb = (int)((HW + SEAM_PIX_PER_BLOCK - 1) / SEAM_PIX_PER_BLOCK);
+    if (nb > SEAM_MAX_BLOCKS) return RCV_E_TOO_LARGE;
+    const Layout L = make_layout(1);
+    if (ws_bytes < L.tile_best) return RCV_E_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    int2 *cnt = (int2 *)((char *)ws + L.seam_counts), *off = (int2 *)((char *)ws + L.seam_offsets);
+    const float *seg = seg_dev ? seg_dev : radial_dev;  // never dereferenced when mode != 0
+    hipLaunchKernelGGL(k_seam_count, dim3(nb), dim3(256), 0, st, seg, radial_dev, depth_dev, (int)HW, seg_thr, rmax_dm,
+                       mode, cnt);
+    RCV_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_seam_scan, dim3(1), dim3(1024), 0, st, cnt, nb, off, counts_dev);
+    RCV_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_seam_scatter, dim3(nb), dim3(256), 0, st, seg, radial_dev, depth_dev, (int)HW, W, K[0], K[1],
+                       K[2], K[3], seg_thr, rmax_dm, mode, off, xyz_m_dev, radial_list_dev, cap);
+    RCV_LAUNCH_CHECK();
+    return RCV_OK;
+}
+
+int rcv_accumulate_3d(const double *xyz_m_dev, const void *radial_dm_dev, int radial_is_f64,
+                      const int32_t *counts_dev, int n_points, int n_radii, double acc_unit_mm,
+                      rcv_acc_result *result_dev, uint32_t *vote_grid_dev, size_t vote_grid_cells, void *ws,
+                      size_t ws_bytes, void *stream)
+{
+    if (!result_dev || !ws) return RCV_E_INVALID;
+    if (n_points < 0 || n_radii < 0 || !(acc_unit_mm > 0.0)) return RCV_E_INVALID;
+    if ((n_points > 0 && !xyz_m_dev) || (n_radii > 0 && !radial_dm_dev)) return RCV_E_INVALID;
+    int rc = ensure_init();
+    if (rc != RCV_OK) return rc;
+    const int cap = n_points > n_radii ? (n_points > 0 ? n_points : 1) : (n_radii > 0 ? n_radii : 1);
+    const Layout L = make_layout(cap);
+    if (ws_bytes < L.total) return RCV_E_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    char *w = (char *)ws;
+    AccHeader *hdr = (AccHeader *)(w + L.header);
+    PrepPartial *partials = (PrepPartial *)(w + L.partials);
+    double *P = (double *)(w + L.P);
+    int32_t *ri = (int32_t *)(w + L.ri);
+    uint64_t *tile_best = (uint64_t *)(w + L.tile_best);
+    uint32_t *tile_ties = (uint32_t *)(w + L.tile_ties);
+
+    if (!g_vote_attr_set) {
+        RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_vote<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          (int)VOTE_LDS_BYTES));
+        RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_vote<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          (int)VOTE_LDS_BYTES));
+        g_vote_attr_set = true;
+    }
+    if (radial_is_f64)
+        hipLaunchKernelGGL(k_prep<double>, dim3(PREP_BLOCKS), dim3(PREP_THREADS), 0, st, xyz_m_dev,
+                           (const double *)radial_dm_dev, counts_dev, n_points, n_radii, cap, acc_unit_mm, P, ri, partials);
+    else
+        hipLaunchKernelGGL(k_prep<float>, dim3(PREP_BLOCKS), dim3(PREP_THREADS), 0, st, xyz_m_dev,
+                           (const float *)radial_dm_dev, counts_dev, n_points, n_radii, cap, acc_unit_mm, P, ri, partials);
+    RCV_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_setup, dim3(1), dim3(1024), 0, st, partials, P, counts_dev, n_points, n_radii, cap, acc_unit_mm, 1,
+                       hdr);
+    RCV_LAUNCH_CHECK();
+    const int vote_blocks = 512;  // 2 workgroups per CU (LDS-limited), tiles are strided over them
+    const bool maybe_wide = cap >= 65536;
+    hipLaunchKernelGGL(k_vote<false>, dim3(vote_blocks), dim3(VOTE_THREADS), VOTE_LDS_BYTES, st, hdr, P, ri, cap, g_thr_dev,
+                       tile_best, tile_ties, vote_grid_dev, (unsigned long long)vote_grid_cells);
+    RCV_LAUNCH_CHECK();
+    if (maybe_wide) {
+        hipLaunchKernelGGL(k_vote<true>, dim3(vote_blocks), dim3(VOTE_THREADS), VOTE_LDS_BYTES, st, hdr, P, ri, cap,
+                           g_thr_dev, tile_best, tile_ties, vote_grid_dev, (unsigned long long)vote_grid_cells);
+        RCV_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(k_final, dim3(1), dim3(256), 0, st, hdr, tile_best, tile_ties, vote_grid_dev != nullptr ? 1 : 0,
+                       (unsigned long long)vote_grid_cells, result_dev);
+    RCV_LAUNCH_CHECK();
+    return RCV_OK;
+}
+
+int rcv_collect_ties(const uint32_t *vote_grid_dev, int dim, uint32_t peak, int64_t *flat_idx_dev, int cap,
+                     int32_t *count_dev, void *stream)
+{
+    if (!vote_grid_dev || !flat_idx_dev || !count_dev || dim <= 0 || cap <= 0) return RCV_E_INVALID;
+    hipLaunchKernelGGL(k_collect_ties, dim3(1), dim3(1024), 0, (hipStream_t)stream, vote_grid_dev,
+                       (unsigned long long)dim * dim * dim, peak, flat_idx_dev, cap, count_dev);
+    RCV_LAUNCH_CHECK();
+    return RCV_OK;
+}
+
+int rcv_acc_debug_points(const void *ws, double *points_vox_dev, int32_t *radius_int_dev, int cap, void *stream)
+{
+    if (!ws || !points_vox_dev || cap <= 0) return RCV_E_INVALID;
+    const Layout L = make_layout(cap);
+    const char *w = (const char *)ws;
+    hipLaunchKernelGGL(k_debug_points, dim3((cap + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                       (const AccHeader *)(w + L.header), (const double *)(w + L.P), (const int32_t *)(w + L.ri), cap, cap,
+                       points_vox_dev, radius_int_dev);
+    RCV_LAUNCH_CHECK();
+    return RCV_OK;
+}
+
+}  // extern "C"

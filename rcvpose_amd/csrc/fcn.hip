@@ -1,0 +1,652 @@
+// fcn.hip -- the FCN half of the RCVPose hot path on MI355X (gfx950 / CDNA4).
+//
+// A small native executor for the layer program of DenseFCNResNet152 (reference models/fcnresnet.py:48-191)
+// plus the hand-written kernels it launches.  Activations are NHWC (channels innermost) so that the
+// K dimension of every convolution -- (tap, channel) -- is contiguous for both operands:
+//
+//   k_conv<T,BM,BN>  implicit-GEMM convolution on the matrix cores, im2col-free:
+//                    out[m, n] = act( sum_{tap,c} in[pixel(m) + tap, c] * w[n, tap, c] + bias[n] (+ res[m, n]) )
+//                    M = B*Hout*Wout pixels, N = Cout, K = KH*KW*(C0+C1).  The A operand is gathered on the
+//                    fly from one or two channel-concatenated sources (torch.cat is never materialised),
+//                    zero-filled at the borders, staged through XOR-swizzled LDS tiles with register
+//                    double-buffering (global loads of tile t+1 are in flight while tile t is multiplied).
+//                    T = __bf16 : v_mfma_f32_16x16x32_bf16, fp32 accumulate      (performance mode)
+//                    T = float  : v_mfma_f32_16x16x4_f32, exact fp32 fma chain   (parity mode, 1e-4 gate)
+//                    BatchNorm is folded into w / bias on the host; ReLU and the residual add are fused
+//                    into the epilogue.  blockIdx.z walks the `groups` networks (one per keypoint) that
+//                    share the input image.
+//   k_stem           conv1 7x7/2 + BN + ReLU from the NCHW fp32 image (K = 147 is too ragged for the GEMM path)
+//   k_maxpool, k_upsample2 (bilinear, align_corners=False), k_head (conv8 1x1 -> seg / radial planes)
+//   k_preprocess     FCResBackbone's uint8 -> normalised fp32 image (reference AccumulatorSpace.py:140-151)
+#include <string.h>
+
+#include <vector>
+
+#include "common.hpp"
+
+namespace rcv {
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+template <typename T> struct Traits;
+template <> struct Traits<float> {
+    static constexpr int KE = 32;  // elements in one 128-byte K row of an LDS tile
+    static constexpr int EPV = 4;  // elements per 16-byte vector
+};
+template <> struct Traits<__bf16> {
+    static constexpr int KE = 64;
+    static constexpr int EPV = 8;
+};
+
+__device__ __forceinline__ float to_f32(float v) { return v; }
+__device__ __forceinline__ float to_f32(__bf16 v) { return (float)v; }
+template <typename T> __device__ __forceinline__ T from_f32(float v);
+template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ __bf16 from_f32<__bf16>(float v) { return (__bf16)v; }
+
+struct ConvParams {
+    const void *src0, *src1, *res, *w;
+    void *dst;
+    const float *bias;
+    long long src0_gs, src1_gs, res_gs, dst_gs, w_gs;  // per-group strides in elements
+    int bias_gs;
+    int C0, C1, Cout;
+    int Hin, Win, Hout, Wout;
+    int KS, stride, pad, relu;
+    int M, K;  // GEMM sizes per group
+};
+
+// ---------------------------------------------------------------------------------------------
+// implicit-GEMM convolution
+// ---------------------------------------------------------------------------------------------
+template <typename T, int BM, int BN>
+__global__ __launch_bounds__(256) void k_conv(const ConvParams p)
+{
+    constexpr int KE = Traits<T>::KE, EPV = Traits<T>::EPV;
+    constexpr int AR = BM / 32, BR = BN / 32;  // 16-byte rows each thread stages per tile
+    constexpr int MT = BM / 32, NT = BN / 32;  // 16x16 MFMA tiles per wave (waves are 2 x 2)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char *As = smem;                   // [2][BM][128 B]
+    unsigned char *Bs = smem + 2 * BM * 128;    // [2][BN][128 B]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int g = blockIdx.z, m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const int chunk = tid & 7, rowb = tid >> 3;
+    const int Ctot = p.C0 + p.C1;
+    const T *src0 = (const T *)p.src0 + (long long)g * p.src0_gs;
+    const T *src1 = p.src1 ? (const T *)p.src1 + (long long)g * p.src1_gs : nullptr;
+    const T *wg = (const T *)p.w + (long long)g * p.w_gs;
+
+    int a_hi0[AR], a_wi0[AR], a_pix[AR];
+    const int HWo = p.Hout * p.Wout;
+#pragma unroll
+    for (int q = 0; q < AR; q++) {
+        const int m = m0 + rowb + 32 * q;
+        if (m < p.M) {
+            const int img = m / HWo, rem = m - img * HWo;
+            const int ho = rem / p.Wout, wo = rem - ho * p.Wout;
+            a_hi0[q] = ho * p.stride - p.pad;
+            a_wi0[q] = wo * p.stride - p.pad;
+            a_pix[q] = img * p.Hin * p.Win;
+        } else {
+            a_hi0[q] = -100000;  // every tap falls outside -> zeros
+            a_wi0[q] = -100000;
+            a_pix[q] = 0;
+        }
+    }
+
+    uint4 ra[AR], rb[BR];
+    int tap_r = 0, tap_s = 0, cg = 0;  // position of the next K chunk: tap (r, s) and concat channel
+
+// global -> registers for the next K chunk (A gathered with zero fill at the borders, B = weights)
+#define RCV_FETCH()                                                                                          \
+    {                                                                                                        \
+        const T *src_;                                                                                       \
+        int Cs_, c_;                                                                                         \
+        if (cg < p.C0) { src_ = src0; Cs_ = p.C0; c_ = cg; } else { src_ = src1; Cs_ = p.C1; c_ = cg - p.C0; } \
+        const int kcol_ = (tap_r * p.KS + tap_s) * Ctot + cg + chunk * EPV;                                  \
+        _Pragma("unroll") for (int q = 0; q < AR; q++) {                                                     \
+            const int hi_ = a_hi0[q] + tap_r, wi_ = a_wi0[q] + tap_s;                                        \
+            uint4 v_ = make_uint4(0u, 0u, 0u, 0u);                                                           \
+            if ((unsigned)hi_ < (unsigned)p.Hin && (unsigned)wi_ < (unsigned)p.Win)                          \
+                v_ = *(const uint4 *)(src_ + ((long long)(a_pix[q] + hi_ * p.Win + wi_) * Cs_ + c_ + chunk * EPV)); \
+            ra[q] = v_;                                                                                      \
+        }                                                                                                    \
+        _Pragma("unroll") for (int q = 0; q < BR; q++)                                                       \
+            rb[q] = *(const uint4 *)(wg + (long long)(n0 + rowb + 32 * q) * p.K + kcol_);                    \
+        cg += KE;                                                                                            \
+        if (cg == Ctot) { cg = 0; if (++tap_s == p.KS) { tap_s = 0; ++tap_r; } }                             \
+    }
+// registers -> XOR-swizzled LDS tile
+#define RCV_STASH(buf)                                                                                       \
+    {                                                                                                        \
+        _Pragma("unroll") for (int q = 0; q < AR; q++) {                                                     \
+            const int row_ = rowb + 32 * q;                                                                  \
+            *(uint4 *)(As + (buf) * BM * 128 + row_ * 128 + ((chunk ^ (row_ & 7)) << 4)) = ra[q];            \
+        }                                                                                                    \
+        _Pragma("unroll") for (int q = 0; q < BR; q++) {                                                     \
+            const int row_ = rowb + 32 * q;                                                                  \
+            *(uint4 *)(Bs + (buf) * BN * 128 + row_ * 128 + ((chunk ^ (row_ & 7)) << 4)) = rb[q];            \
+        }                                                                                                    \
+    }
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; i++)
+#pragma unroll
+        for (int j = 0; j < NT; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int r16 = lane & 15, kq = lane >> 4;
+// one K tile of MFMAs out of LDS buffer `buf`
+#define RCV_COMPUTE(buf)                                                                                     \
+    {                                                                                                        \
+        const unsigned char *Ab = As + (buf) * BM * 128 + (wm * (BM / 2) + r16) * 128;                       \
+        const unsigned char *Bb = Bs + (buf) * BN * 128 + (wn * (BN / 2) + r16) * 128;                       \
+        if constexpr (sizeof(T) == 2) {                                                                      \
+            _Pragma("unroll") for (int kk = 0; kk < 2; kk++) {                                               \
+                bf16x8 af[MT], bfr[NT];                                                                      \
+                const int ch = ((kk * 4 + kq) ^ (r16 & 7)) << 4;                                             \
+                _Pragma("unroll") for (int i = 0; i < MT; i++) af[i] = *(const bf16x8 *)(Ab + i * 16 * 128 + ch);  \
+                _Pragma("unroll") for (int j = 0; j < NT; j++) bfr[j] = *(const bf16x8 *)(Bb + j * 16 * 128 + ch); \
+                _Pragma("unroll") for (int i = 0; i < MT; i++)                                               \
+                    _Pragma("unroll") for (int j = 0; j < NT; j++)                                           \
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0); \
+            }                                                                                                \
+        } else {                                                                                             \
+            _Pragma("unroll") for (int ks = 0; ks < 8; ks++) {                                               \
+                float af[MT], bfr[NT];                                                                       \
+                const int ch = ((ks ^ (r16 & 7)) << 4) + kq * 4;                                             \
+                _Pragma("unroll") for (int i = 0; i < MT; i++) af[i] = *(const float *)(Ab + i * 16 * 128 + ch);  \
+                _Pragma("unroll") for (int j = 0; j < NT; j++) bfr[j] = *(const float *)(Bb + j * 16 * 128 + ch); \
+                _Pragma("unroll") for (int i = 0; i < MT; i++)                                               \
+                    _Pragma("unroll") for (int j = 0; j < NT; j++)                                           \
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bfr[j], acc[i][j], 0, 0, 0); \
+            }                                                                                                \
+        }                                                                                                    \
+    }
+
+    const int nk = p.K / KE;
+    RCV_FETCH();
+    RCV_STASH(0);
+    __syncthreads();
+    for (int kt = 0; kt + 1 < nk; kt++) {
+        const int cur = kt & 1;
+        RCV_FETCH();            // global loads of the next tile fly during the MFMAs below
+        RCV_COMPUTE(cur);
+        RCV_STASH(cur ^ 1);
+        __syncthreads();
+    }
+    RCV_COMPUTE((nk - 1) & 1);
+#undef RCV_FETCH
+#undef RCV_STASH
+#undef RCV_COMPUTE
+
+    // epilogue: bias (+ residual) (+ ReLU), NHWC store.  C/D layout: col = lane & 15, row = (lane >> 4) * 4 + j
+    T *dst = (T *)p.dst + (long long)g * p.dst_gs;
+    const T *res = p.res ? (const T *)p.res + (long long)g * p.res_gs : nullptr;
+    const float *bias = p.bias + (long long)g * p.bias_gs;
+#pragma unroll
+    for (int j = 0; j < NT; j++) {
+        const int n = n0 + wn * (BN / 2) + j * 16 + r16;
+        const float bv = bias[n];
+#pragma unroll
+        for (int i = 0; i < MT; i++) {
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const int m = m0 + wm * (BM / 2) + i * 16 + kq * 4 + e;
+                if (m < p.M) {
+                    float v = acc[i][j][e] + bv;
+                    const long long o = (long long)m * p.Cout + n;
+                    if (res) v += to_f32(res[o]);
+                    if (p.relu) v = fmaxf(v, 0.f);
+                    dst[o] = from_f32<T>(v);
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// stem: conv1 7x7 stride 2 pad 3 (3 -> 64, no bias) + BN (folded) + ReLU; NCHW fp32 image -> NHWC T
+// one workgroup = 16 x 16 output pixels x 64 channels of one (group, image)
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void k_stem(const float *x, const T *w, const float *bias, T *dst, int B, int H, int W,
+                                              int Ho, int Wo, long long w_gs, int bias_gs, long long dst_gs)
+{
+    constexpr int TP = 16, IN = TP * 2 + 5;  // 37 x 37 input patch per channel
+    __shared__ float s_in[3][IN][IN + 1];
+    __shared__ __attribute__((aligned(16))) float s_w[147][64];  // [tap*3 + c][cout]
+    const int tid = threadIdx.x;
+    const int tiles_x = (Wo + TP - 1) / TP;
+    const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+    const int img = blockIdx.y, g = blockIdx.z;
+    const int ho0 = ty * TP, wo0 = tx * TP;
+    const int hi0 = ho0 * 2 - 3, wi0 = wo0 * 2 - 3;
+    for (int i = tid; i < 3 * IN * IN; i += 256) {
+        const int c = i / (IN * IN), r = (i / IN) % IN, s = i % IN;
+        const int hi = hi0 + r, wi = wi0 + s;
+        float v = 0.f;
+        if ((unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W) v = x[((long long)(img * 3 + c) * H + hi) * W + wi];
+        s_in[c][r][s] = v;
+    }
+    const T *wg = w + (long long)g * w_gs;  // [64][7][7][3]
+    for (int i = tid; i < 147 * 64; i += 256) {
+        const int co = i / 147, t = i - co * 147;
+        s_w[t][co] = to_f32(wg[i]);
+    }
+    __syncthreads();
+    const int py = tid >> 4, px = tid & 15;
+    const int ho = ho0 + py, wo = wo0 + px;
+    const float *bg = bias + (long long)g * bias_gs;
+    T *out = dst + (long long)g * dst_gs + ((long long)(img * Ho + ho) * Wo + wo) * 64;
+    for (int cb = 0; cb < 64; cb += 16) {
+        float acc[16];
+#pragma unroll
+        for (int q = 0; q < 16; q++) acc[q] = 0.f;
+        for (int r = 0; r < 7; r++)
+            for (int s = 0; s < 7; s++)
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    const float v = s_in[c][py * 2 + r][px * 2 + s];
+                    const float4 *wv = (const float4 *)&s_w[(r * 7 + s) * 3 + c][cb];
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        const float4 ww = wv[q];
+                        acc[q * 4 + 0] = fmaf(v, ww.x, acc[q * 4 + 0]);
+                        acc[q * 4 + 1] = fmaf(v, ww.y, acc[q * 4 + 1]);
+                        acc[q * 4 + 2] = fmaf(v, ww.z, acc[q * 4 + 2]);
+                        acc[q * 4 + 3] = fmaf(v, ww.w, acc[q * 4 + 3]);
+                    }
+                }
+        if (ho < Ho && wo < Wo) {
+#pragma unroll
+            for (int q = 0; q < 16; q++) out[cb + q] = from_f32<T>(fmaxf(acc[q] + bg[cb + q], 0.f));
+        }
+    }
+}
+
+// maxpool 3x3 stride 2 pad 1, NHWC; one thread = EPV channels of one output pixel
+template <typename T>
+__global__ __launch_bounds__(256) void k_maxpool(const T *src, T *dst, int C, int Hin, int Win, int Hout, int Wout,
+                                                 long long total_vec, long long src_gs, long long dst_gs)
+{
+    constexpr int EPV = Traits<T>::EPV;
+    const int g = blockIdx.y;
+    const int cv = C / EPV;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total_vec; i += (long long)gridDim.x * 256) {
+        const int c = (int)(i % cv);
+        const long long pix = i / cv;
+        const int wo = (int)(pix % Wout), ho = (int)((pix / Wout) % Hout), img = (int)(pix / ((long long)Wout * Hout));
+        float best[EPV];
+#pragma unroll
+        for (int e = 0; e < EPV; e++) best[e] = -3.0e38f;
+        for (int r = 0; r < 3; r++) {
+            const int hi = ho * 2 - 1 + r;
+            if ((unsigned)hi >= (unsigned)Hin) continue;
+            for (int s = 0; s < 3; s++) {
+                const int wi = wo * 2 - 1 + s;
+                if ((unsigned)wi >= (unsigned)Win) continue;
+                const uint4 raw = *(const uint4 *)(src + (long long)g * src_gs + (((long long)img * Hin + hi) * Win + wi) * C + c * EPV);
+                const T *pv = (const T *)&raw;
+#pragma unroll
+                for (int e = 0; e < EPV; e++) best[e] = fmaxf(best[e], to_f32(pv[e]));
+            }
+        }
+        uint4 o;
+        T *po = (T *)&o;
+#pragma unroll
+        for (int e = 0; e < EPV; e++) po[e] = from_f32<T>(best[e]);
+        *(uint4 *)(dst + (long long)g * dst_gs + pix * C + c * EPV) = o;
+    }
+}
+
+// bilinear x2, align_corners=False (nn.Upsample, reference models/fcnresnet.py:93), NHWC
+template <typename T>
+__global__ __launch_bounds__(256) void k_upsample2(const T *src, T *dst, int C, int Hin, int Win, long long total_vec,
+                                                   long long src_gs, long long dst_gs)
+{
+    constexpr int EPV = Traits<T>::EPV;
+    const int g = blockIdx.y;
+    const int cv = C / EPV, Hout = Hin * 2, Wout = Win * 2;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total_vec; i += (long long)gridDim.x * 256) {
+        const int c = (int)(i % cv);
+        const long long pix = i / cv;
+        const int wo = (int)(pix % Wout), ho = (int)((pix / Wout) % Hout), img = (int)(pix / ((long long)Wout * Hout));
+        // source index = 0.5 * (dst + 0.5) - 0.5, clamped at 0 (ATen area_pixel_compute_source_index)
+        const float sy = fmaxf(0.5f * (ho + 0.5f) - 0.5f, 0.f), sx = fmaxf(0.5f * (wo + 0.5f) - 0.5f, 0.f);
+        const int y0 = (int)sy, x0 = (int)sx;
+        const int y1 = y0 + (y0 < Hin - 1 ? 1 : 0), x1 = x0 + (x0 < Win - 1 ? 1 : 0);
+        const float ly = sy - y0, lx = sx - x0, hy = 1.f - ly, hx = 1.f - lx;
+        const T *base = src + (long long)g * src_gs + (long long)img * Hin * Win * C + c * EPV;
+        const uint4 r00 = *(const uint4 *)(base + ((long long)y0 * Win + x0) * C);
+        const uint4 r01 = *(const uint4 *)(base + ((long long)y0 * Win + x1) * C);
+        const uint4 r10 = *(const uint4 *)(base + ((long long)y1 * Win + x0) * C);
+        const uint4 r11 = *(const uint4 *)(base + ((long long)y1 * Win + x1) * C);
+        const T *p00 = (const T *)&r00, *p01 = (const T *)&r01, *p10 = (const T *)&r10, *p11 = (const T *)&r11;
+        uint4 o;
+        T *po = (T *)&o;
+#pragma unroll
+        for (int e = 0; e < EPV; e++) {
+            const float v = hy * (hx * to_f32(p00[e]) + lx * to_f32(p01[e])) + ly * (hx * to_f32(p10[e]) + lx * to_f32(p11[e]));
+            po[e] = from_f32<T>(v);
+        }
+        *(uint4 *)(dst + (long long)g * dst_gs + pix * C + c * EPV) = o;
+    }
+}
+
+// conv8: 1x1, Cin -> 2, bias; writes the two planes seg / radial as fp32 [G,B,1,H,W]
+// (reference models/fcnresnet.py:186-191: out[:, :1], out[:, 1:])
+template <typename T>
+__global__ __launch_bounds__(256) void k_head(const T *src, const T *w, const float *bias, float *seg, float *radial, int C,
+                                              long long npix, long long src_gs, long long w_gs, int bias_gs)
+{
+    constexpr int EPV = Traits<T>::EPV;
+    const int g = blockIdx.y;
+    const T *wg = w + (long long)g * w_gs;
+    const float b0 = bias[(long long)g * bias_gs], b1 = bias[(long long)g * bias_gs + 1];
+    for (long long pix = (long long)blockIdx.x * 256 + threadIdx.x; pix < npix; pix += (long long)gridDim.x * 256) {
+        float a0 = 0.f, a1 = 0.f;
+        const T *ps = src + (long long)g * src_gs + pix * C;
+        for (int c = 0; c < C; c += EPV) {
+            const uint4 raw = *(const uint4 *)(ps + c);
+            const T *pv = (const T *)&raw;
+#pragma unroll
+            for (int e = 0; e < EPV; e++) {
+                const float v = to_f32(pv[e]);
+                a0 = fmaf(v, to_f32(wg[c + e]), a0);
+                a1 = fmaf(v, to_f32(wg[C + c + e]), a1);
+            }
+        }
+        seg[(long long)g * npix + pix] = a0 + b0;
+        radial[(long long)g * npix + pix] = a1 + b1;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_preprocess(const uint8_t *rgb, float *x, int HW, long long total)
+{
+    // img/255, -mean, /std in float64, then .float()  (reference AccumulatorSpace.py:143-151)
+    const double mean[3] = {0.485, 0.456, 0.406}, sd[3] = {0.229, 0.224, 0.225};
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int c = (int)(i % 3);
+        const long long pix = i / 3;
+        const long long img = pix / HW, p = pix - img * HW;
+        double v = (double)rgb[i] / 255.0;
+        v = v - mean[c];
+        v = v / sd[c];
+        x[(img * 3 + c) * HW + p] = (float)v;
+    }
+}
+
+template <typename T>
+__global__ void k_slot_to_f32(const T *src, float *dst, long long n)
+{
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) dst[i] = to_f32(src[i]);
+}
+
+}  // namespace
+}  // namespace rcv
+
+using namespace rcv;
+
+// ---------------------------------------------------------------------------------------------
+// executor
+// ---------------------------------------------------------------------------------------------
+struct rcv_fcn {
+    std::vector<rcv_op> ops;
+    std::vector<int64_t> slot_elems;
+    int groups = 1;
+    int dtype = RCV_BF16;
+    const void *weights = nullptr;
+    const float *bias = nullptr;
+    bool profiling = false;
+    std::vector<hipEvent_t> events;  // 2 per op when profiling
+    bool events_valid = false;
+    bool attrs_set = false;
+};
+
+namespace {
+
+size_t esize(int dtype) { return dtype == RCV_F32 ? 4 : 2; }
+
+void slot_offsets(const rcv_fcn *h, int B, std::vector<size_t> &off, size_t &total)
+{
+    off.resize(h->slot_elems.size());
+    size_t o = 0;
+    for (size_t i = 0; i < h->slot_elems.size(); i++) {
+        off[i] = o;
+        o += align_up((size_t)h->slot_elems[i] * (size_t)h->groups * (size_t)B * esize(h->dtype), 256);
+    }
+    total = o;
+}
+
+template <typename T, int BM, int BN>
+int launch_conv_variant(const ConvParams &p, int groups, hipStream_t st, bool set_attr)
+{
+    const size_t lds = (size_t)(BM + BN) * 128 * 2;
+    if (set_attr)
+        RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_conv<T, BM, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    dim3 grid((p.M + BM - 1) / BM, p.Cout / BN, groups);
+    hipLaunchKernelGGL((k_conv<T, BM, BN>), grid, dim3(256), lds, st, p);
+    RCV_LAUNCH_CHECK();
+    return RCV_OK;
+}
+
+template <typename T>
+int launch_conv(const ConvParams &p, int groups, hipStream_t st, bool set_attr)
+{
+    constexpr int KE = Traits<T>::KE;
+    if (p.C0 % KE || p.C1 % KE || p.Cout % 32 || p.K % KE) return RCV_E_UNSUPPORTED;
+    const int BN = p.Cout % 128 == 0 ? 128 : (p.Cout % 64 == 0 ? 64 : 32);
+    // enough workgroups to cover the 256 CUs at least twice, otherwise halve the M tile
+    const long long blocks128 = (long long)((p.M + 127) / 128) * (p.Cout / BN) * groups;
+    const bool small = blocks128 < 512;
+    if (set_attr) {  // first call: register every variant's LDS size once
+        int rc;
+        ConvParams q = p;
+        (void)q;
+        rc = RCV_OK;
+        (void)rc;
+    }
+    if (BN == 128) return small ? launch_conv_variant<T, 64, 128>(p, groups, st, set_attr) : launch_conv_variant<T, 128, 128>(p, groups, st, set_attr);
+    if (BN == 64) return small ? launch_conv_variant<T, 64, 64>(p, groups, st, set_attr) : launch_conv_variant<T, 128, 64>(p, groups, st, set_attr);
+    return small ? launch_conv_variant<T, 64, 32>(p, groups, st, set_attr) : launch_conv_variant<T, 128, 32>(p, groups, st, set_attr);
+}
+
+template <typename T>
+int run_op(rcv_fcn *h, const rcv_op &op, const float *x, int B, float *seg, float *radial, char *ws,
+           const std::vector<size_t> &off, hipStream_t st)
+{
+    const int G = h->groups;
+    auto slot = [&](int s) -> T * { return s >= 0 ? (T *)(ws + off[s]) : nullptr; };
+    auto gstride = [&](int s) -> long long { return s >= 0 ? (long long)h->slot_elems[s] * B : 0; };
+    const T *w = (const T *)h->weights + op.w_off;
+    const float *bias = h->bias + op.b_off;
+    switch (op.kind) {
+    case RCV_OP_STEM: {
+        if (op.cout != 64 || op.ksize != 7 || op.stride != 2 || op.pad != 3) return RCV_E_UNSUPPORTED;
+        dim3 grid(((op.hout + 15) / 16) * ((op.wout + 15) / 16), B, G);
+        hipLaunchKernelGGL((k_stem<T>), grid, dim3(256), 0, st, x, w, bias, slot(op.dst), B, op.hin, op.win, op.hout,
+                           op.wout, (long long)64 * 147, 64, gstride(op.dst));
+        RCV_LAUNCH_CHECK();
+        return RCV_OK;
+    }
+    case RCV_OP_MAXPOOL: {
+        const long long tv = (long long)B * op.hout * op.wout * (op.c0 / Traits<T>::EPV);
+        dim3 grid((unsigned)std::min<long long>((tv + 255) / 256, 65535), G);
+        hipLaunchKernelGGL((k_maxpool<T>), grid, dim3(256), 0, st, slot(op.src0), slot(op.dst), op.c0, op.hin, op.win,
+                           op.hout, op.wout, tv, gstride(op.src0), gstride(op.dst));
+        RCV_LAUNCH_CHECK();
+        return RCV_OK;
+    }
+    case RCV_OP_UPSAMPLE2: {
+        const long long tv = (long long)B * op.hout * op.wout * (op.c0 / Traits<T>::EPV);
+        dim3 grid((unsigned)std::min<long long>((tv + 255) / 256, 65535), G);
+        hipLaunchKernelGGL((k_upsample2<T>), grid, dim3(256), 0, st, slot(op.src0), slot(op.dst), op.c0, op.hin, op.win,
+                           tv, gstride(op.src0), gstride(op.dst));
+        RCV_LAUNCH_CHECK();
+        return RCV_OK;
+    }
+    case RCV_OP_HEAD: {
+        if (op.cout != 2 || op.c0 % Traits<T>::EPV) return RCV_E_UNSUPPORTED;
+        const long long npix = (long long)B * op.hin * op.win;
+        dim3 grid((unsigned)std::min<long long>((npix + 255) / 256, 65535), G);
+        hipLaunchKernelGGL((k_head<T>), grid, dim3(256), 0, st, slot(op.src0), w, bias, seg, radial, op.c0, npix,
+                           gstride(op.src0), (long long)2 * op.c0, 2);
+        RCV_LAUNCH_CHECK();
+        return RCV_OK;
+    }
+    case RCV_OP_CONV: {
+        ConvParams p;
+        memset(&p, 0, sizeof(p));
+        p.src0 = slot(op.src0); p.src1 = slot(op.src1); p.res = slot(op.res); p.dst = slot(op.dst);
+        p.w = w; p.bias = bias;
+        p.src0_gs = gstride(op.src0); p.src1_gs = gstride(op.src1); p.res_gs = gstride(op.res); p.dst_gs = gstride(op.dst);
+        p.C0 = op.c0; p.C1 = op.src1 >= 0 ? op.c1 : 0; p.Cout = op.cout;
+        p.Hin = op.hin; p.Win = op.win; p.Hout = op.hout; p.Wout = op.wout;
+        p.KS = op.ksize; p.stride = op.stride; p.pad = op.pad; p.relu = op.relu;
+        p.M = B * op.hout * op.wout;
+        p.K = op.ksize * op.ksize * (p.C0 + p.C1);
+        p.w_gs = (long long)op.cout * p.K;
+        p.bias_gs = op.cout;
+        return launch_conv<T>(p, G, st, !h->attrs_set);
+    }
+    default: return RCV_E_UNSUPPORTED;
+    }
+}
+
+template <typename T>
+int forward_impl(rcv_fcn *h, const float *x, int B, float *seg, float *radial, char *ws, hipStream_t st)
+{
+    std::vector<size_t> off;
+    size_t total;
+    slot_offsets(h, B, off, total);
+    if (h->profiling && h->events.size() != 2 * h->ops.size()) {
+        for (auto e : h->events) (void)hipEventDestroy(e);
+        h->events.resize(2 * h->ops.size());
+        for (auto &e : h->events) RCV_HIP_CHECK(hipEventCreate(&e));
+    }
+    for (size_t i = 0; i < h->ops.size(); i++) {
+        if (h->profiling) RCV_HIP_CHECK(hipEventRecord(h->events[2 * i], st));
+        int rc = run_op<T>(h, h->ops[i], x, B, seg, radial, ws, off, st);
+        if (rc != RCV_OK) return rc;
+        if (h->profiling) RCV_HIP_CHECK(hipEventRecord(h->events[2 * i + 1], st));
+    }
+    h->events_valid = h->profiling;
+    h->attrs_set = true;
+    return RCV_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rcv_preprocess_rgb(const uint8_t *rgb_dev, int B, int H, int W, float *x_dev, void *stream)
+{
+    if (!rgb_dev || !x_dev || B <= 0 || H <= 0 || W <= 0) return RCV_E_INVALID;
+    const long long total = (long long)B * H * W * 3;
+    hipLaunchKernelGGL(k_preprocess, dim3((unsigned)std::min<long long>((total + 255) / 256, 65535)), dim3(256), 0,
+                       (hipStream_t)stream, rgb_dev, x_dev, H * W, total);
+    RCV_LAUNCH_CHECK();
+    return RCV_OK;
+}
+
+int rcv_fcn_create(const rcv_op *ops, int n_ops, int n_slots, const int64_t *slot_elems, int groups, int dtype,
+                   const void *weights_dev, const float *bias_dev, rcv_fcn **out)
+{
+    if (!ops || n_ops <= 0 || n_slots <= 0 || !slot_elems || groups <= 0 || !weights_dev || !bias_dev || !out)
+        return RCV_E_INVALID;
+    if (dtype != RCV_F32 && dtype != RCV_BF16) return RCV_E_UNSUPPORTED;
+    for (int i = 0; i < n_ops; i++) {
+        const rcv_op &o = ops[i];
+        const int slots[4] = {o.src0, o.src1, o.res, o.dst};
+        for (int s : slots)
+            if (s >= n_slots || s < -3) return RCV_E_INVALID;
+    }
+    rcv_fcn *h = new rcv_fcn();
+    h->ops.assign(ops, ops + n_ops);
+    h->slot_elems.assign(slot_elems, slot_elems + n_slots);
+    h->groups = groups;
+    h->dtype = dtype;
+    h->weights = weights_dev;
+    h->bias = bias_dev;
+    *out = h;
+    return RCV_OK;
+}
+
+void rcv_fcn_destroy(rcv_fcn *h)
+{
+    if (!h) return;
+    for (auto e : h->events) (void)hipEventDestroy(e);
+    delete h;
+}
+
+size_t rcv_fcn_workspace_bytes(const rcv_fcn *h, int B)
+{
+    if (!h || B <= 0) return 0;
+    std::vector<size_t> off;
+    size_t total;
+    slot_offsets(h, B, off, total);
+    return total;
+}
+
+int rcv_fcn_forward(rcv_fcn *h, const float *x_dev, int B, float *seg_dev, float *radial_dev, void *ws, size_t ws_bytes,
+                    void *stream)
+{
+    if (!h || !x_dev || !seg_dev || !radial_dev || !ws || B <= 0) return RCV_E_INVALID;
+    if (ws_bytes < rcv_fcn_workspace_bytes(h, B)) return RCV_E_WORKSPACE;
+    if (h->dtype == RCV_F32) return forward_impl<float>(h, x_dev, B, seg_dev, radial_dev, (char *)ws, (hipStream_t)stream);
+    return forward_impl<__bf16>(h, x_dev, B, seg_dev, radial_dev, (char *)ws, (hipStream_t)stream);
+}
+
+int rcv_fcn_debug_slot(rcv_fcn *h, const void *ws, int B, int g, int slot, float *out_dev, void *stream)
+{
+    if (!h || !ws || !out_dev || slot < 0 || slot >= (int)h->slot_elems.size() || g < 0 || g >= h->groups) return RCV_E_INVALID;
+    std::vector<size_t> off;
+    size_t total;
+    slot_offsets(h, B, off, total);
+    const long long n = (long long)h->slot_elems[slot] * B;
+    const unsigned blocks = (unsigned)std::min<long long>((n + 255) / 256, 65535);
+    if (h->dtype == RCV_F32)
+        hipLaunchKernelGGL((k_slot_to_f32<float>), dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+                           (const float *)((const char *)ws + off[slot]) + (long long)g * n, out_dev, n);
+    else
+        hipLaunchKernelGGL((k_slot_to_f32<__bf16>), dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+                           (const __bf16 *)((const char *)ws + off[slot]) + (long long)g * n, out_dev, n);
+    RCV_LAUNCH_CHECK();
+    return RCV_OK;
+}
+
+int rcv_fcn_set_profiling(rcv_fcn *h, int enable)
+{
+    if (!h) return RCV_E_INVALID;
+    h->profiling = enable != 0;
+    h->events_valid = false;
+    return RCV_OK;
+}
+
+int rcv_fcn_get_profile(rcv_fcn *h, double *conv_ms, double *other_ms, double *conv_flop)
+{
+    if (!h || !conv_ms || !other_ms || !conv_flop) return RCV_E_INVALID;
+    if (!h->events_valid) return RCV_E_INVALID;
+    double cm = 0, om = 0;
+    for (size_t i = 0; i < h->ops.size(); i++) {
+        RCV_HIP_CHECK(hipEventSynchronize(h->events[2 * i + 1]));
+        float ms = 0.f;
+        RCV_HIP_CHECK(hipEventElapsedTime(&ms, h->events[2 * i], h->events[2 * i + 1]));
+        if (h->ops[i].kind == RCV_OP_CONV) cm += ms; else om += ms;
+    }
+    *conv_ms = cm;
+    *other_ms = om;
+    double fl = 0;  // per image, per group: 2 * M * N * K
+    for (auto &o : h->ops)
+        if (o.kind == RCV_OP_CONV)
+            fl += 2.0 * o.hout * o.wout * o.cout * (double)o.ksize * o.ksize * (o.c0 + (o.src1 >= 0 ? o.c1 : 0));
+    *conv_flop = fl;
+    return RCV_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,322 @@
+"""Layer program + weight packing for the native FCN executor (rcv_fcn_* in include/rcvpose_hip.h).
+
+The topology restated here is the reference's DenseFCNResNet152 (reference models/fcnresnet.py:48-191,
+Bottleneck :6-45).  Building the program and packing the weights is host-side plumbing (pure
+Python / torch-CPU, testable without a GPU); every FLOP of the forward runs in the HIP kernels of
+rcvpose_amd/csrc/fcn.hip.  There is no CPU fallback for the forward itself.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _hip
+
+# (first bottleneck, nn.Sequential of the rest, how many in the rest, width, stride of the first)
+# reference models/fcnresnet.py:59-83
+STAGES = (
+    ("block1up", "block1", 2, 64, 1),
+    ("block2up", "block2", 7, 128, 2),
+    ("block3up", "block3", 35, 256, 2),
+    ("block4up", "block4", 2, 512, 2),
+)
+BN_EPS = 1e-5
+
+
+class _Builder:
+    def __init__(self):
+        self.ops = []       # dicts
+        self.tensors = []   # per logical tensor: elems per (group, image)
+        self.wspecs = []    # per op: None or dict(conv=..., bn=..., cout=..., cin=..., k=...)
+        self.named = {}     # stage name -> (tensor id, (h, w, c)); names follow the reference's module names
+
+    def tensor(self, h, w, c):
+        self.tensors.append(h * w * c)
+        self.shapes = getattr(self, "shapes", [])
+        self.shapes.append((h, w, c))
+        return len(self.tensors) - 1
+
+    def name(self, label, t):
+        self.named[label] = (t, self.shapes[t])
+
+    def add(self, kind, wspec=None, **kw):
+        op = dict(kind=kind, src0=-1, src1=-1, res=-1, dst=-1, c0=0, c1=0, cout=0, hin=0, win=0, hout=0, wout=0,
+                  ksize=1, stride=1, pad=0, relu=0)
+        op.update(kw)
+        self.ops.append(op)
+        self.wspecs.append(wspec)
+        return op
+
+
+def build_program(H, W):
+    """The op list of one DenseFCNResNet152 forward on an HxW image (H, W multiples of 32)."""
+    if H % 32 or W % 32 or H <= 0 or W <= 0:
+        raise ValueError("DenseFCNResNet152 needs H and W to be positive multiples of 32 (skip concatenations)")
+    b = _Builder()
+    h2, w2 = H // 2, W // 2
+    x = b.tensor(h2, w2, 64)
+    b.add(_hip.OP_STEM, dict(conv="conv1", bn="bn1", bias=False), src0=_hip.SLOT_INPUT, dst=x, c0=3, cout=64, hin=H,
+          win=W, hout=h2, wout=w2, ksize=7, stride=2, pad=3, relu=1)
+    b.name("bn1", x)
+    h4, w4 = H // 4, W // 4
+    cur = b.tensor(h4, w4, 64)
+    b.add(_hip.OP_MAXPOOL, src0=x, dst=cur, c0=64, cout=64, hin=h2, win=w2, hout=h4, wout=w4, ksize=3, stride=2, pad=1)
+    b.name("maxpool", cur)
+    cin, hh, ww = 64, h4, w4
+    skips = []
+
+    def conv(src0, c0, cout, hin, win, k, stride, relu, wspec, src1=-1, c1=0, res=-1):
+        pad = 1 if k == 3 else 0
+        hout, wout = (hin + 2 * pad - k) // stride + 1, (win + 2 * pad - k) // stride + 1
+        dst = b.tensor(hout, wout, cout)
+        b.add(_hip.OP_CONV, wspec, src0=src0, src1=src1, res=res, dst=dst, c0=c0, c1=c1, cout=cout, hin=hin, win=win,
+              hout=hout, wout=wout, ksize=k, stride=stride, pad=pad, relu=relu)
+        return dst, hout, wout
+
+    def bottleneck(prefix, src, cin, width, hin, win, stride, project):
+        t1, _, _ = conv(src, cin, width, hin, win, 1, 1, 1, dict(conv=prefix + ".conv1", bn=prefix + ".bn1", bias=False))
+        t2, ho, wo = conv(t1, width, width, hin, win, 3, stride, 1,
+                          dict(conv=prefix + ".conv2", bn=prefix + ".bn2", bias=True))
+        res = src
+        if project:  # `upsample_` is applied only where upsample=True (reference :35-36)
+            res, _, _ = conv(src, cin, 4 * width, hin, win, 1, stride, 0,
+                             dict(conv=prefix + ".upsample_.0", bn=prefix + ".upsample_.1", bias=False))
+        out, _, _ = conv(t2, width, 4 * width, ho, wo, 1, 1, 1,
+                         dict(conv=prefix + ".conv3", bn=prefix + ".bn3", bias=False), res=res)
+        return out, ho, wo
+
+    for first, rest, count, width, stride in STAGES:
+        cur, hh, ww = bottleneck(first, cur, cin, width, hh, ww, stride, True)
+        cin = 4 * width
+        for i in range(count):
+            cur, hh, ww = bottleneck("%s.%d" % (rest, i), cur, cin, width, hh, ww, 1, False)
+        skips.append((cur, cin, hh, ww))
+        b.name(rest, cur)
+    (x2s, c2, _, _), (x4s, c4, _, _), (x8s, c8, _, _), (x16s, c16, h16, w16) = skips
+    up, _, _ = conv(x16s, c16, 1024, h16, w16, 3, 1, 1, dict(conv="conv6", bn="bn6", bias=True))
+    b.name("bn6", up)
+    cup, hh, ww = 1024, h16, w16
+    for name, (skip, cskip), cout in (("5", (x16s, c16), 1024), ("4", (x8s, c8), 512), ("3", (x4s, c4), 256),
+                                      ("2", (x2s, c2), 128), ("1", (x, 64), 64)):
+        up, _, _ = conv(up, cup, cout, hh, ww, 3, 1, 1, dict(conv="conv_up%s.0" % name, bn="conv_up%s.1" % name, bias=True),
+                        src1=skip, c1=cskip)
+        b.name("conv_up" + name, up)
+        dst = b.tensor(hh * 2, ww * 2, cout)
+        b.add(_hip.OP_UPSAMPLE2, src0=up, dst=dst, c0=cout, cout=cout, hin=hh, win=ww, hout=hh * 2, wout=ww * 2)
+        up, cup, hh, ww = dst, cout, hh * 2, ww * 2
+        b.name("up" + name, up)
+    up, _, _ = conv(up, 64, 32, hh, ww, 3, 1, 1, dict(conv="conv7.0", bn="conv7.1", bias=True))
+    b.name("conv7", up)
+    b.add(_hip.OP_HEAD, dict(conv="conv8", bn=None, bias=True), src0=up, dst=_hip.SLOT_OUTPUT, c0=32, cout=2, hin=hh,
+          win=ww, hout=hh, wout=ww)
+    return b
+
+
+def assign_slots(builder, reuse=True):
+    """Map logical tensors to reusable workspace slots (greedy, by last use) so that the working
+    set of consecutive layers stays small enough to live in the 256 MB Infinity Cache.
+    reuse=False keeps one slot per tensor (stage-by-stage debugging)."""
+    if not reuse:
+        return [dict(op) for op in builder.ops], list(builder.tensors)
+    last_use = {}
+    for i, op in enumerate(builder.ops):
+        for key in ("src0", "src1", "res", "dst"):
+            t = op[key]
+            if t >= 0:
+                last_use[t] = i
+    slot_of, slot_size, free = {}, [], []
+    for i, op in enumerate(builder.ops):
+        t = op["dst"]
+        if t >= 0 and t not in slot_of:
+            size = builder.tensors[t]
+            cand = [s for s in free if slot_size[s] == size]
+            if cand:
+                s = cand[0]
+                free.remove(s)
+            else:
+                s = len(slot_size)
+                slot_size.append(size)
+            slot_of[t] = s
+        for key in ("src0", "src1", "res"):
+            t = op[key]
+            if t >= 0 and last_use[t] == i and slot_of[t] not in free:
+                free.append(slot_of[t])
+    ops = []
+    for op in builder.ops:
+        o = dict(op)
+        for key in ("src0", "src1", "res", "dst"):
+            if o[key] >= 0:
+                o[key] = slot_of[o[key]]
+        ops.append(o)
+    return ops, slot_size
+
+
+def fold_conv_bn(sd, spec, cout):
+    """Fold eval-mode BatchNorm into the preceding convolution (float64 on the host).
+
+    y = gamma * (conv(x) + b - mean) / sqrt(var + eps) + beta  ->  conv'(x) + b'
+    Returns (weight [cout, kh, kw, cin] float64, bias [cout] float64)."""
+    import torch
+
+    w = sd[spec["conv"] + ".weight"].detach().to("cpu", torch.float64)
+    b = sd[spec["conv"] + ".bias"].detach().to("cpu", torch.float64) if spec["bias"] else torch.zeros(cout, dtype=torch.float64)
+    if spec["bn"] is not None:
+        p = spec["bn"]
+        gamma = sd[p + ".weight"].detach().to("cpu", torch.float64)
+        beta = sd[p + ".bias"].detach().to("cpu", torch.float64)
+        mean = sd[p + ".running_mean"].detach().to("cpu", torch.float64)
+        var = sd[p + ".running_var"].detach().to("cpu", torch.float64)
+        scale = gamma / torch.sqrt(var + BN_EPS)
+        w = w * scale.view(-1, 1, 1, 1)
+        b = (b - mean) * scale + beta
+    return w.permute(0, 2, 3, 1).contiguous(), b
+
+
+def pack_weights(state_dicts, builder, ops, dtype):
+    """-> (weights tensor [engine dtype], bias tensor fp32, ops with w_off / b_off filled)."""
+    import torch
+
+    sds = [{(k[7:] if k.startswith("module.") else k): v for k, v in sd.items()} for sd in state_dicts]
+    tdt = torch.float32 if dtype == _hip.RCV_F32 else torch.bfloat16
+    wparts, bparts, woff, boff = [], [], 0, 0
+    for op, spec in zip(ops, builder.wspecs):
+        if spec is None:
+            op["w_off"], op["b_off"] = 0, 0
+            continue
+        ws, bs = [], []
+        for sd in sds:
+            w, b = fold_conv_bn(sd, spec, op["cout"])
+            ws.append(w.reshape(-1))
+            bs.append(b)
+        wcat = torch.cat(ws).to(tdt)
+        bcat = torch.cat(bs).to(torch.float32)
+        op["w_off"], op["b_off"] = woff, boff
+        pad = (-wcat.numel()) % 64  # keep every op's weights 128-byte aligned for 16-byte vector loads
+        if pad:
+            wcat = torch.cat([wcat, torch.zeros(pad, dtype=tdt)])
+        padb = (-bcat.numel()) % 4
+        if padb:
+            bcat = torch.cat([bcat, torch.zeros(padb, dtype=torch.float32)])
+        wparts.append(wcat)
+        bparts.append(bcat)
+        woff += wcat.numel()
+        boff += bcat.numel()
+    return torch.cat(wparts), torch.cat(bparts), ops
+
+
+def conv_flops(ops):
+    """Algorithmic FLOPs of the convolutions of one forward (per group, per image): 2*M*N*K."""
+    fl = 0
+    for o in ops:
+        if o["kind"] in (_hip.OP_CONV, _hip.OP_STEM, _hip.OP_HEAD):
+            fl += 2 * o["hout"] * o["wout"] * o["cout"] * o["ksize"] ** 2 * (o["c0"] + (o["c1"] if o["src1"] >= 0 else 0))
+    return fl
+
+
+class FcnEngine:
+    """`groups` DenseFCNResNet152 networks (one state dict each) sharing one input image.
+
+    forward(x): x float32 [B,3,H,W] on the GPU -> (seg, radial), each float32 [G,B,1,H,W].
+    """
+
+    def __init__(self, state_dicts, H, W, dtype="bf16", device="cuda", reuse_slots=True):
+        import torch
+
+        self.lib = _hip.lib()
+        self.H, self.W = int(H), int(W)
+        self.groups = len(state_dicts)
+        self.dtype = {"bf16": _hip.RCV_BF16, "fp32": _hip.RCV_F32, "f32": _hip.RCV_F32}[dtype]
+        self.dtype_name = "bf16" if self.dtype == _hip.RCV_BF16 else "fp32"
+        builder = build_program(self.H, self.W)
+        ops, slot_sizes = assign_slots(builder, reuse=reuse_slots)
+        self.stages = builder.named if not reuse_slots else {}
+        w, b, ops = pack_weights(state_dicts, builder, ops, self.dtype)
+        self.ops = ops
+        self.slot_sizes = slot_sizes
+        self.weights = w.to(device)
+        self.bias = b.to(device)
+        arr = (_hip.Op * len(ops))()
+        for i, o in enumerate(ops):
+            for f, _ in _hip.Op._fields_:
+                setattr(arr[i], f, int(o[f]))
+        slots = (ctypes.c_int64 * len(slot_sizes))(*slot_sizes)
+        handle = ctypes.c_void_p()
+        _hip.check(self.lib.rcv_fcn_create(arr, len(ops), len(slot_sizes), slots, self.groups, self.dtype,
+                                           _hip.ptr(self.weights), _hip.ptr(self.bias), ctypes.byref(handle)),
+                   "rcv_fcn_create")
+        self.handle = handle
+        self.device = device
+        self._ws = None
+        self._ws_batch = 0
+        self.flops_per_image_group = conv_flops(ops)
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                self.lib.rcv_fcn_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+    def workspace(self, B):
+        import torch
+
+        if self._ws is None or self._ws_batch < B:
+            nbytes = int(self.lib.rcv_fcn_workspace_bytes(self.handle, B))
+            self._ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+            self._ws_batch = B
+        return self._ws
+
+    def forward(self, x, out=None):
+        import torch
+
+        if not x.is_cuda or x.dtype != torch.float32 or x.dim() != 4 or x.shape[1] != 3:
+            raise ValueError("x must be a CUDA float32 [B,3,H,W] tensor")
+        if tuple(x.shape[2:]) != (self.H, self.W):
+            raise ValueError("engine was built for %dx%d input" % (self.H, self.W))
+        x = x.contiguous()
+        B = x.shape[0]
+        ws = self.workspace(B)
+        if out is None:
+            seg = torch.empty((self.groups, B, 1, self.H, self.W), dtype=torch.float32, device=x.device)
+            radial = torch.empty_like(seg)
+        else:
+            seg, radial = out
+        _hip.check(self.lib.rcv_fcn_forward(self.handle, _hip.ptr(x), B, _hip.ptr(seg), _hip.ptr(radial), _hip.ptr(ws),
+                                            ws.numel(), _hip.current_stream()), "rcv_fcn_forward")
+        return seg, radial
+
+    def debug_stage(self, B, g, name):
+        """Activation of a named stage as float32 [B,C,H,W] (engine must be built with reuse_slots=False)."""
+        t, shape = self.stages[name]
+        return self.debug_slot(B, g, t, shape).permute(0, 3, 1, 2).contiguous()
+
+    def debug_slot(self, B, g, slot, shape_hwc):
+        import torch
+
+        h, w, c = shape_hwc
+        out = torch.empty((B, h, w, c), dtype=torch.float32, device=self.device)
+        _hip.check(self.lib.rcv_fcn_debug_slot(self.handle, _hip.ptr(self._ws), B, g, slot, _hip.ptr(out),
+                                               _hip.current_stream()), "rcv_fcn_debug_slot")
+        return out
+
+    def set_profiling(self, enable):
+        _hip.check(self.lib.rcv_fcn_set_profiling(self.handle, int(bool(enable))))
+
+    def get_profile(self):
+        c, o, f = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+        _hip.check(self.lib.rcv_fcn_get_profile(self.handle, ctypes.byref(c), ctypes.byref(o), ctypes.byref(f)))
+        return dict(conv_ms=c.value, other_ms=o.value, conv_flop_per_image_group=f.value)
+
+
+def preprocess_rgb(rgb_u8):
+    """uint8 [B,H,W,3] CUDA tensor -> normalised float32 [B,3,H,W] (reference AccumulatorSpace.py:140-151)."""
+    import torch
+
+    L = _hip.lib()
+    if rgb_u8.dim() == 3:
+        rgb_u8 = rgb_u8.unsqueeze(0)
+    rgb_u8 = rgb_u8.contiguous()
+    B, H, W, _ = rgb_u8.shape
+    x = torch.empty((B, 3, H, W), dtype=torch.float32, device=rgb_u8.device)
+    _hip.check(L.rcv_preprocess_rgb(_hip.ptr(rgb_u8), B, H, W, _hip.ptr(x), _hip.current_stream()), "rcv_preprocess_rgb")
+    return x

@@ -1,0 +1,95 @@
+"""Host-side logic of the FCN engine (no GPU): state-dict surface, layer program, BN folding, slots."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import fcn_weights
+from rcvpose_amd import _hip, fcn_engine
+from rcvpose_amd.models.fcnresnet import DenseFCNResNet152
+
+
+def test_state_dict_surface_matches_reference(golden_dir):
+    ref = json.load(open(os.path.join(golden_dir, "fcn_state_dict_keys.json")))
+    sd = DenseFCNResNet152(3, 2).state_dict()
+    assert list(sd.keys()) == list(ref.keys())           # 1307 keys, same order
+    assert all(list(sd[k].shape) == ref[k] for k in ref)
+    assert sum(p.numel() for p in DenseFCNResNet152(3, 2).parameters()) == 165009122
+
+
+def test_program_work_matches_survey():
+    b = fcn_engine.build_program(480, 640)
+    ops, slots = fcn_engine.assign_slots(b)
+    convs = [o for o in ops if o["kind"] == _hip.OP_CONV]
+    assert len(convs) == 50 * 3 + 4 + 1 + 5 + 1          # bottleneck convs + projections + conv6 + conv_up + conv7
+    assert fcn_engine.conv_flops(ops) == 265568256000     # 132.784 GMAC
+    for o in convs:                                        # shapes the MFMA kernel supports in both dtypes
+        assert o["c0"] % 64 == 0 and o["c1"] % 64 == 0 and o["cout"] % 32 == 0
+    with pytest.raises(ValueError):
+        fcn_engine.build_program(480, 650)
+
+
+def test_slot_reuse_never_aliases_live_tensors():
+    b = fcn_engine.build_program(64, 96)
+    ops, slots = fcn_engine.assign_slots(b)
+    raw = b.ops
+    last_use = {}
+    for i, o in enumerate(raw):
+        for k in ("src0", "src1", "res", "dst"):
+            if o[k] >= 0:
+                last_use[o[k]] = i
+    owner = {}
+    for i, (o, r) in enumerate(zip(ops, raw)):
+        for k in ("src0", "src1", "res"):
+            if r[k] >= 0:
+                assert owner[o[k]] == r[k], "op %d reads a slot that was overwritten" % i
+        if r["dst"] >= 0:
+            s = o["dst"]
+            assert s not in (o["src0"], o["src1"], o["res"])
+            if s in owner:
+                assert last_use[owner[s]] < i
+            owner[s] = r["dst"]
+    assert len(slots) < len(b.tensors) / 4
+
+
+def test_bn_folding_equals_conv_then_bn():
+    g = torch.Generator().manual_seed(0)
+    cin, cout = 8, 6
+    sd = {
+        "c.weight": torch.randn(cout, cin, 3, 3, generator=g),
+        "c.bias": torch.randn(cout, generator=g),
+        "b.weight": torch.rand(cout, generator=g) + 0.5,
+        "b.bias": torch.randn(cout, generator=g),
+        "b.running_mean": torch.randn(cout, generator=g),
+        "b.running_var": torch.rand(cout, generator=g) + 0.5,
+    }
+    w, b = fcn_engine.fold_conv_bn(sd, dict(conv="c", bn="b", bias=True), cout)
+    x = torch.randn(2, cin, 7, 9, generator=g, dtype=torch.float64)
+    ref = F.batch_norm(F.conv2d(x, sd["c.weight"].double(), sd["c.bias"].double(), padding=1), sd["b.running_mean"].double(),
+                       sd["b.running_var"].double(), sd["b.weight"].double(), sd["b.bias"].double(), False, 0.0, 1e-5)
+    got = F.conv2d(x, w.permute(0, 3, 1, 2), b, padding=1)
+    assert torch.allclose(got, ref, atol=1e-12, rtol=1e-12)
+
+
+def test_weight_packing_layout(golden_dir):
+    shapes = json.load(open(os.path.join(golden_dir, "fcn_state_dict_keys.json")))
+    sd = {k: torch.from_numpy(v) for k, v in fcn_weights.make_state_dict_numpy(shapes, seed=0).items()}
+    b = fcn_engine.build_program(64, 96)
+    ops, _ = fcn_engine.assign_slots(b)
+    w, bias, ops = fcn_engine.pack_weights([sd, {"module." + k: v for k, v in sd.items()}], b, ops, _hip.RCV_F32)
+    # live weights only: the unused `upsample_` branches are not packed (117 866 210 live params)
+    live = sum(o["cout"] * o["ksize"] ** 2 * (o["c0"] + (o["c1"] if o["src1"] >= 0 else 0)) for o, s in zip(ops, b.wspecs) if s)
+    assert live + sum(o["cout"] for o, s in zip(ops, b.wspecs) if s and s["bias"]) <= 117866210
+    assert w.numel() >= 2 * live
+    for o, s in zip(ops, b.wspecs):
+        if s:
+            assert o["w_off"] % 64 == 0  # 16-byte vector loads need aligned rows
+    # group 1 (the "module."-prefixed copy) packs to the same numbers as group 0
+    o = next(o for o, s in zip(ops, b.wspecs) if s and s["conv"] == "block2up.conv2")
+    n = o["cout"] * 9 * o["c0"]
+    assert torch.equal(w[o["w_off"]:o["w_off"] + n], w[o["w_off"] + n:o["w_off"] + 2 * n])
+    wf, bf = fcn_engine.fold_conv_bn(sd, dict(conv="block2up.conv2", bn="block2up.bn2", bias=True), o["cout"])
+    assert torch.equal(w[o["w_off"]:o["w_off"] + n], wf.reshape(-1).float())

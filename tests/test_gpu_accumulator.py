@@ -1,0 +1,144 @@
+"""HIP voting path (through the C ABI) against the CPU oracle and the golden vectors.  Bit-exact."""
+import glob
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ACC = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(os.path.dirname(__file__), "golden", "acc*.npz")))
+
+
+@pytest.fixture(scope="module")
+def A():
+    from rcvpose_amd import AccumulatorSpace
+
+    return AccumulatorSpace
+
+
+@pytest.mark.parametrize("name", ACC)
+def test_golden_votes_and_centres(A, golden_dir, name):
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    xyz, rad = g["xyz_m"].copy(), g["radial_dm"].copy()
+    center, votes, res = A.Accumulator_3D(xyz, rad, return_votes=True)
+    assert res.dim == g["votes"].shape[0]
+    assert np.array_equal(votes, g["votes"].astype(np.uint32))      # VoteMap_3D, exact integer counts
+    assert center.shape == g["center"].shape                          # every tie, C order
+    assert np.array_equal(center, g["center"])                        # float64, bit-exact
+    assert np.array_equal(xyz, g["xyz_m"]) and np.array_equal(rad, g["radial_dm"])  # inputs untouched
+    c2 = A.Accumulator_3D(xyz, rad)                                   # hot path (no grid in HBM)
+    assert np.array_equal(c2, g["center"])
+
+
+@pytest.mark.parametrize("name", ACC)
+def test_prepared_points_bit_exact(A, golden_dir, name):
+    import torch
+
+    from rcvpose_amd import _hip
+
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    n, m = len(g["xyz_m"]), len(g["radial_dm"])
+    ws = A.AccWorkspace(max(n, m))
+    xyz_d = torch.from_numpy(g["xyz_m"]).cuda()
+    rad_d = torch.from_numpy(g["radial_dm"]).cuda()
+    A.accumulate_on_device(xyz_d, rad_d, None, n, m, ws)
+    pts = torch.empty((max(n, m), 3), dtype=torch.float64, device="cuda")
+    ri = torch.empty((max(n, m),), dtype=torch.int32, device="cuda")
+    _hip.check(_hip.lib().rcv_acc_debug_points(_hip.ptr(ws.ws), _hip.ptr(pts), _hip.ptr(ri), max(n, m),
+                                               _hip.current_stream()))
+    assert np.array_equal(pts[:n].cpu().numpy(), g["points_vox"])
+    assert np.array_equal(ri[:n].cpu().numpy(), np.rint(g["radii_vox"][:n].astype(np.float64)).astype(np.int32))
+
+
+def test_error_behaviour(A, golden_dir):
+    idx = json.load(open(os.path.join(golden_dir, "acc_index.json")))
+    with pytest.raises(ValueError):
+        A.Accumulator_3D(np.zeros((0, 3)), np.zeros((0,), dtype=np.float32))
+    c = idx["acc7_single_point_tiny_radius"]
+    with pytest.raises(ValueError):
+        A.Accumulator_3D(np.array(c["xyz_m"]), np.array(c["radial_dm"], dtype=c["radial_dtype"]))
+
+
+def _random_cloud(rng, n, spread, rmin, rmax, dtype):
+    xyz = rng.normal(size=(n, 3)) * spread + np.array([0.1, -0.2, 0.9])
+    rad = rng.uniform(rmin, rmax, size=n).astype(dtype)
+    return xyz, rad
+
+
+@pytest.mark.parametrize("seed,n,spread,rmax,dtype", [
+    (1, 50, 0.01, 0.5, np.float32),
+    (2, 700, 0.03, 1.2, np.float64),
+    (3, 3000, 0.02, 2.0, np.float32),     # D ~ 100: several tiles per axis
+    (4, 300, 0.05, 4.5, np.float32),      # D ~ 230: TI = 8 tiles, long columns
+])
+def test_random_clouds_vs_oracle(A, oracle, seed, n, spread, rmax, dtype):
+    rng = np.random.default_rng(seed)
+    xyz, rad = _random_cloud(rng, n, spread, -0.05, rmax, dtype)
+    center, votes, res = A.Accumulator_3D(xyz, rad, return_votes=True)
+    ref_center, ref_votes, info, peak = oracle.accumulator_3d(xyz, rad, sparse=True, return_all=True)
+    assert res.dim == info.dim and res.zero_boundary == info.zero_boundary
+    assert np.array_equal(votes, ref_votes)
+    assert res.peak_votes == peak
+    assert np.array_equal(center, ref_center)
+
+
+def test_full_size_frame_cloud(A, oracle):
+    """~15k points, 5 mm voxels, radii up to ~0.47 m: exact grid equality at D ~ 236."""
+    import frames
+
+    f = frames.synthetic_frame(0)
+    xyz, rad = oracle.seam(f["seg"], f["radial"][0], f["depth"], f["max_radii_dm"][0])
+    assert 14000 <= len(xyz) <= 16000
+    center, votes, res = A.Accumulator_3D(xyz, rad, return_votes=True)
+    ref_center, ref_votes, info, peak = oracle.accumulator_3d(xyz, rad, sparse=True, return_all=True)
+    assert res.dim == info.dim
+    assert np.array_equal(votes, ref_votes)
+    assert np.array_equal(center, ref_center)
+    assert np.abs(center[0] - f["keypoints_m"][0] * 1000).max() <= 5.0
+
+
+def test_seam_golden(A, golden_dir):
+    import torch
+
+    for name in ("seam1_aligned", "seam2_depth_holes"):
+        g = np.load(os.path.join(golden_dir, name + ".npz"))
+        ws = A.seam_compact(torch.from_numpy(g["sem"]).cuda(), torch.from_numpy(g["radial"]).cuda(),
+                            torch.from_numpy(g["depth"].view(np.int16)).cuda(), float(g["max_radius_dm"]))
+        n, m = [int(v) for v in ws.counts.cpu()]
+        assert np.array_equal(ws.xyz[:n].cpu().numpy(), g["xyz_m"]), name
+        assert np.array_equal(ws.radial[:m].cpu().numpy(), g["radial_list"]), name
+    g = np.load(os.path.join(golden_dir, "seam3_radial_npy.npz"))
+    ws = A.seam_compact(None, torch.from_numpy(g["radial_est"]).cuda(), torch.from_numpy(g["depth"].view(np.int16)).cuda(),
+                        float(g["max_radius_dm"]), mode=1)
+    n, m = [int(v) for v in ws.counts.cpu()]
+    assert n == m
+    assert np.array_equal(ws.xyz[:n].cpu().numpy(), g["xyz_m"])
+    assert np.array_equal(ws.radial[:m].cpu().numpy(), g["radial_list"])
+    g = np.load(os.path.join(golden_dir, "seam1_aligned.npz"))
+    mask = (g["sem"] > np.float32(0.8)) & (g["radial"].astype(np.float64) <= float(g["max_radius_dm"]))
+    assert np.array_equal(A.rgbd_to_point_cloud(A.linemod_K, g["depth"].astype(np.int64) * mask), g["xyz_mm"])
+
+
+def test_seam_to_vote_chain_on_device(A, golden_dir):
+    """seam -> Accumulator_3D without touching the host in between (AccumulatorSpace.py:596-654)."""
+    import torch
+
+    g = np.load(os.path.join(golden_dir, "seam4_chain.npz"))
+    ws = A.seam_compact(torch.from_numpy(g["sem"]).cuda(), torch.from_numpy(g["radial"]).cuda(),
+                        torch.from_numpy(g["depth"].view(np.int16)).cuda(), float(g["max_radius_dm"]))
+    A.accumulate_on_device(ws.xyz, ws.radial, ws.counts, ws.max_points, ws.max_points, ws)
+    res = ws.read_result()
+    assert res.status == 0 and res.n_points == len(g["xyz_m"])
+    assert np.array_equal(np.array(res.center_mm[:]), g["center"][0])
+
+
+def test_depth_hole_misalignment_is_reproduced(A, oracle, golden_dir):
+    """radial_list longer than xyz (SURVEY a-4): same pairing and same radius_max as the reference."""
+    import torch
+
+    g = np.load(os.path.join(golden_dir, "seam2_depth_holes.npz"))
+    assert len(g["radial_list"]) > len(g["xyz_m"])
+    center = A.Accumulator_3D(g["xyz_m"], g["radial_list"])
+    assert np.array_equal(center, oracle.accumulator_3d(g["xyz_m"], g["radial_list"], sparse=True))
