@@ -102,6 +102,11 @@ def load_library():
     global _lib
     if _lib is not None:
         return _lib
+    # torch bundles its own libamdhip64.so (same soname as /opt/rocm's).  It must be in the process before
+    # this library is, so that both share ONE HIP runtime; loaded the other way round the process ends up
+    # with two runtimes and the first kernel launch fails with hipErrorNoDevice.
+    import torch  # noqa: F401
+
     if not os.path.exists(LIB_PATH):
         raise HipLibraryError(
             "librcvpose_hip.so is not built (%s). Run `python -m rcvpose_amd.build` (needs hipcc); "

@@ -35,7 +35,7 @@ constexpr int PREP_BLOCKS = 128;
 constexpr int PREP_THREADS = 256;
 constexpr int SEAM_PIX_PER_BLOCK = 1024;
 constexpr int SEAM_MAX_BLOCKS = 4096;
-constexpr int VOTE_THREADS = 512;
+constexpr int VOTE_THREADS = 1024;
 constexpr int VOTE_WAVES = VOTE_THREADS / 64;
 constexpr int CELL_BYTES = 60 * 1024;  // LDS bytes of vote counters per tile
 constexpr int SURV_CAP = 256;          // points staged per cull round
@@ -65,7 +65,8 @@ struct PrepPartial {
 
 struct Surv {
     double x, y, z, tlo, thi;
-    int32_t ri, pad_;
+    float zfr, eps;   // z - floor(z); half-width of the "decide exactly" band around an interval end point
+    int32_t zi, pad_; // floor(z)
 };
 
 struct Layout {
@@ -473,7 +474,7 @@ __global__ __launch_bounds__(1024) void k_setup(const PrepPartial *partials, con
         TK = TKp;
     } else {
         TI = cells / (TJ * TKp);
-        if (TI > 16) TI = 16;
+        if (TI * TJ > 128) TI = 128 / TJ;  // two 64-column passes per point
         if (TI > D) TI = D;
         // prefer at least ~2 workgroups per CU worth of tiles as long as a wave still gets 64 columns
         while (TI > 4 && (long long)((D + TI - 1) / TI) * ((D + TJ - 1) / TJ) < 512) TI >>= 1;
@@ -488,8 +489,31 @@ __global__ __launch_bounds__(1024) void k_setup(const PrepPartial *partials, con
     *hdr = H;
 }
 
+// Tiles are handed out heaviest first: a tile's load is the number of points whose disc covers it, which
+// peaks at the grid centre.  Order index -> tile: rows from the central row outwards, inside a row from the
+// central column outwards (zig-zag around the middle is a bijection of [0, n)).
+__device__ __forceinline__ int zigzag(int o, int n)
+{
+    const int c = n / 2;
+    return (o & 1) ? c - (o + 1) / 2 : c + o / 2;
+}
+__device__ __forceinline__ int tile_from_order(int order, const AccHeader &H)
+{
+    const int o2 = order / H.ntk, tk = order - o2 * H.ntk;
+    const int oi = o2 / H.ntj, oj = o2 - oi * H.ntj;
+    return (zigzag(oi, H.nti) * H.ntj + zigzag(oj, H.ntj)) * H.ntk + tk;
+}
+
 // ---------------------------------------------------------------------------------------------
 // vote: one workgroup per tile, counters in LDS, arg-max straight from LDS
+//
+// Per (point, column) the shell crosses the column in at most two k-intervals whose end points are
+// z -/+ sqrt(T_hi - sxy) and z -/+ sqrt(T_lo - sxy).  The end points are evaluated in fp32 relative to
+// floor(z) (absolute error < 4e-7 * (r + 1) voxels); every integer that is further than `eps` from all
+// end points is decided by them alone (eps is > 5x that error bound and the float64 rounding of d2 is
+// ~1e-12), so those votes are cast without any per-voxel arithmetic.  An integer within eps of an end
+// point (probability ~1e-3 per column) is decided by the exact float64 predicate T_lo <= d2 < T_hi.
+// The resulting counts are therefore identical to the reference's float64 loop.
 // ---------------------------------------------------------------------------------------------
 template <bool WIDE>
 __device__ __forceinline__ uint32_t cell_read(const uint32_t *cells, int cell)
@@ -499,6 +523,15 @@ __device__ __forceinline__ uint32_t cell_read(const uint32_t *cells, int cell)
 }
 
 template <bool WIDE>
+__device__ __forceinline__ void cell_vote(uint32_t *cells, int cell)
+{
+    if (WIDE) atomicAdd(&cells[cell], 1u);
+    else atomicAdd(&cells[cell >> 1], 1u << ((cell & 1) * 16));
+}
+
+constexpr int NONE_K = -0x40000000;
+
+template <bool WIDE>
 __global__ __launch_bounds__(VOTE_THREADS) void k_vote(AccHeader *hdr, const double *P, const int32_t *ri_arr, int cap,
                                                        const double *thr, uint64_t *tile_best, uint32_t *tile_ties,
                                                        uint32_t *grid_out, unsigned long long grid_cells)
@@ -506,25 +539,46 @@ __global__ __launch_bounds__(VOTE_THREADS) void k_vote(AccHeader *hdr, const dou
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t *cells = (uint32_t *)smem;
     Surv *surv = (Surv *)(smem + CELL_BYTES);
-    int *wcount = (int *)(smem + CELL_BYTES + SURV_CAP * sizeof(Surv));           // [VOTE_WAVES]
-    uint64_t *wred = (uint64_t *)(smem + CELL_BYTES + SURV_CAP * sizeof(Surv) + 64);  // [VOTE_WAVES]
-    int *wredi = (int *)(smem + CELL_BYTES + SURV_CAP * sizeof(Surv) + 64 + 8 * VOTE_WAVES);  // [VOTE_WAVES]
+    int *wcount = (int *)(smem + CELL_BYTES + SURV_CAP * sizeof(Surv));                      // [VOTE_WAVES]
+    uint64_t *wred = (uint64_t *)(smem + CELL_BYTES + SURV_CAP * sizeof(Surv) + 4 * VOTE_WAVES);  // [VOTE_WAVES]
+    int *wredi = (int *)(smem + CELL_BYTES + SURV_CAP * sizeof(Surv) + 12 * VOTE_WAVES);     // [VOTE_WAVES]
+    int *s_tile_p = (int *)(smem + CELL_BYTES + SURV_CAP * sizeof(Surv) + 16 * VOTE_WAVES);
 
     const AccHeader H = *hdr;
     if (H.status != RCV_OK || (int)H.wide != (int)WIDE) return;
     const int D = H.dim, n = H.n, TI = H.TI, TJ = H.TJ, TK = H.TK, TKp = H.TKp;
     const int lane = lane_id(), wv = wave_id(), tid = threadIdx.x;
-    const int ncols = TI * TJ;
-    const int npass = (ncols + 63) / 64;
+    const int ncols = TI * TJ;  // <= 128: two 64-column passes per point
     const int ncells = ncols * TKp;
     const int nwords = WIDE ? ncells : ncells / 2;
     const bool flush = grid_out != nullptr && (unsigned long long)D * D * D <= grid_cells;
 
-    for (int tile = blockIdx.x; tile < H.ntiles; tile += gridDim.x) {
+    for (;;) {
+        // tiles are handed out through one counter, heaviest (central) first
+        if (tid == 0) *s_tile_p = (int)atomicAdd(&hdr->tile_counter, 1u);
+        __syncthreads();
+        const int torder = *s_tile_p;
+        __syncthreads();
+        if (torder >= H.ntiles) break;
+        const int tile = tile_from_order(torder, H);
         const int tk = tile % H.ntk, tj = (tile / H.ntk) % H.ntj, ti = tile / (H.ntk * H.ntj);
         const int i0 = ti * TI, j0 = tj * TJ, k0 = tk * TK;
         const int i1 = min(i0 + TI, D), j1 = min(j0 + TJ, D), k1 = min(k0 + TK, D);
         for (int w = tid; w < nwords; w += VOTE_THREADS) cells[w] = 0u;
+
+        // this lane's two columns
+        double ci[2], cj[2];
+        int cbase[2];
+        bool cvalid[2];
+#pragma unroll
+        for (int p = 0; p < 2; p++) {
+            const int col = p * 64 + lane;
+            const int il = col / TJ, jl = col - il * TJ;
+            cvalid[p] = col < ncols && i0 + il < i1 && j0 + jl < j1;
+            ci[p] = (double)(i0 + il);
+            cj[p] = (double)(j0 + jl);
+            cbase[p] = col * TKp - k0;
+        }
         __syncthreads();
 
         for (int base = 0; base < n; base += SURV_CAP) {
@@ -544,8 +598,10 @@ __global__ __launch_bounds__(VOTE_THREADS) void k_vote(AccHeader *hdr, const dou
                         s.z = (P[2 * (size_t)cap + p] - H.mean[2]) - H.shift;
                         s.tlo = thr[2 * r];
                         s.thi = thr[2 * r + 1];
-                        s.ri = r;
-                        s.pad_ = 0;
+                        const double zf = floor(s.z);
+                        s.zi = (int)zf;
+                        s.zfr = (float)(s.z - zf);
+                        s.eps = 2.0e-6f * (float)(r + 8);
                         const double ex = fmax(fmax((double)i0 - s.x, s.x - (double)(i1 - 1)), 0.0);
                         const double ey = fmax(fmax((double)j0 - s.y, s.y - (double)(j1 - 1)), 0.0);
                         const double rr = (double)r;
@@ -568,43 +624,54 @@ __global__ __launch_bounds__(VOTE_THREADS) void k_vote(AccHeader *hdr, const dou
 
             // ---- rasterise: each wave takes whole points, its lanes take the tile's columns ----
             for (int si = wv; si < nsurv; si += VOTE_WAVES) {
-                const Surv s = surv[si];
-                for (int pass = 0; pass < npass; pass++) {
-                    const int col = pass * 64 + lane;
-                    const int il = col / TJ, jl = col - il * TJ;
-                    const int i = i0 + il, j = j0 + jl;
-                    if (col >= ncols || i >= i1 || j >= j1) continue;
-                    const double dx = (double)i - s.x, dy = (double)j - s.y;
+                const Surv sp = surv[si];
+                const int rlo = k0 - sp.zi, rhi = k1 - 1 - sp.zi;  // tile k-range relative to floor(z)
+#pragma unroll
+                for (int p = 0; p < 2; p++) {
+                    if (!cvalid[p]) continue;
+                    const double dx = ci[p] - sp.x, dy = cj[p] - sp.y;
                     const double sxy = dx * dx + dy * dy;  // (i-x)**2 + (j-y)**2, reference order (:337)
-                    const double a = s.thi - sxy;
+                    const double a = sp.thi - sxy;
                     if (!(a > 0.0)) continue;
-                    const double b = s.tlo - sxy;
-                    const double eps = 1e-3;
-                    const double zh = (double)__builtin_sqrtf((float)a) + eps;
-                    int lo1, hi1, lo2 = 1, hi2 = 0;
-                    if (b <= 0.0) {
-                        lo1 = (int)ceil(s.z - zh);
-                        hi1 = (int)floor(s.z + zh);
-                    } else {
-                        const double zl = (double)__builtin_sqrtf((float)b) - eps;
-                        lo1 = (int)ceil(s.z - zh);
-                        hi1 = (int)floor(s.z - zl);
-                        lo2 = (int)ceil(s.z + zl);
-                        hi2 = (int)floor(s.z + zh);
-                        if (lo2 <= hi1) { hi1 = hi2; lo2 = 1; hi2 = 0; }
+                    const double b = sp.tlo - sxy;
+                    const bool two = b > 0.0;
+                    const float zh = __builtin_amdgcn_sqrtf((float)a);
+                    const float zl = two ? __builtin_amdgcn_sqrtf((float)b) : 0.f;
+                    const float eps = sp.eps;
+                    const float e1 = sp.zfr - zh, e4 = sp.zfr + zh;
+                    // end point 1 (lower end of the lower/only interval), end point 4 (upper end)
+                    const int A1 = (int)ceilf(e1 - eps), B1 = (int)ceilf(e1 + eps);
+                    const int A4 = (int)floorf(e4 + eps), B4 = (int)floorf(e4 - eps);
+                    int s1a = B1, s1b = B4, s2a = 1, s2b = 0;
+                    int u1 = A1 != B1 ? A1 : NONE_K, u4 = A4 != B4 ? A4 : NONE_K, u2 = NONE_K, u3 = NONE_K;
+                    if (two) {
+                        const float e2 = sp.zfr - zl, e3 = sp.zfr + zl;
+                        const int A2 = (int)floorf(e2 + eps), B2 = (int)floorf(e2 - eps);
+                        const int A3 = (int)ceilf(e3 - eps), B3 = (int)ceilf(e3 + eps);
+                        s1b = B2; s2a = B3; s2b = B4;
+                        if (A2 != B2) u2 = A2;
+                        if (A3 != B3) u3 = A3;
                     }
-                    lo1 = max(lo1, k0); hi1 = min(hi1, k1 - 1);
-                    lo2 = max(lo2, k0); hi2 = min(hi2, k1 - 1);
-                    const int n1 = max(hi1 - lo1 + 1, 0), n2 = max(hi2 - lo2 + 1, 0);
-                    const int cbase = col * TKp - k0;
+                    s1a = max(s1a, rlo); s1b = min(s1b, rhi);
+                    s2a = max(s2a, rlo); s2b = min(s2b, rhi);
+                    const int n1 = max(s1b - s1a + 1, 0), n2 = max(s2b - s2a + 1, 0);
+                    const int cb = cbase[p] + sp.zi;
                     for (int q = 0; q < n1 + n2; q++) {
-                        const int k = q < n1 ? lo1 + q : lo2 + (q - n1);
-                        const double dz = (double)k - s.z;
-                        const double d2 = sxy + dz * dz;  // ... + (k-z)**2
-                        if (d2 >= s.tlo && d2 < s.thi) {
-                            const int cell = cbase + k;
-                            if (WIDE) atomicAdd(&cells[cell], 1u);
-                            else atomicAdd(&cells[cell >> 1], 1u << ((cell & 1) * 16));
+                        const int r = q < n1 ? s1a + q : s2a + (q - n1);
+                        cell_vote<WIDE>(cells, cb + r);
+                    }
+                    if (u1 != NONE_K || u2 != NONE_K || u3 != NONE_K || u4 != NONE_K) {  // an integer too close to an end point
+                        if (u2 == u1) u2 = NONE_K;
+                        if (u3 == u2 || u3 == u1) u3 = NONE_K;
+                        if (u4 == u3 || u4 == u2 || u4 == u1) u4 = NONE_K;
+                        const int us[4] = {u1, u2, u3, u4};
+#pragma unroll
+                        for (int q = 0; q < 4; q++) {
+                            const int r = us[q];
+                            if (r == NONE_K || r < rlo || r > rhi) continue;
+                            const double dz = (double)(sp.zi + r) - sp.z;
+                            const double d2 = sxy + dz * dz;  // ... + (k-z)**2
+                            if (d2 >= sp.tlo && d2 < sp.thi) cell_vote<WIDE>(cells, cb + r);
                         }
                     }
                 }
@@ -612,18 +679,19 @@ __global__ __launch_bounds__(VOTE_THREADS) void k_vote(AccHeader *hdr, const dou
             __syncthreads();
         }
 
-        // ---- tile arg-max (first maximum in C order) + tie count, optional flush ----
+        // ---- tile arg-max (first maximum in C order) + tie count, optional flush; waves walk columns ----
         uint64_t best = 0;
-        for (int c = tid; c < ncells; c += VOTE_THREADS) {
-            const int col = c / TKp, kk = c - col * TKp;
+        for (int col = wv; col < ncols; col += VOTE_WAVES) {
             const int il = col / TJ, jl = col - il * TJ;
-            const int i = i0 + il, j = j0 + jl, k = k0 + kk;
-            if (i >= i1 || j >= j1 || k >= k1) continue;
-            const uint32_t v = cell_read<WIDE>(cells, c);
-            const uint32_t flat = ((uint32_t)i * (uint32_t)D + (uint32_t)j) * (uint32_t)D + (uint32_t)k;
-            const uint64_t key = ((uint64_t)v << 32) | (uint64_t)(0xFFFFFFFFu - flat);
-            best = key > best ? key : best;
-            if (flush) grid_out[flat] = v;
+            const int i = i0 + il, j = j0 + jl;
+            if (i >= i1 || j >= j1) continue;
+            const uint32_t fbase = ((uint32_t)i * (uint32_t)D + (uint32_t)j) * (uint32_t)D + (uint32_t)k0;
+            for (int kk = lane; kk < k1 - k0; kk += 64) {
+                const uint32_t v = cell_read<WIDE>(cells, col * TKp + kk);
+                const uint64_t key = ((uint64_t)v << 32) | (uint64_t)(0xFFFFFFFFu - (fbase + kk));
+                best = key > best ? key : best;
+                if (flush) grid_out[fbase + kk] = v;
+            }
         }
         best = wave_max_u64(best);
         if (lane == 0) wred[wv] = best;
@@ -632,11 +700,10 @@ __global__ __launch_bounds__(VOTE_THREADS) void k_vote(AccHeader *hdr, const dou
         for (int q = 1; q < VOTE_WAVES; q++) best = wred[q] > best ? wred[q] : best;
         const uint32_t vmax = (uint32_t)(best >> 32);
         int ties = 0;
-        for (int c = tid; c < ncells; c += VOTE_THREADS) {
-            const int col = c / TKp, kk = c - col * TKp;
+        for (int col = wv; col < ncols; col += VOTE_WAVES) {
             const int il = col / TJ, jl = col - il * TJ;
-            if (i0 + il >= i1 || j0 + jl >= j1 || k0 + kk >= k1) continue;
-            ties += cell_read<WIDE>(cells, c) == vmax;
+            if (i0 + il >= i1 || j0 + jl >= j1) continue;
+            for (int kk = lane; kk < k1 - k0; kk += 64) ties += cell_read<WIDE>(cells, col * TKp + kk) == vmax;
         }
         ties = wave_sum_i32(ties);
         if (lane == 0) wredi[wv] = ties;
@@ -734,7 +801,7 @@ __global__ __launch_bounds__(1024) void k_collect_ties(const uint32_t *grid, uns
     if (threadIdx.x == 0) *count_out = running;
 }
 
-constexpr size_t VOTE_LDS_BYTES = CELL_BYTES + SURV_CAP * sizeof(Surv) + 64 + 8 * VOTE_WAVES + 4 * VOTE_WAVES + 32;
+constexpr size_t VOTE_LDS_BYTES = CELL_BYTES + SURV_CAP * sizeof(Surv) + 16 * VOTE_WAVES + 32;
 bool g_vote_attr_set = false;
 
 }  // namespace

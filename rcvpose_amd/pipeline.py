@@ -1,0 +1,105 @@
+"""The per-frame hot loop of `--mode=test` (reference AccumulatorSpace.py:553-659) as one device-side
+pipeline: for a batch of frames and the three keypoint networks,
+
+    uint8 RGB -> normalise -> 3 x FCN forward -> per (frame, keypoint): mask/back-project seam ->
+    radial voting in LDS -> arg-max -> estimated_kpts[frame, keypoint] (mm, camera frame)
+
+Nothing returns to the host between the image upload and the final copy of the 96-byte results.
+"""
+import ctypes
+
+import numpy as np
+
+from . import AccumulatorSpace as A
+from . import _hip, fcn_engine
+
+
+class FramePipeline:
+    def __init__(self, state_dicts, H=480, W=640, dtype="bf16", frames_per_step=1, K=A.linemod_K, acc_unit=A.ACC_UNIT_MM,
+                 device="cuda", n_streams=1):
+        import torch
+
+        assert len(state_dicts) >= 1
+        self.torch = torch
+        self.lib = _hip.lib()
+        _hip.check(self.lib.rcv_init(), "rcv_init")
+        self.H, self.W, self.B, self.G = H, W, int(frames_per_step), len(state_dicts)
+        self.K = np.asarray(K, dtype=np.float64)
+        self.acc_unit = float(acc_unit)
+        self.device = device
+        self.engine = fcn_engine.FcnEngine(state_dicts, H, W, dtype=dtype, device=device)
+        self.engine.workspace(self.B)
+        B, G = self.B, self.G
+        self.x = torch.empty((B, 3, H, W), dtype=torch.float32, device=device)
+        self.seg = torch.empty((G, B, 1, H, W), dtype=torch.float32, device=device)
+        self.radial = torch.empty_like(self.seg)
+        n_items = B * G
+        cap = H * W
+        self.cap = cap
+        ws_bytes = int(self.lib.rcv_acc_workspace_bytes(cap))
+        self.ws_bytes = ws_bytes
+        self.ws = torch.empty((n_items, ws_bytes), dtype=torch.uint8, device=device)
+        self.xyz = torch.empty((n_items, cap, 3), dtype=torch.float64, device=device)
+        self.rlist = torch.empty((n_items, cap), dtype=torch.float32, device=device)
+        self.counts = torch.zeros((n_items, 2), dtype=torch.int32, device=device)
+        self.results = torch.zeros((n_items, ctypes.sizeof(_hip.AccResult)), dtype=torch.uint8, device=device)
+        self.k4 = (ctypes.c_double * 4)(self.K[0, 0], self.K[1, 1], self.K[0, 2], self.K[1, 2])
+        self.streams = [torch.cuda.Stream(device=device) for _ in range(max(0, n_streams - 1))]
+
+    # -- stages ----------------------------------------------------------------------------
+    def forward_fcn(self, rgb_u8):
+        """rgb_u8: uint8 [B,H,W,3] on the device -> fills self.seg / self.radial."""
+        L = self.lib
+        _hip.check(L.rcv_preprocess_rgb(_hip.ptr(rgb_u8), self.B, self.H, self.W, _hip.ptr(self.x), _hip.current_stream()),
+                   "rcv_preprocess_rgb")
+        self.engine.forward(self.x, out=(self.seg, self.radial))
+
+    def vote(self, depth_u16, max_radii_dm):
+        """depth_u16: [B,H,W] (int16 storage of uint16 mm); max_radii_dm: G floats.  Enqueues seam + voting."""
+        L, torch = self.lib, self.torch
+        cur = torch.cuda.current_stream()
+        lanes = [cur] + self.streams
+        if self.streams:
+            ev = torch.cuda.Event()
+            ev.record(cur)
+            for s in self.streams:
+                s.wait_event(ev)
+        item = 0
+        for b in range(self.B):
+            for g in range(self.G):
+                st = lanes[item % len(lanes)]
+                sp = ctypes.c_void_p(st.cuda_stream)
+                _hip.check(L.rcv_seam_compact(_hip.ptr(self.seg[g, b]), _hip.ptr(self.radial[g, b]), _hip.ptr(depth_u16[b]),
+                                              self.H, self.W, self.k4, float(A.SEG_THRESHOLD), float(max_radii_dm[g]), 0,
+                                              _hip.ptr(self.xyz[item]), _hip.ptr(self.rlist[item]), _hip.ptr(self.counts[item]),
+                                              self.cap, _hip.ptr(self.ws[item]), self.ws_bytes, sp), "rcv_seam_compact")
+                _hip.check(L.rcv_accumulate_3d(_hip.ptr(self.xyz[item]), _hip.ptr(self.rlist[item]), 0,
+                                               _hip.ptr(self.counts[item]), self.cap, self.cap, self.acc_unit,
+                                               _hip.ptr(self.results[item]), None, 0, _hip.ptr(self.ws[item]), self.ws_bytes,
+                                               sp), "rcv_accumulate_3d")
+                item += 1
+        for s in self.streams:
+            e = torch.cuda.Event()
+            e.record(s)
+            cur.wait_event(e)
+
+    def read_results(self):
+        """One D2H copy -> (estimated_kpts float64 [B,G,3] mm, list of AccResult)."""
+        raw = self.results.cpu().numpy()
+        res = [_hip.AccResult.from_buffer_copy(raw[i].tobytes()) for i in range(raw.shape[0])]
+        kpts = np.array([[r.center_mm[0], r.center_mm[1], r.center_mm[2]] for r in res]).reshape(self.B, self.G, 3)
+        return kpts, res
+
+    def keypoints_tensor(self):
+        """estimated keypoints as a float64 [B,G,3] device tensor (view of the result records)."""
+        return self.results[:, :24].contiguous().view(self.torch.float64).view(self.B, self.G, 3)
+
+    # -- whole step ------------------------------------------------------------------------
+    def process(self, rgb_u8, depth_u16, max_radii_dm, inject=None):
+        """One batch of frames.  `inject`: optional (seg [G,B,1,H,W], radial [G,B,1,H,W]) copied over the FCN
+        outputs after the forward (measurement with random weights)."""
+        self.forward_fcn(rgb_u8)
+        if inject is not None:
+            self.seg.copy_(inject[0])
+            self.radial.copy_(inject[1])
+        self.vote(depth_u16, max_radii_dm)

@@ -96,7 +96,7 @@ def test_full_size_frame_cloud(A, oracle):
     assert res.dim == info.dim
     assert np.array_equal(votes, ref_votes)
     assert np.array_equal(center, ref_center)
-    assert np.abs(center[0] - f["keypoints_m"][0] * 1000).max() <= 5.0
+    assert np.abs(center[0] - f["keypoints_m"][0] * 1000).max() <= 15.0  # sanity vs the truth; parity is the line above
 
 
 def test_seam_golden(A, golden_dir):

@@ -1,0 +1,72 @@
+"""Frame pipeline (FCN -> seam -> vote -> arg-max, 3 keypoints) on the GPU against the oracle."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import fcn_weights
+import frames
+
+pytestmark = pytest.mark.gpu
+
+
+def _state_dicts(golden_dir, n=3):
+    shapes = json.load(open(os.path.join(golden_dir, "fcn_state_dict_keys.json")))
+    return [{k: torch.from_numpy(v) for k, v in fcn_weights.make_state_dict_numpy(shapes, seed=s).items()} for s in range(n)]
+
+
+def test_full_frames_three_keypoints(golden_dir, oracle):
+    """2 synthetic 640x480 frames x 3 keypoints, ideal maps injected after the forward:
+    recovered keypoints equal the oracle's bit for bit (the north star's gate is <= 1 voxel from the reference)
+    and land near the true keypoints (noisy integer-radius shells seen from ~0.4 m: a few voxels)."""
+    from rcvpose_amd.pipeline import FramePipeline
+
+    B = 2
+    fr = [frames.synthetic_frame(i) for i in range(B)]
+    pipe = FramePipeline(_state_dicts(golden_dir), 480, 640, dtype="bf16", frames_per_step=B)
+    rgb = torch.from_numpy(np.stack([f["rgb"] for f in fr])).cuda()
+    depth = torch.from_numpy(np.stack([f["depth"] for f in fr]).view(np.int16)).cuda()
+    seg = torch.from_numpy(np.stack([np.stack([f["seg"] for f in fr])] * 3))[:, :, None].contiguous().cuda()
+    rad = torch.from_numpy(np.stack([np.stack([f["radial"][k] for f in fr]) for k in range(3)]))[:, :, None].contiguous().cuda()
+    # all frames share max_radii (the reference derives them per class from the model, AccumulatorSpace.py:540-549)
+    rmax = np.max([f["max_radii_dm"] for f in fr], axis=0)
+    pipe.process(rgb, depth, rmax, inject=(seg, rad))
+    kpts, res = pipe.read_results()
+    for b in range(B):
+        for k in range(3):
+            r = res[b * 3 + k]
+            assert r.status == 0
+            xyz, rl = oracle.seam(fr[b]["seg"], fr[b]["radial"][k], fr[b]["depth"], rmax[k])
+            assert r.n_points == len(xyz) and r.n_radii == len(rl)
+            ref = oracle.accumulator_3d(xyz, rl, sparse=True)
+            assert np.array_equal(kpts[b, k], ref[0]), (b, k, kpts[b, k], ref[0])
+            assert np.abs(kpts[b, k] - fr[b]["keypoints_m"][k] * 1000).max() <= 15.0
+    assert torch.equal(pipe.keypoints_tensor().cpu(), torch.from_numpy(kpts))
+
+
+def test_small_frame_fcn_outputs_feed_the_vote(golden_dir, oracle):
+    """No injection: whatever the (random-weight) fp32 FCN emits goes through seam + vote on the device, and the
+    same maps pushed through the oracle give the same keypoint (or the same error)."""
+    from rcvpose_amd.pipeline import FramePipeline
+
+    H, W = 64, 96
+    sds = _state_dicts(golden_dir, 1)
+    pipe = FramePipeline(sds, H, W, dtype="fp32", frames_per_step=1)
+    rng = np.random.default_rng(3)
+    rgb = torch.from_numpy(rng.integers(0, 256, size=(1, H, W, 3), dtype=np.uint8)).cuda()
+    depth_np = (800 + rng.integers(0, 40, size=(1, H, W))).astype(np.uint16)
+    depth = torch.from_numpy(depth_np.view(np.int16)).cuda()
+    pipe.forward_fcn(rgb)
+    # shift the random seg map so that a few hundred pixels pass the 0.8 threshold, keep radii small and positive
+    seg = pipe.seg[0, 0, 0]
+    thr = torch.quantile(seg.flatten(), 0.95)
+    pipe.seg.copy_((seg - thr + 0.8)[None, None, None])
+    pipe.radial.copy_((pipe.radial[0, 0, 0].abs() % 0.9)[None, None, None])
+    pipe.vote(depth, [0.85])
+    kpts, res = pipe.read_results()
+    xyz, rl = oracle.seam(pipe.seg[0, 0, 0].cpu().numpy(), pipe.radial[0, 0, 0].cpu().numpy(), depth_np[0], 0.85)
+    assert res[0].n_points == len(xyz) and res[0].n_radii == len(rl) and len(xyz) > 50
+    ref = oracle.accumulator_3d(xyz, rl, sparse=True)
+    assert res[0].status == 0 and np.array_equal(kpts[0, 0], ref[0])
