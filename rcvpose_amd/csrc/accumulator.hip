@@ -31,6 +31,7 @@ namespace {
 
 constexpr int TABLE_N = 8192;          // largest integer radius (voxels) with a threshold pair
 constexpr int MAX_TILES = 1 << 17;
+constexpr int MAX_REPLICAS = 2048;     // workgroups that share a tile park their counters here (CELL_BYTES each)
 constexpr int PREP_BLOCKS = 128;
 constexpr int PREP_THREADS = 256;
 constexpr int SEAM_PIX_PER_BLOCK = 1024;
@@ -38,7 +39,6 @@ constexpr int SEAM_MAX_BLOCKS = 4096;
 constexpr int VOTE_THREADS = 1024;
 constexpr int VOTE_WAVES = VOTE_THREADS / 64;
 constexpr int CELL_BYTES = 60 * 1024;  // LDS bytes of vote counters per tile
-constexpr int SURV_CAP = 256;          // points staged per cull round
 constexpr int MAX_DIM = 1600;          // flat index must fit 32 bits
 constexpr int NPY_BUFSIZE = 8192;      // numpy ufunc buffer (elements): chunking of add.reduce
 constexpr int PW_BLOCK = 128;          // numpy pairwise-sum leaf size
@@ -53,24 +53,18 @@ struct alignas(16) AccHeader {
     int32_t TI, TJ, TK, TKp;  // tile footprint, k-extent, padded (even) cells per column
     int32_t nti, ntj, ntk, ntiles;
     int32_t wide;     // 1: 32-bit counters (n >= 65536), 0: packed 16-bit
+    int32_t nparts;   // every tile's point list is split over this many workgroups (load balance)
     int32_t status;
     uint32_t tile_counter;
-    int32_t pad_;
 };
 
 struct PrepPartial {
     double mn[3], mx[3], rmax;
-    double pad_;
-};
-
-struct Surv {
-    double x, y, z, tlo, thi;
-    float zfr, eps;   // z - floor(z); half-width of the "decide exactly" band around an interval end point
-    int32_t zi, pad_; // floor(z)
+    double radius_overflow;  // != 0: some integer radius has no threshold pair (>= TABLE_N)
 };
 
 struct Layout {
-    size_t header, partials, seam_counts, seam_offsets, tile_best, tile_ties, P, ri, total;
+    size_t header, partials, seam_counts, seam_offsets, tile_best, tile_ties, replicas, P, ri, total;
 };
 
 Layout make_layout(int cap)
@@ -83,7 +77,8 @@ Layout make_layout(int cap)
     L.seam_offsets = o;  o += align_up(sizeof(int2) * SEAM_MAX_BLOCKS, 256);
     L.tile_best = o;     o += align_up(sizeof(uint64_t) * MAX_TILES, 256);
     L.tile_ties = o;     o += align_up(sizeof(uint32_t) * MAX_TILES, 256);
-    L.P = o;             o += align_up(sizeof(double) * 3 * (size_t)cap, 256);
+    L.replicas = o;      o += (size_t)MAX_REPLICAS * CELL_BYTES;
+    L.P = o;             o += align_up(sizeof(double) * 5 * (size_t)cap, 256);  // x, y, z, T_lo, T_hi per point (SoA)
     L.ri = o;            o += align_up(sizeof(int32_t) * (size_t)cap, 256);
     L.total = o;
     return L;
@@ -306,9 +301,12 @@ __global__ __launch_bounds__(256) void k_seam_scatter(const float *seg, const fl
 // ---------------------------------------------------------------------------------------------
 template <typename RT>
 __global__ __launch_bounds__(PREP_THREADS) void k_prep(const double *xyz_m, const RT *radial, const int32_t *counts,
-                                                       int n_arg, int m_arg, int cap, double unit, double *P,
-                                                       int32_t *ri, PrepPartial *partials)
+                                                       int n_arg, int m_arg, int cap, double unit, const double *thr,
+                                                       double *P, int32_t *ri, PrepPartial *partials)
 {
+    __shared__ int s_overflow;
+    if (threadIdx.x == 0) s_overflow = 0;
+    __syncthreads();
     __shared__ double red[7][PREP_THREADS / 64];
     int n = n_arg, m = m_arg;
     if (counts) { n = min(counts[0], cap); m = min(counts[1], cap); }
@@ -331,7 +329,14 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prep(const double *xyz_m, cons
             if (rd > rmax) rmax = rd;
             if (i < n) {
                 double rr = rint(rd);  // np.around: half to even (:332); exact for float32 values too
-                ri[i] = (rd == rd) ? clamp_to_int(rr) : 0;
+                const int r = (rd == rd) ? clamp_to_int(rr) : 0;
+                ri[i] = r;
+                // shell thresholds of this point's integer radius: vote <=> T_lo <= d2 < T_hi
+                double tlo = 0.0, thi = 0.0;  // radius <= 0 never votes (`radius - distance > 0` fails)
+                if (r >= TABLE_N) s_overflow = 1;
+                else if (r > 0) { tlo = thr[2 * r]; thi = thr[2 * r + 1]; }
+                P[3 * (size_t)cap + i] = tlo;
+                P[4 * (size_t)cap + i] = thi;
             }
         }
     }
@@ -348,7 +353,7 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prep(const double *xyz_m, cons
             for (int w = 1; w < PREP_THREADS / 64; w++) v = q < 3 ? fmin(v, red[q][w]) : fmax(v, red[q][w]);
             if (q < 3) pp.mn[q] = v; else if (q < 6) pp.mx[q - 3] = v; else pp.rmax = v;
         }
-        pp.pad_ = 0;
+        pp.radius_overflow = s_overflow ? 1.0 : 0.0;
         partials[blockIdx.x] = pp;
     }
 }
@@ -441,9 +446,11 @@ __global__ __launch_bounds__(1024) void k_setup(const PrepPartial *partials, con
     }
     const double INF = __longlong_as_double(0x7FF0000000000000ll);
     double mn[3] = {INF, INF, INF}, mx[3] = {-INF, -INF, -INF}, rmax = -INF;
+    bool overflow = false;
     for (int b = 0; b < PREP_BLOCKS; b++) {
         for (int a = 0; a < 3; a++) { mn[a] = fmin(mn[a], partials[b].mn[a]); mx[a] = fmax(mx[a], partials[b].mx[a]); }
         rmax = fmax(rmax, partials[b].rmax);
+        overflow |= partials[b].radius_overflow != 0.0;
     }
     double qmin = INF, qmax = -INF;
     for (int a = 0; a < 3; a++) {
@@ -459,6 +466,7 @@ __global__ __launch_bounds__(1024) void k_setup(const PrepPartial *partials, con
     const int length = clamp_to_int(pmax);                  // :399
     const long long dim = (long long)length + (long long)clamp_to_int(rmax);  // :401
     if (dim <= 0) { H.status = RCV_E_BADGRID; *hdr = H; return; }
+    if (overflow) { H.status = RCV_E_TOO_LARGE; *hdr = H; return; }
     if (dim > MAX_DIM) { H.status = RCV_E_TOO_LARGE; H.dim = (int)min(dim, 2000000000ll); *hdr = H; return; }
     const int D = (int)dim;
     H.dim = D;
@@ -484,6 +492,9 @@ __global__ __launch_bounds__(1024) void k_setup(const PrepPartial *partials, con
     const long long nt = (long long)H.nti * H.ntj * H.ntk;
     if (nt > MAX_TILES) { H.status = RCV_E_TOO_LARGE; *hdr = H; return; }
     H.ntiles = (int)nt;
+    // the central tiles see every point, the outer ones few: split each tile's point list over nparts
+    // workgroups (their LDS counters are summed by k_merge) so that no work item dominates the makespan
+    H.nparts = (int)max(1ll, min(8ll, (long long)MAX_REPLICAS / nt));
     H.status = grid_cells_ok ? RCV_OK : RCV_OK;
     H.tile_counter = 0;
     *hdr = H;
@@ -531,18 +542,141 @@ __device__ __forceinline__ void cell_vote(uint32_t *cells, int cell)
 
 constexpr int NONE_K = -0x40000000;
 
+// tile arg-max (first maximum in C order) + tie count + optional copy of the tile to the HBM grid.
+// Waves walk columns, lanes walk k.  Must be called by all VOTE_THREADS threads after a barrier.
 template <bool WIDE>
-__global__ __launch_bounds__(VOTE_THREADS) void k_vote(AccHeader *hdr, const double *P, const int32_t *ri_arr, int cap,
-                                                       const double *thr, uint64_t *tile_best, uint32_t *tile_ties,
-                                                       uint32_t *grid_out, unsigned long long grid_cells)
+__device__ __forceinline__ void tile_epilogue(const uint32_t *cells, uint64_t *wred, int *wredi, const AccHeader &H, int tile,
+                                              uint32_t *grid_out, uint64_t *tile_best, uint32_t *tile_ties)
+{
+    const int lane = lane_id(), wv = wave_id(), tid = threadIdx.x;
+    const int D = H.dim, TI = H.TI, TJ = H.TJ, TK = H.TK, TKp = H.TKp, ncols = TI * TJ;
+    const int tk = tile % H.ntk, tj = (tile / H.ntk) % H.ntj, ti = tile / (H.ntk * H.ntj);
+    const int i0 = ti * TI, j0 = tj * TJ, k0 = tk * TK;
+    const int i1 = min(i0 + TI, D), j1 = min(j0 + TJ, D), k1 = min(k0 + TK, D);
+    uint64_t best = 0;
+    for (int col = wv; col < ncols; col += VOTE_WAVES) {
+        const int il = col / TJ, jl = col - il * TJ;
+        const int i = i0 + il, j = j0 + jl;
+        if (i >= i1 || j >= j1) continue;
+        const uint32_t fbase = ((uint32_t)i * (uint32_t)D + (uint32_t)j) * (uint32_t)D + (uint32_t)k0;
+        for (int kk = lane; kk < k1 - k0; kk += 64) {
+            const uint32_t v = cell_read<WIDE>(cells, col * TKp + kk);
+            const uint64_t key = ((uint64_t)v << 32) | (uint64_t)(0xFFFFFFFFu - (fbase + kk));
+            best = key > best ? key : best;
+            if (grid_out) grid_out[fbase + kk] = v;
+        }
+    }
+    best = wave_max_u64(best);
+    if (lane == 0) wred[wv] = best;
+    __syncthreads();
+    best = wred[0];
+    for (int q = 1; q < VOTE_WAVES; q++) best = wred[q] > best ? wred[q] : best;
+    const uint32_t vmax = (uint32_t)(best >> 32);
+    int ties = 0;
+    for (int col = wv; col < ncols; col += VOTE_WAVES) {
+        const int il = col / TJ, jl = col - il * TJ;
+        if (i0 + il >= i1 || j0 + jl >= j1) continue;
+        for (int kk = lane; kk < k1 - k0; kk += 64) ties += cell_read<WIDE>(cells, col * TKp + kk) == vmax;
+    }
+    ties = wave_sum_i32(ties);
+    if (lane == 0) wredi[wv] = ties;
+    __syncthreads();
+    if (tid == 0) {
+        int tsum = 0;
+        for (int q = 0; q < VOTE_WAVES; q++) tsum += wredi[q];
+        tile_best[tile] = best;
+        tile_ties[tile] = (uint32_t)tsum;
+    }
+}
+
+// one (point, column): the votes of the shell of `point` along column (ci, cj) of the tile
+template <bool WIDE>
+__device__ __forceinline__ void vote_column(uint32_t *cells, double ci, double cj, int cbase, double px, double py,
+                                            double pz, double tlo, double thi, int zi, float zfr, float eps, int rlo,
+                                            int rhi)
+{
+    const double dx = ci - px, dy = cj - py;
+    const double sxy = dx * dx + dy * dy;  // (i-x)**2 + (j-y)**2, reference order (:337)
+    const double a = thi - sxy;
+    if (!(a > 0.0)) return;
+    const double b = tlo - sxy;
+    const bool two = b > 0.0;
+    const float zh = __builtin_amdgcn_sqrtf((float)a);
+    const float zl = two ? __builtin_amdgcn_sqrtf((float)b) : 0.f;
+    // Interval end points relative to floor(z): lower interval [e1, e2], upper [e3, e4] (one interval
+    // [e1, e4] when the column lies in the rim band, T_lo <= sxy).  Sure votes are the integers at least
+    // eps inside: [ceil(e_lo + eps), floor(e_hi - eps)].  An integer within eps of an end point shows up as
+    // a rounded value that moved by almost a full unit: ceil(t) - t > 1 - 2 eps  (resp. t - floor(t)).
+    const float lim = 1.f - 2.f * eps;
+    const float t1 = (zfr - zh) + eps, t4 = (zfr + zh) - eps;
+    const float c1 = ceilf(t1), f4 = floorf(t4);
+    bool unc = (c1 - t1 > lim) | (t4 - f4 > lim);
+    int s1a = (int)c1, s1b = (int)f4, s2a = 1, s2b = 0;
+    float f2 = 0.f, c3 = 0.f;
+    if (two) {
+        const float t2 = (zfr - zl) - eps, t3 = (zfr + zl) + eps;
+        f2 = floorf(t2);
+        c3 = ceilf(t3);
+        unc |= (t2 - f2 > lim) | (c3 - t3 > lim);
+        s1b = (int)f2; s2a = (int)c3; s2b = (int)f4;
+    }
+    s1a = max(s1a, rlo); s1b = min(s1b, rhi);
+    s2a = max(s2a, rlo); s2b = min(s2b, rhi);
+    const int n1 = s1b - s1a + 1, n2 = s2b - s2a + 1;
+    const int cb = cbase + zi;
+    // cap columns cross the shell in 1-2 voxels per interval: those are voted inline, the rest in a loop
+    if (n1 > 0) cell_vote<WIDE>(cells, cb + s1a);
+    if (n1 > 1) cell_vote<WIDE>(cells, cb + s1a + 1);
+    if (n2 > 0) cell_vote<WIDE>(cells, cb + s2a);
+    if (n2 > 1) cell_vote<WIDE>(cells, cb + s2a + 1);
+    for (int r = s1a + 2; r <= s1b; r++) cell_vote<WIDE>(cells, cb + r);
+    for (int r = s2a + 2; r <= s2b; r++) cell_vote<WIDE>(cells, cb + r);
+    if (unc) {  // some integer is too close to an end point: decide those with the exact float64 predicate
+        // candidates: the integer just outside each sure range (at most one per end point, eps < 0.5)
+        int u1 = (int)c1 - 1, u4 = (int)f4 + 1, u2 = NONE_K, u3 = NONE_K;
+        if (!(c1 - t1 > lim)) u1 = NONE_K;
+        if (!(t4 - f4 > lim)) u4 = NONE_K;
+        if (two) {
+            const float t2 = (zfr - zl) - eps, t3 = (zfr + zl) + eps;
+            if (t2 - f2 > lim) u2 = (int)f2 + 1;
+            if (c3 - t3 > lim) u3 = (int)c3 - 1;
+        }
+        if (u2 == u1) u2 = NONE_K;
+        if (u3 == u2 || u3 == u1) u3 = NONE_K;
+        if (u4 == u3 || u4 == u2 || u4 == u1) u4 = NONE_K;
+        const int us[4] = {u1, u2, u3, u4};
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int r = us[q];
+            if (r == NONE_K || r < rlo || r > rhi) continue;
+            const double dz = (double)(zi + r) - pz;
+            const double d2 = sxy + dz * dz;  // ... + (k-z)**2
+            if (d2 >= tlo && d2 < thi) cell_vote<WIDE>(cells, cb + r);
+        }
+    }
+}
+
+__device__ __forceinline__ double readlane_f64(double v, int l)
+{
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readlane((int)b, l), hi = __builtin_amdgcn_readlane((int)(b >> 32), l);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
+// The waves of a workgroup are independent between the two barriers that frame a tile: wave w takes the
+// 64-point batches w, w+16, ... of the point list, culls them against the tile footprint (one point per
+// lane, loads of the next batch already in flight) and rasterises the survivors one after the other, the
+// point broadcast to the wave with v_readlane, the lanes spread over the tile's (<= 128) columns.
+template <bool WIDE>
+__global__ __launch_bounds__(VOTE_THREADS) void k_vote(AccHeader *hdr, const double *P, int cap, unsigned char *replicas,
+                                                       uint64_t *tile_best, uint32_t *tile_ties, uint32_t *grid_out,
+                                                       unsigned long long grid_cells)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t *cells = (uint32_t *)smem;
-    Surv *surv = (Surv *)(smem + CELL_BYTES);
-    int *wcount = (int *)(smem + CELL_BYTES + SURV_CAP * sizeof(Surv));                      // [VOTE_WAVES]
-    uint64_t *wred = (uint64_t *)(smem + CELL_BYTES + SURV_CAP * sizeof(Surv) + 4 * VOTE_WAVES);  // [VOTE_WAVES]
-    int *wredi = (int *)(smem + CELL_BYTES + SURV_CAP * sizeof(Surv) + 12 * VOTE_WAVES);     // [VOTE_WAVES]
-    int *s_tile_p = (int *)(smem + CELL_BYTES + SURV_CAP * sizeof(Surv) + 16 * VOTE_WAVES);
+    uint64_t *wred = (uint64_t *)(smem + CELL_BYTES);                    // [VOTE_WAVES]
+    int *wredi = (int *)(smem + CELL_BYTES + 8 * VOTE_WAVES);            // [VOTE_WAVES]
+    int *s_tile_p = (int *)(smem + CELL_BYTES + 12 * VOTE_WAVES);
 
     const AccHeader H = *hdr;
     if (H.status != RCV_OK || (int)H.wide != (int)WIDE) return;
@@ -552,6 +686,9 @@ __global__ __launch_bounds__(VOTE_THREADS) void k_vote(AccHeader *hdr, const dou
     const int ncells = ncols * TKp;
     const int nwords = WIDE ? ncells : ncells / 2;
     const bool flush = grid_out != nullptr && (unsigned long long)D * D * D <= grid_cells;
+    const double *Px = P, *Py = P + (size_t)cap, *Pz = P + 2 * (size_t)cap, *Plo = P + 3 * (size_t)cap,
+                 *Phi = P + 4 * (size_t)cap;
+    const int nbatch = (n + 63) / 64;
 
     for (;;) {
         // tiles are handed out through one counter, heaviest (central) first
@@ -559,8 +696,9 @@ __global__ __launch_bounds__(VOTE_THREADS) void k_vote(AccHeader *hdr, const dou
         __syncthreads();
         const int torder = *s_tile_p;
         __syncthreads();
-        if (torder >= H.ntiles) break;
-        const int tile = tile_from_order(torder, H);
+        if (torder >= H.ntiles * H.nparts) break;
+        const int part = torder % H.nparts;
+        const int tile = tile_from_order(torder / H.nparts, H);
         const int tk = tile % H.ntk, tj = (tile / H.ntk) % H.ntj, ti = tile / (H.ntk * H.ntj);
         const int i0 = ti * TI, j0 = tj * TJ, k0 = tk * TK;
         const int i1 = min(i0 + TI, D), j1 = min(j0 + TJ, D), k1 = min(k0 + TK, D);
@@ -579,141 +717,91 @@ __global__ __launch_bounds__(VOTE_THREADS) void k_vote(AccHeader *hdr, const dou
             cj[p] = (double)(j0 + jl);
             cbase[p] = col * TKp - k0;
         }
+        const double fi0 = (double)i0, fi1 = (double)(i1 - 1), fj0 = (double)j0, fj1 = (double)(j1 - 1);
+        const double fk0 = (double)k0, fk1 = (double)(k1 - 1);
         __syncthreads();
 
-        for (int base = 0; base < n; base += SURV_CAP) {
-            // ---- cull SURV_CAP points against the tile footprint (threads 0..SURV_CAP-1 test one each) ----
-            bool keep = false;
-            Surv s;
+        // software pipeline: raw loads of the next batch are issued before the current one is rasterised
+        double nx = 0, ny = 0, nz = 0, nlo = 0, nhi = 0;
+        const int bstride = VOTE_WAVES * H.nparts;
+        {
+            const int p = (part + H.nparts * wv) * 64 + lane;
+            if (p < n) { nx = Px[p]; ny = Py[p]; nz = Pz[p]; nlo = Plo[p]; nhi = Phi[p]; }
+        }
+        for (int batch = part + H.nparts * wv; batch < nbatch; batch += bstride) {
+            // fast_for sees xyz_mm - mean - zero_boundary (AccumulatorSpace.py:384-386,397)
+            const double x = (nx - H.mean[0]) - H.shift, y = (ny - H.mean[1]) - H.shift, z = (nz - H.mean[2]) - H.shift;
+            const double tlo = nlo, thi = nhi;
             {
-                const int p = base + tid;
-                if (tid < SURV_CAP && p < n) {
-                    const int r = ri_arr[p];
-                    if (r >= TABLE_N) {
-                        atomicMin(&hdr->status, (int)RCV_E_TOO_LARGE);
-                    } else if (r > 0) {
-                        // fast_for sees xyz_mm - mean - zero_boundary (AccumulatorSpace.py:384-386,397)
-                        s.x = (P[p] - H.mean[0]) - H.shift;
-                        s.y = (P[(size_t)cap + p] - H.mean[1]) - H.shift;
-                        s.z = (P[2 * (size_t)cap + p] - H.mean[2]) - H.shift;
-                        s.tlo = thr[2 * r];
-                        s.thi = thr[2 * r + 1];
-                        const double zf = floor(s.z);
-                        s.zi = (int)zf;
-                        s.zfr = (float)(s.z - zf);
-                        s.eps = 2.0e-6f * (float)(r + 8);
-                        const double ex = fmax(fmax((double)i0 - s.x, s.x - (double)(i1 - 1)), 0.0);
-                        const double ey = fmax(fmax((double)j0 - s.y, s.y - (double)(j1 - 1)), 0.0);
-                        const double rr = (double)r;
-                        keep = (ex * ex + ey * ey) * (1.0 - 1e-9) < s.thi && s.z + rr >= (double)k0 &&
-                               s.z - rr <= (double)(k1 - 1);
-                    }
-                }
+                const int p = (batch + bstride) * 64 + lane;
+                nhi = 0;
+                if (p < n) { nx = Px[p]; ny = Py[p]; nz = Pz[p]; nlo = Plo[p]; nhi = Phi[p]; }
             }
-            const uint64_t kb = __ballot(keep);
-            if (lane == 0) wcount[wv] = __popcll(kb);
-            __syncthreads();
-            {
-                int before = 0;
-                for (int q = 0; q < wv; q++) before += wcount[q];
-                if (keep) surv[before + __popcll(kb & ((1ull << lane) - 1ull))] = s;
-            }
-            __syncthreads();
-            int nsurv = 0;
-            for (int q = 0; q < VOTE_WAVES; q++) nsurv += wcount[q];
-
-            // ---- rasterise: each wave takes whole points, its lanes take the tile's columns ----
-            for (int si = wv; si < nsurv; si += VOTE_WAVES) {
-                const Surv sp = surv[si];
-                const int rlo = k0 - sp.zi, rhi = k1 - 1 - sp.zi;  // tile k-range relative to floor(z)
+            // cull: the disc of radius < sqrt(T_hi) <= r around (x, y) against the tile footprint, the k-extent
+            const double ex = fmax(fmax(fi0 - x, x - fi1), 0.0), ey = fmax(fmax(fj0 - y, y - fj1), 0.0);
+            const double rr = ceil(sqrt(thi));
+            const bool keep = thi > 0.0 && (ex * ex + ey * ey) * (1.0 - 1e-9) < thi && z + rr >= fk0 && z - rr <= fk1;
+            const double zf = floor(z);
+            const int zi = (int)zf;
+            const float zfr = (float)(z - zf);
+            const float eps = 2.0e-6f * ((float)rr + 8.f);
+            uint64_t mask = __ballot(keep);
+            while (mask) {
+                const int L = __ffsll((unsigned long long)mask) - 1;
+                mask &= mask - 1;
+                const double sx = readlane_f64(x, L), sy = readlane_f64(y, L), sz = readlane_f64(z, L);
+                const double slo = readlane_f64(tlo, L), shi = readlane_f64(thi, L);
+                const int szi = __builtin_amdgcn_readlane(zi, L);
+                const float szfr = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(zfr), L));
+                const float seps = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(eps), L));
+                const int rlo = k0 - szi, rhi = k1 - 1 - szi;  // tile k-range relative to floor(z)
 #pragma unroll
-                for (int p = 0; p < 2; p++) {
-                    if (!cvalid[p]) continue;
-                    const double dx = ci[p] - sp.x, dy = cj[p] - sp.y;
-                    const double sxy = dx * dx + dy * dy;  // (i-x)**2 + (j-y)**2, reference order (:337)
-                    const double a = sp.thi - sxy;
-                    if (!(a > 0.0)) continue;
-                    const double b = sp.tlo - sxy;
-                    const bool two = b > 0.0;
-                    const float zh = __builtin_amdgcn_sqrtf((float)a);
-                    const float zl = two ? __builtin_amdgcn_sqrtf((float)b) : 0.f;
-                    const float eps = sp.eps;
-                    const float e1 = sp.zfr - zh, e4 = sp.zfr + zh;
-                    // end point 1 (lower end of the lower/only interval), end point 4 (upper end)
-                    const int A1 = (int)ceilf(e1 - eps), B1 = (int)ceilf(e1 + eps);
-                    const int A4 = (int)floorf(e4 + eps), B4 = (int)floorf(e4 - eps);
-                    int s1a = B1, s1b = B4, s2a = 1, s2b = 0;
-                    int u1 = A1 != B1 ? A1 : NONE_K, u4 = A4 != B4 ? A4 : NONE_K, u2 = NONE_K, u3 = NONE_K;
-                    if (two) {
-                        const float e2 = sp.zfr - zl, e3 = sp.zfr + zl;
-                        const int A2 = (int)floorf(e2 + eps), B2 = (int)floorf(e2 - eps);
-                        const int A3 = (int)ceilf(e3 - eps), B3 = (int)ceilf(e3 + eps);
-                        s1b = B2; s2a = B3; s2b = B4;
-                        if (A2 != B2) u2 = A2;
-                        if (A3 != B3) u3 = A3;
-                    }
-                    s1a = max(s1a, rlo); s1b = min(s1b, rhi);
-                    s2a = max(s2a, rlo); s2b = min(s2b, rhi);
-                    const int n1 = max(s1b - s1a + 1, 0), n2 = max(s2b - s2a + 1, 0);
-                    const int cb = cbase[p] + sp.zi;
-                    for (int q = 0; q < n1 + n2; q++) {
-                        const int r = q < n1 ? s1a + q : s2a + (q - n1);
-                        cell_vote<WIDE>(cells, cb + r);
-                    }
-                    if (u1 != NONE_K || u2 != NONE_K || u3 != NONE_K || u4 != NONE_K) {  // an integer too close to an end point
-                        if (u2 == u1) u2 = NONE_K;
-                        if (u3 == u2 || u3 == u1) u3 = NONE_K;
-                        if (u4 == u3 || u4 == u2 || u4 == u1) u4 = NONE_K;
-                        const int us[4] = {u1, u2, u3, u4};
-#pragma unroll
-                        for (int q = 0; q < 4; q++) {
-                            const int r = us[q];
-                            if (r == NONE_K || r < rlo || r > rhi) continue;
-                            const double dz = (double)(sp.zi + r) - sp.z;
-                            const double d2 = sxy + dz * dz;  // ... + (k-z)**2
-                            if (d2 >= sp.tlo && d2 < sp.thi) cell_vote<WIDE>(cells, cb + r);
-                        }
-                    }
-                }
+                for (int p = 0; p < 2; p++)
+                    if (cvalid[p])
+                        vote_column<WIDE>(cells, ci[p], cj[p], cbase[p], sx, sy, sz, slo, shi, szi, szfr, seps, rlo, rhi);
             }
-            __syncthreads();
         }
+        __syncthreads();
 
-        // ---- tile arg-max (first maximum in C order) + tie count, optional flush; waves walk columns ----
-        uint64_t best = 0;
-        for (int col = wv; col < ncols; col += VOTE_WAVES) {
-            const int il = col / TJ, jl = col - il * TJ;
-            const int i = i0 + il, j = j0 + jl;
-            if (i >= i1 || j >= j1) continue;
-            const uint32_t fbase = ((uint32_t)i * (uint32_t)D + (uint32_t)j) * (uint32_t)D + (uint32_t)k0;
-            for (int kk = lane; kk < k1 - k0; kk += 64) {
-                const uint32_t v = cell_read<WIDE>(cells, col * TKp + kk);
-                const uint64_t key = ((uint64_t)v << 32) | (uint64_t)(0xFFFFFFFFu - (fbase + kk));
-                best = key > best ? key : best;
-                if (flush) grid_out[fbase + kk] = v;
+        if (H.nparts > 1) {
+            // park this workgroup's share of the tile; k_merge adds the shares and takes the arg-max
+            uint4 *dst = (uint4 *)(replicas + ((size_t)tile * H.nparts + part) * CELL_BYTES);
+            const uint4 *src = (const uint4 *)cells;
+            for (int w = tid; w < (nwords + 3) / 4; w += VOTE_THREADS) dst[w] = src[w];
+        } else {
+            tile_epilogue<WIDE>(cells, wred, wredi, H, tile, flush ? grid_out : nullptr, tile_best, tile_ties);
+        }
+        __syncthreads();
+    }
+}
+
+// sums the nparts LDS images of every tile and takes its arg-max (only launched work when nparts > 1)
+template <bool WIDE>
+__global__ __launch_bounds__(VOTE_THREADS) void k_merge(const AccHeader *hdr, const unsigned char *replicas,
+                                                        uint64_t *tile_best, uint32_t *tile_ties, uint32_t *grid_out,
+                                                        unsigned long long grid_cells)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t *cells = (uint32_t *)smem;
+    uint64_t *wred = (uint64_t *)(smem + CELL_BYTES);
+    int *wredi = (int *)(smem + CELL_BYTES + 8 * VOTE_WAVES);
+    const AccHeader H = *hdr;
+    if (H.status != RCV_OK || (int)H.wide != (int)WIDE || H.nparts <= 1) return;
+    const int ncells = H.TI * H.TJ * H.TKp;
+    const int nvec = ((WIDE ? ncells : ncells / 2) + 3) / 4;
+    const bool flush = grid_out != nullptr && (unsigned long long)H.dim * H.dim * H.dim <= grid_cells;
+    for (int tile = blockIdx.x; tile < H.ntiles; tile += gridDim.x) {
+        const uint4 *src = (const uint4 *)(replicas + (size_t)tile * H.nparts * CELL_BYTES);
+        for (int w = threadIdx.x; w < nvec; w += VOTE_THREADS) {
+            uint4 acc = src[w];
+            for (int q = 1; q < H.nparts; q++) {
+                const uint4 v = src[(size_t)q * (CELL_BYTES / 16) + w];
+                acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;  // packed 16-bit halves never carry (n < 65536)
             }
+            ((uint4 *)cells)[w] = acc;
         }
-        best = wave_max_u64(best);
-        if (lane == 0) wred[wv] = best;
         __syncthreads();
-        best = wred[0];
-        for (int q = 1; q < VOTE_WAVES; q++) best = wred[q] > best ? wred[q] : best;
-        const uint32_t vmax = (uint32_t)(best >> 32);
-        int ties = 0;
-        for (int col = wv; col < ncols; col += VOTE_WAVES) {
-            const int il = col / TJ, jl = col - il * TJ;
-            if (i0 + il >= i1 || j0 + jl >= j1) continue;
-            for (int kk = lane; kk < k1 - k0; kk += 64) ties += cell_read<WIDE>(cells, col * TKp + kk) == vmax;
-        }
-        ties = wave_sum_i32(ties);
-        if (lane == 0) wredi[wv] = ties;
-        __syncthreads();
-        if (tid == 0) {
-            int tsum = 0;
-            for (int q = 0; q < VOTE_WAVES; q++) tsum += wredi[q];
-            tile_best[tile] = best;
-            tile_ties[tile] = (uint32_t)tsum;
-        }
+        tile_epilogue<WIDE>(cells, wred, wredi, H, tile, flush ? grid_out : nullptr, tile_best, tile_ties);
         __syncthreads();
     }
 }
@@ -801,7 +889,7 @@ __global__ __launch_bounds__(1024) void k_collect_ties(const uint32_t *grid, uns
     if (threadIdx.x == 0) *count_out = running;
 }
 
-constexpr size_t VOTE_LDS_BYTES = CELL_BYTES + SURV_CAP * sizeof(Surv) + 16 * VOTE_WAVES + 32;
+constexpr size_t VOTE_LDS_BYTES = CELL_BYTES + 12 * VOTE_WAVES + 64;
 bool g_vote_attr_set = false;
 
 }  // namespace
@@ -874,26 +962,37 @@ int rcv_accumulate_3d(const double *xyz_m_dev, const void *radial_dm_dev, int ra
                                           (int)VOTE_LDS_BYTES));
         RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_vote<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                           (int)VOTE_LDS_BYTES));
+        RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_merge<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          (int)VOTE_LDS_BYTES));
+        RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_merge<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          (int)VOTE_LDS_BYTES));
         g_vote_attr_set = true;
     }
     if (radial_is_f64)
         hipLaunchKernelGGL(k_prep<double>, dim3(PREP_BLOCKS), dim3(PREP_THREADS), 0, st, xyz_m_dev,
-                           (const double *)radial_dm_dev, counts_dev, n_points, n_radii, cap, acc_unit_mm, P, ri, partials);
+                           (const double *)radial_dm_dev, counts_dev, n_points, n_radii, cap, acc_unit_mm, g_thr_dev, P, ri, partials);
     else
         hipLaunchKernelGGL(k_prep<float>, dim3(PREP_BLOCKS), dim3(PREP_THREADS), 0, st, xyz_m_dev,
-                           (const float *)radial_dm_dev, counts_dev, n_points, n_radii, cap, acc_unit_mm, P, ri, partials);
+                           (const float *)radial_dm_dev, counts_dev, n_points, n_radii, cap, acc_unit_mm, g_thr_dev, P, ri, partials);
     RCV_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_setup, dim3(1), dim3(1024), 0, st, partials, P, counts_dev, n_points, n_radii, cap, acc_unit_mm, 1,
                        hdr);
     RCV_LAUNCH_CHECK();
     const int vote_blocks = 512;  // 2 workgroups per CU (LDS-limited), tiles are strided over them
     const bool maybe_wide = cap >= 65536;
-    hipLaunchKernelGGL(k_vote<false>, dim3(vote_blocks), dim3(VOTE_THREADS), VOTE_LDS_BYTES, st, hdr, P, ri, cap, g_thr_dev,
+    unsigned char *replicas = (unsigned char *)(w + L.replicas);
+    hipLaunchKernelGGL(k_vote<false>, dim3(vote_blocks), dim3(VOTE_THREADS), VOTE_LDS_BYTES, st, hdr, P, cap, replicas,
                        tile_best, tile_ties, vote_grid_dev, (unsigned long long)vote_grid_cells);
     RCV_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_merge<false>, dim3(vote_blocks), dim3(VOTE_THREADS), VOTE_LDS_BYTES, st, hdr, replicas, tile_best,
+                       tile_ties, vote_grid_dev, (unsigned long long)vote_grid_cells);
+    RCV_LAUNCH_CHECK();
     if (maybe_wide) {
-        hipLaunchKernelGGL(k_vote<true>, dim3(vote_blocks), dim3(VOTE_THREADS), VOTE_LDS_BYTES, st, hdr, P, ri, cap,
-                           g_thr_dev, tile_best, tile_ties, vote_grid_dev, (unsigned long long)vote_grid_cells);
+        hipLaunchKernelGGL(k_vote<true>, dim3(vote_blocks), dim3(VOTE_THREADS), VOTE_LDS_BYTES, st, hdr, P, cap, replicas,
+                           tile_best, tile_ties, vote_grid_dev, (unsigned long long)vote_grid_cells);
+        RCV_LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_merge<true>, dim3(vote_blocks), dim3(VOTE_THREADS), VOTE_LDS_BYTES, st, hdr, replicas, tile_best,
+                           tile_ties, vote_grid_dev, (unsigned long long)vote_grid_cells);
         RCV_LAUNCH_CHECK();
     }
     hipLaunchKernelGGL(k_final, dim3(1), dim3(256), 0, st, hdr, tile_best, tile_ties, vote_grid_dev != nullptr ? 1 : 0,
