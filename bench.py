@@ -127,17 +127,15 @@ def main():
         rad = rad_pool[it].permute(1, 0, 2, 3)[:, :, None]
         return ids, rgb_pool[it], depth_pool[it], (seg, rad)
 
-    gathered = [torch.empty((B, G, 3), dtype=torch.float64, device="cuda") for _ in range(world)]
+    from rcvpose_amd import sharding
 
     def step_fn(step):
         ids, rgb, depth, inject = batch(step)
         pipe.process(rgb, depth, rmax, inject=inject)
         k = pipe.keypoints_tensor()
-        if world > 1:
-            dist.all_gather(gathered, k)  # the single collective of the path: 72 B per frame over xGMI
-            out = torch.stack(gathered).cpu()
-        else:
-            out = k.cpu()
+        # the single collective of the path: one RCCL all_gather of 72 B per frame over xGMI; the step's
+        # B*world frames come back in global frame order (frame f lives on rank f % world) on every rank
+        out = sharding.gather_keypoints(k, B * world).cpu()
         return ids, out
 
     def fence():
@@ -166,10 +164,10 @@ def main():
 
     # sanity of the last step on rank 0: recovered keypoints within one voxel of the truth
     ids, out = last
-    mine = out[rank] if world > 1 else out
-    err_vox = 0.0
+    mine = out[rank::world]
+    truth_vox = 0.0
     for i, fid in enumerate(ids):
-        err_vox = max(err_vox, float(np.abs(mine[i].numpy() - fr[fid]["keypoints_m"] * 1000).max() / 5.0))
+        truth_vox = max(truth_vox, float(np.abs(mine[i].numpy() - fr[fid]["keypoints_m"] * 1000).max() / 5.0))
 
     if rank == 0:
         conv_flop_step = prof["conv_flop_per_image_group"] * B * G
@@ -190,11 +188,20 @@ def main():
                          "kernel": "k_conv<%s> implicit-GEMM family, %d launches/forward, algorithmic 265.568 GFLOP per "
                                    "network forward" % (args.dtype, sum(1 for o in pipe.engine.ops if o["kind"] == 3)),
                          "fcn_conv_ms_per_step": prof["conv_ms"], "fcn_other_ms_per_step": prof["other_ms"]},
-            "parity": {"max_keypoint_error_voxels": err_vox},
+            "sanity": {"max_distance_to_true_keypoint_voxels": truth_vox},
         }
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(fr[0], rmax, args.cpu_seconds)
             line["speedup_vs_cpu_baseline"] = fps / line["cpu_baseline"]["value"]
+            # parity of the timed path against the oracle (the reference's algorithm) on the last step's first frame
+            from oracle import cpu_oracle
+
+            fid, worst = ids[0], 0.0
+            for k in range(G):
+                xyz, rl = cpu_oracle.seam(fr[fid]["seg"], fr[fid]["radial"][k], fr[fid]["depth"], rmax[k])
+                ref = cpu_oracle.accumulator_3d(xyz, rl, sparse=True)[0]
+                worst = max(worst, float(np.abs(mine[0, k].numpy() - ref).max() / 5.0))
+            line["parity"] = {"keypoints_vs_oracle_max_voxels": worst, "gate_voxels": 1.0, "frames_checked": 1}
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()

@@ -3,7 +3,7 @@
 Every tensor is drawn from its own numpy PCG64 stream keyed by (seed, crc32(state-dict key)),
 so the same state dict can be rebuilt bit-for-bit wherever numpy is available: in the golden
 generator (which loads it into the *reference* model, reference models/fcnresnet.py:48-119),
-in the CPU tests (oracle/fcn_torch.py) and on the GPU box (rcvpose_amd.models.fcnresnet).
+in the CPU tests (the torch-CPU restatement) and on the GPU box (rcvpose_amd.models.fcnresnet).
 
 The distributions are chosen so that activations stay O(1) through the 50 residual blocks
 ("Random-weight numerics"): He-scaled convolutions, non-trivial BN
