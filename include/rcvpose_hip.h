@@ -184,6 +184,8 @@ int rcv_fcn_debug_slot(rcv_fcn *h, const void *ws, int B, int g, int slot, float
  * profiled forward; used by bench.py for the roofline line.  Enable with rcv_fcn_set_profiling. */
 int rcv_fcn_set_profiling(rcv_fcn *h, int enable);
 int rcv_fcn_get_profile(rcv_fcn *h, double *conv_ms, double *other_ms, double *conv_flop);
+/* Per-op device times (ms) of the last profiled forward; ms_out has room for n_ops doubles. */
+int rcv_fcn_get_op_times(rcv_fcn *h, double *ms_out, int n_ops);
 
 #ifdef __cplusplus
 }

@@ -8,7 +8,8 @@
 //                    out[m, n] = act( sum_{tap,c} in[pixel(m) + tap, c] * w[n, tap, c] + bias[n] (+ res[m, n]) )
 //                    M = B*Hout*Wout pixels, N = Cout, K = KH*KW*(C0+C1).  The A operand is gathered on the
 //                    fly from one or two channel-concatenated sources (torch.cat is never materialised),
-//                    zero-filled at the borders, staged through XOR-swizzled LDS tiles with register
+//                    zero-filled at the borders, staged through XOR-swizzled LDS tiles (16-byte chunk ^= (row>>1)&7:
+//                    the 16 lanes of a ds_read_b128 group land on 16 distinct slots of the 256-byte bank row) with register
 //                    double-buffering (global loads of tile t+1 are in flight while tile t is multiplied).
 //                    T = __bf16 : v_mfma_f32_16x16x32_bf16, fp32 accumulate      (performance mode)
 //                    T = float  : v_mfma_f32_16x16x4_f32, exact fp32 fma chain   (parity mode, 1e-4 gate)
@@ -125,11 +126,11 @@ __global__ __launch_bounds__(256) void k_conv(const ConvParams p)
     {                                                                                                        \
         _Pragma("unroll") for (int q = 0; q < AR; q++) {                                                     \
             const int row_ = rowb + 32 * q;                                                                  \
-            *(uint4 *)(As + (buf) * BM * 128 + row_ * 128 + ((chunk ^ (row_ & 7)) << 4)) = ra[q];            \
+            *(uint4 *)(As + (buf) * BM * 128 + row_ * 128 + ((chunk ^ ((row_ >> 1) & 7)) << 4)) = ra[q];            \
         }                                                                                                    \
         _Pragma("unroll") for (int q = 0; q < BR; q++) {                                                     \
             const int row_ = rowb + 32 * q;                                                                  \
-            *(uint4 *)(Bs + (buf) * BN * 128 + row_ * 128 + ((chunk ^ (row_ & 7)) << 4)) = rb[q];            \
+            *(uint4 *)(Bs + (buf) * BN * 128 + row_ * 128 + ((chunk ^ ((row_ >> 1) & 7)) << 4)) = rb[q];            \
         }                                                                                                    \
     }
 
@@ -148,7 +149,7 @@ __global__ __launch_bounds__(256) void k_conv(const ConvParams p)
         if constexpr (sizeof(T) == 2) {                                                                      \
             _Pragma("unroll") for (int kk = 0; kk < 2; kk++) {                                               \
                 bf16x8 af[MT], bfr[NT];                                                                      \
-                const int ch = ((kk * 4 + kq) ^ (r16 & 7)) << 4;                                             \
+                const int ch = ((kk * 4 + kq) ^ ((r16 >> 1) & 7)) << 4;                                             \
                 _Pragma("unroll") for (int i = 0; i < MT; i++) af[i] = *(const bf16x8 *)(Ab + i * 16 * 128 + ch);  \
                 _Pragma("unroll") for (int j = 0; j < NT; j++) bfr[j] = *(const bf16x8 *)(Bb + j * 16 * 128 + ch); \
                 _Pragma("unroll") for (int i = 0; i < MT; i++)                                               \
@@ -158,7 +159,7 @@ __global__ __launch_bounds__(256) void k_conv(const ConvParams p)
         } else {                                                                                             \
             _Pragma("unroll") for (int ks = 0; ks < 8; ks++) {                                               \
                 float af[MT], bfr[NT];                                                                       \
-                const int ch = ((ks ^ (r16 & 7)) << 4) + kq * 4;                                             \
+                const int ch = ((ks ^ ((r16 >> 1) & 7)) << 4) + kq * 4;                                             \
                 _Pragma("unroll") for (int i = 0; i < MT; i++) af[i] = *(const float *)(Ab + i * 16 * 128 + ch);  \
                 _Pragma("unroll") for (int j = 0; j < NT; j++) bfr[j] = *(const float *)(Bb + j * 16 * 128 + ch); \
                 _Pragma("unroll") for (int i = 0; i < MT; i++)                                               \
@@ -184,27 +185,58 @@ __global__ __launch_bounds__(256) void k_conv(const ConvParams p)
 #undef RCV_STASH
 #undef RCV_COMPUTE
 
-    // epilogue: bias (+ residual) (+ ReLU), NHWC store.  C/D layout: col = lane & 15, row = (lane >> 4) * 4 + j
+    // epilogue: the accumulators (C/D layout: col = lane & 15, row = (lane >> 4) * 4 + e) go through LDS so that
+    // bias + residual + ReLU and the NHWC store run on whole 16-byte vectors of contiguous channels.
+    // Two rounds (one per wave row) keep the fp32 staging tile within the K-loop's LDS footprint.
     T *dst = (T *)p.dst + (long long)g * p.dst_gs;
     const T *res = p.res ? (const T *)p.res + (long long)g * p.res_gs : nullptr;
     const float *bias = p.bias + (long long)g * p.bias_gs;
+    constexpr int SROW = BN + 4;                 // padded fp32 row: the 4 row groups of a store hit disjoint banks
+    constexpr int CPR = BN / EPV;                // 16-byte output chunks per tile row
+    constexpr int CHUNKS = (BM / 2) * CPR;
+    float *stage = (float *)smem;
 #pragma unroll
-    for (int j = 0; j < NT; j++) {
-        const int n = n0 + wn * (BN / 2) + j * 16 + r16;
-        const float bv = bias[n];
+    for (int round = 0; round < 2; round++) {
+        __syncthreads();  // K loop (round 0) / previous round's readers are done with LDS
+        if (wm == round) {
 #pragma unroll
-        for (int i = 0; i < MT; i++) {
+            for (int j = 0; j < NT; j++) {
+                const int nl = wn * (BN / 2) + j * 16 + r16;
+                const float bv = bias[n0 + nl];
 #pragma unroll
-            for (int e = 0; e < 4; e++) {
-                const int m = m0 + wm * (BM / 2) + i * 16 + kq * 4 + e;
-                if (m < p.M) {
-                    float v = acc[i][j][e] + bv;
-                    const long long o = (long long)m * p.Cout + n;
-                    if (res) v += to_f32(res[o]);
-                    if (p.relu) v = fmaxf(v, 0.f);
-                    dst[o] = from_f32<T>(v);
-                }
+                for (int i = 0; i < MT; i++)
+#pragma unroll
+                    for (int e = 0; e < 4; e++) stage[(i * 16 + kq * 4 + e) * SROW + nl] = acc[i][j][e] + bv;
             }
+        }
+        __syncthreads();
+        for (int c = tid; c < CHUNKS; c += 256) {
+            const int row = c / CPR, cc = c - row * CPR;
+            const int m = m0 + round * (BM / 2) + row;
+            if (m >= p.M) continue;
+            const long long o = (long long)m * p.Cout + n0 + cc * EPV;
+            float v[EPV];
+            const float4 *sp4 = (const float4 *)(stage + row * SROW + cc * EPV);
+#pragma unroll
+            for (int q = 0; q < EPV / 4; q++) {
+                const float4 t = sp4[q];
+                v[q * 4 + 0] = t.x; v[q * 4 + 1] = t.y; v[q * 4 + 2] = t.z; v[q * 4 + 3] = t.w;
+            }
+            if (res) {
+                const uint4 rraw = *(const uint4 *)(res + o);
+                const T *rp = (const T *)&rraw;
+#pragma unroll
+                for (int q = 0; q < EPV; q++) v[q] += to_f32(rp[q]);
+            }
+            if (p.relu) {
+#pragma unroll
+                for (int q = 0; q < EPV; q++) v[q] = fmaxf(v[q], 0.f);
+            }
+            uint4 outv;
+            T *op = (T *)&outv;
+#pragma unroll
+            for (int q = 0; q < EPV; q++) op[q] = from_f32<T>(v[q]);
+            *(uint4 *)(dst + o) = outv;
         }
     }
 }
@@ -625,6 +657,18 @@ int rcv_fcn_set_profiling(rcv_fcn *h, int enable)
     if (!h) return RCV_E_INVALID;
     h->profiling = enable != 0;
     h->events_valid = false;
+    return RCV_OK;
+}
+
+int rcv_fcn_get_op_times(rcv_fcn *h, double *ms_out, int n_ops)
+{
+    if (!h || !ms_out || n_ops != (int)h->ops.size() || !h->events_valid) return RCV_E_INVALID;
+    for (size_t i = 0; i < h->ops.size(); i++) {
+        RCV_HIP_CHECK(hipEventSynchronize(h->events[2 * i + 1]));
+        float ms = 0.f;
+        RCV_HIP_CHECK(hipEventElapsedTime(&ms, h->events[2 * i], h->events[2 * i + 1]));
+        ms_out[i] = ms;
+    }
     return RCV_OK;
 }
 

@@ -307,6 +307,11 @@ class FcnEngine:
         _hip.check(self.lib.rcv_fcn_get_profile(self.handle, ctypes.byref(c), ctypes.byref(o), ctypes.byref(f)))
         return dict(conv_ms=c.value, other_ms=o.value, conv_flop_per_image_group=f.value)
 
+    def get_op_times(self):
+        arr = (ctypes.c_double * len(self.ops))()
+        _hip.check(self.lib.rcv_fcn_get_op_times(self.handle, arr, len(self.ops)))
+        return list(arr)
+
 
 def preprocess_rgb(rgb_u8):
     """uint8 [B,H,W,3] CUDA tensor -> normalised float32 [B,3,H,W] (reference AccumulatorSpace.py:140-151)."""
