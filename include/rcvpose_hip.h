@@ -110,6 +110,12 @@ int rcv_accumulate_3d(const double *xyz_m_dev, const void *radial_dm_dev, int ra
                       rcv_acc_result *result_dev, uint32_t *vote_grid_dev, size_t vote_grid_cells, void *ws,
                       size_t ws_bytes, void *stream);
 
+/* How rcv_accumulate_3d finds the arg-max when no vote_grid_dev is requested (process-wide setting):
+ *   0 (default): exact branch-and-bound peak search; the LDS rasteriser takes over when the search gives up
+ *   1: LDS rasteriser only (the full VoteMap is accumulated tile by tile in LDS).
+ * Both give the identical result (peak, tie count, first index in C order). */
+int rcv_set_vote_mode(int mode);
+
 /* argwhere(VoteMap_3D == peak) in C order over a grid produced by rcv_accumulate_3d
  * (AccumulatorSpace.py:406): writes up to cap flat indices (ascending) and the total count. */
 int rcv_collect_ties(const uint32_t *vote_grid_dev, int dim, uint32_t peak, int64_t *flat_idx_dev, int cap,

@@ -113,6 +113,12 @@ def accumulate_on_device(xyz_dev, radial_dev, counts_dev, n_cap, m_cap, workspac
     _hip.check(rc, "rcv_accumulate_3d")
 
 
+def set_vote_mode(mode):
+    """'auto' (default): exact branch-and-bound peak search with the LDS rasteriser as fallback;
+    'full': LDS rasteriser only.  Identical results; see rcv_set_vote_mode in include/rcvpose_hip.h."""
+    _hip.check(_hip.lib().rcv_set_vote_mode({"auto": 0, "full": 1}[mode]), "rcv_set_vote_mode")
+
+
 def _raise_like_reference(status):
     if status in (_hip.RCV_E_EMPTY, _hip.RCV_E_BADGRID):
         # the reference fails with numpy's ValueError here (AccumulatorSpace.py:390 / :401,406)

@@ -77,6 +77,7 @@ SYMBOLS = {
     "rcv_acc_workspace_bytes": (_sz, [_i]),
     "rcv_seam_compact": (_i, [_vp, _vp, _vp, _i, _i, ctypes.POINTER(_d), _f, _d, _i, _vp, _vp, _vp, _i, _vp, _sz, _vp]),
     "rcv_accumulate_3d": (_i, [_vp, _vp, _i, _vp, _i, _i, _d, _vp, _vp, _sz, _vp, _sz, _vp]),
+    "rcv_set_vote_mode": (_i, [_i]),
     "rcv_collect_ties": (_i, [_vp, _i, ctypes.c_uint32, _vp, _i, _vp, _vp]),
     "rcv_acc_debug_points": (_i, [_vp, _vp, _vp, _i, _vp]),
     "rcv_preprocess_rgb": (_i, [_vp, _i, _i, _i, _vp, _vp]),

@@ -31,7 +31,12 @@ namespace {
 
 constexpr int TABLE_N = 8192;          // largest integer radius (voxels) with a threshold pair
 constexpr int MAX_TILES = 1 << 17;
-constexpr int MAX_REPLICAS = 2048;     // workgroups that share a tile park their counters here (CELL_BYTES each)
+constexpr int MAX_REPLICAS = 2048;
+constexpr int BB_CAP = 1 << 19;         // candidate blocks per level of the branch-and-bound peak search
+constexpr int BB_ROOT = 64;            // edge (voxels) of the root blocks; 6 halvings down to single voxels
+constexpr int BB_LEVELS = 6;
+constexpr int BB_BEAM = 8;             // blocks per level followed by the greedy probe that seeds the lower bound
+constexpr int BB_THREADS = 1024;     // workgroups that share a tile park their counters here (CELL_BYTES each)
 constexpr int PREP_BLOCKS = 128;
 constexpr int PREP_THREADS = 256;
 constexpr int SEAM_PIX_PER_BLOCK = 1024;
@@ -56,6 +61,14 @@ struct alignas(16) AccHeader {
     int32_t nparts;   // every tile's point list is split over this many workgroups (load balance)
     int32_t status;
     uint32_t tile_counter;
+    // exact branch-and-bound peak search (k_bb_*): state shared by its level kernels
+    int32_t bb_enabled;      // 0: skip the search, the LDS rasteriser decides
+    int32_t bb_done;         // set by k_bb_final when the search produced the result (rasteriser is skipped)
+    int32_t bb_best;         // best exact vote count seen so far (lower bound of the peak)
+    int32_t bb_overflow;     // a candidate list ran out of room -> fall back
+    uint32_t bb_count[8];    // entries of the candidate list consumed by level l (count[0] = root blocks)
+    uint32_t pb_count[8];    // same for the greedy probe (beam of BB_BEAM blocks per level)
+    uint32_t sel_count[8];
 };
 
 struct PrepPartial {
@@ -64,7 +77,7 @@ struct PrepPartial {
 };
 
 struct Layout {
-    size_t header, partials, seam_counts, seam_offsets, tile_best, tile_ties, replicas, P, ri, total;
+    size_t header, partials, seam_counts, seam_offsets, tile_best, tile_ties, replicas, bb_lists, bb_probe, Q, P, ri, total;
 };
 
 Layout make_layout(int cap)
@@ -78,6 +91,9 @@ Layout make_layout(int cap)
     L.tile_best = o;     o += align_up(sizeof(uint64_t) * MAX_TILES, 256);
     L.tile_ties = o;     o += align_up(sizeof(uint32_t) * MAX_TILES, 256);
     L.replicas = o;      o += (size_t)MAX_REPLICAS * CELL_BYTES;
+    L.bb_lists = o;      o += (size_t)2 * BB_CAP * 16;
+    L.bb_probe = o;      o += 4096;  // probe lists: BB_BEAM selected blocks + their 8*BB_BEAM children, twice
+    L.Q = o;             o += align_up(sizeof(double) * 3 * (size_t)cap, 256);  // final voxel-space coordinates (SoA)
     L.P = o;             o += align_up(sizeof(double) * 5 * (size_t)cap, 256);  // x, y, z, T_lo, T_hi per point (SoA)
     L.ri = o;            o += align_up(sizeof(int32_t) * (size_t)cap, 256);
     L.total = o;
@@ -385,7 +401,7 @@ __device__ double pw_leaf(const double *a, int n)
 //   one thread per heap node finds its (offset, length) by walking down from the root, leaves are
 //   summed in parallel, inner nodes level by level; the chunk totals are then added sequentially.
 __global__ __launch_bounds__(1024) void k_setup(const PrepPartial *partials, const double *P, const int32_t *counts,
-                                                int n_arg, int m_arg, int cap, double unit, int grid_cells_ok,
+                                                int n_arg, int m_arg, int cap, double unit, int bb_enable,
                                                 AccHeader *hdr)
 {
     __shared__ double val[4][3][256];
@@ -495,8 +511,13 @@ __global__ __launch_bounds__(1024) void k_setup(const PrepPartial *partials, con
     // the central tiles see every point, the outer ones few: split each tile's point list over nparts
     // workgroups (their LDS counters are summed by k_merge) so that no work item dominates the makespan
     H.nparts = (int)max(1ll, min(8ll, (long long)MAX_REPLICAS / nt));
-    H.status = grid_cells_ok ? RCV_OK : RCV_OK;
+    H.status = RCV_OK;
     H.tile_counter = 0;
+    {
+        const long long nb = (D + BB_ROOT - 1) / BB_ROOT;
+        H.bb_enabled = bb_enable && nb * nb * nb <= BB_CAP;
+        H.bb_count[0] = (uint32_t)(nb * nb * nb);
+    }
     *hdr = H;
 }
 
@@ -679,7 +700,7 @@ __global__ __launch_bounds__(VOTE_THREADS) void k_vote(AccHeader *hdr, const dou
     int *s_tile_p = (int *)(smem + CELL_BYTES + 12 * VOTE_WAVES);
 
     const AccHeader H = *hdr;
-    if (H.status != RCV_OK || (int)H.wide != (int)WIDE) return;
+    if (H.status != RCV_OK || (int)H.wide != (int)WIDE || H.bb_done) return;
     const int D = H.dim, n = H.n, TI = H.TI, TJ = H.TJ, TK = H.TK, TKp = H.TKp;
     const int lane = lane_id(), wv = wave_id(), tid = threadIdx.x;
     const int ncols = TI * TJ;  // <= 128: two 64-column passes per point
@@ -786,7 +807,7 @@ __global__ __launch_bounds__(VOTE_THREADS) void k_merge(const AccHeader *hdr, co
     uint64_t *wred = (uint64_t *)(smem + CELL_BYTES);
     int *wredi = (int *)(smem + CELL_BYTES + 8 * VOTE_WAVES);
     const AccHeader H = *hdr;
-    if (H.status != RCV_OK || (int)H.wide != (int)WIDE || H.nparts <= 1) return;
+    if (H.status != RCV_OK || (int)H.wide != (int)WIDE || H.nparts <= 1 || H.bb_done) return;
     const int ncells = H.TI * H.TJ * H.TKp;
     const int nvec = ((WIDE ? ncells : ncells / 2) + 3) / 4;
     const bool flush = grid_out != nullptr && (unsigned long long)H.dim * H.dim * H.dim <= grid_cells;
@@ -806,12 +827,240 @@ __global__ __launch_bounds__(VOTE_THREADS) void k_merge(const AccHeader *hdr, co
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Exact branch-and-bound search of the arg-max (the common case: one sharp peak)
+//
+// The hot path only needs argwhere(VoteMap == VoteMap.max()) (AccumulatorSpace.py:406), not the map.
+// For an axis-aligned block of voxels, a point can vote inside it only if its shell can reach the
+// block: dmin^2 < T_hi and dmax^2 >= T_lo (box distances).  The number of such points is an UPPER bound
+// of every voxel count in the block; the exact count of one voxel of the block (its centre) is a LOWER
+// bound of the peak.  Blocks whose upper bound is below the best lower bound cannot hold a maximum
+// (nor a tie) and are dropped; the others are split in 8 down to single voxels, where the bound is the
+// exact reference predicate.  The voxel attaining the maximum is never dropped (its ancestors' bounds
+// are >= the peak >= every lower bound), so peak, tie count and first index are exact.  Cost: a few
+// 10^7 box tests instead of ~10^8.5 shell/column evaluations when the peak is sharp.  When it is not
+// (lists overflow, or nothing votes) the LDS rasteriser below decides; it is also the path that
+// produces the full grid.  All arithmetic is float64; the bound tests carry a 1e-12 relative slack.
+// ---------------------------------------------------------------------------------------------
+struct BBEntry {
+    uint16_t i, j, k, pad_;
+    int32_t ub, lb;
+};
+static_assert(sizeof(BBEntry) == 16, "BBEntry");
+
+__global__ __launch_bounds__(256) void k_bb_init(const AccHeader *hdr, const double *P, int cap, double *Q, BBEntry *roots)
+{
+    const AccHeader H = *hdr;
+    if (H.status != RCV_OK || !H.bb_enabled) return;
+    const int nb = (H.dim + BB_ROOT - 1) / BB_ROOT;
+    const int nroot = nb * nb * nb;
+    const int top = H.n > nroot ? H.n : nroot;
+    for (int t = blockIdx.x * 256 + threadIdx.x; t < top; t += gridDim.x * 256) {
+        if (t < H.n)  // fast_for sees xyz_mm - mean - zero_boundary (AccumulatorSpace.py:384-386,397)
+            for (int a = 0; a < 3; a++) Q[(size_t)a * cap + t] = (P[(size_t)a * cap + t] - H.mean[a]) - H.shift;
+        if (t < nroot) {
+            BBEntry e;
+            e.i = (uint16_t)((t / (nb * nb)) * BB_ROOT);
+            e.j = (uint16_t)(((t / nb) % nb) * BB_ROOT);
+            e.k = (uint16_t)((t % nb) * BB_ROOT);
+            e.pad_ = 0;
+            e.ub = 0x7FFFFFFF;
+            e.lb = 0;
+            roots[t] = e;
+        }
+    }
+}
+
+template <bool LAST>
+__global__ __launch_bounds__(BB_THREADS) void k_bb_level(AccHeader *hdr, const double *Q, const double *P, int cap,
+                                                         const BBEntry *in_list, const uint32_t *in_count, int in_cap,
+                                                         BBEntry *out_list, uint32_t *out_count, int out_cap, int level)
+{
+    __shared__ int red[BB_THREADS / 64][16];
+    __shared__ int s_skip;
+    const AccHeader H = *hdr;
+    if (H.status != RCV_OK || !H.bb_enabled) return;
+    const int D = H.dim, n = H.n;
+    const int S = BB_ROOT >> level, s = S >> 1;  // parent / child edge
+    const unsigned nin = min(*in_count, (uint32_t)in_cap);
+    const double *Qx = Q, *Qy = Q + (size_t)cap, *Qz = Q + 2 * (size_t)cap;
+    const double *Plo = P + 3 * (size_t)cap, *Phi = P + 4 * (size_t)cap;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    for (unsigned pi = blockIdx.x; pi < nin; pi += gridDim.x) {
+        const BBEntry e = in_list[pi];
+        __syncthreads();
+        if (tid == 0)  // one decision per workgroup (the bound moves while other workgroups run)
+            s_skip = e.ub < __hip_atomic_load(&hdr->bb_best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ||
+                     __hip_atomic_load(&hdr->bb_overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        if (s_skip) continue;
+        // the two halves of the parent along each axis: voxel range [lo, hi], centre voxel c
+        const int org[3] = {e.i, e.j, e.k};
+        double lo[3][2], hi[3][2], ce[3][2];
+        bool ok[3][2];
+#pragma unroll
+        for (int a = 0; a < 3; a++)
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const int l = org[a] + h * s, u = min(l + s - 1, D - 1);
+                ok[a][h] = l <= D - 1;
+                lo[a][h] = (double)l;
+                hi[a][h] = (double)u;
+                ce[a][h] = (double)min(l + s / 2, D - 1);
+            }
+        int ub[8], lb[8];
+#pragma unroll
+        for (int c = 0; c < 8; c++) { ub[c] = 0; lb[c] = 0; }
+        for (int p = tid; p < n; p += BB_THREADS) {
+            const double thi = Phi[p];
+            if (!(thi > 0.0)) continue;
+            const double tlo = Plo[p];
+            const double q[3] = {Qx[p], Qy[p], Qz[p]};
+            double mn2[3][2], mx2[3][2], c2[3][2];
+#pragma unroll
+            for (int a = 0; a < 3; a++)
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    const double dc = ce[a][h] - q[a];  // (i - x), reference operand order (:337)
+                    c2[a][h] = dc * dc;
+                    if (!LAST) {
+                        const double e1 = lo[a][h] - q[a], e2 = q[a] - hi[a][h];
+                        const double dmin = fmax(fmax(e1, e2), 0.0), dmax = fmax(fabs(e1), fabs(e2));
+                        mn2[a][h] = dmin * dmin;
+                        mx2[a][h] = dmax * dmax;
+                    }
+                }
+#pragma unroll
+            for (int c = 0; c < 8; c++) {
+                const int hx = (c >> 2) & 1, hy = (c >> 1) & 1, hz = c & 1;
+                const double d2 = (c2[0][hx] + c2[1][hy]) + c2[2][hz];  // exact reference d2 of the centre voxel
+                const bool v = d2 >= tlo && d2 < thi;
+                lb[c] += v;
+                if (!LAST) {
+                    const double smin = (mn2[0][hx] + mn2[1][hy]) + mn2[2][hz];
+                    const double smax = (mx2[0][hx] + mx2[1][hy]) + mx2[2][hz];
+                    ub[c] += (smin * (1.0 - 1e-12) < thi) && (smax * (1.0 + 1e-12) >= tlo);
+                }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 8; c++) {
+            const int u = wave_sum_i32(LAST ? lb[c] : ub[c]), l = wave_sum_i32(lb[c]);
+            if (lane == 0) { red[wv][c] = u; red[wv][8 + c] = l; }
+        }
+        __syncthreads();
+        if (tid < 8) {
+            const int c = tid, hx = (c >> 2) & 1, hy = (c >> 1) & 1, hz = c & 1;
+            int u = 0, l = 0;
+            for (int w = 0; w < BB_THREADS / 64; w++) { u += red[w][c]; l += red[w][8 + c]; }
+            if (ok[0][hx] && ok[1][hy] && ok[2][hz]) {
+                const int prev = atomicMax(&hdr->bb_best, l);
+                const int best = max(prev, l);
+                if (u > 0 && u >= best) {
+                    const unsigned slot = atomicAdd(out_count, 1u);
+                    if (slot < (unsigned)out_cap) {
+                        BBEntry o;
+                        o.i = (uint16_t)(org[0] + hx * s); o.j = (uint16_t)(org[1] + hy * s); o.k = (uint16_t)(org[2] + hz * s);
+                        o.pad_ = 0; o.ub = u; o.lb = l;
+                        out_list[slot] = o;
+                    } else {
+                        atomicExch(&hdr->bb_overflow, 1);
+                    }
+                }
+            }
+        }
+    }
+}
+
+// the BB_BEAM entries with the largest upper bound (ties: larger lower bound), for the greedy probe
+__global__ __launch_bounds__(1024) void k_bb_topk(const AccHeader *hdr, const BBEntry *list, const uint32_t *count, int cap,
+                                                  BBEntry *sel, uint32_t *sel_count)
+{
+    __shared__ unsigned long long s_key[16];
+    __shared__ unsigned long long s_taken[BB_BEAM];
+    const AccHeader H = *hdr;
+    if (H.status != RCV_OK || !H.bb_enabled) return;
+    const uint32_t n = min(*count, (uint32_t)cap);
+    const int tid = threadIdx.x;
+    int picked = 0;
+    for (int round = 0; round < BB_BEAM && round < (int)n; round++) {
+        unsigned long long best = 0;
+        for (uint32_t t = tid; t < n; t += 1024) {
+            const BBEntry e = list[t];
+            // key: ub (31 bits) | lb (clamped to 12 bits) | index (20 bits) + 1 so that 0 means "none"
+            unsigned long long key = ((unsigned long long)(uint32_t)min(e.ub, 0x7FFFFFFF) << 32) |
+                                     ((unsigned long long)min(e.lb, 4095) << 20) | (unsigned long long)(t & 0xFFFFF);
+            bool taken = false;
+            for (int q = 0; q < round; q++) taken |= s_taken[q] == key;
+            if (!taken && key + 1 > best) best = key + 1;
+        }
+        best = wave_max_u64(best);
+        if (lane_id() == 0) s_key[wave_id()] = best;
+        __syncthreads();
+        if (tid == 0) {
+            unsigned long long b = 0;
+            for (int w = 0; w < 16; w++) b = s_key[w] > b ? s_key[w] : b;
+            s_taken[round] = b ? b - 1 : ~0ull;
+            if (b) sel[round] = list[(uint32_t)((b - 1) & 0xFFFFF)];
+        }
+        __syncthreads();
+        if (s_taken[round] != ~0ull) picked = round + 1;
+    }
+    if (tid == 0) *sel_count = (uint32_t)picked;
+}
+
+__global__ __launch_bounds__(1024) void k_bb_final(AccHeader *hdr, const BBEntry *voxels, rcv_acc_result *out)
+{
+    __shared__ uint32_t s_first[16];
+    __shared__ int s_ties[16];
+    const AccHeader H = *hdr;
+    if (H.status != RCV_OK || !H.bb_enabled || H.bb_overflow || H.bb_best <= 0) return;  // the rasteriser decides
+    const uint32_t nv = H.bb_count[BB_LEVELS];
+    if (nv == 0 || nv > (uint32_t)BB_CAP) return;
+    const int peak = H.bb_best;
+    const uint32_t D = (uint32_t)H.dim;
+    uint32_t first = 0xFFFFFFFFu;
+    int ties = 0;
+    for (uint32_t t = threadIdx.x; t < nv; t += 1024) {
+        const BBEntry e = voxels[t];
+        if (e.lb == peak) {
+            ties++;
+            const uint32_t flat = ((uint32_t)e.i * D + e.j) * D + e.k;
+            first = flat < first ? flat : first;
+        }
+    }
+    for (int m = 32; m; m >>= 1) { const uint32_t o = __shfl_xor(first, m); first = o < first ? o : first; }
+    ties = wave_sum_i32(ties);
+    if (lane_id() == 0) { s_first[wave_id()] = first; s_ties[wave_id()] = ties; }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    for (int w = 1; w < 16; w++) { first = s_first[w] < first ? s_first[w] : first; ties += s_ties[w]; }
+    if (ties <= 0) return;  // cannot happen (the peak voxel is in the list); leave it to the rasteriser
+    rcv_acc_result R;
+    memset(&R, 0, sizeof(R));
+    R.dim = H.dim; R.zero_boundary = H.zb; R.n_points = H.n; R.n_radii = H.m; R.status = RCV_OK;
+    R.radius_max = H.rmax;
+    const int idx[3] = {(int)(first / (D * D)), (int)((first / D) % D), (int)(first % D)};
+    for (int a = 0; a < 3; a++) {
+        R.mean_vox[a] = H.mean[a];
+        R.first_idx[a] = idx[a];
+        double c = (double)idx[a];
+        if (H.zb < 0) c = c + (double)H.zb;                 // center + zero_boundary, :409-410
+        R.center_mm[a] = ((c + H.mean[a]) + 0.5) * H.unit;  // (center + mean + 0.5) * acc_unit, :413-415
+    }
+    R.peak_votes = peak;
+    R.n_ties = ties;
+    *out = R;
+    hdr->bb_done = 1;
+}
+
 __global__ __launch_bounds__(256) void k_final(const AccHeader *hdr, const uint64_t *tile_best, const uint32_t *tile_ties,
                                                int grid_given, unsigned long long grid_cells, rcv_acc_result *out)
 {
     __shared__ uint64_t sb[4];
     __shared__ unsigned long long st[4];
     const AccHeader H = *hdr;
+    if (H.bb_done) return;  // k_bb_final already wrote the result
     rcv_acc_result R;
     memset(&R, 0, sizeof(R));
     R.dim = H.dim; R.zero_boundary = H.zb; R.n_points = H.n; R.n_radii = H.m; R.status = H.status;
@@ -889,6 +1138,7 @@ __global__ __launch_bounds__(1024) void k_collect_ties(const uint32_t *grid, uns
     if (threadIdx.x == 0) *count_out = running;
 }
 
+int g_vote_mode = 0;  // 0: exact peak search first, rasteriser as fallback; 1: rasteriser only
 constexpr size_t VOTE_LDS_BYTES = CELL_BYTES + 12 * VOTE_WAVES + 64;
 bool g_vote_attr_set = false;
 
@@ -975,9 +1225,52 @@ int rcv_accumulate_3d(const double *xyz_m_dev, const void *radial_dm_dev, int ra
         hipLaunchKernelGGL(k_prep<float>, dim3(PREP_BLOCKS), dim3(PREP_THREADS), 0, st, xyz_m_dev,
                            (const float *)radial_dm_dev, counts_dev, n_points, n_radii, cap, acc_unit_mm, g_thr_dev, P, ri, partials);
     RCV_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_setup, dim3(1), dim3(1024), 0, st, partials, P, counts_dev, n_points, n_radii, cap, acc_unit_mm, 1,
-                       hdr);
+    // the exact peak search runs first unless the caller wants the full grid (or forced the rasteriser)
+    const int bb_enable = (g_vote_mode == 0 && vote_grid_dev == nullptr) ? 1 : 0;
+    hipLaunchKernelGGL(k_setup, dim3(1), dim3(1024), 0, st, partials, P, counts_dev, n_points, n_radii, cap, acc_unit_mm,
+                       bb_enable, hdr);
     RCV_LAUNCH_CHECK();
+    if (bb_enable) {
+        double *Q = (double *)(w + L.Q);
+        BBEntry *la = (BBEntry *)(w + L.bb_lists), *lb = la + BB_CAP;
+        hipLaunchKernelGGL(k_bb_init, dim3(256), dim3(256), 0, st, hdr, P, cap, Q, la);
+        RCV_LAUNCH_CHECK();
+        BBEntry *psel = (BBEntry *)(w + L.bb_probe), *pkids[2] = {psel + 16, psel + 16 + 8 * BB_BEAM};
+        auto level_launch = [&](int level, const BBEntry *in, const uint32_t *in_count, int in_cap, BBEntry *out,
+                                uint32_t *out_count, int out_cap, int grid) {
+            if (level == BB_LEVELS - 1)
+                hipLaunchKernelGGL(k_bb_level<true>, dim3(grid), dim3(BB_THREADS), 0, st, hdr, Q, P, cap, in, in_count, in_cap,
+                                   out, out_count, out_cap, level);
+            else
+                hipLaunchKernelGGL(k_bb_level<false>, dim3(grid), dim3(BB_THREADS), 0, st, hdr, Q, P, cap, in, in_count, in_cap,
+                                   out, out_count, out_cap, level);
+        };
+        // level 0 of the breadth-first search scores the 32-voxel blocks (children of the 64-voxel roots)
+        level_launch(0, la, &hdr->bb_count[0], BB_CAP, lb, &hdr->bb_count[1], BB_CAP, 512);
+        RCV_LAUNCH_CHECK();
+        // greedy probe: follow the BB_BEAM most promising blocks of each level down to voxels; the exact
+        // counts found there give the search a lower bound close to the peak before it widens
+        {
+            const BBEntry *src = lb;
+            const uint32_t *src_count = &hdr->bb_count[1];
+            int src_cap = BB_CAP;
+            for (int level = 1; level < BB_LEVELS; level++) {
+                hipLaunchKernelGGL(k_bb_topk, dim3(1), dim3(1024), 0, st, hdr, src, src_count, src_cap, psel, &hdr->sel_count[level]);
+                RCV_LAUNCH_CHECK();
+                BBEntry *kids = pkids[level & 1];
+                level_launch(level, psel, &hdr->sel_count[level], BB_BEAM, kids, &hdr->pb_count[level], 8 * BB_BEAM, BB_BEAM);
+                RCV_LAUNCH_CHECK();
+                src = kids; src_count = &hdr->pb_count[level]; src_cap = 8 * BB_BEAM;
+            }
+        }
+        for (int level = 1; level < BB_LEVELS; level++) {
+            BBEntry *in = (level & 1) ? lb : la, *out = (level & 1) ? la : lb;
+            level_launch(level, in, &hdr->bb_count[level], BB_CAP, out, &hdr->bb_count[level + 1], BB_CAP, 512);
+            RCV_LAUNCH_CHECK();
+        }
+        hipLaunchKernelGGL(k_bb_final, dim3(1), dim3(1024), 0, st, hdr, (BB_LEVELS & 1) ? lb : la, result_dev);
+        RCV_LAUNCH_CHECK();
+    }
     const int vote_blocks = 512;  // 2 workgroups per CU (LDS-limited), tiles are strided over them
     const bool maybe_wide = cap >= 65536;
     unsigned char *replicas = (unsigned char *)(w + L.replicas);
@@ -998,6 +1291,13 @@ int rcv_accumulate_3d(const double *xyz_m_dev, const void *radial_dm_dev, int ra
     hipLaunchKernelGGL(k_final, dim3(1), dim3(256), 0, st, hdr, tile_best, tile_ties, vote_grid_dev != nullptr ? 1 : 0,
                        (unsigned long long)vote_grid_cells, result_dev);
     RCV_LAUNCH_CHECK();
+    return RCV_OK;
+}
+
+int rcv_set_vote_mode(int mode)
+{
+    if (mode != 0 && mode != 1) return RCV_E_INVALID;
+    g_vote_mode = mode;
     return RCV_OK;
 }
 

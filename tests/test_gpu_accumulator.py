@@ -28,8 +28,13 @@ def test_golden_votes_and_centres(A, golden_dir, name):
     assert center.shape == g["center"].shape                          # every tie, C order
     assert np.array_equal(center, g["center"])                        # float64, bit-exact
     assert np.array_equal(xyz, g["xyz_m"]) and np.array_equal(rad, g["radial_dm"])  # inputs untouched
-    c2 = A.Accumulator_3D(xyz, rad)                                   # hot path (no grid in HBM)
-    assert np.array_equal(c2, g["center"])
+    for mode in ("auto", "full"):                                     # hot path (no grid in HBM), both arg-max engines
+        A.set_vote_mode(mode)
+        try:
+            c2 = A.Accumulator_3D(xyz, rad)
+        finally:
+            A.set_vote_mode("auto")
+        assert np.array_equal(c2, g["center"]), mode
 
 
 @pytest.mark.parametrize("name", ACC)
@@ -82,6 +87,25 @@ def test_random_clouds_vs_oracle(A, oracle, seed, n, spread, rmax, dtype):
     assert np.array_equal(votes, ref_votes)
     assert res.peak_votes == peak
     assert np.array_equal(center, ref_center)
+    _check_hot_path_modes(A, xyz, rad, ref_center, peak)
+
+
+def _check_hot_path_modes(A, xyz, rad, ref_center, peak):
+    """The two arg-max engines of the hot path (exact peak search / LDS rasteriser) against the oracle."""
+    import torch
+
+    n, m = len(xyz), len(rad)
+    xyz_d, rad_d = torch.from_numpy(np.ascontiguousarray(xyz)).cuda(), torch.from_numpy(np.ascontiguousarray(rad)).cuda()
+    ws = A.AccWorkspace(max(n, m))
+    for mode in ("auto", "full"):
+        A.set_vote_mode(mode)
+        try:
+            A.accumulate_on_device(xyz_d, rad_d, None, n, m, ws)
+            res = ws.read_result()
+        finally:
+            A.set_vote_mode("auto")
+        assert res.status == 0 and res.peak_votes == peak and res.n_ties == len(ref_center), (mode, res.peak_votes, res.n_ties)
+        assert np.array_equal(np.array(res.center_mm[:]), ref_center[0]), mode
 
 
 def test_full_size_frame_cloud(A, oracle):
@@ -96,6 +120,7 @@ def test_full_size_frame_cloud(A, oracle):
     assert res.dim == info.dim
     assert np.array_equal(votes, ref_votes)
     assert np.array_equal(center, ref_center)
+    _check_hot_path_modes(A, xyz, rad, ref_center, peak)
     assert np.abs(center[0] - f["keypoints_m"][0] * 1000).max() <= 15.0  # sanity vs the truth; parity is the line above
 
 

@@ -23,7 +23,9 @@ def main():
     ap.add_argument("--kp", type=int, default=0)
     ap.add_argument("--shape", default="lm")
     ap.add_argument("--unit", type=float, default=5.0)
+    ap.add_argument("--mode", default="auto", choices=["auto", "full"])
     args = ap.parse_args()
+    A.set_vote_mode(args.mode)
     f = synthetic.synthetic_frame(0, shape=args.shape)
     seg = torch.from_numpy(f["seg"]).cuda()
     rad = torch.from_numpy(f["radial"][args.kp]).cuda()
