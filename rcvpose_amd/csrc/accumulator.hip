@@ -450,6 +450,23 @@ __global__ __launch_bounds__(1024) void k_setup(const PrepPartial *partials, con
         }
         __syncthreads();
     }
+    // extrema of the per-block partials (k_prep), reduced by the first wave
+    __shared__ double s_ext[8];
+    if (t < 64) {
+        const double INF_ = __longlong_as_double(0x7FF0000000000000ll);
+        double v[8] = {INF_, INF_, INF_, -INF_, -INF_, -INF_, -INF_, 0.0};
+        for (int b = t; b < PREP_BLOCKS; b += 64) {
+            const PrepPartial pp = partials[b];
+            for (int a = 0; a < 3; a++) { v[a] = fmin(v[a], pp.mn[a]); v[3 + a] = fmax(v[3 + a], pp.mx[a]); }
+            v[6] = fmax(v[6], pp.rmax);
+            v[7] = fmax(v[7], pp.radius_overflow);
+        }
+        for (int q = 0; q < 8; q++) {
+            const double r = q < 3 ? wave_min(v[q]) : wave_max(v[q]);
+            if (t == 0) s_ext[q] = r;
+        }
+    }
+    __syncthreads();
     if (t != 0) return;
 
     AccHeader H;
@@ -462,12 +479,9 @@ __global__ __launch_bounds__(1024) void k_setup(const PrepPartial *partials, con
     }
     const double INF = __longlong_as_double(0x7FF0000000000000ll);
     double mn[3] = {INF, INF, INF}, mx[3] = {-INF, -INF, -INF}, rmax = -INF;
-    bool overflow = false;
-    for (int b = 0; b < PREP_BLOCKS; b++) {
-        for (int a = 0; a < 3; a++) { mn[a] = fmin(mn[a], partials[b].mn[a]); mx[a] = fmax(mx[a], partials[b].mx[a]); }
-        rmax = fmax(rmax, partials[b].rmax);
-        overflow |= partials[b].radius_overflow != 0.0;
-    }
+    for (int a = 0; a < 3; a++) { mn[a] = s_ext[a]; mx[a] = s_ext[3 + a]; }
+    rmax = s_ext[6];
+    const bool overflow = s_ext[7] != 0.0;
     double qmin = INF, qmax = -INF;
     for (int a = 0; a < 3; a++) {
         H.mean[a] = total[a] / (double)n;                 // np.mean: sum / count
@@ -871,13 +885,24 @@ __global__ __launch_bounds__(256) void k_bb_init(const AccHeader *hdr, const dou
     }
 }
 
-template <bool LAST>
-__global__ __launch_bounds__(BB_THREADS) void k_bb_level(AccHeader *hdr, const double *Q, const double *P, int cap,
-                                                         const BBEntry *in_list, const uint32_t *in_count, int in_cap,
-                                                         BBEntry *out_list, uint32_t *out_count, int out_cap, int level)
+// One level of the search: every surviving parent block is split in 8 children; a workgroup scores the
+// children of one parent against all points.
+//   upper bound  (levels above voxels): float32 box distances relative to the parent origin, widened by an
+//                absolute slack that covers the float32 rounding (so it never under-counts)
+//   lower bound  (WITH_LB: probe and voxel level): exact float64 reference predicate on the child's centre
+//                voxel; at the voxel level it IS the vote count.
+// Points that cannot reach the parent at all are compacted away first.  NT = 1024: one parent finishes fast
+// (few parents: latency matters).
+constexpr int BB_CHUNK = 4096;
+
+template <bool LAST, bool WITH_LB, int NT>
+__global__ __launch_bounds__(NT) void k_bb_level(AccHeader *hdr, const double *Q, const double *P, int cap,
+                                                 const BBEntry *in_list, const uint32_t *in_count, int in_cap,
+                                                 BBEntry *out_list, uint32_t *out_count, int out_cap, int level)
 {
-    __shared__ int red[BB_THREADS / 64][16];
-    __shared__ int s_skip;
+    __shared__ int red[NT / 64][16];
+    __shared__ int s_skip, s_cnt;
+    __shared__ int s_idx[BB_CHUNK];
     const AccHeader H = *hdr;
     if (H.status != RCV_OK || !H.bb_enabled) return;
     const int D = H.dim, n = H.n;
@@ -886,6 +911,7 @@ __global__ __launch_bounds__(BB_THREADS) void k_bb_level(AccHeader *hdr, const d
     const double *Qx = Q, *Qy = Q + (size_t)cap, *Qz = Q + 2 * (size_t)cap;
     const double *Plo = P + 3 * (size_t)cap, *Phi = P + 4 * (size_t)cap;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const float slack_k = 1.0e-6f * (float)(D + 2 * BB_ROOT);  // float32 rounding of coordinates up to D + block
     for (unsigned pi = blockIdx.x; pi < nin; pi += gridDim.x) {
         const BBEntry e = in_list[pi];
         __syncthreads();
@@ -894,52 +920,104 @@ __global__ __launch_bounds__(BB_THREADS) void k_bb_level(AccHeader *hdr, const d
                      __hip_atomic_load(&hdr->bb_overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();
         if (s_skip) continue;
-        // the two halves of the parent along each axis: voxel range [lo, hi], centre voxel c
         const int org[3] = {e.i, e.j, e.k};
-        double lo[3][2], hi[3][2], ce[3][2];
+        const double forg[3] = {(double)e.i, (double)e.j, (double)e.k};
+        // the two halves of the parent along each axis, relative to the parent origin: voxel range [lo, hi], centre c
+        float lo[3][2], hi[3][2];
+        double ce[3][2];
         bool ok[3][2];
+        float phi_[3];  // the parent's own upper corner (for the compaction test; its lower corner is 0)
 #pragma unroll
-        for (int a = 0; a < 3; a++)
+        for (int a = 0; a < 3; a++) {
 #pragma unroll
             for (int h = 0; h < 2; h++) {
                 const int l = org[a] + h * s, u = min(l + s - 1, D - 1);
                 ok[a][h] = l <= D - 1;
-                lo[a][h] = (double)l;
-                hi[a][h] = (double)u;
+                lo[a][h] = (float)(l - org[a]);
+                hi[a][h] = (float)(u - org[a]);
                 ce[a][h] = (double)min(l + s / 2, D - 1);
             }
+            phi_[a] = (float)(min(org[a] + S - 1, D - 1) - org[a]);
+        }
         int ub[8], lb[8];
 #pragma unroll
         for (int c = 0; c < 8; c++) { ub[c] = 0; lb[c] = 0; }
-        for (int p = tid; p < n; p += BB_THREADS) {
-            const double thi = Phi[p];
-            if (!(thi > 0.0)) continue;
-            const double tlo = Plo[p];
-            const double q[3] = {Qx[p], Qy[p], Qz[p]};
-            double mn2[3][2], mx2[3][2], c2[3][2];
+
+        for (int base = 0; base < n; base += BB_CHUNK) {
+            const int cend = min(base + BB_CHUNK, n);
+            __syncthreads();
+            if (tid == 0) s_cnt = 0;
+            __syncthreads();
+            // pass 1: points of this chunk whose shell can reach the parent block
+            for (int p0 = base + wv * 64; p0 < cend; p0 += NT) {
+                const int p = p0 + lane;
+                bool keep = false;
+                if (p < cend) {
+                    const float thi = (float)Phi[p] * (1.f + 1e-6f);
+                    if (thi > 0.f) {
+                        const float tlo = (float)Plo[p] * (1.f - 1e-6f);
+                        const float qr[3] = {(float)(Qx[p] - forg[0]), (float)(Qy[p] - forg[1]), (float)(Qz[p] - forg[2])};
+                        float smin = 0.f, smax = 0.f, asum = 0.f;
 #pragma unroll
-            for (int a = 0; a < 3; a++)
-#pragma unroll
-                for (int h = 0; h < 2; h++) {
-                    const double dc = ce[a][h] - q[a];  // (i - x), reference operand order (:337)
-                    c2[a][h] = dc * dc;
-                    if (!LAST) {
-                        const double e1 = lo[a][h] - q[a], e2 = q[a] - hi[a][h];
-                        const double dmin = fmax(fmax(e1, e2), 0.0), dmax = fmax(fabs(e1), fabs(e2));
-                        mn2[a][h] = dmin * dmin;
-                        mx2[a][h] = dmax * dmax;
+                        for (int a = 0; a < 3; a++) {
+                            const float e1 = -qr[a], e2 = qr[a] - phi_[a];
+                            const float dmin = fmaxf(fmaxf(e1, e2), 0.f), dmax = fmaxf(fabsf(e1), fabsf(e2));
+                            smin += dmin * dmin; smax += dmax * dmax; asum += dmax;
+                        }
+                        const float slack = slack_k * asum + 1e-5f;
+                        keep = (smin - slack < thi) && (smax + slack >= tlo);
                     }
                 }
-#pragma unroll
-            for (int c = 0; c < 8; c++) {
-                const int hx = (c >> 2) & 1, hy = (c >> 1) & 1, hz = c & 1;
-                const double d2 = (c2[0][hx] + c2[1][hy]) + c2[2][hz];  // exact reference d2 of the centre voxel
-                const bool v = d2 >= tlo && d2 < thi;
-                lb[c] += v;
+                const uint64_t m = __ballot(keep);
+                int wbase = 0;
+                if (lane == 0 && m) wbase = atomicAdd(&s_cnt, __popcll(m));
+                wbase = __shfl(wbase, 0);
+                if (keep) s_idx[wbase + __popcll(m & ((1ull << lane) - 1ull))] = p;
+            }
+            __syncthreads();
+            const int cnt = s_cnt;
+            // pass 2: the 8 children against the compacted points
+            for (int t = tid; t < cnt; t += NT) {
+                const int p = s_idx[t];
+                const double q[3] = {Qx[p], Qy[p], Qz[p]};
+                const double thi_d = Phi[p], tlo_d = Plo[p];
                 if (!LAST) {
-                    const double smin = (mn2[0][hx] + mn2[1][hy]) + mn2[2][hz];
-                    const double smax = (mx2[0][hx] + mx2[1][hy]) + mx2[2][hz];
-                    ub[c] += (smin * (1.0 - 1e-12) < thi) && (smax * (1.0 + 1e-12) >= tlo);
+                    const float thi = (float)thi_d * (1.f + 1e-6f), tlo = (float)tlo_d * (1.f - 1e-6f);
+                    float mn2[3][2], mx2[3][2], ax[3][2];
+#pragma unroll
+                    for (int a = 0; a < 3; a++) {
+                        const float qr = (float)(q[a] - forg[a]);
+#pragma unroll
+                        for (int h = 0; h < 2; h++) {
+                            const float e1 = lo[a][h] - qr, e2 = qr - hi[a][h];
+                            const float dmin = fmaxf(fmaxf(e1, e2), 0.f), dmax = fmaxf(fabsf(e1), fabsf(e2));
+                            mn2[a][h] = dmin * dmin; mx2[a][h] = dmax * dmax; ax[a][h] = dmax;
+                        }
+                    }
+#pragma unroll
+                    for (int c = 0; c < 8; c++) {
+                        const int hx = (c >> 2) & 1, hy = (c >> 1) & 1, hz = c & 1;
+                        const float smin = mn2[0][hx] + mn2[1][hy] + mn2[2][hz];
+                        const float smax = mx2[0][hx] + mx2[1][hy] + mx2[2][hz];
+                        const float slack = slack_k * (ax[0][hx] + ax[1][hy] + ax[2][hz]) + 1e-5f;
+                        ub[c] += (smin - slack < thi) && (smax + slack >= tlo);
+                    }
+                }
+                if (WITH_LB) {
+                    double c2[3][2];
+#pragma unroll
+                    for (int a = 0; a < 3; a++)
+#pragma unroll
+                        for (int h = 0; h < 2; h++) {
+                            const double dc = ce[a][h] - q[a];  // (i - x), reference operand order (:337)
+                            c2[a][h] = dc * dc;
+                        }
+#pragma unroll
+                    for (int c = 0; c < 8; c++) {
+                        const int hx = (c >> 2) & 1, hy = (c >> 1) & 1, hz = c & 1;
+                        const double d2 = (c2[0][hx] + c2[1][hy]) + c2[2][hz];  // exact reference d2 of the centre voxel
+                        lb[c] += d2 >= tlo_d && d2 < thi_d;
+                    }
                 }
             }
         }
@@ -952,16 +1030,137 @@ __global__ __launch_bounds__(BB_THREADS) void k_bb_level(AccHeader *hdr, const d
         if (tid < 8) {
             const int c = tid, hx = (c >> 2) & 1, hy = (c >> 1) & 1, hz = c & 1;
             int u = 0, l = 0;
-            for (int w = 0; w < BB_THREADS / 64; w++) { u += red[w][c]; l += red[w][8 + c]; }
+            for (int w = 0; w < NT / 64; w++) { u += red[w][c]; l += red[w][8 + c]; }
             if (ok[0][hx] && ok[1][hy] && ok[2][hz]) {
-                const int prev = atomicMax(&hdr->bb_best, l);
-                const int best = max(prev, l);
+                int best = __hip_atomic_load(&hdr->bb_best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (WITH_LB) best = max(atomicMax(&hdr->bb_best, l), l);
                 if (u > 0 && u >= best) {
                     const unsigned slot = atomicAdd(out_count, 1u);
                     if (slot < (unsigned)out_cap) {
                         BBEntry o;
                         o.i = (uint16_t)(org[0] + hx * s); o.j = (uint16_t)(org[1] + hy * s); o.k = (uint16_t)(org[2] + hz * s);
                         o.pad_ = 0; o.ub = u; o.lb = l;
+                        out_list[slot] = o;
+                    } else {
+                        atomicExch(&hdr->bb_overflow, 1);
+                    }
+                }
+            }
+        }
+    }
+}
+
+// Wide levels of the search (upper bounds only): one 256-thread workgroup per parent, the point list
+// streamed through LDS in float32 chunks (bulk coalesced loads, 8 points per thread per chunk), three
+// workgroups per CU.  Same conservative float32 box test as k_bb_level (absolute voxel coordinates).
+constexpr int BBW_THREADS = 256;
+constexpr int BBW_CHUNK = 2048;
+
+__global__ __launch_bounds__(BBW_THREADS) void k_bb_wide(AccHeader *hdr, const double *Q, const double *P, int cap,
+                                                         const BBEntry *in_list, const uint32_t *in_count, int in_cap,
+                                                         BBEntry *out_list, uint32_t *out_count, int out_cap, int level)
+{
+    __shared__ float sx[BBW_CHUNK], sy[BBW_CHUNK], sz[BBW_CHUNK], slo[BBW_CHUNK], shi[BBW_CHUNK];
+    __shared__ int red[BBW_THREADS / 64][8];
+    __shared__ int s_skip;
+    const AccHeader H = *hdr;
+    if (H.status != RCV_OK || !H.bb_enabled) return;
+    const int D = H.dim, n = H.n;
+    const int S = BB_ROOT >> level, s = S >> 1;
+    const unsigned nin = min(*in_count, (uint32_t)in_cap);
+    const double *Qx = Q, *Qy = Q + (size_t)cap, *Qz = Q + 2 * (size_t)cap;
+    const double *Plo = P + 3 * (size_t)cap, *Phi = P + 4 * (size_t)cap;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const float slack_k = 1.0e-6f * (float)(D + 2 * BB_ROOT);
+    constexpr int PT = BBW_CHUNK / BBW_THREADS;
+    for (unsigned pi = blockIdx.x; pi < nin; pi += gridDim.x) {
+        const BBEntry e = in_list[pi];
+        __syncthreads();
+        if (tid == 0)
+            s_skip = e.ub < __hip_atomic_load(&hdr->bb_best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ||
+                     __hip_atomic_load(&hdr->bb_overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        if (s_skip) continue;
+        const int org[3] = {e.i, e.j, e.k};
+        float lo[3][2], hi[3][2];
+        bool ok[3][2];
+#pragma unroll
+        for (int a = 0; a < 3; a++)
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const int l = org[a] + h * s, u = min(l + s - 1, D - 1);
+                ok[a][h] = l <= D - 1;
+                lo[a][h] = (float)l;
+                hi[a][h] = (float)u;
+            }
+        int ub[8];
+#pragma unroll
+        for (int c = 0; c < 8; c++) ub[c] = 0;
+        for (int base = 0; base < n; base += BBW_CHUNK) {
+            __syncthreads();
+            {
+                // all loads of the chunk are issued before any is consumed (no data-dependent branch in between)
+                double rx[PT], ry[PT], rz[PT], rl[PT], rh[PT];
+#pragma unroll
+                for (int t = 0; t < PT; t++) {
+                    const int p = min(base + t * BBW_THREADS + tid, n - 1);
+                    rx[t] = Qx[p]; ry[t] = Qy[p]; rz[t] = Qz[p]; rl[t] = Plo[p]; rh[t] = Phi[p];
+                }
+#pragma unroll
+                for (int t = 0; t < PT; t++) {
+                    const int li = t * BBW_THREADS + tid;
+                    const bool live = base + li < n && rh[t] > 0.0;
+                    sx[li] = (float)rx[t]; sy[li] = (float)ry[t]; sz[li] = (float)rz[t];
+                    slo[li] = (float)rl[t] * (1.f - 1e-6f);
+                    shi[li] = live ? (float)rh[t] * (1.f + 1e-6f) : -1.f;  // < 0: never counts
+                }
+            }
+            __syncthreads();
+#pragma unroll 1
+            for (int t = 0; t < PT; t++) {
+                const int li = t * BBW_THREADS + tid;
+                const float q[3] = {sx[li], sy[li], sz[li]};
+                const float tlo = slo[li], thi = shi[li];
+                float mn2[3][2], mx2[3][2], ax[3][2];
+#pragma unroll
+                for (int a = 0; a < 3; a++)
+#pragma unroll
+                    for (int h = 0; h < 2; h++) {
+                        const float e1 = lo[a][h] - q[a], e2 = q[a] - hi[a][h];
+                        const float dmin = fmaxf(fmaxf(e1, e2), 0.f), dmax = fmaxf(fabsf(e1), fabsf(e2));
+                        mn2[a][h] = dmin * dmin; mx2[a][h] = dmax * dmax; ax[a][h] = dmax;
+                    }
+#pragma unroll
+                for (int c = 0; c < 8; c++) {
+                    const int hx = (c >> 2) & 1, hy = (c >> 1) & 1, hz = c & 1;
+                    const float smin = mn2[0][hx] + mn2[1][hy] + mn2[2][hz];
+                    const float smax = mx2[0][hx] + mx2[1][hy] + mx2[2][hz];
+                    const float slack = slack_k * (ax[0][hx] + ax[1][hy] + ax[2][hz]) + 1e-5f;
+                    // (smin - slack < thi) && (smax + slack >= tlo) as sign bits: no compare -> SGPR -> select chain
+                    const int below = __float_as_int((smin - slack) - thi);      // negative  <=>  smin - slack < thi
+                    const int reach = ~__float_as_int((smax + slack) - tlo);     // sign set  <=>  smax + slack >= tlo
+                    ub[c] += (int)((unsigned)(below & reach) >> 31);
+                }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 8; c++) {
+            const int u = wave_sum_i32(ub[c]);
+            if (lane == 0) red[wv][c] = u;
+        }
+        __syncthreads();
+        if (tid < 8) {
+            const int c = tid, hx = (c >> 2) & 1, hy = (c >> 1) & 1, hz = c & 1;
+            int u = 0;
+            for (int w = 0; w < BBW_THREADS / 64; w++) u += red[w][c];
+            if (ok[0][hx] && ok[1][hy] && ok[2][hz]) {
+                const int best = __hip_atomic_load(&hdr->bb_best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (u > 0 && u >= best) {
+                    const unsigned slot = atomicAdd(out_count, 1u);
+                    if (slot < (unsigned)out_cap) {
+                        BBEntry o;
+                        o.i = (uint16_t)(org[0] + hx * s); o.j = (uint16_t)(org[1] + hy * s); o.k = (uint16_t)(org[2] + hz * s);
+                        o.pad_ = 0; o.ub = u; o.lb = 0;
                         out_list[slot] = o;
                     } else {
                         atomicExch(&hdr->bb_overflow, 1);
@@ -1236,17 +1435,20 @@ int rcv_accumulate_3d(const double *xyz_m_dev, const void *radial_dm_dev, int ra
         hipLaunchKernelGGL(k_bb_init, dim3(256), dim3(256), 0, st, hdr, P, cap, Q, la);
         RCV_LAUNCH_CHECK();
         BBEntry *psel = (BBEntry *)(w + L.bb_probe), *pkids[2] = {psel + 16, psel + 16 + 8 * BB_BEAM};
-        auto level_launch = [&](int level, const BBEntry *in, const uint32_t *in_count, int in_cap, BBEntry *out,
-                                uint32_t *out_count, int out_cap, int grid) {
-            if (level == BB_LEVELS - 1)
-                hipLaunchKernelGGL(k_bb_level<true>, dim3(grid), dim3(BB_THREADS), 0, st, hdr, Q, P, cap, in, in_count, in_cap,
-                                   out, out_count, out_cap, level);
-            else
-                hipLaunchKernelGGL(k_bb_level<false>, dim3(grid), dim3(BB_THREADS), 0, st, hdr, Q, P, cap, in, in_count, in_cap,
-                                   out, out_count, out_cap, level);
+        auto level_launch = [&](int level, bool with_lb, const BBEntry *in, const uint32_t *in_count, int in_cap,
+                                BBEntry *out, uint32_t *out_count, int out_cap, int grid) {
+#define RCV_BB_LAUNCH(LAST_, LB_) \
+    hipLaunchKernelGGL((k_bb_level<LAST_, LB_, 1024>), dim3(grid), dim3(1024), 0, st, hdr, Q, P, cap, in, in_count, in_cap, out, \
+                       out_count, out_cap, level)
+            if (level == BB_LEVELS - 1) RCV_BB_LAUNCH(true, true);
+            else if (with_lb) RCV_BB_LAUNCH(false, true);
+            else  // wide level, upper bounds only: LDS-streamed 256-thread workgroups
+                hipLaunchKernelGGL(k_bb_wide, dim3(2048), dim3(BBW_THREADS), 0, st, hdr, Q, P, cap, in, in_count, in_cap, out,
+                                   out_count, out_cap, level);
+#undef RCV_BB_LAUNCH
         };
         // level 0 of the breadth-first search scores the 32-voxel blocks (children of the 64-voxel roots)
-        level_launch(0, la, &hdr->bb_count[0], BB_CAP, lb, &hdr->bb_count[1], BB_CAP, 512);
+        level_launch(0, true, la, &hdr->bb_count[0], BB_CAP, lb, &hdr->bb_count[1], BB_CAP, 512);
         RCV_LAUNCH_CHECK();
         // greedy probe: follow the BB_BEAM most promising blocks of each level down to voxels; the exact
         // counts found there give the search a lower bound close to the peak before it widens
@@ -1258,14 +1460,15 @@ int rcv_accumulate_3d(const double *xyz_m_dev, const void *radial_dm_dev, int ra
                 hipLaunchKernelGGL(k_bb_topk, dim3(1), dim3(1024), 0, st, hdr, src, src_count, src_cap, psel, &hdr->sel_count[level]);
                 RCV_LAUNCH_CHECK();
                 BBEntry *kids = pkids[level & 1];
-                level_launch(level, psel, &hdr->sel_count[level], BB_BEAM, kids, &hdr->pb_count[level], 8 * BB_BEAM, BB_BEAM);
+                level_launch(level, true, psel, &hdr->sel_count[level], BB_BEAM, kids, &hdr->pb_count[level], 8 * BB_BEAM, BB_BEAM);
                 RCV_LAUNCH_CHECK();
                 src = kids; src_count = &hdr->pb_count[level]; src_cap = 8 * BB_BEAM;
             }
         }
         for (int level = 1; level < BB_LEVELS; level++) {
             BBEntry *in = (level & 1) ? lb : la, *out = (level & 1) ? la : lb;
-            level_launch(level, in, &hdr->bb_count[level], BB_CAP, out, &hdr->bb_count[level + 1], BB_CAP, 512);
+            // the probe has (normally) found the peak already: the wide levels only need upper bounds
+            level_launch(level, false, in, &hdr->bb_count[level], BB_CAP, out, &hdr->bb_count[level + 1], BB_CAP, 512);
             RCV_LAUNCH_CHECK();
         }
         hipLaunchKernelGGL(k_bb_final, dim3(1), dim3(1024), 0, st, hdr, (BB_LEVELS & 1) ? lb : la, result_dev);
