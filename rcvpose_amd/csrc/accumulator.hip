@@ -31,12 +31,11 @@ namespace {
 
 constexpr int TABLE_N = 8192;          // largest integer radius (voxels) with a threshold pair
 constexpr int MAX_TILES = 1 << 17;
-constexpr int MAX_REPLICAS = 2048;
+constexpr int MAX_REPLICAS = 2048;      // workgroups that share a tile park their counters here (CELL_BYTES each)
 constexpr int BB_CAP = 1 << 19;         // candidate blocks per level of the branch-and-bound peak search
 constexpr int BB_ROOT = 64;            // edge (voxels) of the root blocks; 6 halvings down to single voxels
 constexpr int BB_LEVELS = 6;
 constexpr int BB_BEAM = 8;             // blocks per level followed by the greedy probe that seeds the lower bound
-constexpr int BB_THREADS = 1024;     // workgroups that share a tile park their counters here (CELL_BYTES each)
 constexpr int PREP_BLOCKS = 128;
 constexpr int PREP_THREADS = 256;
 constexpr int SEAM_PIX_PER_BLOCK = 1024;
