@@ -99,11 +99,11 @@ __global__ __launch_bounds__(256) void k_conv(const ConvParams p)
         }
     }
 
-    uint4 ra[AR], rb[BR];
+    uint4 ra0[AR], rb0[BR], ra1[AR], rb1[BR];  // two register sets: global loads run two K tiles ahead
     int tap_r = 0, tap_s = 0, cg = 0;  // position of the next K chunk: tap (r, s) and concat channel
 
 // global -> registers for the next K chunk (A gathered with zero fill at the borders, B = weights)
-#define RCV_FETCH()                                                                                          \
+#define RCV_FETCH(RA, RB, LIVE)                                                                                        \
     {                                                                                                        \
         const T *src_;                                                                                       \
         int Cs_, c_;                                                                                         \
@@ -112,25 +112,28 @@ __global__ __launch_bounds__(256) void k_conv(const ConvParams p)
         _Pragma("unroll") for (int q = 0; q < AR; q++) {                                                     \
             const int hi_ = a_hi0[q] + tap_r, wi_ = a_wi0[q] + tap_s;                                        \
             uint4 v_ = make_uint4(0u, 0u, 0u, 0u);                                                           \
-            if ((unsigned)hi_ < (unsigned)p.Hin && (unsigned)wi_ < (unsigned)p.Win)                          \
+            if ((LIVE) && (unsigned)hi_ < (unsigned)p.Hin && (unsigned)wi_ < (unsigned)p.Win)                \
                 v_ = *(const uint4 *)(src_ + ((long long)(a_pix[q] + hi_ * p.Win + wi_) * Cs_ + c_ + chunk * EPV)); \
-            ra[q] = v_;                                                                                      \
+            RA[q] = v_;                                                                                      \
         }                                                                                                    \
-        _Pragma("unroll") for (int q = 0; q < BR; q++)                                                       \
-            rb[q] = *(const uint4 *)(wg + (long long)(n0 + rowb + 32 * q) * p.K + kcol_);                    \
+        _Pragma("unroll") for (int q = 0; q < BR; q++) {                                                     \
+            uint4 w_ = make_uint4(0u, 0u, 0u, 0u);                                                           \
+            if (LIVE) w_ = *(const uint4 *)(wg + (long long)(n0 + rowb + 32 * q) * p.K + kcol_);             \
+            RB[q] = w_;                                                                                      \
+        }                                                                                                    \
         cg += KE;                                                                                            \
         if (cg == Ctot) { cg = 0; if (++tap_s == p.KS) { tap_s = 0; ++tap_r; } }                             \
     }
 // registers -> XOR-swizzled LDS tile
-#define RCV_STASH(buf)                                                                                       \
+#define RCV_STASH(buf, RA, RB)                                                                                     \
     {                                                                                                        \
         _Pragma("unroll") for (int q = 0; q < AR; q++) {                                                     \
             const int row_ = rowb + 32 * q;                                                                  \
-            *(uint4 *)(As + (buf) * BM * 128 + row_ * 128 + ((chunk ^ ((row_ >> 1) & 7)) << 4)) = ra[q];            \
+            *(uint4 *)(As + (buf) * BM * 128 + row_ * 128 + ((chunk ^ ((row_ >> 1) & 7)) << 4)) = RA[q];            \
         }                                                                                                    \
         _Pragma("unroll") for (int q = 0; q < BR; q++) {                                                     \
             const int row_ = rowb + 32 * q;                                                                  \
-            *(uint4 *)(Bs + (buf) * BN * 128 + row_ * 128 + ((chunk ^ ((row_ >> 1) & 7)) << 4)) = rb[q];            \
+            *(uint4 *)(Bs + (buf) * BN * 128 + row_ * 128 + ((chunk ^ ((row_ >> 1) & 7)) << 4)) = RB[q];            \
         }                                                                                                    \
     }
 
@@ -170,17 +173,30 @@ __global__ __launch_bounds__(256) void k_conv(const ConvParams p)
     }
 
     const int nk = p.K / KE;
-    RCV_FETCH();
-    RCV_STASH(0);
+    // software pipeline, two tiles deep: while tile t is multiplied out of LDS, tile t+1 sits in one register
+    // set (stored to the other LDS buffer after the MFMAs) and the loads of tile t+2 are in flight in the other
+    RCV_FETCH(ra0, rb0, true);
+    RCV_FETCH(ra1, rb1, nk > 1);
+    RCV_STASH(0, ra0, rb0);
     __syncthreads();
-    for (int kt = 0; kt + 1 < nk; kt++) {
-        const int cur = kt & 1;
-        RCV_FETCH();            // global loads of the next tile fly during the MFMAs below
-        RCV_COMPUTE(cur);
-        RCV_STASH(cur ^ 1);
+    int kt = 0;
+    for (; kt + 2 <= nk - 1; kt += 2) {
+        RCV_FETCH(ra0, rb0, true);      // tile kt+2
+        RCV_COMPUTE(0);                 // tile kt
+        RCV_STASH(1, ra1, rb1);         // tile kt+1
+        __syncthreads();
+        RCV_FETCH(ra1, rb1, kt + 3 < nk);  // tile kt+3 (predicated off past the end)
+        RCV_COMPUTE(1);                 // tile kt+1
+        RCV_STASH(0, ra0, rb0);         // tile kt+2
         __syncthreads();
     }
-    RCV_COMPUTE((nk - 1) & 1);
+    // tail: kt is even; tiles kt (in LDS buffer 0) and possibly kt+1 (in register set 1) remain
+    RCV_COMPUTE(0);
+    if (kt + 1 < nk) {
+        RCV_STASH(1, ra1, rb1);
+        __syncthreads();
+        RCV_COMPUTE(1);
+    }
 #undef RCV_FETCH
 #undef RCV_STASH
 #undef RCV_COMPUTE
