@@ -110,6 +110,28 @@ int rcv_accumulate_3d(const double *xyz_m_dev, const void *radial_dm_dev, int ra
                       rcv_acc_result *result_dev, uint32_t *vote_grid_dev, size_t vote_grid_cells, void *ws,
                       size_t ws_bytes, void *stream);
 
+/*
+ * Batched forms: one launch sequence for n_frames x n_keypoints independent (frame, keypoint) items -- the
+ * per-frame loop body of estimate_6d_pose_lm (reference AccumulatorSpace.py:566-659) for a whole batch.
+ * Every buffer is given as base + frame * stride_frame + keypoint * stride_kp (bytes; stride 0 = shared,
+ * e.g. one depth map per frame, one max_radii_dm entry per keypoint).  Same results as the single-item calls.
+ */
+typedef struct rcv_strided {
+    void *ptr;
+    int64_t stride_frame;
+    int64_t stride_kp;
+} rcv_strided;
+
+/* rmax_dm: device float64 per item (max_radii_dm[k], AccumulatorSpace.py:540-549). */
+int rcv_seam_compact_batch(rcv_strided seg, rcv_strided radial, rcv_strided depth, int H, int W, const double K[4], float seg_thr,
+                           rcv_strided rmax_dm, int mode, rcv_strided xyz_m, rcv_strided radial_list, rcv_strided counts, int cap,
+                           rcv_strided ws, size_t ws_bytes, int n_frames, int n_keypoints, void *stream);
+/* counts (int32[2] per item, device) give the list lengths; cap bounds them.  radial lists are float32 unless
+ * radial_is_f64. */
+int rcv_accumulate_3d_batch(rcv_strided xyz_m, rcv_strided radial_dm, int radial_is_f64, rcv_strided counts, int cap,
+                            double acc_unit_mm, rcv_strided result, rcv_strided ws, size_t ws_bytes, int n_frames,
+                            int n_keypoints, void *stream);
+
 /* How rcv_accumulate_3d finds the arg-max when no vote_grid_dev is requested (process-wide setting):
  *   0 (default): exact branch-and-bound peak search; the LDS rasteriser takes over when the search gives up
  *   1: LDS rasteriser only (the full VoteMap is accumulated tile by tile in LDS).

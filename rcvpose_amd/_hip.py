@@ -26,6 +26,10 @@ OP_STEM, OP_MAXPOOL, OP_CONV, OP_UPSAMPLE2, OP_HEAD = 1, 2, 3, 4, 5
 SLOT_NONE, SLOT_INPUT, SLOT_OUTPUT = -1, -2, -3
 
 
+class Strided(ctypes.Structure):
+    _fields_ = [("ptr", ctypes.c_void_p), ("stride_frame", ctypes.c_int64), ("stride_kp", ctypes.c_int64)]
+
+
 class AccResult(ctypes.Structure):
     _fields_ = [
         ("center_mm", ctypes.c_double * 3),
@@ -78,6 +82,9 @@ SYMBOLS = {
     "rcv_seam_compact": (_i, [_vp, _vp, _vp, _i, _i, ctypes.POINTER(_d), _f, _d, _i, _vp, _vp, _vp, _i, _vp, _sz, _vp]),
     "rcv_accumulate_3d": (_i, [_vp, _vp, _i, _vp, _i, _i, _d, _vp, _vp, _sz, _vp, _sz, _vp]),
     "rcv_set_vote_mode": (_i, [_i]),
+    "rcv_seam_compact_batch": (_i, [Strided, Strided, Strided, _i, _i, ctypes.POINTER(_d), _f, Strided, _i, Strided, Strided,
+                                     Strided, _i, Strided, _sz, _i, _i, _vp]),
+    "rcv_accumulate_3d_batch": (_i, [Strided, Strided, _i, Strided, _i, _d, Strided, Strided, _sz, _i, _i, _vp]),
     "rcv_collect_ties": (_i, [_vp, _i, ctypes.c_uint32, _vp, _i, _vp, _vp]),
     "rcv_acc_debug_points": (_i, [_vp, _vp, _vp, _i, _vp]),
     "rcv_preprocess_rgb": (_i, [_vp, _i, _i, _i, _vp, _vp]),

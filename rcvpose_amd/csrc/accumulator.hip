@@ -23,6 +23,7 @@
 #include <string.h>
 
 #include <mutex>
+#include <type_traits>
 
 #include "common.hpp"
 
@@ -211,7 +212,7 @@ __device__ __forceinline__ void seam_flags(const float *seg, const float *rad, c
     }
 }
 
-__global__ __launch_bounds__(256) void k_seam_count(const float *seg, const float *rad, const uint16_t *depth, int HW,
+__device__ __forceinline__ void d_seam_count(const float *seg, const float *rad, const uint16_t *depth, int HW,
                                                     float thr, double rmax, int mode, int2 *blk_counts)
 {
     __shared__ int sp[4], sr[4];
@@ -233,7 +234,7 @@ __global__ __launch_bounds__(256) void k_seam_count(const float *seg, const floa
     if (threadIdx.x == 0) blk_counts[blockIdx.x] = make_int2(sp[0] + sp[1] + sp[2] + sp[3], sr[0] + sr[1] + sr[2] + sr[3]);
 }
 
-__global__ __launch_bounds__(1024) void k_seam_scan(const int2 *blk_counts, int nb, int2 *blk_offsets, int32_t *counts_out)
+__device__ __forceinline__ void d_seam_scan(const int2 *blk_counts, int nb, int2 *blk_offsets, int32_t *counts_out)
 {
     __shared__ int2 s[1024];
     const int t = threadIdx.x;
@@ -265,7 +266,7 @@ __global__ __launch_bounds__(1024) void k_seam_scan(const int2 *blk_counts, int 
     if (t == 1023) { counts_out[0] = s[t].x; counts_out[1] = s[t].y; }
 }
 
-__global__ __launch_bounds__(256) void k_seam_scatter(const float *seg, const float *rad, const uint16_t *depth, int HW,
+__device__ __forceinline__ void d_seam_scatter(const float *seg, const float *rad, const uint16_t *depth, int HW,
                                                       int W, double fx, double fy, double cx, double cy, float thr,
                                                       double rmax, int mode, const int2 *blk_offsets, double *xyz_m,
                                                       float *radial_list, int cap)
@@ -315,7 +316,7 @@ __global__ __launch_bounds__(256) void k_seam_scatter(const float *seg, const fl
 // prepare: voxel-space points, integer radii, per-block extrema  (AccumulatorSpace.py:376,388,332)
 // ---------------------------------------------------------------------------------------------
 template <typename RT>
-__global__ __launch_bounds__(PREP_THREADS) void k_prep(const double *xyz_m, const RT *radial, const int32_t *counts,
+__device__ __forceinline__ void d_prep(const double *xyz_m, const RT *radial, const int32_t *counts,
                                                        int n_arg, int m_arg, int cap, double unit, const double *thr,
                                                        double *P, int32_t *ri, PrepPartial *partials)
 {
@@ -399,7 +400,7 @@ __device__ double pw_leaf(const double *a, int n)
 //   running total in order.  Here a chunk's recursion tree is laid out as a binary heap (<= 255 nodes):
 //   one thread per heap node finds its (offset, length) by walking down from the root, leaves are
 //   summed in parallel, inner nodes level by level; the chunk totals are then added sequentially.
-__global__ __launch_bounds__(1024) void k_setup(const PrepPartial *partials, const double *P, const int32_t *counts,
+__device__ __forceinline__ void d_setup(const PrepPartial *partials, const double *P, const int32_t *counts,
                                                 int n_arg, int m_arg, int cap, double unit, int bb_enable,
                                                 AccHeader *hdr)
 {
@@ -702,7 +703,7 @@ __device__ __forceinline__ double readlane_f64(double v, int l)
 // lane, loads of the next batch already in flight) and rasterises the survivors one after the other, the
 // point broadcast to the wave with v_readlane, the lanes spread over the tile's (<= 128) columns.
 template <bool WIDE>
-__global__ __launch_bounds__(VOTE_THREADS) void k_vote(AccHeader *hdr, const double *P, int cap, unsigned char *replicas,
+__device__ __forceinline__ void d_vote(AccHeader *hdr, const double *P, int cap, unsigned char *replicas,
                                                        uint64_t *tile_best, uint32_t *tile_ties, uint32_t *grid_out,
                                                        unsigned long long grid_cells)
 {
@@ -811,7 +812,7 @@ __global__ __launch_bounds__(VOTE_THREADS) void k_vote(AccHeader *hdr, const dou
 
 // sums the nparts LDS images of every tile and takes its arg-max (only launched work when nparts > 1)
 template <bool WIDE>
-__global__ __launch_bounds__(VOTE_THREADS) void k_merge(const AccHeader *hdr, const unsigned char *replicas,
+__device__ __forceinline__ void d_merge(const AccHeader *hdr, const unsigned char *replicas,
                                                         uint64_t *tile_best, uint32_t *tile_ties, uint32_t *grid_out,
                                                         unsigned long long grid_cells)
 {
@@ -861,7 +862,7 @@ struct BBEntry {
 };
 static_assert(sizeof(BBEntry) == 16, "BBEntry");
 
-__global__ __launch_bounds__(256) void k_bb_init(const AccHeader *hdr, const double *P, int cap, double *Q, BBEntry *roots)
+__device__ __forceinline__ void d_bb_init(const AccHeader *hdr, const double *P, int cap, double *Q, BBEntry *roots)
 {
     const AccHeader H = *hdr;
     if (H.status != RCV_OK || !H.bb_enabled) return;
@@ -895,7 +896,7 @@ __global__ __launch_bounds__(256) void k_bb_init(const AccHeader *hdr, const dou
 constexpr int BB_CHUNK = 4096;
 
 template <bool LAST, bool WITH_LB, int NT>
-__global__ __launch_bounds__(NT) void k_bb_level(AccHeader *hdr, const double *Q, const double *P, int cap,
+__device__ __forceinline__ void d_bb_level(AccHeader *hdr, const double *Q, const double *P, int cap,
                                                  const BBEntry *in_list, const uint32_t *in_count, int in_cap,
                                                  BBEntry *out_list, uint32_t *out_count, int out_cap, int level)
 {
@@ -1055,7 +1056,7 @@ __global__ __launch_bounds__(NT) void k_bb_level(AccHeader *hdr, const double *Q
 constexpr int BBW_THREADS = 256;
 constexpr int BBW_CHUNK = 2048;
 
-__global__ __launch_bounds__(BBW_THREADS) void k_bb_wide(AccHeader *hdr, const double *Q, const double *P, int cap,
+__device__ __forceinline__ void d_bb_wide(AccHeader *hdr, const double *Q, const double *P, int cap,
                                                          const BBEntry *in_list, const uint32_t *in_count, int in_cap,
                                                          BBEntry *out_list, uint32_t *out_count, int out_cap, int level)
 {
@@ -1171,7 +1172,7 @@ __global__ __launch_bounds__(BBW_THREADS) void k_bb_wide(AccHeader *hdr, const d
 }
 
 // the BB_BEAM entries with the largest upper bound (ties: larger lower bound), for the greedy probe
-__global__ __launch_bounds__(1024) void k_bb_topk(const AccHeader *hdr, const BBEntry *list, const uint32_t *count, int cap,
+__device__ __forceinline__ void d_bb_topk(const AccHeader *hdr, const BBEntry *list, const uint32_t *count, int cap,
                                                   BBEntry *sel, uint32_t *sel_count)
 {
     __shared__ unsigned long long s_key[16];
@@ -1207,7 +1208,7 @@ __global__ __launch_bounds__(1024) void k_bb_topk(const AccHeader *hdr, const BB
     if (tid == 0) *sel_count = (uint32_t)picked;
 }
 
-__global__ __launch_bounds__(1024) void k_bb_final(AccHeader *hdr, const BBEntry *voxels, rcv_acc_result *out)
+__device__ __forceinline__ void d_bb_final(AccHeader *hdr, const BBEntry *voxels, rcv_acc_result *out)
 {
     __shared__ uint32_t s_first[16];
     __shared__ int s_ties[16];
@@ -1252,7 +1253,7 @@ __global__ __launch_bounds__(1024) void k_bb_final(AccHeader *hdr, const BBEntry
     hdr->bb_done = 1;
 }
 
-__global__ __launch_bounds__(256) void k_final(const AccHeader *hdr, const uint64_t *tile_best, const uint32_t *tile_ties,
+__device__ __forceinline__ void d_final(const AccHeader *hdr, const uint64_t *tile_best, const uint32_t *tile_ties,
                                                int grid_given, unsigned long long grid_cells, rcv_acc_result *out)
 {
     __shared__ uint64_t sb[4];
@@ -1336,6 +1337,141 @@ __global__ __launch_bounds__(1024) void k_collect_ties(const uint32_t *grid, uns
     if (threadIdx.x == 0) *count_out = running;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Kernels.  Every launch covers a batch of independent (frame, keypoint) items: blockIdx.y = frame,
+// blockIdx.z = keypoint; each buffer is addressed as base + frame * stride_frame + keypoint * stride_kp
+// (stride 0 = shared, e.g. the depth map of a frame is shared by its keypoints).
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+struct SP {
+    T *p;
+    long long sb, sg;
+    __device__ __forceinline__ T *get() const
+    {
+        return p ? (T *)((char *)const_cast<typename std::remove_const<T>::type *>(p) + (long long)blockIdx.y * sb +
+                         (long long)blockIdx.z * sg)
+                 : nullptr;
+    }
+};
+
+__global__ __launch_bounds__(256) void k_seam_count(SP<const float> seg, SP<const float> rad, SP<const uint16_t> depth, int HW,
+                                                    float thr, SP<const double> rmax, double rmax_scalar, int mode,
+                                                    SP<unsigned char> ws, Layout L)
+{
+    d_seam_count(seg.get(), rad.get(), depth.get(), HW, thr, rmax.p ? *rmax.get() : rmax_scalar, mode,
+                 (int2 *)(ws.get() + L.seam_counts));
+}
+__global__ __launch_bounds__(1024) void k_seam_scan(int nb, SP<int32_t> counts, SP<unsigned char> ws, Layout L)
+{
+    unsigned char *w = ws.get();
+    d_seam_scan((const int2 *)(w + L.seam_counts), nb, (int2 *)(w + L.seam_offsets), counts.get());
+}
+__global__ __launch_bounds__(256) void k_seam_scatter(SP<const float> seg, SP<const float> rad, SP<const uint16_t> depth, int HW,
+                                                      int W, double fx, double fy, double cx, double cy, float thr,
+                                                      SP<const double> rmax, double rmax_scalar, int mode, SP<double> xyz,
+                                                      SP<float> radial_list, int cap, SP<unsigned char> ws, Layout L)
+{
+    d_seam_scatter(seg.get(), rad.get(), depth.get(), HW, W, fx, fy, cx, cy, thr, rmax.p ? *rmax.get() : rmax_scalar, mode,
+                   (const int2 *)(ws.get() + L.seam_offsets), xyz.get(), radial_list.get(), cap);
+}
+template <typename RT>
+__global__ __launch_bounds__(PREP_THREADS) void k_prep(SP<const double> xyz, SP<const RT> radial, SP<const int32_t> counts,
+                                                       int n_arg, int m_arg, int cap, double unit, const double *thr,
+                                                       SP<unsigned char> ws, Layout L)
+{
+    unsigned char *w = ws.get();
+    d_prep<RT>(xyz.get(), radial.get(), counts.get(), n_arg, m_arg, cap, unit, thr, (double *)(w + L.P), (int32_t *)(w + L.ri),
+               (PrepPartial *)(w + L.partials));
+}
+__global__ __launch_bounds__(1024) void k_setup(SP<const int32_t> counts, int n_arg, int m_arg, int cap, double unit,
+                                                int bb_enable, SP<unsigned char> ws, Layout L)
+{
+    unsigned char *w = ws.get();
+    d_setup((const PrepPartial *)(w + L.partials), (const double *)(w + L.P), counts.get(), n_arg, m_arg, cap, unit, bb_enable,
+            (AccHeader *)(w + L.header));
+}
+__global__ __launch_bounds__(256) void k_bb_init(int cap, SP<unsigned char> ws, Layout L)
+{
+    unsigned char *w = ws.get();
+    d_bb_init((const AccHeader *)(w + L.header), (const double *)(w + L.P), cap, (double *)(w + L.Q), (BBEntry *)(w + L.bb_lists));
+}
+// which candidate lists a level kernel reads / writes (all live in the item's workspace)
+struct BBIo {
+    int in_sel;      // 0: breadth-first list `level & 1`, 1: probe selection
+    int out_sel;     // 0: breadth-first list `(level + 1) & 1`, 1: probe children list `level & 1`
+};
+__device__ __forceinline__ void bb_resolve(unsigned char *w, const Layout &L, int level, BBIo io, const BBEntry *&in,
+                                           const uint32_t *&in_count, int &in_cap, BBEntry *&out, uint32_t *&out_count,
+                                           int &out_cap)
+{
+    AccHeader *hdr = (AccHeader *)(w + L.header);
+    BBEntry *la = (BBEntry *)(w + L.bb_lists), *lb = la + BB_CAP;
+    BBEntry *psel = (BBEntry *)(w + L.bb_probe);
+    BBEntry *pkids[2] = {psel + 16, psel + 16 + 8 * BB_BEAM};
+    if (io.in_sel) { in = psel; in_count = &hdr->sel_count[level]; in_cap = BB_BEAM; }
+    else { in = (level & 1) ? lb : la; in_count = &hdr->bb_count[level]; in_cap = BB_CAP; }
+    if (io.out_sel) { out = pkids[level & 1]; out_count = &hdr->pb_count[level]; out_cap = 8 * BB_BEAM; }
+    else { out = (level & 1) ? la : lb; out_count = &hdr->bb_count[level + 1]; out_cap = BB_CAP; }
+}
+template <bool LAST, bool WITH_LB, int NT>
+__global__ __launch_bounds__(NT) void k_bb_level(int cap, int level, BBIo io, SP<unsigned char> ws, Layout L)
+{
+    unsigned char *w = ws.get();
+    const BBEntry *in; const uint32_t *in_count; int in_cap; BBEntry *out; uint32_t *out_count; int out_cap;
+    bb_resolve(w, L, level, io, in, in_count, in_cap, out, out_count, out_cap);
+    d_bb_level<LAST, WITH_LB, NT>((AccHeader *)(w + L.header), (const double *)(w + L.Q), (const double *)(w + L.P), cap, in,
+                                  in_count, in_cap, out, out_count, out_cap, level);
+}
+__global__ __launch_bounds__(BBW_THREADS) void k_bb_wide(int cap, int level, SP<unsigned char> ws, Layout L)
+{
+    unsigned char *w = ws.get();
+    const BBEntry *in; const uint32_t *in_count; int in_cap; BBEntry *out; uint32_t *out_count; int out_cap;
+    bb_resolve(w, L, level, BBIo{0, 0}, in, in_count, in_cap, out, out_count, out_cap);
+    d_bb_wide((AccHeader *)(w + L.header), (const double *)(w + L.Q), (const double *)(w + L.P), cap, in, in_count, in_cap, out,
+              out_count, out_cap, level);
+}
+// probe selection before level `level`: from the breadth-first list (level 1) or the previous probe children
+__global__ __launch_bounds__(1024) void k_bb_topk(int level, SP<unsigned char> ws, Layout L)
+{
+    unsigned char *w = ws.get();
+    AccHeader *hdr = (AccHeader *)(w + L.header);
+    BBEntry *la = (BBEntry *)(w + L.bb_lists), *lb = la + BB_CAP;
+    BBEntry *psel = (BBEntry *)(w + L.bb_probe);
+    BBEntry *pkids[2] = {psel + 16, psel + 16 + 8 * BB_BEAM};
+    const BBEntry *src = level == 1 ? lb : pkids[(level - 1) & 1];
+    const uint32_t *src_count = level == 1 ? &hdr->bb_count[1] : &hdr->pb_count[level - 1];
+    d_bb_topk(hdr, src, src_count, level == 1 ? BB_CAP : 8 * BB_BEAM, psel, &hdr->sel_count[level]);
+}
+__global__ __launch_bounds__(1024) void k_bb_final(SP<rcv_acc_result> out, SP<unsigned char> ws, Layout L)
+{
+    unsigned char *w = ws.get();
+    BBEntry *la = (BBEntry *)(w + L.bb_lists), *lb = la + BB_CAP;
+    d_bb_final((AccHeader *)(w + L.header), (BB_LEVELS & 1) ? lb : la, out.get());
+}
+template <bool WIDE>
+__global__ __launch_bounds__(VOTE_THREADS) void k_vote(int cap, SP<uint32_t> grid, unsigned long long grid_cells,
+                                                       SP<unsigned char> ws, Layout L)
+{
+    unsigned char *w = ws.get();
+    d_vote<WIDE>((AccHeader *)(w + L.header), (const double *)(w + L.P), cap, w + L.replicas, (uint64_t *)(w + L.tile_best),
+                 (uint32_t *)(w + L.tile_ties), grid.get(), grid_cells);
+}
+template <bool WIDE>
+__global__ __launch_bounds__(VOTE_THREADS) void k_merge(SP<uint32_t> grid, unsigned long long grid_cells, SP<unsigned char> ws,
+                                                        Layout L)
+{
+    unsigned char *w = ws.get();
+    d_merge<WIDE>((const AccHeader *)(w + L.header), w + L.replicas, (uint64_t *)(w + L.tile_best), (uint32_t *)(w + L.tile_ties),
+                  grid.get(), grid_cells);
+}
+__global__ __launch_bounds__(256) void k_final(int grid_given, unsigned long long grid_cells, SP<rcv_acc_result> out,
+                                               SP<unsigned char> ws, Layout L)
+{
+    unsigned char *w = ws.get();
+    d_final((const AccHeader *)(w + L.header), (const uint64_t *)(w + L.tile_best), (const uint32_t *)(w + L.tile_ties), grid_given,
+            grid_cells, out.get());
+}
+
 int g_vote_mode = 0;  // 0: exact peak search first, rasteriser as fallback; 1: rasteriser only
 constexpr size_t VOTE_LDS_BYTES = CELL_BYTES + 12 * VOTE_WAVES + 64;
 bool g_vote_attr_set = false;
@@ -1355,32 +1491,150 @@ size_t rcv_acc_workspace_bytes(int max_points)
     return make_layout(max_points).total;
 }
 
+static int seam_batch(rcv_strided seg, rcv_strided rad, rcv_strided depth, int H, int W, const double K[4], float seg_thr,
+                      rcv_strided rmax, double rmax_scalar, int mode, rcv_strided xyz, rcv_strided rlist, rcv_strided counts,
+                      int cap, rcv_strided ws, size_t ws_bytes, int n_frames, int n_kp, void *stream)
+{
+    if (!depth.ptr || !K || !xyz.ptr || !counts.ptr || !ws.ptr) return RCV_E_INVALID;
+    if (mode < 0 || mode > 2) return RCV_E_INVALID;
+    if (mode != 2 && (!rad.ptr || !rlist.ptr)) return RCV_E_INVALID;
+    if (mode == 0 && !seg.ptr) return RCV_E_INVALID;
+    if (H <= 0 || W <= 0 || cap <= 0 || n_frames <= 0 || n_kp <= 0 || n_frames > 65535 || n_kp > 65535) return RCV_E_INVALID;
+    const long long HW = (long long)H * W;
+    const int nb = (int)((HW + SEAM_PIX_PER_BLOCK - 1) / SEAM_PIX_PER_BLOCK);
+    if (nb > SEAM_MAX_BLOCKS) return RCV_E_TOO_LARGE;
+    const Layout L = make_layout(cap);
+    if (ws_bytes < L.tile_best) return RCV_E_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    if (!seg.ptr) seg = rad;  // never dereferenced when mode != 0
+    const SP<const float> sseg{(const float *)seg.ptr, seg.stride_frame, seg.stride_kp};
+    const SP<const float> srad{(const float *)rad.ptr, rad.stride_frame, rad.stride_kp};
+    const SP<const uint16_t> sdep{(const uint16_t *)depth.ptr, depth.stride_frame, depth.stride_kp};
+    const SP<const double> srmax{(const double *)rmax.ptr, rmax.stride_frame, rmax.stride_kp};
+    const SP<unsigned char> sws{(unsigned char *)ws.ptr, ws.stride_frame, ws.stride_kp};
+    hipLaunchKernelGGL(k_seam_count, dim3(nb, n_frames, n_kp), dim3(256), 0, st, sseg, srad, sdep, (int)HW, seg_thr, srmax,
+                       rmax_scalar, mode, sws, L);
+    RCV_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_seam_scan, dim3(1, n_frames, n_kp), dim3(1024), 0, st, nb,
+                       SP<int32_t>{(int32_t *)counts.ptr, counts.stride_frame, counts.stride_kp}, sws, L);
+    RCV_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_seam_scatter, dim3(nb, n_frames, n_kp), dim3(256), 0, st, sseg, srad, sdep, (int)HW, W, K[0], K[1], K[2],
+                       K[3], seg_thr, srmax, rmax_scalar, mode, SP<double>{(double *)xyz.ptr, xyz.stride_frame, xyz.stride_kp},
+                       SP<float>{(float *)rlist.ptr, rlist.stride_frame, rlist.stride_kp}, cap, sws, L);
+    RCV_LAUNCH_CHECK();
+    return RCV_OK;
+}
+
+static int accumulate_batch(rcv_strided xyz, rcv_strided radial, int radial_is_f64, rcv_strided counts, int n_points, int n_radii,
+                            double acc_unit_mm, rcv_strided result, rcv_strided grid, size_t grid_cells, rcv_strided ws,
+                            size_t ws_bytes, int n_frames, int n_kp, void *stream)
+{
+    if (!result.ptr || !ws.ptr) return RCV_E_INVALID;
+    if (n_points < 0 || n_radii < 0 || !(acc_unit_mm > 0.0)) return RCV_E_INVALID;
+    if ((n_points > 0 && !xyz.ptr) || (n_radii > 0 && !radial.ptr)) return RCV_E_INVALID;
+    if (n_frames <= 0 || n_kp <= 0 || n_frames > 65535 || n_kp > 65535) return RCV_E_INVALID;
+    int rc = ensure_init();
+    if (rc != RCV_OK) return rc;
+    const int cap = n_points > n_radii ? (n_points > 0 ? n_points : 1) : (n_radii > 0 ? n_radii : 1);
+    const Layout L = make_layout(cap);
+    if (ws_bytes < L.total) return RCV_E_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    if (!g_vote_attr_set) {
+        RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_vote<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)VOTE_LDS_BYTES));
+        RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_vote<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)VOTE_LDS_BYTES));
+        RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_merge<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)VOTE_LDS_BYTES));
+        RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_merge<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)VOTE_LDS_BYTES));
+        g_vote_attr_set = true;
+    }
+    const SP<unsigned char> sws{(unsigned char *)ws.ptr, ws.stride_frame, ws.stride_kp};
+    const SP<const double> sxyz{(const double *)xyz.ptr, xyz.stride_frame, xyz.stride_kp};
+    const SP<const int32_t> scnt{(const int32_t *)counts.ptr, counts.stride_frame, counts.stride_kp};
+    const SP<rcv_acc_result> sres{(rcv_acc_result *)result.ptr, result.stride_frame, result.stride_kp};
+    const SP<uint32_t> sgrid{(uint32_t *)grid.ptr, grid.stride_frame, grid.stride_kp};
+    const dim3 items(1, n_frames, n_kp);
+    auto grid3 = [&](int x) { return dim3(x, n_frames, n_kp); };
+    if (radial_is_f64)
+        hipLaunchKernelGGL(k_prep<double>, grid3(PREP_BLOCKS), dim3(PREP_THREADS), 0, st, sxyz,
+                           SP<const double>{(const double *)radial.ptr, radial.stride_frame, radial.stride_kp}, scnt, n_points,
+                           n_radii, cap, acc_unit_mm, g_thr_dev, sws, L);
+    else
+        hipLaunchKernelGGL(k_prep<float>, grid3(PREP_BLOCKS), dim3(PREP_THREADS), 0, st, sxyz,
+                           SP<const float>{(const float *)radial.ptr, radial.stride_frame, radial.stride_kp}, scnt, n_points,
+                           n_radii, cap, acc_unit_mm, g_thr_dev, sws, L);
+    RCV_LAUNCH_CHECK();
+    // the exact peak search runs first unless the caller wants the full grid (or forced the rasteriser)
+    const int bb_enable = (g_vote_mode == 0 && grid.ptr == nullptr) ? 1 : 0;
+    hipLaunchKernelGGL(k_setup, items, dim3(1024), 0, st, scnt, n_points, n_radii, cap, acc_unit_mm, bb_enable, sws, L);
+    RCV_LAUNCH_CHECK();
+    const int n_items = n_frames * n_kp;
+    if (bb_enable) {
+        hipLaunchKernelGGL(k_bb_init, grid3(256), dim3(256), 0, st, cap, sws, L);
+        RCV_LAUNCH_CHECK();
+        // level 0 of the breadth-first search scores the 32-voxel blocks (children of the 64-voxel roots)
+        hipLaunchKernelGGL((k_bb_level<false, true, 1024>), grid3(512 / (n_items > 8 ? 8 : n_items) + 1), dim3(1024), 0, st, cap, 0,
+                           BBIo{0, 0}, sws, L);
+        RCV_LAUNCH_CHECK();
+        // greedy probe: follow the BB_BEAM most promising blocks of each level down to voxels; the exact
+        // counts found there give the search a lower bound close to the peak before it widens
+        for (int level = 1; level < BB_LEVELS; level++) {
+            hipLaunchKernelGGL(k_bb_topk, items, dim3(1024), 0, st, level, sws, L);
+            RCV_LAUNCH_CHECK();
+            if (level == BB_LEVELS - 1)
+                hipLaunchKernelGGL((k_bb_level<true, true, 1024>), grid3(BB_BEAM), dim3(1024), 0, st, cap, level, BBIo{1, 1}, sws, L);
+            else
+                hipLaunchKernelGGL((k_bb_level<false, true, 1024>), grid3(BB_BEAM), dim3(1024), 0, st, cap, level, BBIo{1, 1}, sws, L);
+            RCV_LAUNCH_CHECK();
+        }
+        // the probe has (normally) found the peak already: the wide levels only need upper bounds
+        const int wide_grid = n_items >= 8 ? 256 : 2048 / n_items;
+        for (int level = 1; level < BB_LEVELS - 1; level++) {
+            hipLaunchKernelGGL(k_bb_wide, grid3(wide_grid), dim3(BBW_THREADS), 0, st, cap, level, sws, L);
+            RCV_LAUNCH_CHECK();
+        }
+        hipLaunchKernelGGL((k_bb_level<true, true, 1024>), grid3(n_items >= 8 ? 64 : 512 / n_items), dim3(1024), 0, st, cap,
+                           BB_LEVELS - 1, BBIo{0, 0}, sws, L);
+        RCV_LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_bb_final, items, dim3(1024), 0, st, sres, sws, L);
+        RCV_LAUNCH_CHECK();
+    }
+    const int vote_blocks = n_items >= 4 ? 128 : 512 / n_items;  // work items are handed out by a per-item counter
+    const bool maybe_wide = cap >= 65536;
+    hipLaunchKernelGGL(k_vote<false>, grid3(vote_blocks), dim3(VOTE_THREADS), VOTE_LDS_BYTES, st, cap, sgrid,
+                       (unsigned long long)grid_cells, sws, L);
+    RCV_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_merge<false>, grid3(vote_blocks), dim3(VOTE_THREADS), VOTE_LDS_BYTES, st, sgrid,
+                       (unsigned long long)grid_cells, sws, L);
+    RCV_LAUNCH_CHECK();
+    if (maybe_wide) {
+        hipLaunchKernelGGL(k_vote<true>, grid3(vote_blocks), dim3(VOTE_THREADS), VOTE_LDS_BYTES, st, cap, sgrid,
+                           (unsigned long long)grid_cells, sws, L);
+        RCV_LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_merge<true>, grid3(vote_blocks), dim3(VOTE_THREADS), VOTE_LDS_BYTES, st, sgrid,
+                           (unsigned long long)grid_cells, sws, L);
+        RCV_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(k_final, items, dim3(256), 0, st, grid.ptr != nullptr ? 1 : 0, (unsigned long long)grid_cells, sres, sws, L);
+    RCV_LAUNCH_CHECK();
+    return RCV_OK;
+}
+
 int rcv_seam_compact(const float *seg_dev, const float *radial_dev, const uint16_t *depth_dev, int H, int W,
                      const double K[4], float seg_thr, double rmax_dm, int mode, double *xyz_m_dev,
                      float *radial_list_dev, int32_t *counts_dev, int cap, void *ws, size_t ws_bytes, void *stream)
 {
-    if (!depth_dev || !K || !xyz_m_dev || !counts_dev || !ws) return RCV_E_INVALID;
-    if (mode < 0 || mode > 2) return RCV_E_INVALID;
-    if (mode != 2 && (!radial_dev || !radial_list_dev)) return RCV_E_INVALID;
-    if (mode == 0 && !seg_dev) return RCV_E_INVALID;
-    if (H <= 0 || W <= 0 || cap <= 0) return RCV_E_INVALID;
-    const long long HW = (long long)H * W;
-    const int nb = (int)((HW + SEAM_PIX_PER_BLOCK - 1) / SEAM_PIX_PER_BLOCK);
-    if (nb > SEAM_MAX_BLOCKS) return RCV_E_TOO_LARGE;
-    const Layout L = make_layout(1);
-    if (ws_bytes < L.tile_best) return RCV_E_WORKSPACE;
-    hipStream_t st = (hipStream_t)stream;
-    int2 *cnt = (int2 *)((char *)ws + L.seam_counts), *off = (int2 *)((char *)ws + L.seam_offsets);
-    const float *seg = seg_dev ? seg_dev : radial_dev;  // never dereferenced when mode != 0
-    hipLaunchKernelGGL(k_seam_count, dim3(nb), dim3(256), 0, st, seg, radial_dev, depth_dev, (int)HW, seg_thr, rmax_dm,
-                       mode, cnt);
-    RCV_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_seam_scan, dim3(1), dim3(1024), 0, st, cnt, nb, off, counts_dev);
-    RCV_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_seam_scatter, dim3(nb), dim3(256), 0, st, seg, radial_dev, depth_dev, (int)HW, W, K[0], K[1],
-                       K[2], K[3], seg_thr, rmax_dm, mode, off, xyz_m_dev, radial_list_dev, cap);
-    RCV_LAUNCH_CHECK();
-    return RCV_OK;
+    const rcv_strided none{nullptr, 0, 0};
+    return seam_batch(rcv_strided{(void *)seg_dev, 0, 0}, rcv_strided{(void *)radial_dev, 0, 0}, rcv_strided{(void *)depth_dev, 0, 0}, H,
+                      W, K, seg_thr, none, rmax_dm, mode, rcv_strided{xyz_m_dev, 0, 0}, rcv_strided{radial_list_dev, 0, 0},
+                      rcv_strided{counts_dev, 0, 0}, cap, rcv_strided{ws, 0, 0}, ws_bytes, 1, 1, stream);
+}
+
+int rcv_seam_compact_batch(rcv_strided seg, rcv_strided radial, rcv_strided depth, int H, int W, const double K[4], float seg_thr,
+                           rcv_strided rmax_dm, int mode, rcv_strided xyz_m, rcv_strided radial_list, rcv_strided counts, int cap,
+                           rcv_strided ws, size_t ws_bytes, int n_frames, int n_keypoints, void *stream)
+{
+    if (!rmax_dm.ptr && mode != 2) return RCV_E_INVALID;
+    return seam_batch(seg, radial, depth, H, W, K, seg_thr, rmax_dm, 0.0, mode, xyz_m, radial_list, counts, cap, ws, ws_bytes,
+                      n_frames, n_keypoints, stream);
 }
 
 int rcv_accumulate_3d(const double *xyz_m_dev, const void *radial_dm_dev, int radial_is_f64,
@@ -1388,112 +1642,18 @@ int rcv_accumulate_3d(const double *xyz_m_dev, const void *radial_dm_dev, int ra
                       rcv_acc_result *result_dev, uint32_t *vote_grid_dev, size_t vote_grid_cells, void *ws,
                       size_t ws_bytes, void *stream)
 {
-    if (!result_dev || !ws) return RCV_E_INVALID;
-    if (n_points < 0 || n_radii < 0 || !(acc_unit_mm > 0.0)) return RCV_E_INVALID;
-    if ((n_points > 0 && !xyz_m_dev) || (n_radii > 0 && !radial_dm_dev)) return RCV_E_INVALID;
-    int rc = ensure_init();
-    if (rc != RCV_OK) return rc;
-    const int cap = n_points > n_radii ? (n_points > 0 ? n_points : 1) : (n_radii > 0 ? n_radii : 1);
-    const Layout L = make_layout(cap);
-    if (ws_bytes < L.total) return RCV_E_WORKSPACE;
-    hipStream_t st = (hipStream_t)stream;
-    char *w = (char *)ws;
-    AccHeader *hdr = (AccHeader *)(w + L.header);
-    PrepPartial *partials = (PrepPartial *)(w + L.partials);
-    double *P = (double *)(w + L.P);
-    int32_t *ri = (int32_t *)(w + L.ri);
-    uint64_t *tile_best = (uint64_t *)(w + L.tile_best);
-    uint32_t *tile_ties = (uint32_t *)(w + L.tile_ties);
+    return accumulate_batch(rcv_strided{(void *)xyz_m_dev, 0, 0}, rcv_strided{(void *)radial_dm_dev, 0, 0}, radial_is_f64,
+                            rcv_strided{(void *)counts_dev, 0, 0}, n_points, n_radii, acc_unit_mm, rcv_strided{result_dev, 0, 0},
+                            rcv_strided{vote_grid_dev, 0, 0}, vote_grid_cells, rcv_strided{ws, 0, 0}, ws_bytes, 1, 1, stream);
+}
 
-    if (!g_vote_attr_set) {
-        RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_vote<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                          (int)VOTE_LDS_BYTES));
-        RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_vote<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                          (int)VOTE_LDS_BYTES));
-        RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_merge<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                          (int)VOTE_LDS_BYTES));
-        RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_merge<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                          (int)VOTE_LDS_BYTES));
-        g_vote_attr_set = true;
-    }
-    if (radial_is_f64)
-        hipLaunchKernelGGL(k_prep<double>, dim3(PREP_BLOCKS), dim3(PREP_THREADS), 0, st, xyz_m_dev,
-                           (const double *)radial_dm_dev, counts_dev, n_points, n_radii, cap, acc_unit_mm, g_thr_dev, P, ri, partials);
-    else
-        hipLaunchKernelGGL(k_prep<float>, dim3(PREP_BLOCKS), dim3(PREP_THREADS), 0, st, xyz_m_dev,
-                           (const float *)radial_dm_dev, counts_dev, n_points, n_radii, cap, acc_unit_mm, g_thr_dev, P, ri, partials);
-    RCV_LAUNCH_CHECK();
-    // the exact peak search runs first unless the caller wants the full grid (or forced the rasteriser)
-    const int bb_enable = (g_vote_mode == 0 && vote_grid_dev == nullptr) ? 1 : 0;
-    hipLaunchKernelGGL(k_setup, dim3(1), dim3(1024), 0, st, partials, P, counts_dev, n_points, n_radii, cap, acc_unit_mm,
-                       bb_enable, hdr);
-    RCV_LAUNCH_CHECK();
-    if (bb_enable) {
-        double *Q = (double *)(w + L.Q);
-        BBEntry *la = (BBEntry *)(w + L.bb_lists), *lb = la + BB_CAP;
-        hipLaunchKernelGGL(k_bb_init, dim3(256), dim3(256), 0, st, hdr, P, cap, Q, la);
-        RCV_LAUNCH_CHECK();
-        BBEntry *psel = (BBEntry *)(w + L.bb_probe), *pkids[2] = {psel + 16, psel + 16 + 8 * BB_BEAM};
-        auto level_launch = [&](int level, bool with_lb, const BBEntry *in, const uint32_t *in_count, int in_cap,
-                                BBEntry *out, uint32_t *out_count, int out_cap, int grid) {
-#define RCV_BB_LAUNCH(LAST_, LB_) \
-    hipLaunchKernelGGL((k_bb_level<LAST_, LB_, 1024>), dim3(grid), dim3(1024), 0, st, hdr, Q, P, cap, in, in_count, in_cap, out, \
-                       out_count, out_cap, level)
-            if (level == BB_LEVELS - 1) RCV_BB_LAUNCH(true, true);
-            else if (with_lb) RCV_BB_LAUNCH(false, true);
-            else  // wide level, upper bounds only: LDS-streamed 256-thread workgroups
-                hipLaunchKernelGGL(k_bb_wide, dim3(2048), dim3(BBW_THREADS), 0, st, hdr, Q, P, cap, in, in_count, in_cap, out,
-                                   out_count, out_cap, level);
-#undef RCV_BB_LAUNCH
-        };
-        // level 0 of the breadth-first search scores the 32-voxel blocks (children of the 64-voxel roots)
-        level_launch(0, true, la, &hdr->bb_count[0], BB_CAP, lb, &hdr->bb_count[1], BB_CAP, 512);
-        RCV_LAUNCH_CHECK();
-        // greedy probe: follow the BB_BEAM most promising blocks of each level down to voxels; the exact
-        // counts found there give the search a lower bound close to the peak before it widens
-        {
-            const BBEntry *src = lb;
-            const uint32_t *src_count = &hdr->bb_count[1];
-            int src_cap = BB_CAP;
-            for (int level = 1; level < BB_LEVELS; level++) {
-                hipLaunchKernelGGL(k_bb_topk, dim3(1), dim3(1024), 0, st, hdr, src, src_count, src_cap, psel, &hdr->sel_count[level]);
-                RCV_LAUNCH_CHECK();
-                BBEntry *kids = pkids[level & 1];
-                level_launch(level, true, psel, &hdr->sel_count[level], BB_BEAM, kids, &hdr->pb_count[level], 8 * BB_BEAM, BB_BEAM);
-                RCV_LAUNCH_CHECK();
-                src = kids; src_count = &hdr->pb_count[level]; src_cap = 8 * BB_BEAM;
-            }
-        }
-        for (int level = 1; level < BB_LEVELS; level++) {
-            BBEntry *in = (level & 1) ? lb : la, *out = (level & 1) ? la : lb;
-            // the probe has (normally) found the peak already: the wide levels only need upper bounds
-            level_launch(level, false, in, &hdr->bb_count[level], BB_CAP, out, &hdr->bb_count[level + 1], BB_CAP, 512);
-            RCV_LAUNCH_CHECK();
-        }
-        hipLaunchKernelGGL(k_bb_final, dim3(1), dim3(1024), 0, st, hdr, (BB_LEVELS & 1) ? lb : la, result_dev);
-        RCV_LAUNCH_CHECK();
-    }
-    const int vote_blocks = 512;  // 2 workgroups per CU (LDS-limited), tiles are strided over them
-    const bool maybe_wide = cap >= 65536;
-    unsigned char *replicas = (unsigned char *)(w + L.replicas);
-    hipLaunchKernelGGL(k_vote<false>, dim3(vote_blocks), dim3(VOTE_THREADS), VOTE_LDS_BYTES, st, hdr, P, cap, replicas,
-                       tile_best, tile_ties, vote_grid_dev, (unsigned long long)vote_grid_cells);
-    RCV_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_merge<false>, dim3(vote_blocks), dim3(VOTE_THREADS), VOTE_LDS_BYTES, st, hdr, replicas, tile_best,
-                       tile_ties, vote_grid_dev, (unsigned long long)vote_grid_cells);
-    RCV_LAUNCH_CHECK();
-    if (maybe_wide) {
-        hipLaunchKernelGGL(k_vote<true>, dim3(vote_blocks), dim3(VOTE_THREADS), VOTE_LDS_BYTES, st, hdr, P, cap, replicas,
-                           tile_best, tile_ties, vote_grid_dev, (unsigned long long)vote_grid_cells);
-        RCV_LAUNCH_CHECK();
-        hipLaunchKernelGGL(k_merge<true>, dim3(vote_blocks), dim3(VOTE_THREADS), VOTE_LDS_BYTES, st, hdr, replicas, tile_best,
-                           tile_ties, vote_grid_dev, (unsigned long long)vote_grid_cells);
-        RCV_LAUNCH_CHECK();
-    }
-    hipLaunchKernelGGL(k_final, dim3(1), dim3(256), 0, st, hdr, tile_best, tile_ties, vote_grid_dev != nullptr ? 1 : 0,
-                       (unsigned long long)vote_grid_cells, result_dev);
-    RCV_LAUNCH_CHECK();
-    return RCV_OK;
+int rcv_accumulate_3d_batch(rcv_strided xyz_m, rcv_strided radial_dm, int radial_is_f64, rcv_strided counts, int cap,
+                            double acc_unit_mm, rcv_strided result, rcv_strided ws, size_t ws_bytes, int n_frames,
+                            int n_keypoints, void *stream)
+{
+    if (!counts.ptr) return RCV_E_INVALID;
+    return accumulate_batch(xyz_m, radial_dm, radial_is_f64, counts, cap, cap, acc_unit_mm, result, rcv_strided{nullptr, 0, 0}, 0, ws,
+                            ws_bytes, n_frames, n_keypoints, stream);
 }
 
 int rcv_set_vote_mode(int mode)

@@ -54,34 +54,33 @@ class FramePipeline:
                    "rcv_preprocess_rgb")
         self.engine.forward(self.x, out=(self.seg, self.radial))
 
+    def _strided(self, t, stride_frame, stride_kp):
+        return _hip.Strided(t.data_ptr(), int(stride_frame), int(stride_kp))
+
     def vote(self, depth_u16, max_radii_dm):
-        """depth_u16: [B,H,W] (int16 storage of uint16 mm); max_radii_dm: G floats.  Enqueues seam + voting."""
+        """depth_u16: [B,H,W] (int16 storage of uint16 mm); max_radii_dm: G floats.  Enqueues seam + voting for all
+        B*G (frame, keypoint) items as ONE batched launch sequence (item = blockIdx.y/z of every kernel)."""
         L, torch = self.lib, self.torch
-        cur = torch.cuda.current_stream()
-        lanes = [cur] + self.streams
-        if self.streams:
-            ev = torch.cuda.Event()
-            ev.record(cur)
-            for s in self.streams:
-                s.wait_event(ev)
-        item = 0
-        for b in range(self.B):
-            for g in range(self.G):
-                st = lanes[item % len(lanes)]
-                sp = ctypes.c_void_p(st.cuda_stream)
-                _hip.check(L.rcv_seam_compact(_hip.ptr(self.seg[g, b]), _hip.ptr(self.radial[g, b]), _hip.ptr(depth_u16[b]),
-                                              self.H, self.W, self.k4, float(A.SEG_THRESHOLD), float(max_radii_dm[g]), 0,
-                                              _hip.ptr(self.xyz[item]), _hip.ptr(self.rlist[item]), _hip.ptr(self.counts[item]),
-                                              self.cap, _hip.ptr(self.ws[item]), self.ws_bytes, sp), "rcv_seam_compact")
-                _hip.check(L.rcv_accumulate_3d(_hip.ptr(self.xyz[item]), _hip.ptr(self.rlist[item]), 0,
-                                               _hip.ptr(self.counts[item]), self.cap, self.cap, self.acc_unit,
-                                               _hip.ptr(self.results[item]), None, 0, _hip.ptr(self.ws[item]), self.ws_bytes,
-                                               sp), "rcv_accumulate_3d")
-                item += 1
-        for s in self.streams:
-            e = torch.cuda.Event()
-            e.record(s)
-            cur.wait_event(e)
+        B, G, HW = self.B, self.G, self.H * self.W
+        if not torch.is_tensor(max_radii_dm):
+            max_radii_dm = torch.tensor(np.asarray(max_radii_dm, dtype=np.float64), device=self.device)
+        self._rmax = max_radii_dm.to(torch.float64).contiguous()  # keep alive until the kernels ran
+        st = _hip.current_stream()
+        S = self._strided
+        item = lambda t, per: S(t, G * per, per)  # buffers indexed [frame * G + keypoint]
+        seg = S(self.seg, HW * 4, B * HW * 4)
+        rad = S(self.radial, HW * 4, B * HW * 4)
+        dep = S(depth_u16, HW * 2, 0)
+        rmx = S(self._rmax, 0, 8)
+        xyz = item(self.xyz, self.cap * 24)
+        rl = item(self.rlist, self.cap * 4)
+        cnt = item(self.counts, 8)
+        ws = item(self.ws, self.ws_bytes)
+        res = item(self.results, ctypes.sizeof(_hip.AccResult))
+        _hip.check(L.rcv_seam_compact_batch(seg, rad, dep, self.H, self.W, self.k4, float(A.SEG_THRESHOLD), rmx, 0, xyz, rl, cnt,
+                                            self.cap, ws, self.ws_bytes, B, G, st), "rcv_seam_compact_batch")
+        _hip.check(L.rcv_accumulate_3d_batch(xyz, rl, 0, cnt, self.cap, self.acc_unit, res, ws, self.ws_bytes, B, G, st),
+                   "rcv_accumulate_3d_batch")
 
     def read_results(self):
         """One D2H copy -> (estimated_kpts float64 [B,G,3] mm, list of AccResult)."""
