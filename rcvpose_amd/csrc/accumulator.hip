@@ -69,6 +69,7 @@ struct alignas(16) AccHeader {
     uint32_t bb_count[8];    // entries of the candidate list consumed by level l (count[0] = root blocks)
     uint32_t pb_count[8];    // same for the greedy probe (beam of BB_BEAM blocks per level)
     uint32_t sel_count[8];
+    unsigned long long bb_best_key;  // bb_best << 32 | flat index of a voxel attaining it (hill-climb start)
 };
 
 struct PrepPartial {
@@ -1033,7 +1034,12 @@ __device__ __forceinline__ void d_bb_level(AccHeader *hdr, const double *Q, cons
             for (int w = 0; w < NT / 64; w++) { u += red[w][c]; l += red[w][8 + c]; }
             if (ok[0][hx] && ok[1][hy] && ok[2][hz]) {
                 int best = __hip_atomic_load(&hdr->bb_best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (WITH_LB) best = max(atomicMax(&hdr->bb_best, l), l);
+                if (WITH_LB) {
+                    best = max(atomicMax(&hdr->bb_best, l), l);
+                    const unsigned long long flat = ((unsigned long long)ce[0][hx] * D + (unsigned long long)ce[1][hy]) * D +
+                                                    (unsigned long long)ce[2][hz];
+                    atomicMax(&hdr->bb_best_key, ((unsigned long long)l << 32) | flat);
+                }
                 if (u > 0 && u >= best) {
                     const unsigned slot = atomicAdd(out_count, 1u);
                     if (slot < (unsigned)out_cap) {
@@ -1168,6 +1174,45 @@ __device__ __forceinline__ void d_bb_wide(AccHeader *hdr, const double *Q, const
                 }
             }
         }
+    }
+}
+
+// Hill-climb on exact voxel counts around the best voxel found so far (5 x 5 x 5 neighbourhood, one workgroup
+// per voxel).  The greedy probe lands near the peak; a few rounds of this bring the lower bound to the peak
+// itself (or next to it), which is what lets the wide levels prune.  Purely an accelerator: any exact count
+// is a valid lower bound.
+constexpr int BB_CLIMB_R = 2;
+constexpr int BB_CLIMB_N = (2 * BB_CLIMB_R + 1) * (2 * BB_CLIMB_R + 1) * (2 * BB_CLIMB_R + 1);
+
+__device__ __forceinline__ void d_bb_climb(AccHeader *hdr, const double *Q, const double *P, int cap)
+{
+    __shared__ int red[4];
+    const AccHeader H = *hdr;
+    if (H.status != RCV_OK || !H.bb_enabled || H.bb_best_key == 0) return;
+    const int D = H.dim, n = H.n;
+    const unsigned long long flat = H.bb_best_key & 0xFFFFFFFFull;
+    const int w = 2 * BB_CLIMB_R + 1;
+    const int o = blockIdx.x;
+    const int ci = (int)(flat / ((unsigned long long)D * D)) + o / (w * w) - BB_CLIMB_R;
+    const int cj = (int)((flat / D) % D) + (o / w) % w - BB_CLIMB_R;
+    const int ck = (int)(flat % D) + o % w - BB_CLIMB_R;
+    if (ci < 0 || cj < 0 || ck < 0 || ci >= D || cj >= D || ck >= D) return;
+    const double fi = (double)ci, fj = (double)cj, fk = (double)ck;
+    const double *Qx = Q, *Qy = Q + (size_t)cap, *Qz = Q + 2 * (size_t)cap;
+    const double *Plo = P + 3 * (size_t)cap, *Phi = P + 4 * (size_t)cap;
+    int cnt = 0;
+    for (int p = threadIdx.x; p < n; p += 256) {
+        const double dx = fi - Qx[p], dy = fj - Qy[p], dz = fk - Qz[p];
+        const double d2 = (dx * dx + dy * dy) + dz * dz;  // reference operand order (:337)
+        cnt += d2 >= Plo[p] && d2 < Phi[p];
+    }
+    cnt = wave_sum_i32(cnt);
+    if (lane_id() == 0) red[wave_id()] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        cnt = red[0] + red[1] + red[2] + red[3];
+        atomicMax(&hdr->bb_best, cnt);
+        atomicMax(&hdr->bb_best_key, ((unsigned long long)cnt << 32) | (((unsigned long long)ci * D + cj) * D + ck));
     }
 }
 
@@ -1430,6 +1475,11 @@ __global__ __launch_bounds__(BBW_THREADS) void k_bb_wide(int cap, int level, SP<
     d_bb_wide((AccHeader *)(w + L.header), (const double *)(w + L.Q), (const double *)(w + L.P), cap, in, in_count, in_cap, out,
               out_count, out_cap, level);
 }
+__global__ __launch_bounds__(256) void k_bb_climb(int cap, SP<unsigned char> ws, Layout L)
+{
+    unsigned char *w = ws.get();
+    d_bb_climb((AccHeader *)(w + L.header), (const double *)(w + L.Q), (const double *)(w + L.P), cap);
+}
 // probe selection before level `level`: from the breadth-first list (level 1) or the previous probe children
 __global__ __launch_bounds__(1024) void k_bb_topk(int level, SP<unsigned char> ws, Layout L)
 {
@@ -1585,7 +1635,11 @@ static int accumulate_batch(rcv_strided xyz, rcv_strided radial, int radial_is_f
                 hipLaunchKernelGGL((k_bb_level<false, true, 1024>), grid3(BB_BEAM), dim3(1024), 0, st, cap, level, BBIo{1, 1}, sws, L);
             RCV_LAUNCH_CHECK();
         }
-        // the probe has (normally) found the peak already: the wide levels only need upper bounds
+        for (int round = 0; round < 3; round++) {  // exact hill-climb from the probe's best voxel
+            hipLaunchKernelGGL(k_bb_climb, grid3(BB_CLIMB_N), dim3(256), 0, st, cap, sws, L);
+            RCV_LAUNCH_CHECK();
+        }
+        // the lower bound now sits at (or next to) the peak: the wide levels only need upper bounds
         const int wide_grid = n_items >= 8 ? 256 : 2048 / n_items;
         for (int level = 1; level < BB_LEVELS - 1; level++) {
             hipLaunchKernelGGL(k_bb_wide, grid3(wide_grid), dim3(BBW_THREADS), 0, st, cap, level, sws, L);

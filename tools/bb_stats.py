@@ -1,0 +1,25 @@
+#!/usr/bin/env python3
+"""Candidate-list sizes of the branch-and-bound peak search for the bench workload (debug/tuning aid)."""
+import json, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from rcvpose_amd import synthetic, synthetic_weights
+from rcvpose_amd.pipeline import FramePipeline
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+B = 4
+shapes = json.load(open(os.path.join(ROOT, "tests", "golden", "fcn_state_dict_keys.json")))
+sds = [{k: torch.from_numpy(v) for k, v in synthetic_weights.make_state_dict_numpy(shapes, seed=s).items()} for s in range(3)]
+pipe = FramePipeline(sds, 480, 640, dtype="bf16", frames_per_step=B)
+fr = [synthetic.synthetic_frame(i) for i in range(B)]
+rmax = np.max([f["max_radii_dm"] for f in fr], axis=0) + 0.05
+pipe.seg.copy_(torch.from_numpy(np.stack([np.stack([f["seg"] for f in fr])] * 3))[:, :, None].cuda())
+pipe.radial.copy_(torch.from_numpy(np.stack([np.stack([f["radial"][k] for f in fr]) for k in range(3)]))[:, :, None].cuda())
+depth = torch.from_numpy(np.stack([f["depth"] for f in fr]).view(np.int16)).cuda()
+pipe.vote(depth, rmax)
+torch.cuda.synchronize()
+kp, res = pipe.read_results()
+for i in range(B * 3):
+    ints = pipe.ws[i, 48:224].cpu().numpy().view(np.int32)
+    print("item %2d (frame %d kp %d) n %d dim %d peak %d | bb done %d best %d | lists %s | probe %s" %
+          (i, i // 3, i % 3, ints[0], ints[3], res[i].peak_votes, ints[17], ints[18], list(ints[20:27]), list(ints[28:34])))
