@@ -33,9 +33,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--frames-per-step", type=int, default=4, help="frames per GPU per step")
+    ap.add_argument("--frames-per-step", type=int, default=8, help="frames per GPU per step")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
-    ap.add_argument("--streams", type=int, default=2, help="HIP streams the (frame, keypoint) vote items rotate over")
+    ap.add_argument("--overlap", action="store_true", help="FCN of batch s+1 and voting of batch s on two HIP streams")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU vote sample")
     return ap.parse_args()
@@ -107,7 +107,7 @@ def main():
     shapes = json.load(open(os.path.join(ROOT, "tests", "golden", "fcn_state_dict_keys.json")))
     sds = [{k: torch.from_numpy(v) for k, v in synthetic_weights.make_state_dict_numpy(shapes, seed=s).items()}
            for s in range(G)]
-    pipe = FramePipeline(sds, H, W, dtype=args.dtype, frames_per_step=B, n_streams=args.streams)
+    pipe = FramePipeline(sds, H, W, dtype=args.dtype, frames_per_step=B, overlap=args.overlap)
     del sds
 
     # frames are sharded over ranks: global frame f -> rank f % world; a pool of distinct
@@ -129,28 +129,38 @@ def main():
 
     from rcvpose_amd import sharding
 
+    # results of every step land in pinned host memory through an async copy on the voting stream
+    host_out = [torch.empty((B * world, G, 3), dtype=torch.float64).pin_memory() for _ in range(args.steps + args.warmup)]
+    rmax_dev = torch.tensor(rmax, dtype=torch.float64, device="cuda")
+
     def step_fn(step):
+        """One batch: FCN on one HIP stream; seam + voting + the single collective of the path (one RCCL all_gather of
+        72 B per frame over xGMI, frames back in global order f = i*world + rank) + result copy on another.  Batch s+1's
+        forward overlaps batch s's voting; nothing waits on the host inside the timed region."""
         ids, rgb, depth, inject = batch(step)
-        pipe.process(rgb, depth, rmax, inject=inject)
-        k = pipe.keypoints_tensor()
-        # the single collective of the path: one RCCL all_gather of 72 B per frame over xGMI; the step's
-        # B*world frames come back in global frame order (frame f lives on rank f % world) on every rank
-        out = sharding.gather_keypoints(k, B * world).cpu()
-        return ids, out
+
+        def collect(k):
+            out = sharding.gather_keypoints(k, B * world)
+            host_out[step].copy_(out, non_blocking=True)
+
+        pipe.enqueue_step(rgb, depth, rmax_dev, inject=inject, collect=collect)
+        return ids
 
     def fence():
+        pipe.finish()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
     for s in range(args.warmup):
         step_fn(s)
+    fence()
     pipe.engine.set_profiling(True)   # HIP events around every FCN op, on the launch stream
     fence()
     t0 = time.perf_counter()
-    last = None
+    last_ids = None
     for s in range(args.steps):
-        last = step_fn(args.warmup + s)
+        last_ids = step_fn(args.warmup + s)
     fence()
     dt = time.perf_counter() - t0
     prof = pipe.engine.get_profile()
@@ -161,6 +171,7 @@ def main():
     dt = float(tmax.item())
     frames_total = args.steps * B * world
     fps = frames_total / dt
+    last = (last_ids, host_out[args.warmup + args.steps - 1])
 
     # sanity of the last step on rank 0: recovered keypoints within one voxel of the truth
     ids, out = last
@@ -182,7 +193,7 @@ def main():
             "config": {"workload": "1-GPU full pipeline: 3x DenseFCNResNet152 forward + seam + LDS radial voting + arg-max, "
                                    "3 keypoints, ~15.5k back-projected pts, 5 mm voxel grid (D~228), 640x480",
                        "frames_per_step_per_gpu": B, "weights": "random (seeded He), ideal maps injected after the forward",
-                       "vote_streams": args.streams, "parallelism": "frames sharded f%%%d, 1 RCCL all_gather/step" % world},
+                       "overlap": bool(args.overlap), "parallelism": "frames sharded f%%%d, 1 RCCL all_gather/step" % world},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                          "traffic": None,
                          "kernel": "k_conv<%s> implicit-GEMM family, %d launches/forward, algorithmic 265.568 GFLOP per "

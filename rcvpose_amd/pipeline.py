@@ -16,7 +16,7 @@ from . import _hip, fcn_engine
 
 class FramePipeline:
     def __init__(self, state_dicts, H=480, W=640, dtype="bf16", frames_per_step=1, K=A.linemod_K, acc_unit=A.ACC_UNIT_MM,
-                 device="cuda", n_streams=1):
+                 device="cuda", overlap=False):
         import torch
 
         assert len(state_dicts) >= 1
@@ -31,8 +31,10 @@ class FramePipeline:
         self.engine.workspace(self.B)
         B, G = self.B, self.G
         self.x = torch.empty((B, 3, H, W), dtype=torch.float32, device=device)
-        self.seg = torch.empty((G, B, 1, H, W), dtype=torch.float32, device=device)
-        self.radial = torch.empty_like(self.seg)
+        # two sets of FCN outputs: the forward of batch s+1 may run while batch s is being voted on
+        self._seg2 = [torch.empty((G, B, 1, H, W), dtype=torch.float32, device=device) for _ in range(2)]
+        self._rad2 = [torch.empty((G, B, 1, H, W), dtype=torch.float32, device=device) for _ in range(2)]
+        self.seg, self.radial = self._seg2[0], self._rad2[0]
         n_items = B * G
         cap = H * W
         self.cap = cap
@@ -44,7 +46,13 @@ class FramePipeline:
         self.counts = torch.zeros((n_items, 2), dtype=torch.int32, device=device)
         self.results = torch.zeros((n_items, ctypes.sizeof(_hip.AccResult)), dtype=torch.uint8, device=device)
         self.k4 = (ctypes.c_double * 4)(self.K[0, 0], self.K[1, 1], self.K[0, 2], self.K[1, 2])
-        self.streams = [torch.cuda.Stream(device=device) for _ in range(max(0, n_streams - 1))]
+        # overlapped mode (enqueue_step): FCN on one stream, seam + voting + result copy on another
+        # overlap=False: one stream for both (kernel timings free of cross-stream time slicing)
+        self.s_fcn = torch.cuda.Stream(device=device)
+        self.s_vote = torch.cuda.Stream(device=device) if overlap else self.s_fcn
+        self._ev_fcn = [None, None]
+        self._ev_vote = [None, None]
+        self._step = 0
 
     # -- stages ----------------------------------------------------------------------------
     def forward_fcn(self, rgb_u8):
@@ -92,6 +100,50 @@ class FramePipeline:
     def keypoints_tensor(self):
         """estimated keypoints as a float64 [B,G,3] device tensor (view of the result records)."""
         return self.results[:, :24].contiguous().view(self.torch.float64).view(self.B, self.G, 3)
+
+    # -- overlapped stream of batches ------------------------------------------------------
+    def enqueue_step(self, rgb_u8, depth_u16, max_radii_dm, inject=None, collect=None):
+        """Enqueue one batch without waiting for it: the FCN of this batch runs on its own stream while the
+        previous batch is still being voted on (double-buffered FCN outputs; everything downstream of the
+        forward is ordered on the voting stream).  `collect(kpts_dev)` is called on the voting stream after the
+        arg-max (e.g. all_gather + async copy to pinned memory) and must only enqueue work.  Call finish() to
+        wait.  The caller keeps rgb_u8 / depth_u16 alive and unmodified until then."""
+        torch = self.torch
+        buf = self._step & 1
+        self._step += 1
+        cur = torch.cuda.current_stream()
+        self.s_fcn.wait_stream(cur)  # inputs prepared on the caller's stream
+        # the inputs were allocated on the caller's stream but are consumed on ours: tell the caching allocator
+        rgb_u8.record_stream(self.s_fcn)
+        depth_u16.record_stream(self.s_vote)
+        if torch.is_tensor(max_radii_dm):
+            max_radii_dm.record_stream(self.s_vote)
+        if inject is not None:
+            inject[0].record_stream(self.s_fcn)
+            inject[1].record_stream(self.s_fcn)
+        with torch.cuda.stream(self.s_fcn):
+            if self._ev_vote[buf] is not None:
+                self.s_fcn.wait_event(self._ev_vote[buf])  # the votes that read this buffer two batches ago are done
+            self.seg, self.radial = self._seg2[buf], self._rad2[buf]
+            self.forward_fcn(rgb_u8)
+            if inject is not None:
+                self.seg.copy_(inject[0])
+                self.radial.copy_(inject[1])
+            ev = torch.cuda.Event()
+            ev.record(self.s_fcn)
+            self._ev_fcn[buf] = ev
+        with torch.cuda.stream(self.s_vote):
+            self.s_vote.wait_event(self._ev_fcn[buf])
+            self.vote(depth_u16, max_radii_dm)
+            ev = torch.cuda.Event()
+            ev.record(self.s_vote)
+            self._ev_vote[buf] = ev
+            if collect is not None:
+                collect(self.keypoints_tensor())
+
+    def finish(self):
+        self.s_fcn.synchronize()
+        self.s_vote.synchronize()
 
     # -- whole step ------------------------------------------------------------------------
     def process(self, rgb_u8, depth_u16, max_radii_dm, inject=None):
