@@ -95,6 +95,7 @@ SYMBOLS = {
     "rcv_fcn_forward": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _sz, _vp]),
     "rcv_fcn_debug_slot": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "rcv_fcn_set_profiling": (_i, [_vp, _i]),
+    "rcv_fcn_set_option": (_i, [_vp, _i, _i]),
     "rcv_fcn_get_profile": (_i, [_vp, ctypes.POINTER(_d), ctypes.POINTER(_d), ctypes.POINTER(_d)]),
     "rcv_fcn_get_op_times": (_i, [_vp, ctypes.POINTER(_d), _i]),
 }

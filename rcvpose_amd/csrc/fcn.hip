@@ -210,7 +210,21 @@ __global__ __launch_bounds__(256) void k_conv(const ConvParams p)
     constexpr int SROW = BN + 4;                 // padded fp32 row: the 4 row groups of a store hit disjoint banks
     constexpr int CPR = BN / EPV;                // 16-byte output chunks per tile row
     constexpr int CHUNKS = (BM / 2) * CPR;
+    constexpr int PER = (CHUNKS + 255) / 256;    // chunks per thread per round
     float *stage = (float *)smem;
+    // the residual tile is fetched for both rounds up front: its latency hides behind the LDS staging
+    uint4 rres[2][PER];
+    if (res) {
+#pragma unroll
+        for (int round = 0; round < 2; round++)
+#pragma unroll
+            for (int q = 0; q < PER; q++) {
+                const int c = q * 256 + tid, row = c / CPR, cc = c - row * CPR;
+                const int m = m0 + round * (BM / 2) + row;
+                rres[round][q] = (c < CHUNKS && m < p.M) ? *(const uint4 *)(res + (long long)m * p.Cout + n0 + cc * EPV)
+                                                         : make_uint4(0u, 0u, 0u, 0u);
+            }
+    }
 #pragma unroll
     for (int round = 0; round < 2; round++) {
         __syncthreads();  // K loop (round 0) / previous round's readers are done with LDS
@@ -226,32 +240,219 @@ __global__ __launch_bounds__(256) void k_conv(const ConvParams p)
             }
         }
         __syncthreads();
-        for (int c = tid; c < CHUNKS; c += 256) {
-            const int row = c / CPR, cc = c - row * CPR;
+#pragma unroll
+        for (int q = 0; q < PER; q++) {
+            const int c = q * 256 + tid, row = c / CPR, cc = c - row * CPR;
             const int m = m0 + round * (BM / 2) + row;
-            if (m >= p.M) continue;
+            if (c >= CHUNKS || m >= p.M) continue;
             const long long o = (long long)m * p.Cout + n0 + cc * EPV;
             float v[EPV];
             const float4 *sp4 = (const float4 *)(stage + row * SROW + cc * EPV);
 #pragma unroll
-            for (int q = 0; q < EPV / 4; q++) {
-                const float4 t = sp4[q];
-                v[q * 4 + 0] = t.x; v[q * 4 + 1] = t.y; v[q * 4 + 2] = t.z; v[q * 4 + 3] = t.w;
+            for (int qq = 0; qq < EPV / 4; qq++) {
+                const float4 t = sp4[qq];
+                v[qq * 4 + 0] = t.x; v[qq * 4 + 1] = t.y; v[qq * 4 + 2] = t.z; v[qq * 4 + 3] = t.w;
             }
             if (res) {
-                const uint4 rraw = *(const uint4 *)(res + o);
-                const T *rp = (const T *)&rraw;
+                const T *rp = (const T *)&rres[round][q];
 #pragma unroll
-                for (int q = 0; q < EPV; q++) v[q] += to_f32(rp[q]);
+                for (int qq = 0; qq < EPV; qq++) v[qq] += to_f32(rp[qq]);
             }
             if (p.relu) {
 #pragma unroll
-                for (int q = 0; q < EPV; q++) v[q] = fmaxf(v[q], 0.f);
+                for (int qq = 0; qq < EPV; qq++) v[qq] = fmaxf(v[qq], 0.f);
             }
             uint4 outv;
             T *op = (T *)&outv;
 #pragma unroll
-            for (int q = 0; q < EPV; q++) op[q] = from_f32<T>(v[q]);
+            for (int qq = 0; qq < EPV; qq++) op[qq] = from_f32<T>(v[qq]);
+            *(uint4 *)(dst + o) = outv;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_conv_dma: the same implicit GEMM with the operand tiles brought in by LDS-DMA (global_load_lds,
+// 16 bytes per lane, 1 KB per wave-instruction) instead of through registers.  bf16 only.
+//   tile 256 x 128 x 64, 512 threads = 4 x 2 waves of 64 x 64, three LDS stages of 48 KB: the loads of tile
+//   t+2 are issued right after the barrier that starts tile t and stay in flight across the next barrier
+//   (counted s_waitcnt vmcnt, raw s_barrier), one barrier per K step, no staging VGPRs, no ds_write.
+//   The LDS image is lane-linear per DMA ([8 rows][8 x 16 B]); the bank swizzle is applied to the per-lane
+//   SOURCE chunk (chunk ^= (row>>1)&7) and undone by the same XOR on the fragment reads.
+//   Padding taps / rows beyond M read a 16-byte zero page.
+// ---------------------------------------------------------------------------------------------
+constexpr int DMA_BM = 256, DMA_BN = 128, DMA_STAGES = 3;
+constexpr int DMA_STAGE_BYTES = (DMA_BM + DMA_BN) * 128;
+
+__device__ __forceinline__ void glds16(const void *gptr, unsigned char *lds_wave_base)
+{
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gptr,
+                                     (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
+}
+
+__global__ __launch_bounds__(512) void k_conv_dma(const ConvParams p, const void *zero_page)
+{
+    using T = __bf16;
+    constexpr int KE = 64, EPV = 8, BM = DMA_BM, BN = DMA_BN;
+    constexpr int MT = 4, NT = 4;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int g = blockIdx.z, m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const int Ctot = p.C0 + p.C1;
+    const T *src0 = (const T *)p.src0 + (long long)g * p.src0_gs;
+    const T *src1 = p.src1 ? (const T *)p.src1 + (long long)g * p.src1_gs : nullptr;
+    const T *wg = (const T *)p.w + (long long)g * p.w_gs;
+    const T *zero = (const T *)zero_page;
+
+    // loader role of this lane: 4 A rows (wave*32 + c*8 + lane/8) and 2 B rows (wave*16 + c*8 + lane/8), 16-byte
+    // slot lane%8 of the LDS row, which receives the source chunk slot ^ ((row>>1)&7)
+    const int lrow = lane >> 3, lpos = lane & 7;
+    int a_hi0[4], a_wi0[4], a_pix[4], a_ch[4];
+    const int HWo = p.Hout * p.Wout;
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        const int row = wave * 32 + c * 8 + lrow;
+        const int m = m0 + row;
+        a_ch[c] = (lpos ^ ((row >> 1) & 7)) * EPV;
+        if (m < p.M) {
+            const int img = m / HWo, rem = m - img * HWo;
+            const int ho = rem / p.Wout, wo = rem - ho * p.Wout;
+            a_hi0[c] = ho * p.stride - p.pad;
+            a_wi0[c] = wo * p.stride - p.pad;
+            a_pix[c] = img * p.Hin * p.Win;
+        } else {
+            a_hi0[c] = -100000; a_wi0[c] = -100000; a_pix[c] = 0;
+        }
+    }
+    const T *b_ptr[2];
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+        const int row = wave * 16 + c * 8 + lrow;
+        b_ptr[c] = wg + (long long)(n0 + row) * p.K + (lpos ^ ((row >> 1) & 7)) * EPV;
+    }
+    int tap_r = 0, tap_s = 0, cg = 0;
+
+#define RCV_DMA_ISSUE(stage)                                                                                   \
+    {                                                                                                          \
+        unsigned char *As_ = smem + (stage) * DMA_STAGE_BYTES;                                                 \
+        unsigned char *Bs_ = As_ + BM * 128;                                                                   \
+        const T *src_;                                                                                         \
+        int Cs_, c_;                                                                                           \
+        if (cg < p.C0) { src_ = src0; Cs_ = p.C0; c_ = cg; } else { src_ = src1; Cs_ = p.C1; c_ = cg - p.C0; } \
+        const int kcol_ = (tap_r * p.KS + tap_s) * Ctot + cg;                                                  \
+        _Pragma("unroll") for (int c = 0; c < 4; c++) {                                                        \
+            const int hi_ = a_hi0[c] + tap_r, wi_ = a_wi0[c] + tap_s;                                          \
+            const T *ptr_ = zero;                                                                              \
+            if ((unsigned)hi_ < (unsigned)p.Hin && (unsigned)wi_ < (unsigned)p.Win)                            \
+                ptr_ = src_ + ((long long)(a_pix[c] + hi_ * p.Win + wi_) * Cs_ + c_ + a_ch[c]);                \
+            glds16(ptr_, As_ + (wave * 32 + c * 8) * 128);                                                     \
+        }                                                                                                      \
+        _Pragma("unroll") for (int c = 0; c < 2; c++) glds16(b_ptr[c] + kcol_, Bs_ + (wave * 16 + c * 8) * 128); \
+        cg += KE;                                                                                              \
+        if (cg == Ctot) { cg = 0; if (++tap_s == p.KS) { tap_s = 0; ++tap_r; } }                               \
+    }
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; i++)
+#pragma unroll
+        for (int j = 0; j < NT; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int r16 = lane & 15, kq = lane >> 4;
+
+    const int nk = p.K / KE;
+    RCV_DMA_ISSUE(0);
+    if (nk > 1) RCV_DMA_ISSUE(1);
+    int stage = 0;
+    for (int kt = 0; kt < nk; kt++) {
+        // tile kt has landed once at most the 6 DMAs of tile kt+1 are still outstanding (loads retire in order)
+        if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        // every wave is past its reads of tile kt-1, whose stage is the one tile kt+2 goes to
+        if (kt + 2 < nk) {
+            const int st2 = stage + 2 >= DMA_STAGES ? stage + 2 - DMA_STAGES : stage + 2;
+            RCV_DMA_ISSUE(st2);
+        }
+        const unsigned char *Ab = smem + stage * DMA_STAGE_BYTES + (wm * 64 + r16) * 128;
+        const unsigned char *Bb = smem + stage * DMA_STAGE_BYTES + BM * 128 + (wn * 64 + r16) * 128;
+#pragma unroll
+        for (int kk = 0; kk < 2; kk++) {
+            bf16x8 af[MT], bfr[NT];
+            const int ch = ((kk * 4 + kq) ^ ((r16 >> 1) & 7)) << 4;
+#pragma unroll
+            for (int i = 0; i < MT; i++) af[i] = *(const bf16x8 *)(Ab + i * 16 * 128 + ch);
+#pragma unroll
+            for (int j = 0; j < NT; j++) bfr[j] = *(const bf16x8 *)(Bb + j * 16 * 128 + ch);
+#pragma unroll
+            for (int i = 0; i < MT; i++)
+#pragma unroll
+                for (int j = 0; j < NT; j++)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        }
+        stage = stage + 1 == DMA_STAGES ? 0 : stage + 1;
+    }
+#undef RCV_DMA_ISSUE
+
+    // epilogue (as k_conv): fp32 staging through LDS, one wave row (64 tile rows) per round
+    T *dst = (T *)p.dst + (long long)g * p.dst_gs;
+    const T *res = p.res ? (const T *)p.res + (long long)g * p.res_gs : nullptr;
+    const float *bias = p.bias + (long long)g * p.bias_gs;
+    constexpr int SROW = BN + 4, CPR = BN / EPV, CHUNKS = 64 * CPR, PER = CHUNKS / 512;
+    float *stg = (float *)smem;
+    // the residual tile is fetched for all four rounds up front: its latency hides behind the LDS staging
+    uint4 rres[4][PER];
+    if (res) {
+#pragma unroll
+        for (int round = 0; round < 4; round++)
+#pragma unroll
+            for (int q = 0; q < PER; q++) {
+                const int c = q * 512 + tid, row = c / CPR, cc = c - row * CPR;
+                const int m = m0 + round * 64 + row;
+                rres[round][q] = m < p.M ? *(const uint4 *)(res + (long long)m * p.Cout + n0 + cc * EPV) : make_uint4(0u, 0u, 0u, 0u);
+            }
+    }
+#pragma unroll
+    for (int round = 0; round < 4; round++) {
+        __syncthreads();
+        if (wm == round) {
+#pragma unroll
+            for (int j = 0; j < NT; j++) {
+                const int nl = wn * 64 + j * 16 + r16;
+                const float bv = bias[n0 + nl];
+#pragma unroll
+                for (int i = 0; i < MT; i++)
+#pragma unroll
+                    for (int e = 0; e < 4; e++) stg[(i * 16 + kq * 4 + e) * SROW + nl] = acc[i][j][e] + bv;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < PER; q++) {
+            const int c = q * 512 + tid, row = c / CPR, cc = c - row * CPR;
+            const int m = m0 + round * 64 + row;
+            if (m >= p.M) continue;
+            const long long o = (long long)m * p.Cout + n0 + cc * EPV;
+            float v[EPV];
+            const float4 *sp4 = (const float4 *)(stg + row * SROW + cc * EPV);
+#pragma unroll
+            for (int qq = 0; qq < EPV / 4; qq++) {
+                const float4 t = sp4[qq];
+                v[qq * 4 + 0] = t.x; v[qq * 4 + 1] = t.y; v[qq * 4 + 2] = t.z; v[qq * 4 + 3] = t.w;
+            }
+            if (res) {
+                const T *rp = (const T *)&rres[round][q];
+#pragma unroll
+                for (int qq = 0; qq < EPV; qq++) v[qq] += to_f32(rp[qq]);
+            }
+            if (p.relu) {
+#pragma unroll
+                for (int qq = 0; qq < EPV; qq++) v[qq] = fmaxf(v[qq], 0.f);
+            }
+            uint4 outv;
+            T *op = (T *)&outv;
+#pragma unroll
+            for (int qq = 0; qq < EPV; qq++) op[qq] = from_f32<T>(v[qq]);
             *(uint4 *)(dst + o) = outv;
         }
     }
@@ -454,9 +655,12 @@ struct rcv_fcn {
     std::vector<hipEvent_t> events;  // 2 per op when profiling
     bool events_valid = false;
     bool attrs_set = false;
+    bool use_dma = true;  // LDS-DMA conv kernel for the shapes it covers (bf16, Cout % 128 == 0, enough tiles)
 };
 
 namespace {
+
+void *g_zero_page = nullptr;  // 256 zero bytes: source of padding taps for the LDS-DMA loader
 
 size_t esize(int dtype) { return dtype == RCV_F32 ? 4 : 2; }
 
@@ -483,11 +687,25 @@ int launch_conv_variant(const ConvParams &p, int groups, hipStream_t st, bool se
     return RCV_OK;
 }
 
+int launch_conv_dma(const ConvParams &p, int groups, hipStream_t st, bool set_attr)
+{
+    const size_t lds = (size_t)DMA_STAGES * DMA_STAGE_BYTES;
+    if (set_attr)
+        RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_conv_dma, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    dim3 grid((p.M + DMA_BM - 1) / DMA_BM, p.Cout / DMA_BN, groups);
+    hipLaunchKernelGGL(k_conv_dma, grid, dim3(512), lds, st, p, (const void *)g_zero_page);
+    RCV_LAUNCH_CHECK();
+    return RCV_OK;
+}
+
 template <typename T>
-int launch_conv(const ConvParams &p, int groups, hipStream_t st, bool set_attr)
+int launch_conv(const ConvParams &p, int groups, hipStream_t st, bool set_attr, bool allow_dma)
 {
     constexpr int KE = Traits<T>::KE;
     if (p.C0 % KE || p.C1 % KE || p.Cout % 32 || p.K % KE) return RCV_E_UNSUPPORTED;
+    if (sizeof(T) == 2 && allow_dma && g_zero_page && p.Cout % DMA_BN == 0 &&
+        (long long)((p.M + DMA_BM - 1) / DMA_BM) * (p.Cout / DMA_BN) * groups >= 192)
+        return launch_conv_dma(p, groups, st, set_attr);
     const int BN = p.Cout % 128 == 0 ? 128 : (p.Cout % 64 == 0 ? 64 : 32);
     // enough workgroups to cover the 256 CUs at least twice, otherwise halve the M tile
     const long long blocks128 = (long long)((p.M + 127) / 128) * (p.Cout / BN) * groups;
@@ -560,7 +778,7 @@ int run_op(rcv_fcn *h, const rcv_op &op, const float *x, int B, float *seg, floa
         p.K = op.ksize * op.ksize * (p.C0 + p.C1);
         p.w_gs = (long long)op.cout * p.K;
         p.bias_gs = op.cout;
-        return launch_conv<T>(p, G, st, !h->attrs_set);
+        return launch_conv<T>(p, G, st, !h->attrs_set, h->use_dma);
     }
     default: return RCV_E_UNSUPPORTED;
     }
@@ -614,6 +832,12 @@ int rcv_fcn_create(const rcv_op *ops, int n_ops, int n_slots, const int64_t *slo
         for (int s : slots)
             if (s >= n_slots || s < -3) return RCV_E_INVALID;
     }
+    if (!g_zero_page) {
+        void *z = nullptr;
+        RCV_HIP_CHECK(hipMalloc(&z, 256));
+        RCV_HIP_CHECK(hipMemset(z, 0, 256));
+        g_zero_page = z;
+    }
     rcv_fcn *h = new rcv_fcn();
     h->ops.assign(ops, ops + n_ops);
     h->slot_elems.assign(slot_elems, slot_elems + n_slots);
@@ -666,6 +890,13 @@ int rcv_fcn_debug_slot(rcv_fcn *h, const void *ws, int B, int g, int slot, float
                            (const __bf16 *)((const char *)ws + off[slot]) + (long long)g * n, out_dev, n);
     RCV_LAUNCH_CHECK();
     return RCV_OK;
+}
+
+int rcv_fcn_set_option(rcv_fcn *h, int key, int value)
+{
+    if (!h) return RCV_E_INVALID;
+    if (key == 1) { h->use_dma = value != 0; h->attrs_set = false; return RCV_OK; }
+    return RCV_E_INVALID;
 }
 
 int rcv_fcn_set_profiling(rcv_fcn *h, int enable)

@@ -299,6 +299,9 @@ class FcnEngine:
                                                _hip.current_stream()), "rcv_fcn_debug_slot")
         return out
 
+    def set_option(self, key, value):
+        _hip.check(self.lib.rcv_fcn_set_option(self.handle, int(key), int(value)))
+
     def set_profiling(self, enable):
         _hip.check(self.lib.rcv_fcn_set_profiling(self.handle, int(bool(enable))))
 

@@ -83,6 +83,25 @@ def test_bf16_vs_golden(state_dict, golden_dir):
     assert er <= REL_BF16 and es <= REL_BF16
 
 
+def test_bf16_full_size_both_conv_kernels(shapes, state_dict, golden_dir):
+    """480x640, three networks: the LDS-DMA convolution kernel (used where the grid is large enough) and the
+    register-staged one give the same bf16 result, and both sit within the bf16 tolerance of the reference."""
+    from rcvpose_amd.fcn_engine import FcnEngine
+
+    g = np.load(os.path.join(golden_dir, "fcn2_480x640_samples.npz"))
+    x = torch.from_numpy(fcn_weights.make_input(int(g["input_seed"]), (1, 3, 480, 640))).cuda()
+    eng = FcnEngine([state_dict, _sd(shapes, 1), _sd(shapes, 2)], 480, 640, dtype="bf16")
+    seg_a, rad_a = eng.forward(x)
+    seg_a, rad_a = seg_a.clone(), rad_a.clone()
+    eng.set_option(1, 0)  # register-staged kernel everywhere
+    seg_b, rad_b = eng.forward(x)
+    assert torch.equal(rad_a, rad_b) and torch.equal(seg_a, seg_b)  # same K order, same fp32 accumulation chain
+    pix = g["pix"]
+    err = np.abs(rad_a[0].cpu().numpy().reshape(-1)[pix] - g["radial"]).max() / float(g["radial_absmax"])
+    print("bf16 full-size radial relative error %.3e" % err)
+    assert err <= REL_BF16
+
+
 def test_groups_and_batch(shapes, state_dict):
     """3 networks x 2 images in one launch sequence == the six single runs (blockIdx.z / batch indexing)."""
     from rcvpose_amd.fcn_engine import FcnEngine

@@ -27,12 +27,15 @@ def main():
     ap.add_argument("--groups", type=int, default=3)
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--iters", type=int, default=5)
+    ap.add_argument("--no-dma", action="store_true", help="disable the LDS-DMA conv kernel")
     ap.add_argument("--all", action="store_true", help="print every op, not the per-shape summary")
     args = ap.parse_args()
     shapes = json.load(open(os.path.join(ROOT, "tests", "golden", "fcn_state_dict_keys.json")))
     sds = [{k: torch.from_numpy(v) for k, v in synthetic_weights.make_state_dict_numpy(shapes, seed=s).items()}
            for s in range(args.groups)]
     eng = FcnEngine(sds, 480, 640, dtype=args.dtype)
+    if args.no_dma:
+        eng.set_option(1, 0)
     x = torch.randn(args.batch, 3, 480, 640, device="cuda")
     for _ in range(2):
         eng.forward(x)
