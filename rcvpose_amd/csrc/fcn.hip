@@ -305,6 +305,22 @@ __global__ __launch_bounds__(512) void k_conv_dma(const ConvParams p, const void
     const T *wg = (const T *)p.w + (long long)g * p.w_gs;
     const T *zero = (const T *)zero_page;
 
+    // the residual tile (if any) is requested before anything else: for the short-K expand convolutions the
+    // kernel is a stream of (operand tile, residual tile, output tile) and this overlaps the first two
+    const T *res = p.res ? (const T *)p.res + (long long)g * p.res_gs : nullptr;
+    constexpr int E_CPR = DMA_BN / 8, E_PER = (64 * E_CPR) / 512;
+    uint4 rres[4][E_PER];
+    if (res) {
+#pragma unroll
+        for (int round = 0; round < 4; round++)
+#pragma unroll
+            for (int q = 0; q < E_PER; q++) {
+                const int c = q * 512 + tid, row = c / E_CPR, cc = c - row * E_CPR;
+                const int m = m0 + round * 64 + row;
+                rres[round][q] = m < p.M ? *(const uint4 *)(res + (long long)m * p.Cout + n0 + cc * 8) : make_uint4(0u, 0u, 0u, 0u);
+            }
+    }
+
     // loader role of this lane: 4 A rows (wave*32 + c*8 + lane/8) and 2 B rows (wave*16 + c*8 + lane/8), 16-byte
     // slot lane%8 of the LDS row, which receives the source chunk slot ^ ((row>>1)&7)
     const int lrow = lane >> 3, lpos = lane & 7;
@@ -396,22 +412,9 @@ __global__ __launch_bounds__(512) void k_conv_dma(const ConvParams p, const void
 
     // epilogue (as k_conv): fp32 staging through LDS, one wave row (64 tile rows) per round
     T *dst = (T *)p.dst + (long long)g * p.dst_gs;
-    const T *res = p.res ? (const T *)p.res + (long long)g * p.res_gs : nullptr;
     const float *bias = p.bias + (long long)g * p.bias_gs;
     constexpr int SROW = BN + 4, CPR = BN / EPV, CHUNKS = 64 * CPR, PER = CHUNKS / 512;
     float *stg = (float *)smem;
-    // the residual tile is fetched for all four rounds up front: its latency hides behind the LDS staging
-    uint4 rres[4][PER];
-    if (res) {
-#pragma unroll
-        for (int round = 0; round < 4; round++)
-#pragma unroll
-            for (int q = 0; q < PER; q++) {
-                const int c = q * 512 + tid, row = c / CPR, cc = c - row * CPR;
-                const int m = m0 + round * 64 + row;
-                rres[round][q] = m < p.M ? *(const uint4 *)(res + (long long)m * p.Cout + n0 + cc * EPV) : make_uint4(0u, 0u, 0u, 0u);
-            }
-    }
 #pragma unroll
     for (int round = 0; round < 4; round++) {
         __syncthreads();
