@@ -132,6 +132,17 @@ int rcv_accumulate_3d_batch(rcv_strided xyz_m, rcv_strided radial_dm, int radial
                             double acc_unit_mm, rcv_strided result, rcv_strided ws, size_t ws_bytes, int n_frames,
                             int n_keypoints, void *stream);
 
+/*
+ * Horn absolute orientation, reference util/horn.py:75-181 (HornPoseFitting.lmshorn), as called on the three
+ * keypoints of a frame at AccumulatorSpace.py:659-661: RT (4x4 row-major float64) with est ~ R * model + T.
+ *   model_kpts_dev  float64 [n_points,3] (mm), shared by all frames
+ *   est_kpts        float64 [3] per (frame, point): ptr + frame * stride_frame + point * stride_kp -- e.g. the
+ *                   center_mm fields of the rcv_acc_result records (stride_kp = sizeof(rcv_acc_result))
+ *   rt_out_dev      float64 [n_frames,4,4]
+ */
+int rcv_horn_pose_batch(const double *model_kpts_dev, rcv_strided est_kpts, int n_points, int n_frames, double *rt_out_dev,
+                        void *stream);
+
 /* How rcv_accumulate_3d finds the arg-max when no vote_grid_dev is requested (process-wide setting):
  *   0 (default): exact branch-and-bound peak search; the LDS rasteriser takes over when the search gives up
  *   1: LDS rasteriser only (the full VoteMap is accumulated tile by tile in LDS).

@@ -159,3 +159,12 @@ def accumulator_3d(xyz_m, radial_dm, acc_unit=5.0, sparse=False, threads=0, retu
     if return_all:
         return center, votes, info, peak
     return center
+
+
+def horn(P1, P2):
+    """HornPoseFitting.lmshorn, util/horn.py:75-181 -> 4x4 RT with P2 ~ R P1 + T."""
+    P1 = np.ascontiguousarray(P1, dtype=np.float64)
+    P2 = np.ascontiguousarray(P2, dtype=np.float64)
+    A = np.zeros((4, 4), dtype=np.float64)
+    lib().orc_horn(_p(P1), _p(P2), int(len(P1)), _p(A))
+    return A

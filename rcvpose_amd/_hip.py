@@ -82,6 +82,7 @@ SYMBOLS = {
     "rcv_seam_compact": (_i, [_vp, _vp, _vp, _i, _i, ctypes.POINTER(_d), _f, _d, _i, _vp, _vp, _vp, _i, _vp, _sz, _vp]),
     "rcv_accumulate_3d": (_i, [_vp, _vp, _i, _vp, _i, _i, _d, _vp, _vp, _sz, _vp, _sz, _vp]),
     "rcv_set_vote_mode": (_i, [_i]),
+    "rcv_horn_pose_batch": (_i, [_vp, Strided, _i, _i, _vp, _vp]),
     "rcv_seam_compact_batch": (_i, [Strided, Strided, Strided, _i, _i, ctypes.POINTER(_d), _f, Strided, _i, Strided, Strided,
                                      Strided, _i, Strided, _sz, _i, _i, _vp]),
     "rcv_accumulate_3d_batch": (_i, [Strided, Strided, _i, Strided, _i, _d, Strided, Strided, _sz, _i, _i, _vp]),

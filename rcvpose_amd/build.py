@@ -20,6 +20,7 @@ SOURCES = {
     "core.hip": [],
     "accumulator.hip": ["-ffp-contract=off"],
     "fcn.hip": [],
+    "pose.hip": ["-ffp-contract=off"],
 }
 COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC,
           "-Wall", "-Wno-unused-function"]

@@ -366,8 +366,37 @@ def gen_fcn(A):
     print("  fcn3 backbone:", sem_out.shape, sem_out.dtype, radial_out.dtype)
 
 
+# --------------------------------------------------------------------------------------
+# HORN-*: util/horn.py:75-181 (HornPoseFitting.lmshorn), called at AccumulatorSpace.py:659-661
+# --------------------------------------------------------------------------------------
+def gen_horn(A):
+    from util.horn import HornPoseFitting
+
+    horn = HornPoseFitting()
+    rng = np.random.default_rng(99)
+    P1s, P2s, RTs, ns = [], [], [], []
+    for case in range(12):
+        n = 3 if case < 8 else int(rng.integers(4, 9))
+        P1 = rng.normal(size=(n, 3)) * 120.0                       # model keypoints, mm
+        ang = rng.normal(size=3)
+        th = np.linalg.norm(ang)
+        k = ang / th
+        K = np.array([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
+        R = np.eye(3) + np.sin(th) * K + (1 - np.cos(th)) * K @ K
+        t = rng.normal(size=3) * 300.0 + np.array([0, 0, 900.0])
+        P2 = P1 @ R.T + t + (rng.normal(size=(n, 3)) * (0.0 if case % 2 == 0 else 2.0))  # estimated keypoints (+ noise)
+        if case == 7:                                             # degenerate: identical sets
+            P2 = P1.copy()
+        RT = np.zeros((4, 4))
+        horn.lmshorn(P1.copy(), P2.copy(), n, RT)
+        pad = np.zeros((8, 3))
+        P1s.append(np.vstack([P1, pad])[:8]); P2s.append(np.vstack([P2, pad])[:8]); RTs.append(RT); ns.append(n)
+    np.savez_compressed(os.path.join(HERE, "horn_cases.npz"), P1=np.array(P1s), P2=np.array(P2s), RT=np.array(RTs), n=np.array(ns))
+    print("  horn: %d cases" % len(ns))
+
+
 def main():
-    which = set(sys.argv[1:]) or {"acc", "seam", "fcn"}
+    which = set(sys.argv[1:]) or {"acc", "seam", "fcn", "horn"}
     A = _import_reference()
     if "acc" in which:
         print("ACC cases (reference fast_for runs as pure Python, ~1 us per point*voxel test)")
@@ -376,6 +405,8 @@ def main():
         gen_seam(A)
     if "fcn" in which:
         gen_fcn(A)
+    if "horn" in which:
+        gen_horn(A)
 
 
 if __name__ == "__main__":

@@ -102,3 +102,11 @@ def test_chain_golden(oracle, golden_dir):
     center = oracle.accumulator_3d(xyz, rl)
     assert np.array_equal(center, g["center"])
     assert np.abs(center[0] - g["keypoint_m"] * 1000).max() <= 5.0  # within one 5 mm voxel of the truth
+
+
+def test_horn_golden(oracle, golden_dir):
+    """util/horn.py:75-181 restated in C: bit-exact on the reference's outputs (incl. the degenerate identical sets)."""
+    g = _load(golden_dir, "horn_cases")
+    for i in range(len(g["n"])):
+        n = int(g["n"][i])
+        assert np.array_equal(oracle.horn(g["P1"][i][:n], g["P2"][i][:n]), g["RT"][i]), i
