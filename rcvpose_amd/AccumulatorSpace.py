@@ -19,6 +19,17 @@ linemod_K = np.array([[572.4114, 0., 325.2611],
                       [0., 573.57043, 242.04899],
                       [0., 0., 1.]])
 
+# reference AccumulatorSpace.py:19-57
+lm_cls_names = ['ape', 'benchvise', 'cam', 'can', 'cat', 'duck', 'driller', 'eggbox', 'glue', 'holepuncher', 'iron', 'lamp',
+                'phone']
+lmo_cls_names = ['ape', 'can', 'cat', 'duck', 'driller', 'eggbox', 'glue', 'holepuncher']
+lm_syms = ['eggbox', 'glue']
+add_threshold = {
+    'eggbox': 0.019735770122546523, 'ape': 0.01421240983190395, 'cat': 0.018594838977253875, 'cam': 0.02222763033276377,
+    'duck': 0.015569664208967385, 'glue': 0.01930723067998101, 'can': 0.028415044264086586, 'driller': 0.031877906042,
+    'holepuncher': 0.019606109985, 'benchvise': .033091264970068, 'iron': .03172344425531, 'lamp': .03165980764376,
+    'phone': .02543407135792}
+
 ACC_UNIT_MM = 5.0  # reference AccumulatorSpace.py:374 hard-codes 5 mm voxels
 SEG_THRESHOLD = 0.8  # reference AccumulatorSpace.py:603
 
@@ -199,3 +210,165 @@ def FCResBackbone(model, input_img_path, normalized_depth=None):
         sem_out, radial_out = model(x)
     sem_out, radial_out = sem_out.cpu(), radial_out.cpu()
     return np.asarray(sem_out[0][0]), np.asarray(radial_out[0][0])
+
+
+# ---------------------------------------------------------------------------------------------------
+# Dataset ingest + the evaluation driver: reference AccumulatorSpace.py:64-75, :482-490,
+# :495-740.  The hot loop runs in rcvpose_amd.pipeline.FramePipeline; the Horn fit on the device (f-1).
+# Not reproduced: Open3D ICP refinement and the ADD(-S) after ICP (f-3, third-party C++ in the reference).
+# ---------------------------------------------------------------------------------------------------
+def project(xyz, K, RT):
+    """reference AccumulatorSpace.py:64-75: xyz [N,3], K [3,3], RT [3,4] -> (pixel xy [N,2], camera-frame xyz [N,3])."""
+    xyz = np.dot(xyz, RT[:, :3].T) + RT[:, 3:].T
+    actual_xyz = xyz
+    xyz = np.dot(xyz, K.T)
+    xy = xyz[:, :2] / xyz[:, 2:]
+    return xy, actual_xyz
+
+
+def read_depth(path):
+    """reference AccumulatorSpace.py:482-490: `.dpt` = uint32 h, w + uint16[h*w]; anything else through PIL."""
+    if path[-3:] == 'dpt':
+        with open(path, 'rb') as f:
+            h, w = np.fromfile(f, dtype=np.uint32, count=2)
+            data = np.fromfile(f, dtype=np.uint16, count=int(w) * int(h))
+            depth = data.reshape((int(h), int(w)))
+    else:
+        from PIL import Image
+
+        depth = np.asarray(Image.open(path)).copy()
+    return depth
+
+
+def read_ply_points(path):
+    """Vertex positions of a PLY model (ascii or binary_little_endian), the part of
+    open3d.io.read_point_cloud(...).points the reference uses (AccumulatorSpace.py:507,536)."""
+    with open(path, 'rb') as f:
+        fmt, n, props, in_vertex = None, 0, [], False
+        while True:
+            line = f.readline().decode('ascii', 'replace').strip()
+            if line.startswith('format'):
+                fmt = line.split()[1]
+            elif line.startswith('element'):
+                in_vertex = line.split()[1] == 'vertex'
+                if in_vertex:
+                    n = int(line.split()[2])
+            elif line.startswith('property') and in_vertex:
+                props.append((line.split()[1], line.split()[2]))
+            elif line == 'end_header':
+                break
+        names = [p[1] for p in props]
+        ix = [names.index(a) for a in ('x', 'y', 'z')]
+        if fmt == 'ascii':
+            rows = np.loadtxt(f, max_rows=n, ndmin=2)
+            return rows[:, ix].astype(np.float64)
+        types = {'float': '<f4', 'float32': '<f4', 'double': '<f8', 'float64': '<f8', 'uchar': 'u1', 'uint8': 'u1', 'char': 'i1',
+                 'short': '<i2', 'ushort': '<u2', 'int': '<i4', 'int32': '<i4', 'uint': '<u4'}
+        dt = np.dtype([(nm, types[t]) for t, nm in props])
+        data = np.fromfile(f, dtype=dt, count=n)
+        return np.stack([data['x'], data['y'], data['z']], axis=1).astype(np.float64)
+
+
+def _nn_distances(a, b):
+    """open3d PointCloud.compute_point_cloud_distance(a -> b): distance from every point of a to its nearest in b."""
+    from scipy.spatial import cKDTree
+
+    return cKDTree(b).query(a)[0]
+
+
+def estimate_6d_pose_lm(opts, return_details=False):
+    """The LINEMOD evaluation loop of the reference (AccumulatorSpace.py:495-740) on the MI355X hot path.
+
+    opts attributes read (as in the reference): root_dataset, model_dir, using_ckpts, demo_mode (ignored), plus the
+    optional class_names (default: every LINEMOD class present under root_dataset).  Per frame: 3 keypoints (FCN ->
+    seam -> voting, or pre-computed radial maps when using_ckpts is False) -> Horn pose -> ADD(-S) before ICP.
+    """
+    torch = _torch()
+    from . import utils
+    from .models.fcnresnet import DenseFCNResNet152
+    from .pipeline import FramePipeline
+    from .util.horn import horn_batch
+
+    _hip.lib()
+    results = {}
+    details = {}
+    names = getattr(opts, 'class_names', None) or lm_cls_names
+    import os
+
+    for class_name in names:
+        rootPath = opts.root_dataset + "LINEMOD_ORIG/" + class_name + "/"
+        rootpvPath = opts.root_dataset + "LINEMOD/" + class_name + "/"
+        if not os.path.isdir(rootpvPath):
+            continue
+        print("Evaluation on ", class_name)
+        test_list = [s.replace('\n', '') for s in open(rootpvPath + "Split/val.txt", "r").readlines()]
+        xyz_load = read_ply_points(rootpvPath + class_name + ".ply")
+        keypoints = np.load(rootpvPath + "Outside9.npy")
+        max_radii_dm = np.zeros(3)
+        for i in range(3):  # reference :541-548
+            max_radii_dm[i] = (((xyz_load - keypoints[i + 1]) ** 2).sum(axis=1) ** 0.5).max() * 10
+        pipe = None
+        if opts.using_ckpts:
+            sds = []
+            for i in range(1, 4):
+                model_path = opts.model_dir + class_name + "_pt" + str(i) + ".pth.tar"
+                if not os.path.exists(model_path):
+                    raise ValueError(model_path + " not found")  # reference :571-573
+                model = DenseFCNResNet152(3, 2)
+                model, _, _, _ = utils.load_checkpoint(model, None, model_path)
+                sds.append(model.state_dict())
+        bf_icp, general_counter = 0, 0
+        per_frame = {}
+        dataPath = rootpvPath + 'JPEGImages/'
+        for filename in sorted(os.listdir(dataPath)):
+            stem = os.path.splitext(filename)[0]
+            if not filename.endswith(".jpg") or stem not in test_list:
+                continue
+            print("Evaluating ", filename)
+            RTGT = np.load(rootpvPath + "pose/pose" + str(int(stem)) + '.npy')
+            depth_map1 = read_depth(rootPath + 'data/depth' + str(int(stem)) + '.dpt')
+            H, W = depth_map1.shape
+            depth_dev = _depth_to_u16(depth_map1, "cuda")
+            if opts.using_ckpts:
+                from PIL import Image
+
+                if pipe is None:
+                    pipe = FramePipeline(sds, H, W, dtype=getattr(opts, 'dtype', 'bf16'), frames_per_step=1)
+                rgb = np.array(Image.open(dataPath + filename).convert('RGB'), dtype=np.uint8)
+                pipe.process(torch.from_numpy(rgb)[None].cuda(), depth_dev[None], max_radii_dm)
+                estimated_kpts, res = pipe.read_results()
+                estimated_kpts = estimated_kpts[0]
+                statuses = [r.status for r in res]
+            else:
+                estimated_kpts, statuses = np.zeros((3, 3)), []
+                ws = AccWorkspace(H * W)
+                for k in range(1, 4):  # reference :611-618
+                    radial_est = np.load(os.path.join(opts.root_dataset + "LINEMOD_ORIG/", 'estRadialMap', class_name,
+                                                      "Out_pt" + str(k) + "_dm", stem + '.npy'))
+                    rad_dev = torch.from_numpy(np.ascontiguousarray(radial_est, dtype=np.float32)).cuda()
+                    seam_compact(None, rad_dev, depth_dev, max_radii_dm[k - 1], mode=1, workspace=ws)
+                    accumulate_on_device(ws.xyz, ws.radial, ws.counts, ws.max_points, ws.max_points, ws)
+                    r = ws.read_result()
+                    statuses.append(r.status)
+                    estimated_kpts[k - 1] = r.center_mm[:]
+            for st in statuses:
+                _raise_like_reference(st)
+            kpts = keypoints[1:4, :] * 1000
+            RT = horn_batch(kpts, torch.from_numpy(np.ascontiguousarray(estimated_kpts[None])).cuda())[0].cpu().numpy()  # :659-661
+            _, est_model = project(xyz_load * 1000, linemod_K, RT[0:3, :])
+            RTGT_mm = np.array(RTGT, dtype=np.float64, copy=True)
+            RTGT_mm[:, 3] = RTGT_mm[:, 3] * 1000
+            _, gt_model = project(xyz_load * 1000, linemod_K, RTGT_mm)
+            d = _nn_distances(gt_model, est_model)
+            dist = d.min() if class_name in lm_syms else d.mean()  # reference :686-694
+            if dist <= add_threshold[class_name] * 1000:
+                bf_icp += 1
+            general_counter += 1
+            per_frame[stem] = dict(estimated_kpts=estimated_kpts.copy(), RT=RT, add_distance_mm=float(dist))
+            print('Current ADD\\(s\\) of ' + class_name + ' before ICP: ', bf_icp / general_counter)
+        if general_counter:
+            tag = 'ADDs' if class_name in lm_syms else 'ADD'
+            print(tag + ' of ' + class_name + ' before ICP: ', bf_icp / general_counter)
+            results[class_name] = dict(frames=general_counter, add_before_icp=bf_icp / general_counter)
+            details[class_name] = per_frame
+    return (results, details) if return_details else results

@@ -1,0 +1,91 @@
+"""estimate_6d_pose_lm on a synthetic LINEMOD-layout dataset written to a temp dir."""
+import os
+import types
+
+import numpy as np
+import pytest
+
+import frames
+
+pytestmark = pytest.mark.gpu
+
+
+def _write_dataset(root, n_frames=2):
+    cls = "ape"
+    pv = os.path.join(root, "LINEMOD", cls)
+    orig = os.path.join(root, "LINEMOD_ORIG", cls)
+    for d in (os.path.join(pv, "Split"), os.path.join(pv, "pose"), os.path.join(pv, "JPEGImages"), os.path.join(orig, "data")):
+        os.makedirs(d)
+    from PIL import Image
+
+    f0 = frames.synthetic_frame(0)
+    a, b, c = 0.12, 0.10, 0.08
+    rng = np.random.default_rng(0)
+    u = rng.normal(size=(3000, 3))
+    u /= np.linalg.norm(u, axis=1, keepdims=True)
+    model = u * np.array([a, b, c])                      # object frame, metres
+    with open(os.path.join(pv, cls + ".ply"), "w") as f:
+        f.write("ply\nformat ascii 1.0\nelement vertex %d\nproperty float x\nproperty float y\nproperty float z\nend_header\n" % len(model))
+        for p in model:
+            f.write("%.9f %.9f %.9f\n" % tuple(p))
+    sign = np.array([[1, 1, 1], [-1, 1, -1], [1, -1, -1]], dtype=np.float64)
+    kps_obj = np.zeros((9, 3))
+    kps_obj[1:4] = 2.0 * sign * np.array([a, b, c])      # rows 1..3 are the ones the driver uses (reference :541-548)
+    np.save(os.path.join(pv, "Outside9.npy"), kps_obj)
+    names, poses = [], {}
+    for i in range(n_frames):
+        fr = frames.synthetic_frame(i)
+        stem = "%06d" % i
+        names.append(stem)
+        Image.fromarray(fr["rgb"]).save(os.path.join(pv, "JPEGImages", stem + ".jpg"))
+        centre = fr["keypoints_m"][0] - kps_obj[1]       # object centre in the camera frame
+        RT = np.concatenate([np.eye(3), centre[:, None]], axis=1)
+        np.save(os.path.join(pv, "pose", "pose%d.npy" % i), RT)
+        poses[stem] = RT
+        with open(os.path.join(orig, "data", "depth%d.dpt" % i), "wb") as f:
+            np.array(fr["depth"].shape, dtype=np.uint32).tofile(f)
+            fr["depth"].astype(np.uint16).tofile(f)
+        for k in range(3):
+            d = os.path.join(root, "LINEMOD_ORIG", "estRadialMap", cls, "Out_pt%d_dm" % (k + 1))
+            os.makedirs(d, exist_ok=True)
+            np.save(os.path.join(d, stem + ".npy"), fr["radial"][k])
+    with open(os.path.join(pv, "Split", "val.txt"), "w") as f:
+        f.write("\n".join(names) + "\n")
+    return cls, poses
+
+
+def test_driver_with_precomputed_radial_maps(tmp_path, oracle):
+    from rcvpose_amd import AccumulatorSpace as A
+
+    root = str(tmp_path) + "/"
+    cls, poses = _write_dataset(root)
+    opts = types.SimpleNamespace(root_dataset=root, model_dir=root, using_ckpts=False, demo_mode=False, test_occ=False,
+                                 class_names=[cls])
+    results, details = A.estimate_6d_pose_lm(opts, return_details=True)
+    assert results[cls]["frames"] == 2
+    kps_obj = np.load(os.path.join(root, "LINEMOD", cls, "Outside9.npy"))
+    model = A.read_ply_points(os.path.join(root, "LINEMOD", cls, cls + ".ply"))
+    max_radii_dm = [(((model - kps_obj[i + 1]) ** 2).sum(axis=1) ** 0.5).max() * 10 for i in range(3)]
+    for stem, d in details[cls].items():
+        i = int(stem)
+        fr = frames.synthetic_frame(i)
+        # every keypoint equals what the oracle recovers from the same files (the reference's using_ckpts=False branch)
+        for k in range(3):
+            xyz, rl = oracle.seam_radial_only(fr["radial"][k], fr["depth"], max_radii_dm[k])
+            ref = oracle.accumulator_3d(xyz, rl, sparse=True)
+            assert np.array_equal(d["estimated_kpts"][k], ref[0]), (stem, k)
+        assert np.array_equal(d["RT"], oracle.horn(kps_obj[1:4] * 1000, d["estimated_kpts"]))
+        # and the pose is close to the ground truth (keypoints are within ~2 voxels of the truth)
+        t_gt = poses[stem][:, 3] * 1000
+        assert np.abs(d["RT"][:3, 3] - t_gt).max() < 25.0
+        assert d["add_distance_mm"] < 15.0
+    assert results[cls]["add_before_icp"] == 1.0
+
+
+def test_main_entry_runs_the_driver(tmp_path):
+    from rcvpose_amd.main import main
+
+    root = str(tmp_path) + "/"
+    _write_dataset(root, n_frames=1)
+    res = main(["--mode", "test", "--root_dataset", root, "--model_dir", root, "--using_ckpts", "false"])
+    assert res["ape"]["frames"] == 1
