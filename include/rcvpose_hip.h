@@ -67,6 +67,8 @@ typedef struct rcv_acc_result {
     int32_t status;        /* rcv_status */
 } rcv_acc_result;
 
+#define RCV_SEAM_RADIAL_F16 256
+
 /* Bytes of workspace needed by rcv_seam_compact / rcv_accumulate_3d for clouds of up to
  * max_points points (and radii). */
 size_t rcv_acc_workspace_bytes(int max_points);
@@ -83,6 +85,8 @@ size_t rcv_acc_workspace_bytes(int max_points);
  *         radii gathered at depth.nonzero(); seg_dev is ignored.
  * mode 2: rgbd_to_point_cloud(K, depth) alone (:77-85): points of depth.nonzero() in MILLIMETRES
  *         (no /1000); seg_dev, radial_dev and radial_list_dev are ignored (may be null).
+ * OR RCV_SEAM_RADIAL_F16 into mode when radial_dev holds float16 (the stress configuration of BASELINE.json); the
+ * values then enter the reference arithmetic as the float32 numbers they convert to.
  * seg_dev, radial_dev: float32 [H,W]; depth_dev: uint16 [H,W] (mm); K = {fx, fy, cx, cy}.
  * Outputs: xyz_m_dev float64 [cap,3], radial_list_dev float32 [cap], counts_dev int32[2] =
  * {n_points, n_radii}.  cap must be >= H*W unless the caller knows a tighter bound.

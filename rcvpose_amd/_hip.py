@@ -19,6 +19,8 @@ RCV_E_TOO_LARGE = -6
 RCV_E_GRID_BUFFER = -7
 RCV_E_UNSUPPORTED = -8
 
+RCV_SEAM_RADIAL_F16 = 256
+
 RCV_F32 = 0
 RCV_BF16 = 1
 

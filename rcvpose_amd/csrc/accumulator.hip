@@ -195,14 +195,17 @@ __device__ __forceinline__ int clamp_to_int(double v)
 // ---------------------------------------------------------------------------------------------
 // seam: ordered stream compaction of the masked pixels
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void seam_flags(const float *seg, const float *rad, const uint16_t *depth, int p, float thr,
+// radial maps may be stored as float32 (the FCN head's output) or float16 (BASELINE.json stress config); a
+// float16 value takes part in the reference arithmetic as the float32 it converts to exactly
+template <typename RT>
+__device__ __forceinline__ void seam_flags(const float *seg, const RT *rad, const uint16_t *depth, int p, float thr,
                                            double rmax, int mode, bool &m_rad, bool &m_pt)
 {
     if (mode == 2) {  // plain rgbd_to_point_cloud: depth.nonzero()
         m_rad = m_pt = depth[p] != 0;
         return;
     }
-    const float r = rad[p];
+    const float r = (float)rad[p];
     const bool rok = (double)r <= rmax;  // float32 array vs float64 scalar: compared in float64
     if (mode == 0) {
         m_rad = (seg[p] > thr) && rok;   // python float vs float32 array: compared in float32
@@ -213,7 +216,8 @@ __device__ __forceinline__ void seam_flags(const float *seg, const float *rad, c
     }
 }
 
-__device__ __forceinline__ void d_seam_count(const float *seg, const float *rad, const uint16_t *depth, int HW,
+template <typename RT>
+__device__ __forceinline__ void d_seam_count(const float *seg, const RT *rad, const uint16_t *depth, int HW,
                                                     float thr, double rmax, int mode, int2 *blk_counts)
 {
     __shared__ int sp[4], sr[4];
@@ -267,7 +271,8 @@ __device__ __forceinline__ void d_seam_scan(const int2 *blk_counts, int nb, int2
     if (t == 1023) { counts_out[0] = s[t].x; counts_out[1] = s[t].y; }
 }
 
-__device__ __forceinline__ void d_seam_scatter(const float *seg, const float *rad, const uint16_t *depth, int HW,
+template <typename RT>
+__device__ __forceinline__ void d_seam_scatter(const float *seg, const RT *rad, const uint16_t *depth, int HW,
                                                       int W, double fx, double fy, double cx, double cy, float thr,
                                                       double rmax, int mode, const int2 *blk_offsets, double *xyz_m,
                                                       float *radial_list, int cap)
@@ -295,7 +300,7 @@ __device__ __forceinline__ void d_seam_scatter(const float *seg, const float *ra
         for (int q = 0; q < j * 4 + wv; q++) { before_p += segp[q]; before_r += segr[q]; }
         if (mr[j] && mode != 2) {
             int dst = off.y + before_r + pre_r[j];
-            if (dst < cap) radial_list[dst] = rad[p];
+            if (dst < cap) radial_list[dst] = (float)rad[p];
         }
         if (mp[j]) {
             int dst = off.x + before_p + pre_p[j];
@@ -1399,24 +1404,26 @@ struct SP {
     }
 };
 
-__global__ __launch_bounds__(256) void k_seam_count(SP<const float> seg, SP<const float> rad, SP<const uint16_t> depth, int HW,
+template <typename RT>
+__global__ __launch_bounds__(256) void k_seam_count(SP<const float> seg, SP<const RT> rad, SP<const uint16_t> depth, int HW,
                                                     float thr, SP<const double> rmax, double rmax_scalar, int mode,
                                                     SP<unsigned char> ws, Layout L)
 {
-    d_seam_count(seg.get(), rad.get(), depth.get(), HW, thr, rmax.p ? *rmax.get() : rmax_scalar, mode,
-                 (int2 *)(ws.get() + L.seam_counts));
+    d_seam_count<RT>(seg.get(), rad.get(), depth.get(), HW, thr, rmax.p ? *rmax.get() : rmax_scalar, mode,
+                     (int2 *)(ws.get() + L.seam_counts));
 }
 __global__ __launch_bounds__(1024) void k_seam_scan(int nb, SP<int32_t> counts, SP<unsigned char> ws, Layout L)
 {
     unsigned char *w = ws.get();
     d_seam_scan((const int2 *)(w + L.seam_counts), nb, (int2 *)(w + L.seam_offsets), counts.get());
 }
-__global__ __launch_bounds__(256) void k_seam_scatter(SP<const float> seg, SP<const float> rad, SP<const uint16_t> depth, int HW,
+template <typename RT>
+__global__ __launch_bounds__(256) void k_seam_scatter(SP<const float> seg, SP<const RT> rad, SP<const uint16_t> depth, int HW,
                                                       int W, double fx, double fy, double cx, double cy, float thr,
                                                       SP<const double> rmax, double rmax_scalar, int mode, SP<double> xyz,
                                                       SP<float> radial_list, int cap, SP<unsigned char> ws, Layout L)
 {
-    d_seam_scatter(seg.get(), rad.get(), depth.get(), HW, W, fx, fy, cx, cy, thr, rmax.p ? *rmax.get() : rmax_scalar, mode,
+    d_seam_scatter<RT>(seg.get(), rad.get(), depth.get(), HW, W, fx, fy, cx, cy, thr, rmax.p ? *rmax.get() : rmax_scalar, mode,
                    (const int2 *)(ws.get() + L.seam_offsets), xyz.get(), radial_list.get(), cap);
 }
 template <typename RT>
@@ -1546,6 +1553,8 @@ static int seam_batch(rcv_strided seg, rcv_strided rad, rcv_strided depth, int H
                       int cap, rcv_strided ws, size_t ws_bytes, int n_frames, int n_kp, void *stream)
 {
     if (!depth.ptr || !K || !xyz.ptr || !counts.ptr || !ws.ptr) return RCV_E_INVALID;
+    const bool rad_f16 = (mode & RCV_SEAM_RADIAL_F16) != 0;
+    mode &= ~RCV_SEAM_RADIAL_F16;
     if (mode < 0 || mode > 2) return RCV_E_INVALID;
     if (mode != 2 && (!rad.ptr || !rlist.ptr)) return RCV_E_INVALID;
     if (mode == 0 && !seg.ptr) return RCV_E_INVALID;
@@ -1559,18 +1568,28 @@ static int seam_batch(rcv_strided seg, rcv_strided rad, rcv_strided depth, int H
     if (!seg.ptr) seg = rad;  // never dereferenced when mode != 0
     const SP<const float> sseg{(const float *)seg.ptr, seg.stride_frame, seg.stride_kp};
     const SP<const float> srad{(const float *)rad.ptr, rad.stride_frame, rad.stride_kp};
+    const SP<const _Float16> srad16{(const _Float16 *)rad.ptr, rad.stride_frame, rad.stride_kp};
     const SP<const uint16_t> sdep{(const uint16_t *)depth.ptr, depth.stride_frame, depth.stride_kp};
     const SP<const double> srmax{(const double *)rmax.ptr, rmax.stride_frame, rmax.stride_kp};
     const SP<unsigned char> sws{(unsigned char *)ws.ptr, ws.stride_frame, ws.stride_kp};
-    hipLaunchKernelGGL(k_seam_count, dim3(nb, n_frames, n_kp), dim3(256), 0, st, sseg, srad, sdep, (int)HW, seg_thr, srmax,
-                       rmax_scalar, mode, sws, L);
+    if (rad_f16)
+        hipLaunchKernelGGL(k_seam_count<_Float16>, dim3(nb, n_frames, n_kp), dim3(256), 0, st, sseg, srad16, sdep, (int)HW, seg_thr,
+                           srmax, rmax_scalar, mode, sws, L);
+    else
+        hipLaunchKernelGGL(k_seam_count<float>, dim3(nb, n_frames, n_kp), dim3(256), 0, st, sseg, srad, sdep, (int)HW, seg_thr, srmax,
+                           rmax_scalar, mode, sws, L);
     RCV_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_seam_scan, dim3(1, n_frames, n_kp), dim3(1024), 0, st, nb,
                        SP<int32_t>{(int32_t *)counts.ptr, counts.stride_frame, counts.stride_kp}, sws, L);
     RCV_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_seam_scatter, dim3(nb, n_frames, n_kp), dim3(256), 0, st, sseg, srad, sdep, (int)HW, W, K[0], K[1], K[2],
-                       K[3], seg_thr, srmax, rmax_scalar, mode, SP<double>{(double *)xyz.ptr, xyz.stride_frame, xyz.stride_kp},
-                       SP<float>{(float *)rlist.ptr, rlist.stride_frame, rlist.stride_kp}, cap, sws, L);
+    const SP<double> sxyz{(double *)xyz.ptr, xyz.stride_frame, xyz.stride_kp};
+    const SP<float> srl{(float *)rlist.ptr, rlist.stride_frame, rlist.stride_kp};
+    if (rad_f16)
+        hipLaunchKernelGGL(k_seam_scatter<_Float16>, dim3(nb, n_frames, n_kp), dim3(256), 0, st, sseg, srad16, sdep, (int)HW, W, K[0],
+                           K[1], K[2], K[3], seg_thr, srmax, rmax_scalar, mode, sxyz, srl, cap, sws, L);
+    else
+        hipLaunchKernelGGL(k_seam_scatter<float>, dim3(nb, n_frames, n_kp), dim3(256), 0, st, sseg, srad, sdep, (int)HW, W, K[0], K[1],
+                           K[2], K[3], seg_thr, srmax, rmax_scalar, mode, sxyz, srl, cap, sws, L);
     RCV_LAUNCH_CHECK();
     return RCV_OK;
 }

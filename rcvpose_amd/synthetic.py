@@ -12,7 +12,7 @@ LINEMOD_K = (572.4114, 573.57043, 325.2611, 242.04899)  # fx, fy, cx, cy -- Accu
 YCB_K = (1066.778, 1067.487, 312.9869, 241.3109)        # public YCB-Video camera (cmu) intrinsics
 
 _LM = dict(K=LINEMOD_K, axes=(0.12, 0.10, 0.08), centre=(0.02, -0.03, 0.90))
-_YCB = dict(K=YCB_K, axes=(0.105, 0.085, 0.07), centre=(0.01, -0.02, 0.75))  # ~50k silhouette pixels
+_YCB = dict(K=YCB_K, axes=(0.0975, 0.079, 0.065), centre=(0.01, -0.02, 0.75))  # ~50k silhouette pixels
 
 
 def synthetic_frame(frame_idx, H=480, W=640, shape="lm", noise_dm=0.02):
