@@ -59,6 +59,20 @@ struct ConvParams {
     int M, K;  // GEMM sizes per group
 };
 
+// Tile order.  Blocks are numbered so that the N tiles of one M tile are neighbours (they share the gathered
+// A rows, the big operand) and -- blocks being dealt round-robin over the 8 XCDs -- so that neighbours in that
+// order land on the SAME XCD and meet in its L2 (bijective XCD remap, cdna_hip_programming.md T1).  Placement only
+// affects speed.
+__device__ __forceinline__ void tile_of_block(int n_tiles, int &mt, int &nt)
+{
+    const unsigned total = gridDim.x * gridDim.y;
+    const unsigned id = blockIdx.x + gridDim.x * blockIdx.y;
+    const unsigned q = total / 8, r = total % 8, xcd = id % 8;
+    const unsigned s = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + id / 8;
+    nt = (int)(s % (unsigned)n_tiles);
+    mt = (int)(s / (unsigned)n_tiles);
+}
+
 // ---------------------------------------------------------------------------------------------
 // implicit-GEMM convolution
 // ---------------------------------------------------------------------------------------------
@@ -74,7 +88,9 @@ __global__ __launch_bounds__(256) void k_conv(const ConvParams p)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int g = blockIdx.z, m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    int mt_, nt_;
+    tile_of_block(p.Cout / BN, mt_, nt_);
+    const int g = blockIdx.z, m0 = mt_ * BM, n0 = nt_ * BN;
     const int chunk = tid & 7, rowb = tid >> 3;
     const int Ctot = p.C0 + p.C1;
     const T *src0 = (const T *)p.src0 + (long long)g * p.src0_gs;
@@ -298,7 +314,9 @@ __global__ __launch_bounds__(512) void k_conv_dma(const ConvParams p, const void
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int g = blockIdx.z, m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    int mt_, nt_;
+    tile_of_block(p.Cout / BN, mt_, nt_);
+    const int g = blockIdx.z, m0 = mt_ * BM, n0 = nt_ * BN;
     const int Ctot = p.C0 + p.C1;
     const T *src0 = (const T *)p.src0 + (long long)g * p.src0_gs;
     const T *src1 = p.src1 ? (const T *)p.src1 + (long long)g * p.src1_gs : nullptr;
@@ -684,7 +702,7 @@ int launch_conv_variant(const ConvParams &p, int groups, hipStream_t st, bool se
     const size_t lds = (size_t)(BM + BN) * 128 * 2;
     if (set_attr)
         RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_conv<T, BM, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    dim3 grid((p.M + BM - 1) / BM, p.Cout / BN, groups);
+    dim3 grid(p.Cout / BN, (p.M + BM - 1) / BM, groups);
     hipLaunchKernelGGL((k_conv<T, BM, BN>), grid, dim3(256), lds, st, p);
     RCV_LAUNCH_CHECK();
     return RCV_OK;
@@ -695,7 +713,7 @@ int launch_conv_dma(const ConvParams &p, int groups, hipStream_t st, bool set_at
     const size_t lds = (size_t)DMA_STAGES * DMA_STAGE_BYTES;
     if (set_attr)
         RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_conv_dma, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    dim3 grid((p.M + DMA_BM - 1) / DMA_BM, p.Cout / DMA_BN, groups);
+    dim3 grid(p.Cout / DMA_BN, (p.M + DMA_BM - 1) / DMA_BM, groups);
     hipLaunchKernelGGL(k_conv_dma, grid, dim3(512), lds, st, p, (const void *)g_zero_page);
     RCV_LAUNCH_CHECK();
     return RCV_OK;
