@@ -428,34 +428,33 @@ __global__ __launch_bounds__(512) void k_conv_dma(const ConvParams p, const void
     }
 #undef RCV_DMA_ISSUE
 
-    // epilogue (as k_conv): fp32 staging through LDS, one wave row (64 tile rows) per round
+    // epilogue: the whole 256 x 128 fp32 tile fits the (now idle) 144 KB of LDS, so all eight waves stage their
+    // accumulators at once and the tile leaves as 16-byte vectors of contiguous channels after a single barrier
     T *dst = (T *)p.dst + (long long)g * p.dst_gs;
     const float *bias = p.bias + (long long)g * p.bias_gs;
-    constexpr int SROW = BN + 4, CPR = BN / EPV, CHUNKS = 64 * CPR, PER = CHUNKS / 512;
+    constexpr int SROW = BN + 4, CPR = BN / EPV;
     float *stg = (float *)smem;
+    __syncthreads();  // every wave is done reading the last operand tile
+#pragma unroll
+    for (int j = 0; j < NT; j++) {
+        const int nl = wn * 64 + j * 16 + r16;
+        const float bv = bias[n0 + nl];
+#pragma unroll
+        for (int i = 0; i < MT; i++)
+#pragma unroll
+            for (int e = 0; e < 4; e++) stg[(wm * 64 + i * 16 + kq * 4 + e) * SROW + nl] = acc[i][j][e] + bv;
+    }
+    __syncthreads();
 #pragma unroll
     for (int round = 0; round < 4; round++) {
-        __syncthreads();
-        if (wm == round) {
 #pragma unroll
-            for (int j = 0; j < NT; j++) {
-                const int nl = wn * 64 + j * 16 + r16;
-                const float bv = bias[n0 + nl];
-#pragma unroll
-                for (int i = 0; i < MT; i++)
-#pragma unroll
-                    for (int e = 0; e < 4; e++) stg[(i * 16 + kq * 4 + e) * SROW + nl] = acc[i][j][e] + bv;
-            }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int q = 0; q < PER; q++) {
+        for (int q = 0; q < E_PER; q++) {
             const int c = q * 512 + tid, row = c / CPR, cc = c - row * CPR;
             const int m = m0 + round * 64 + row;
             if (m >= p.M) continue;
             const long long o = (long long)m * p.Cout + n0 + cc * EPV;
             float v[EPV];
-            const float4 *sp4 = (const float4 *)(stg + row * SROW + cc * EPV);
+            const float4 *sp4 = (const float4 *)(stg + (round * 64 + row) * SROW + cc * EPV);
 #pragma unroll
             for (int qq = 0; qq < EPV / 4; qq++) {
                 const float4 t = sp4[qq];
