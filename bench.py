@@ -185,6 +185,13 @@ def main():
         conv_s = prof["conv_ms"] * 1e-3
         achieved = conv_flop_step / conv_s / 1e12
         peak = MFMA_PEAK_TFLOPS[args.dtype]
+        # HBM bytes of the conv family from the committed PMC passes (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
+        # runs, gfx950 correction applied: profiles/r01b_conv_hbm_traffic.json); only valid for the profiled workload
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r01b_conv_hbm_traffic.json")
+        if os.path.exists(tpath) and args.dtype == "bf16":
+            tj = json.load(open(tpath))["conv_family"]
+            traffic = tj["hbm_bytes_per_network_forward"] * B * G  # bytes per step on this GPU
         line = {
             "metric": "end-to-end frames/sec (FCN+3-kpt voting), 640x480 RGB-D",
             "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -195,7 +202,8 @@ def main():
                        "frames_per_step_per_gpu": B, "weights": "random (seeded He), ideal maps injected after the forward",
                        "overlap": bool(args.overlap), "parallelism": "frames sharded f%%%d, 1 RCCL all_gather/step" % world},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-                         "traffic": None,
+                         "traffic": traffic, "traffic_unit": "HBM bytes per step (all conv launches, PMC passes)",
+                         "algorithmic_flop_per_step": conv_flop_step,
                          "kernel": "k_conv<%s> implicit-GEMM family, %d launches/forward, algorithmic 265.568 GFLOP per "
                                    "network forward" % (args.dtype, sum(1 for o in pipe.engine.ops if o["kind"] == 3)),
                          "fcn_conv_ms_per_step": prof["conv_ms"], "fcn_other_ms_per_step": prof["other_ms"]},

@@ -1131,25 +1131,33 @@ __device__ __forceinline__ void d_bb_wide(AccHeader *hdr, const double *Q, const
             for (int t = 0; t < PT; t++) {
                 const int li = t * BBW_THREADS + tid;
                 const float q[3] = {sx[li], sy[li], sz[li]};
-                const float tlo = slo[li], thi = shi[li];
-                float mn2[3][2], mx2[3][2], ax[3][2];
+                float mn2[3][2], mx2[3][2], amax = 0.f;
 #pragma unroll
-                for (int a = 0; a < 3; a++)
+                for (int a = 0; a < 3; a++) {
+                    float am = 0.f;
 #pragma unroll
                     for (int h = 0; h < 2; h++) {
                         const float e1 = lo[a][h] - q[a], e2 = q[a] - hi[a][h];
                         const float dmin = fmaxf(fmaxf(e1, e2), 0.f), dmax = fmaxf(fabsf(e1), fabsf(e2));
-                        mn2[a][h] = dmin * dmin; mx2[a][h] = dmax * dmax; ax[a][h] = dmax;
+                        mn2[a][h] = dmin * dmin; mx2[a][h] = dmax * dmax;
+                        am = fmaxf(am, dmax);
                     }
+                    amax += am;
+                }
+                // one slack per point (the largest any child needs) folded into the thresholds
+                const float slack = slack_k * amax + 1e-5f;
+                const float thi = shi[li] + slack, tlo = slo[li] - slack;
+                // (smin < thi) && (smax >= tlo) as sign bits; the xy partial sums are shared by the two z halves
+                float mnxy[4], mxxy[4];
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    mnxy[c] = mn2[0][c >> 1] + mn2[1][c & 1];
+                    mxxy[c] = mx2[0][c >> 1] + mx2[1][c & 1];
+                }
 #pragma unroll
                 for (int c = 0; c < 8; c++) {
-                    const int hx = (c >> 2) & 1, hy = (c >> 1) & 1, hz = c & 1;
-                    const float smin = mn2[0][hx] + mn2[1][hy] + mn2[2][hz];
-                    const float smax = mx2[0][hx] + mx2[1][hy] + mx2[2][hz];
-                    const float slack = slack_k * (ax[0][hx] + ax[1][hy] + ax[2][hz]) + 1e-5f;
-                    // (smin - slack < thi) && (smax + slack >= tlo) as sign bits: no compare -> SGPR -> select chain
-                    const int below = __float_as_int((smin - slack) - thi);      // negative  <=>  smin - slack < thi
-                    const int reach = ~__float_as_int((smax + slack) - tlo);     // sign set  <=>  smax + slack >= tlo
+                    const int below = __float_as_int((mnxy[c >> 1] + mn2[2][c & 1]) - thi);   // negative <=> smin < thi
+                    const int reach = ~__float_as_int((mxxy[c >> 1] + mx2[2][c & 1]) - tlo);  // sign set <=> smax >= tlo
                     ub[c] += (int)((unsigned)(below & reach) >> 31);
                 }
             }
