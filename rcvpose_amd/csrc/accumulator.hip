@@ -1195,37 +1195,64 @@ __device__ __forceinline__ void d_bb_wide(AccHeader *hdr, const double *Q, const
 // itself (or next to it), which is what lets the wide levels prune.  Purely an accelerator: any exact count
 // is a valid lower bound.
 constexpr int BB_CLIMB_R = 2;
-constexpr int BB_CLIMB_N = (2 * BB_CLIMB_R + 1) * (2 * BB_CLIMB_R + 1) * (2 * BB_CLIMB_R + 1);
+constexpr int BB_CLIMB_W = 2 * BB_CLIMB_R + 1;
+constexpr int BB_CLIMB_ROUNDS = 8;
 
+// one workgroup per i-offset of the (2R+1)^3 neighbourhood; every thread scores the (2R+1)^2 voxels of that slice for
+// its points (dx^2 shared), then the slice's counts are reduced and folded into the running best
 __device__ __forceinline__ void d_bb_climb(AccHeader *hdr, const double *Q, const double *P, int cap)
 {
-    __shared__ int red[4];
+    constexpr int W = BB_CLIMB_W, NV = W * W;
+    __shared__ int red[4][NV];
     const AccHeader H = *hdr;
     if (H.status != RCV_OK || !H.bb_enabled || H.bb_best_key == 0) return;
     const int D = H.dim, n = H.n;
     const unsigned long long flat = H.bb_best_key & 0xFFFFFFFFull;
-    const int w = 2 * BB_CLIMB_R + 1;
-    const int o = blockIdx.x;
-    const int ci = (int)(flat / ((unsigned long long)D * D)) + o / (w * w) - BB_CLIMB_R;
-    const int cj = (int)((flat / D) % D) + (o / w) % w - BB_CLIMB_R;
-    const int ck = (int)(flat % D) + o % w - BB_CLIMB_R;
-    if (ci < 0 || cj < 0 || ck < 0 || ci >= D || cj >= D || ck >= D) return;
-    const double fi = (double)ci, fj = (double)cj, fk = (double)ck;
+    const int ci = (int)(flat / ((unsigned long long)D * D)) + (int)blockIdx.x - BB_CLIMB_R;
+    const int cj0 = (int)((flat / D) % D) - BB_CLIMB_R, ck0 = (int)(flat % D) - BB_CLIMB_R;
+    if (ci < 0 || ci >= D) return;
+    const double fi = (double)ci;
     const double *Qx = Q, *Qy = Q + (size_t)cap, *Qz = Q + 2 * (size_t)cap;
     const double *Plo = P + 3 * (size_t)cap, *Phi = P + 4 * (size_t)cap;
-    int cnt = 0;
+    int cnt[NV];
+#pragma unroll
+    for (int v = 0; v < NV; v++) cnt[v] = 0;
     for (int p = threadIdx.x; p < n; p += 256) {
-        const double dx = fi - Qx[p], dy = fj - Qy[p], dz = fk - Qz[p];
-        const double d2 = (dx * dx + dy * dy) + dz * dz;  // reference operand order (:337)
-        cnt += d2 >= Plo[p] && d2 < Phi[p];
+        const double thi = Phi[p];
+        if (!(thi > 0.0)) continue;
+        const double tlo = Plo[p], qy = Qy[p], qz = Qz[p];
+        const double dx = fi - Qx[p], dx2 = dx * dx;
+        double y2[W], z2[W];
+#pragma unroll
+        for (int o = 0; o < W; o++) {
+            const double dy = (double)(cj0 + o) - qy, dz = (double)(ck0 + o) - qz;  // (j - y), (k - z)
+            y2[o] = dy * dy; z2[o] = dz * dz;
+        }
+#pragma unroll
+        for (int a = 0; a < W; a++) {
+            const double xy = dx2 + y2[a];  // reference operand order (:337)
+#pragma unroll
+            for (int b = 0; b < W; b++) {
+                const double d2 = xy + z2[b];
+                const int below = (int)(__double_as_longlong(d2 - thi) >> 32);
+                const int reach = ~(int)(__double_as_longlong(d2 - tlo) >> 32);
+                cnt[a * W + b] += (int)((unsigned)(below & reach) >> 31);
+            }
+        }
     }
-    cnt = wave_sum_i32(cnt);
-    if (lane_id() == 0) red[wave_id()] = cnt;
+#pragma unroll
+    for (int v = 0; v < NV; v++) {
+        const int c = wave_sum_i32(cnt[v]);
+        if (lane_id() == 0) red[wave_id()][v] = c;
+    }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        cnt = red[0] + red[1] + red[2] + red[3];
-        atomicMax(&hdr->bb_best, cnt);
-        atomicMax(&hdr->bb_best_key, ((unsigned long long)cnt << 32) | (((unsigned long long)ci * D + cj) * D + ck));
+    if (threadIdx.x < NV) {
+        const int v = threadIdx.x, cj = cj0 + v / W, ck = ck0 + v % W;
+        if (cj >= 0 && ck >= 0 && cj < D && ck < D) {
+            const int c = red[0][v] + red[1][v] + red[2][v] + red[3][v];
+            atomicMax(&hdr->bb_best, c);
+            atomicMax(&hdr->bb_best_key, ((unsigned long long)c << 32) | (((unsigned long long)ci * D + cj) * D + ck));
+        }
     }
 }
 
@@ -1788,8 +1815,8 @@ static int accumulate_batch(rcv_strided xyz, rcv_strided radial, int radial_is_f
                 hipLaunchKernelGGL((k_bb_level<false, true, 1024>), grid3(BB_BEAM), dim3(1024), 0, st, cap, level, BBIo{1, 1}, sws, L);
             RCV_LAUNCH_CHECK();
         }
-        for (int round = 0; round < 3; round++) {  // exact hill-climb from the probe's best voxel
-            hipLaunchKernelGGL(k_bb_climb, grid3(BB_CLIMB_N), dim3(256), 0, st, cap, sws, L);
+        for (int round = 0; round < BB_CLIMB_ROUNDS; round++) {  // exact hill-climb from the probe's best voxel
+            hipLaunchKernelGGL(k_bb_climb, grid3(BB_CLIMB_W), dim3(256), 0, st, cap, sws, L);
             RCV_LAUNCH_CHECK();
         }
         // the lower bound now sits at (or next to) the peak: the wide levels only need upper bounds
