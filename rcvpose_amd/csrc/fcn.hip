@@ -403,11 +403,6 @@ __global__ __launch_bounds__(512) void k_conv_dma(const ConvParams p, const void
         if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        // every wave is past its reads of tile kt-1, whose stage is the one tile kt+2 goes to
-        if (kt + 2 < nk) {
-            const int st2 = stage + 2 >= DMA_STAGES ? stage + 2 - DMA_STAGES : stage + 2;
-            RCV_DMA_ISSUE(st2);
-        }
         const unsigned char *Ab = smem + stage * DMA_STAGE_BYTES + (wm * 64 + r16) * 128;
         const unsigned char *Bb = smem + stage * DMA_STAGE_BYTES + BM * 128 + (wn * 64 + r16) * 128;
 #pragma unroll
@@ -418,6 +413,13 @@ __global__ __launch_bounds__(512) void k_conv_dma(const ConvParams p, const void
             for (int i = 0; i < MT; i++) af[i] = *(const bf16x8 *)(Ab + i * 16 * 128 + ch);
 #pragma unroll
             for (int j = 0; j < NT; j++) bfr[j] = *(const bf16x8 *)(Bb + j * 16 * 128 + ch);
+            if (kk == 1 && kt + 2 < nk) {
+                // every wave is past its reads of tile kt-1 (barrier above), whose stage is the one tile kt+2 goes to.
+                // The DMAs are issued between the two MFMA halves: the first half's MFMAs are already queued on the
+                // matrix pipe while this wave spends its issue slots on the six LDS-DMA pieces.
+                const int st2 = stage + 2 >= DMA_STAGES ? stage + 2 - DMA_STAGES : stage + 2;
+                RCV_DMA_ISSUE(st2);
+            }
 #pragma unroll
             for (int i = 0; i < MT; i++)
 #pragma unroll
