@@ -1065,7 +1065,7 @@ __device__ __forceinline__ void d_bb_level(AccHeader *hdr, const double *Q, cons
 // streamed through LDS in float32 chunks (bulk coalesced loads, 8 points per thread per chunk), three
 // workgroups per CU.  Same conservative float32 box test as k_bb_level (absolute voxel coordinates).
 constexpr int BBW_THREADS = 256;
-constexpr int BBW_CHUNK = 2048;
+constexpr int BBW_CHUNK = 1024;
 
 __device__ __forceinline__ void d_bb_wide(AccHeader *hdr, const double *Q, const double *P, int cap,
                                                          const BBEntry *in_list, const uint32_t *in_count, int in_cap,
