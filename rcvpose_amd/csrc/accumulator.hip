@@ -78,7 +78,7 @@ struct PrepPartial {
 };
 
 struct Layout {
-    size_t header, partials, seam_counts, seam_offsets, tile_best, tile_ties, replicas, bb_lists, bb_probe, Q, P, ri, total;
+    size_t header, partials, seam_counts, seam_offsets, tile_best, tile_ties, replicas, bb_lists, bb_probe, Q, P, ri, F, capF, total;
 };
 
 Layout make_layout(int cap)
@@ -97,6 +97,8 @@ Layout make_layout(int cap)
     L.Q = o;             o += align_up(sizeof(double) * 3 * (size_t)cap, 256);  // final voxel-space coordinates (SoA)
     L.P = o;             o += align_up(sizeof(double) * 5 * (size_t)cap, 256);  // x, y, z, T_lo, T_hi per point (SoA)
     L.ri = o;            o += align_up(sizeof(int32_t) * (size_t)cap, 256);
+    L.capF = align_up((size_t)cap, 1024);  // float32 copy for the wide search levels, padded to whole LDS chunks
+    L.F = o;             o += sizeof(float) * 5 * L.capF;  // x, y, z, T_lo - slack, T_hi + slack (SoA)
     L.total = o;
     return L;
 }
@@ -868,16 +870,38 @@ struct BBEntry {
 };
 static_assert(sizeof(BBEntry) == 16, "BBEntry");
 
-__device__ __forceinline__ void d_bb_init(const AccHeader *hdr, const double *P, int cap, double *Q, BBEntry *roots)
+// conservative float32 slack on squared distances: coordinates lie in [0, D), block edges within 2 * BB_ROOT of
+// them, so every per-axis distance is below D + 2 * BB_ROOT and the sum of the three below 3 * (D + 2 * BB_ROOT)
+__device__ __forceinline__ float bb_f32_slack(int D)
+{
+    return 1.0e-6f * (float)(D + 2 * BB_ROOT) * 3.f * (float)(D + 2 * BB_ROOT) + 1e-5f;
+}
+
+__device__ __forceinline__ void d_bb_init(const AccHeader *hdr, const double *P, int cap, double *Q, BBEntry *roots, float *F,
+                                          size_t capF)
 {
     const AccHeader H = *hdr;
     if (H.status != RCV_OK || !H.bb_enabled) return;
     const int nb = (H.dim + BB_ROOT - 1) / BB_ROOT;
     const int nroot = nb * nb * nb;
-    const int top = H.n > nroot ? H.n : nroot;
+    const int npad = (H.n + 1023) & ~1023;  // the wide levels stream whole 1024-point chunks
+    const int top = npad > nroot ? npad : nroot;
+    const float slack = bb_f32_slack(H.dim);
     for (int t = blockIdx.x * 256 + threadIdx.x; t < top; t += gridDim.x * 256) {
-        if (t < H.n)  // fast_for sees xyz_mm - mean - zero_boundary (AccumulatorSpace.py:384-386,397)
-            for (int a = 0; a < 3; a++) Q[(size_t)a * cap + t] = (P[(size_t)a * cap + t] - H.mean[a]) - H.shift;
+        if (t < H.n) {  // fast_for sees xyz_mm - mean - zero_boundary (AccumulatorSpace.py:384-386,397)
+            double q[3];
+            for (int a = 0; a < 3; a++) {
+                q[a] = (P[(size_t)a * cap + t] - H.mean[a]) - H.shift;
+                Q[(size_t)a * cap + t] = q[a];
+                F[(size_t)a * capF + t] = (float)q[a];
+            }
+            const double tlo = P[3 * (size_t)cap + t], thi = P[4 * (size_t)cap + t];
+            F[3 * capF + t] = (float)tlo * (1.f - 1e-6f) - slack;
+            F[4 * capF + t] = thi > 0.0 ? (float)thi * (1.f + 1e-6f) + slack : -1.f;  // < 0: never counts
+        } else if (t < npad) {
+            for (int a = 0; a < 4; a++) F[(size_t)a * capF + t] = 0.f;
+            F[4 * capF + t] = -1.f;
+        }
         if (t < nroot) {
             BBEntry e;
             e.i = (uint16_t)((t / (nb * nb)) * BB_ROOT);
@@ -1061,125 +1085,153 @@ __device__ __forceinline__ void d_bb_level(AccHeader *hdr, const double *Q, cons
     }
 }
 
-// Wide levels of the search (upper bounds only): one 256-thread workgroup per parent, the point list
-// streamed through LDS in float32 chunks (bulk coalesced loads, 8 points per thread per chunk), three
-// workgroups per CU.  Same conservative float32 box test as k_bb_level (absolute voxel coordinates).
+// Wide levels of the search (upper bounds only).  A 256-thread workgroup scores the children of BBW_NP parents per
+// pass over the point list; the list is the float32 copy written by k_bb_init (slack folded into the thresholds,
+// padded to whole chunks) and arrives in LDS by LDS-DMA (global_load_lds, 16 B per lane), double buffered: the
+// chunk after the current one is in flight while this one is scored, one barrier per chunk.  Same conservative
+// float32 box test as k_bb_level (absolute voxel coordinates).
+typedef __attribute__((ext_vector_type(2))) float f32x2;
 constexpr int BBW_THREADS = 256;
 constexpr int BBW_CHUNK = 1024;
+constexpr int BBW_NP = 2;
 
-__device__ __forceinline__ void d_bb_wide(AccHeader *hdr, const double *Q, const double *P, int cap,
+__device__ __forceinline__ void bbw_dma16(const float *gptr, float *lds_wave_base)
+{
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gptr,
+                                     (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
+}
+
+__device__ __forceinline__ void d_bb_wide(AccHeader *hdr, const float *F, size_t capF,
                                                          const BBEntry *in_list, const uint32_t *in_count, int in_cap,
                                                          BBEntry *out_list, uint32_t *out_count, int out_cap, int level)
 {
-    __shared__ float sx[BBW_CHUNK], sy[BBW_CHUNK], sz[BBW_CHUNK], slo[BBW_CHUNK], shi[BBW_CHUNK];
-    __shared__ int red[BBW_THREADS / 64][8];
-    __shared__ int s_skip;
+    __shared__ __attribute__((aligned(16))) float sbuf[2][5][BBW_CHUNK];  // [stage][x, y, z, T_lo, T_hi][point]
+    __shared__ int red[BBW_THREADS / 64][8 * BBW_NP];
+    __shared__ int s_valid[BBW_NP], s_org[BBW_NP][3];
     const AccHeader H = *hdr;
     if (H.status != RCV_OK || !H.bb_enabled) return;
     const int D = H.dim, n = H.n;
     const int S = BB_ROOT >> level, s = S >> 1;
     const unsigned nin = min(*in_count, (uint32_t)in_cap);
-    const double *Qx = Q, *Qy = Q + (size_t)cap, *Qz = Q + 2 * (size_t)cap;
-    const double *Plo = P + 3 * (size_t)cap, *Phi = P + 4 * (size_t)cap;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const float slack_k = 1.0e-6f * (float)(D + 2 * BB_ROOT);
     constexpr int PT = BBW_CHUNK / BBW_THREADS;
-    for (unsigned pi = blockIdx.x; pi < nin; pi += gridDim.x) {
-        const BBEntry e = in_list[pi];
+    static_assert(32 % PT == 0, "vote-bit histories are counted every 32 points per thread");
+    const int nchunks = (n + BBW_CHUNK - 1) / BBW_CHUNK;
+    // wave wv brings floats [wv * 256, wv * 256 + 256) of each of the five arrays of a chunk
+    const float *src = F + wv * 256 + lane * 4;
+#define RCV_BBW_ISSUE(chunk, stage)                                                                        \
+    {                                                                                                      \
+        _Pragma("unroll") for (int a = 0; a < 5; a++)                                                      \
+            bbw_dma16(src + (size_t)a * capF + (size_t)(chunk) * BBW_CHUNK, &sbuf[stage][a][wv * 256]);    \
+    }
+    if (blockIdx.x * BBW_NP >= nin) return;
+    int g = 0;  // running chunk number of this workgroup: chunk g sits in stage g & 1
+    RCV_BBW_ISSUE(0, 0);
+    for (unsigned pp = blockIdx.x; pp * BBW_NP < nin; pp += gridDim.x) {
+        BBEntry e[BBW_NP];
+#pragma unroll
+        for (int u = 0; u < BBW_NP; u++) e[u] = in_list[min(pp * BBW_NP + u, nin - 1)];
         __syncthreads();
-        if (tid == 0)
-            s_skip = e.ub < __hip_atomic_load(&hdr->bb_best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ||
-                     __hip_atomic_load(&hdr->bb_overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid < BBW_NP) {
+            const int best = __hip_atomic_load(&hdr->bb_best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int ovf = __hip_atomic_load(&hdr->bb_overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const BBEntry me = in_list[min(pp * BBW_NP + tid, nin - 1)];
+            s_valid[tid] = pp * BBW_NP + tid < nin && me.ub >= best && !ovf;
+            s_org[tid][0] = me.i; s_org[tid][1] = me.j; s_org[tid][2] = me.k;
+        }
         __syncthreads();
-        if (s_skip) continue;
-        const int org[3] = {e.i, e.j, e.k};
-        float lo[3][2], hi[3][2];
-        bool ok[3][2];
+        bool valid[BBW_NP], any = false;
 #pragma unroll
-        for (int a = 0; a < 3; a++)
+        for (int u = 0; u < BBW_NP; u++) { valid[u] = s_valid[u] != 0; any = any || valid[u]; }
+        if (!any) continue;  // (workgroup-uniform) chunk 0 stays in stage g & 1 for the next pass
+        f32x2 lo2[BBW_NP][3], hi2[BBW_NP][3];
 #pragma unroll
-            for (int h = 0; h < 2; h++) {
-                const int l = org[a] + h * s, u = min(l + s - 1, D - 1);
-                ok[a][h] = l <= D - 1;
-                lo[a][h] = (float)l;
-                hi[a][h] = (float)u;
+        for (int u = 0; u < BBW_NP; u++) {
+            const int org[3] = {e[u].i, e[u].j, e[u].k};
+#pragma unroll
+            for (int a = 0; a < 3; a++) {
+                const int l0 = org[a], l1 = org[a] + s;
+                lo2[u][a] = f32x2{(float)l0, (float)l1};
+                hi2[u][a] = f32x2{(float)min(l0 + s - 1, D - 1), (float)min(l1 + s - 1, D - 1)};
             }
-        int ub[8];
+        }
+        int ub[BBW_NP][8];
+        unsigned hist[BBW_NP][8];  // per child: the last <= 32 vote bits, one shifted in per point, counted every 8 chunks
 #pragma unroll
-        for (int c = 0; c < 8; c++) ub[c] = 0;
-        for (int base = 0; base < n; base += BBW_CHUNK) {
-            __syncthreads();
-            {
-                // all loads of the chunk are issued before any is consumed (no data-dependent branch in between)
-                double rx[PT], ry[PT], rz[PT], rl[PT], rh[PT];
+        for (int u = 0; u < BBW_NP; u++)
 #pragma unroll
-                for (int t = 0; t < PT; t++) {
-                    const int p = min(base + t * BBW_THREADS + tid, n - 1);
-                    rx[t] = Qx[p]; ry[t] = Qy[p]; rz[t] = Qz[p]; rl[t] = Plo[p]; rh[t] = Phi[p];
-                }
-#pragma unroll
-                for (int t = 0; t < PT; t++) {
-                    const int li = t * BBW_THREADS + tid;
-                    const bool live = base + li < n && rh[t] > 0.0;
-                    sx[li] = (float)rx[t]; sy[li] = (float)ry[t]; sz[li] = (float)rz[t];
-                    slo[li] = (float)rl[t] * (1.f - 1e-6f);
-                    shi[li] = live ? (float)rh[t] * (1.f + 1e-6f) : -1.f;  // < 0: never counts
-                }
-            }
-            __syncthreads();
+            for (int c = 0; c < 8; c++) { ub[u][c] = 0; hist[u][c] = 0u; }
+        for (int ch = 0; ch < nchunks; ch++, g++) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of chunk g have landed
+            __syncthreads();                                  // ... and everybody's; stage (g + 1) & 1 is free again
+            RCV_BBW_ISSUE(ch + 1 < nchunks ? ch + 1 : 0, (g + 1) & 1);  // next chunk (or chunk 0 of the next pass)
+            const float(*sb)[BBW_CHUNK] = sbuf[g & 1];
 #pragma unroll 1
             for (int t = 0; t < PT; t++) {
                 const int li = t * BBW_THREADS + tid;
-                const float q[3] = {sx[li], sy[li], sz[li]};
-                float mn2[3][2], mx2[3][2], amax = 0.f;
+                const float q[3] = {sb[0][li], sb[1][li], sb[2][li]};
+                const float tlo = sb[3][li], thi = sb[4][li];
+                const f32x2 thi2 = {thi, thi}, tlo2 = {tlo, tlo};
 #pragma unroll
-                for (int a = 0; a < 3; a++) {
-                    float am = 0.f;
+                for (int u = 0; u < BBW_NP; u++) {
+                    // both halves of an axis as one float2 (v_pk_add_f32 / v_pk_mul_f32)
+                    f32x2 mn2[3], mx2[3];
 #pragma unroll
-                    for (int h = 0; h < 2; h++) {
-                        const float e1 = lo[a][h] - q[a], e2 = q[a] - hi[a][h];
-                        const float dmin = fmaxf(fmaxf(e1, e2), 0.f), dmax = fmaxf(fabsf(e1), fabsf(e2));
-                        mn2[a][h] = dmin * dmin; mx2[a][h] = dmax * dmax;
-                        am = fmaxf(am, dmax);
+                    for (int a = 0; a < 3; a++) {
+                        const f32x2 qq = {q[a], q[a]};
+                        const f32x2 e1 = lo2[u][a] - qq, e2 = qq - hi2[u][a];
+                        const f32x2 s1 = e1 * e1, s2 = e2 * e2;
+                        const f32x2 dmin = {fmaxf(fmaxf(e1.x, e2.x), 0.f), fmaxf(fmaxf(e1.y, e2.y), 0.f)};
+                        mn2[a] = dmin * dmin;
+                        mx2[a] = f32x2{fmaxf(s1.x, s2.x), fmaxf(s1.y, s2.y)};
                     }
-                    amax += am;
-                }
-                // one slack per point (the largest any child needs) folded into the thresholds
-                const float slack = slack_k * amax + 1e-5f;
-                const float thi = shi[li] + slack, tlo = slo[li] - slack;
-                // (smin < thi) && (smax >= tlo) as sign bits; the xy partial sums are shared by the two z halves
-                float mnxy[4], mxxy[4];
+                    // (smin < thi) && (smax > tlo) as sign bits; the xy partial sums are shared by the two z halves
+                    // and the thresholds are folded into the z terms
+                    const f32x2 mnxy[2] = {f32x2{mn2[0].x, mn2[0].x} + mn2[1], f32x2{mn2[0].y, mn2[0].y} + mn2[1]};
+                    const f32x2 mxxy[2] = {f32x2{mx2[0].x, mx2[0].x} + mx2[1], f32x2{mx2[0].y, mx2[0].y} + mx2[1]};
+                    const f32x2 zb = mn2[2] - thi2;
+                    const f32x2 zr = tlo2 - mx2[2];
 #pragma unroll
-                for (int c = 0; c < 4; c++) {
-                    mnxy[c] = mn2[0][c >> 1] + mn2[1][c & 1];
-                    mxxy[c] = mx2[0][c >> 1] + mx2[1][c & 1];
+                    for (int c = 0; c < 4; c++) {
+                        const float mn = (c & 1) ? mnxy[c >> 1].y : mnxy[c >> 1].x;
+                        const float mx = (c & 1) ? mxxy[c >> 1].y : mxxy[c >> 1].x;
+                        const f32x2 below = f32x2{mn, mn} + zb;  // negative <=> smin < thi
+                        const f32x2 reach = zr - f32x2{mx, mx};  // negative <=> smax > tlo
+                        hist[u][2 * c] = __builtin_amdgcn_alignbit(
+                            hist[u][2 * c], (unsigned)(__float_as_int(below.x) & __float_as_int(reach.x)), 31);
+                        hist[u][2 * c + 1] = __builtin_amdgcn_alignbit(
+                            hist[u][2 * c + 1], (unsigned)(__float_as_int(below.y) & __float_as_int(reach.y)), 31);
+                    }
                 }
+            }
+            if ((ch & (32 / PT - 1)) == 32 / PT - 1) {
 #pragma unroll
-                for (int c = 0; c < 8; c++) {
-                    const int below = __float_as_int((mnxy[c >> 1] + mn2[2][c & 1]) - thi);   // negative <=> smin < thi
-                    const int reach = ~__float_as_int((mxxy[c >> 1] + mx2[2][c & 1]) - tlo);  // sign set <=> smax >= tlo
-                    ub[c] += (int)((unsigned)(below & reach) >> 31);
-                }
+                for (int u = 0; u < BBW_NP; u++)
+#pragma unroll
+                    for (int c = 0; c < 8; c++) { ub[u][c] += __popc(hist[u][c]); hist[u][c] = 0u; }
             }
         }
 #pragma unroll
-        for (int c = 0; c < 8; c++) {
-            const int u = wave_sum_i32(ub[c]);
-            if (lane == 0) red[wv][c] = u;
-        }
+        for (int u = 0; u < BBW_NP; u++)
+#pragma unroll
+            for (int c = 0; c < 8; c++) {
+                const int v = wave_sum_i32(ub[u][c] + __popc(hist[u][c]));
+                if (lane == 0) red[wv][u * 8 + c] = v;
+            }
         __syncthreads();
-        if (tid < 8) {
-            const int c = tid, hx = (c >> 2) & 1, hy = (c >> 1) & 1, hz = c & 1;
-            int u = 0;
-            for (int w = 0; w < BBW_THREADS / 64; w++) u += red[w][c];
-            if (ok[0][hx] && ok[1][hy] && ok[2][hz]) {
+        if (tid < 8 * BBW_NP) {
+            const int u = tid >> 3, c = tid & 7, hx = (c >> 2) & 1, hy = (c >> 1) & 1, hz = c & 1;
+            int cnt = 0;
+            for (int w = 0; w < BBW_THREADS / 64; w++) cnt += red[w][tid];
+            const int oi = s_org[u][0] + hx * s, oj = s_org[u][1] + hy * s, ok_ = s_org[u][2] + hz * s;
+            if (s_valid[u] && oi <= D - 1 && oj <= D - 1 && ok_ <= D - 1) {
                 const int best = __hip_atomic_load(&hdr->bb_best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (u > 0 && u >= best) {
+                if (cnt > 0 && cnt >= best) {
                     const unsigned slot = atomicAdd(out_count, 1u);
                     if (slot < (unsigned)out_cap) {
                         BBEntry o;
-                        o.i = (uint16_t)(org[0] + hx * s); o.j = (uint16_t)(org[1] + hy * s); o.k = (uint16_t)(org[2] + hz * s);
-                        o.pad_ = 0; o.ub = u; o.lb = 0;
+                        o.i = (uint16_t)oi; o.j = (uint16_t)oj; o.k = (uint16_t)ok_;
+                        o.pad_ = 0; o.ub = cnt; o.lb = 0;
                         out_list[slot] = o;
                     } else {
                         atomicExch(&hdr->bb_overflow, 1);
@@ -1188,6 +1240,8 @@ __device__ __forceinline__ void d_bb_wide(AccHeader *hdr, const double *Q, const
             }
         }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the look-ahead chunk of the last pass
+#undef RCV_BBW_ISSUE
 }
 
 // Hill-climb on exact voxel counts around the best voxel found so far (5 x 5 x 5 neighbourhood, one workgroup
@@ -1598,7 +1652,8 @@ __global__ __launch_bounds__(1024) void k_setup(SP<const int32_t> counts, int n_
 __global__ __launch_bounds__(256) void k_bb_init(int cap, SP<unsigned char> ws, Layout L)
 {
     unsigned char *w = ws.get();
-    d_bb_init((const AccHeader *)(w + L.header), (const double *)(w + L.P), cap, (double *)(w + L.Q), (BBEntry *)(w + L.bb_lists));
+    d_bb_init((const AccHeader *)(w + L.header), (const double *)(w + L.P), cap, (double *)(w + L.Q), (BBEntry *)(w + L.bb_lists),
+              (float *)(w + L.F), L.capF);
 }
 // which candidate lists a level kernel reads / writes (all live in the item's workspace)
 struct BBIo {
@@ -1632,8 +1687,7 @@ __global__ __launch_bounds__(BBW_THREADS) void k_bb_wide(int cap, int level, SP<
     unsigned char *w = ws.get();
     const BBEntry *in; const uint32_t *in_count; int in_cap; BBEntry *out; uint32_t *out_count; int out_cap;
     bb_resolve(w, L, level, BBIo{0, 0}, in, in_count, in_cap, out, out_count, out_cap);
-    d_bb_wide((AccHeader *)(w + L.header), (const double *)(w + L.Q), (const double *)(w + L.P), cap, in, in_count, in_cap, out,
-              out_count, out_cap, level);
+    d_bb_wide((AccHeader *)(w + L.header), (const float *)(w + L.F), L.capF, in, in_count, in_cap, out, out_count, out_cap, level);
 }
 __global__ __launch_bounds__(256) void k_bb_climb(int cap, SP<unsigned char> ws, Layout L)
 {
