@@ -1093,7 +1093,7 @@ __device__ __forceinline__ void d_bb_level(AccHeader *hdr, const double *Q, cons
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 constexpr int BBW_THREADS = 256;
 constexpr int BBW_CHUNK = 1024;
-constexpr int BBW_NP = 2;
+constexpr int BBW_NP = 4;
 
 __device__ __forceinline__ void bbw_dma16(const float *gptr, float *lds_wave_base)
 {
