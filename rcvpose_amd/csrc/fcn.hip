@@ -312,7 +312,7 @@ __global__ __launch_bounds__(512) void k_conv_dma(const ConvParams p, const void
     constexpr int KE = 64, EPV = 8, BM = DMA_BM, BN = DMA_BN;
     constexpr int MT = 4, NT = 4;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     int mt_, nt_;
     tile_of_block(p.Cout / BN, mt_, nt_);
@@ -321,7 +321,7 @@ __global__ __launch_bounds__(512) void k_conv_dma(const ConvParams p, const void
     const T *src0 = (const T *)p.src0 + (long long)g * p.src0_gs;
     const T *src1 = p.src1 ? (const T *)p.src1 + (long long)g * p.src1_gs : nullptr;
     const T *wg = (const T *)p.w + (long long)g * p.w_gs;
-    const T *zero = (const T *)zero_page;
+    (void)zero_page;
 
     // the residual tile (if any) is requested before anything else: for the short-K expand convolutions the
     // kernel is a stream of (operand tile, residual tile, output tile) and this overlaps the first two
@@ -340,51 +340,72 @@ __global__ __launch_bounds__(512) void k_conv_dma(const ConvParams p, const void
     }
 
     // loader role of this lane: 4 A rows (wave*32 + c*8 + lane/8) and 2 B rows (wave*16 + c*8 + lane/8), 16-byte
-    // slot lane%8 of the LDS row, which receives the source chunk slot ^ ((row>>1)&7)
+    // slot lane%8 of the LDS row, which receives the source chunk slot ^ ((row>>1)&7).
+    // The pieces are buffer loads (buffer_load_dwordx4 ... lds): the per-lane byte offset of a row (its own input
+    // pixel, its channel chunk) is fixed for the whole tile, the tap / channel-slice displacement of a K step goes
+    // into the (wave-uniform) base address of the buffer descriptor, i.e. is scalar arithmetic, and padding taps or
+    // rows beyond M get an out-of-range offset, for which the hardware returns zeros.  Per piece that leaves three
+    // VALU instructions (test the tap bit, select), cheap enough to sit between MFMAs.
     const int lrow = lane >> 3, lpos = lane & 7;
-    int a_hi0[4], a_wi0[4], a_pix[4], a_ch[4];
+    constexpr int OOB = (int)0x80000000;
+    int a_off0[4], a_off1[4];
+    unsigned a_ok[4];
     const int HWo = p.Hout * p.Wout;
 #pragma unroll
     for (int c = 0; c < 4; c++) {
         const int row = wave * 32 + c * 8 + lrow;
         const int m = m0 + row;
-        a_ch[c] = (lpos ^ ((row >> 1) & 7)) * EPV;
+        const int chunk = (lpos ^ ((row >> 1) & 7)) * EPV;
+        a_off0[c] = OOB; a_off1[c] = OOB; a_ok[c] = 0u;
         if (m < p.M) {
             const int img = m / HWo, rem = m - img * HWo;
             const int ho = rem / p.Wout, wo = rem - ho * p.Wout;
-            a_hi0[c] = ho * p.stride - p.pad;
-            a_wi0[c] = wo * p.stride - p.pad;
-            a_pix[c] = img * p.Hin * p.Win;
-        } else {
-            a_hi0[c] = -100000; a_wi0[c] = -100000; a_pix[c] = 0;
+            const int hc = ho * p.stride, wc = wo * p.stride;  // the pixel under tap (pad, pad): always inside the image
+            const int lin = (img * p.Hin + hc) * p.Win + wc;
+            a_off0[c] = (lin * p.C0 + chunk) * 2;
+            a_off1[c] = (lin * p.C1 + chunk) * 2;
+            for (int r = 0; r < p.KS; r++)
+                for (int q = 0; q < p.KS; q++)
+                    if ((unsigned)(hc - p.pad + r) < (unsigned)p.Hin && (unsigned)(wc - p.pad + q) < (unsigned)p.Win)
+                        a_ok[c] |= 1u << (r * p.KS + q);
         }
     }
-    const T *b_ptr[2];
+    int b_off[2];
 #pragma unroll
     for (int c = 0; c < 2; c++) {
         const int row = wave * 16 + c * 8 + lrow;
-        b_ptr[c] = wg + (long long)(n0 + row) * p.K + (lpos ^ ((row >> 1) & 7)) * EPV;
+        b_off[c] = (row * p.K + (lpos ^ ((row >> 1) & 7)) * EPV) * 2;
     }
+    const char *b_base = (const char *)(wg + (long long)n0 * p.K);
+    const int n_img = __builtin_amdgcn_readfirstlane(p.M / HWo);  // (uniform, but the division runs on the VALU)
+    const int a_bytes0 = (int)((long long)p.C0 * p.Hin * p.Win * n_img * 2), a_bytes1 = (int)((long long)p.C1 * p.Hin * p.Win * n_img * 2);
+    const int b_bytes = BN * p.K * 2;
     int tap_r = 0, tap_s = 0, cg = 0;
 
 #define RCV_DMA_ISSUE(stage)                                                                                   \
     {                                                                                                          \
         unsigned char *As_ = smem + (stage) * DMA_STAGE_BYTES;                                                 \
         unsigned char *Bs_ = As_ + BM * 128;                                                                   \
-        const T *src_;                                                                                         \
-        int Cs_, c_;                                                                                           \
-        if (cg < p.C0) { src_ = src0; Cs_ = p.C0; c_ = cg; } else { src_ = src1; Cs_ = p.C1; c_ = cg - p.C0; } \
-        const int kcol_ = (tap_r * p.KS + tap_s) * Ctot + cg;                                                  \
+        const bool first_ = cg < p.C0;                                                                         \
+        const int Cs_ = first_ ? p.C0 : p.C1, c_ = first_ ? cg : cg - p.C0;                                    \
+        const int tap_ = tap_r * p.KS + tap_s;                                                                 \
+        const long long disp_ = ((long long)((tap_r - p.pad) * p.Win + (tap_s - p.pad)) * Cs_ + c_) * 2;      \
+        const char *abase_ = (const char *)(first_ ? src0 : src1) + disp_;                                     \
+        const __amdgpu_buffer_rsrc_t ra_ = __builtin_amdgcn_make_buffer_rsrc((void *)abase_, 0, first_ ? a_bytes0 : a_bytes1, 0x00020000); \
+        const __amdgpu_buffer_rsrc_t rb_ = __builtin_amdgcn_make_buffer_rsrc((void *)(b_base + (long long)(tap_ * Ctot + cg) * 2), 0, b_bytes, 0x00020000); \
         _Pragma("unroll") for (int c = 0; c < 4; c++) {                                                        \
-            const int hi_ = a_hi0[c] + tap_r, wi_ = a_wi0[c] + tap_s;                                          \
-            const T *ptr_ = zero;                                                                              \
-            if ((unsigned)hi_ < (unsigned)p.Hin && (unsigned)wi_ < (unsigned)p.Win)                            \
-                ptr_ = src_ + ((long long)(a_pix[c] + hi_ * p.Win + wi_) * Cs_ + c_ + a_ch[c]);                \
-            glds16(ptr_, As_ + (wave * 32 + c * 8) * 128);                                                     \
+            const int off_ = ((a_ok[c] >> tap_) & 1u) ? (first_ ? a_off0[c] : a_off1[c]) : OOB;                \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra_, (__attribute__((address_space(3))) void *)(As_ + (wave * 32 + c * 8) * 128), 16, off_, 0, 0, 0); \
         }                                                                                                      \
-        _Pragma("unroll") for (int c = 0; c < 2; c++) glds16(b_ptr[c] + kcol_, Bs_ + (wave * 16 + c * 8) * 128); \
+        _Pragma("unroll") for (int c = 0; c < 2; c++)                                                          \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rb_, (__attribute__((address_space(3))) void *)(Bs_ + (wave * 16 + c * 8) * 128), 16, b_off[c], 0, 0, 0); \
         cg += KE;                                                                                              \
-        if (cg == Ctot) { cg = 0; if (++tap_s == p.KS) { tap_s = 0; ++tap_r; } }                               \
+        const bool wrap_ = cg == Ctot;                                                                         \
+        cg = wrap_ ? 0 : cg;                                                                                   \
+        tap_s += wrap_ ? 1 : 0;                                                                                \
+        const bool wrap2_ = tap_s == p.KS;                                                                     \
+        tap_s = wrap2_ ? 0 : tap_s;                                                                            \
+        tap_r += wrap2_ ? 1 : 0;                                                                               \
     }
 
     f32x4 acc[MT][NT];
@@ -393,41 +414,62 @@ __global__ __launch_bounds__(512) void k_conv_dma(const ConvParams p, const void
 #pragma unroll
         for (int j = 0; j < NT; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int r16 = lane & 15, kq = lane >> 4;
+    const int ch0 = ((0 * 4 + kq) ^ ((r16 >> 1) & 7)) << 4, ch1 = ((1 * 4 + kq) ^ ((r16 >> 1) & 7)) << 4;
+
+// One K step.  All 16 fragment reads, the six LDS-DMA pieces of tile kt+2 (ISSUE) and the 32 MFMAs sit in one basic
+// block; the sched_group_barrier sequence asks for: the kk=0 fragments, then MFMAs with the kk=1 fragment reads
+// and the DMA pieces (with their address arithmetic) slotted between them, one memory instruction per MFMA.
+#define RCV_DMA_STEP(ISSUE, LASTWAIT)                                                                          \
+    {                                                                                                          \
+        if (LASTWAIT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                         \
+        else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                                                  \
+        __builtin_amdgcn_s_barrier();                                                                          \
+        const unsigned char *Ab = smem + stage * DMA_STAGE_BYTES + (wm * 64 + r16) * 128;                      \
+        const unsigned char *Bb = smem + stage * DMA_STAGE_BYTES + BM * 128 + (wn * 64 + r16) * 128;           \
+        bf16x8 af0[MT], bf0[NT], af1[MT], bf1[NT];                                                             \
+        _Pragma("unroll") for (int i = 0; i < MT; i++) af0[i] = *(const bf16x8 *)(Ab + i * 16 * 128 + ch0);    \
+        _Pragma("unroll") for (int j = 0; j < NT; j++) bf0[j] = *(const bf16x8 *)(Bb + j * 16 * 128 + ch0);    \
+        _Pragma("unroll") for (int i = 0; i < MT; i++) af1[i] = *(const bf16x8 *)(Ab + i * 16 * 128 + ch1);    \
+        _Pragma("unroll") for (int j = 0; j < NT; j++) bf1[j] = *(const bf16x8 *)(Bb + j * 16 * 128 + ch1);    \
+        if (ISSUE) {                                                                                           \
+            const int st2 = stage + 2 >= DMA_STAGES ? stage + 2 - DMA_STAGES : stage + 2;                      \
+            RCV_DMA_ISSUE(st2);                                                                                \
+        }                                                                                                      \
+        _Pragma("unroll") for (int i = 0; i < MT; i++)                                                         \
+            _Pragma("unroll") for (int j = 0; j < NT; j++)                                                     \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af0[i], bf0[j], acc[i][j], 0, 0, 0);       \
+        _Pragma("unroll") for (int i = 0; i < MT; i++)                                                         \
+            _Pragma("unroll") for (int j = 0; j < NT; j++)                                                     \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af1[i], bf1[j], acc[i][j], 0, 0, 0);       \
+        __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);                                                     \
+        _Pragma("unroll") for (int u = 0; u < 8; u++) {                                                        \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                 \
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                 \
+        }                                                                                                      \
+        if (ISSUE) {                                                                                           \
+            _Pragma("unroll") for (int u = 0; u < 6; u++) {                                                    \
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                             \
+                __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);                                             \
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                             \
+            }                                                                                                  \
+            __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);                                                \
+        } else {                                                                                               \
+            __builtin_amdgcn_sched_group_barrier(0x008, 24, 0);                                                \
+        }                                                                                                      \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                     \
+        stage = stage + 1 == DMA_STAGES ? 0 : stage + 1;                                                       \
+    }
 
     const int nk = p.K / KE;
     RCV_DMA_ISSUE(0);
     if (nk > 1) RCV_DMA_ISSUE(1);
     int stage = 0;
-    for (int kt = 0; kt < nk; kt++) {
-        // tile kt has landed once at most the 6 DMAs of tile kt+1 are still outstanding (loads retire in order)
-        if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        const unsigned char *Ab = smem + stage * DMA_STAGE_BYTES + (wm * 64 + r16) * 128;
-        const unsigned char *Bb = smem + stage * DMA_STAGE_BYTES + BM * 128 + (wn * 64 + r16) * 128;
-#pragma unroll
-        for (int kk = 0; kk < 2; kk++) {
-            bf16x8 af[MT], bfr[NT];
-            const int ch = ((kk * 4 + kq) ^ ((r16 >> 1) & 7)) << 4;
-#pragma unroll
-            for (int i = 0; i < MT; i++) af[i] = *(const bf16x8 *)(Ab + i * 16 * 128 + ch);
-#pragma unroll
-            for (int j = 0; j < NT; j++) bfr[j] = *(const bf16x8 *)(Bb + j * 16 * 128 + ch);
-            if (kk == 1 && kt + 2 < nk) {
-                // every wave is past its reads of tile kt-1 (barrier above), whose stage is the one tile kt+2 goes to.
-                // The DMAs are issued between the two MFMA halves: the first half's MFMAs are already queued on the
-                // matrix pipe while this wave spends its issue slots on the six LDS-DMA pieces.
-                const int st2 = stage + 2 >= DMA_STAGES ? stage + 2 - DMA_STAGES : stage + 2;
-                RCV_DMA_ISSUE(st2);
-            }
-#pragma unroll
-            for (int i = 0; i < MT; i++)
-#pragma unroll
-                for (int j = 0; j < NT; j++)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
-        }
-        stage = stage + 1 == DMA_STAGES ? 0 : stage + 1;
-    }
+    // tile kt has landed once at most the 6 DMAs of tile kt+1 are still outstanding (loads retire in order); every
+    // wave is past its reads of tile kt-1 at the barrier, whose stage is the one tile kt+2 goes to
+    for (int kt = 0; kt + 2 < nk; kt++) RCV_DMA_STEP(true, false);
+    if (nk > 1) RCV_DMA_STEP(false, false);
+    RCV_DMA_STEP(false, true);
+#undef RCV_DMA_STEP
 #undef RCV_DMA_ISSUE
 
     // epilogue: the whole 256 x 128 fp32 tile fits the (now idle) 144 KB of LDS, so all eight waves stage their
