@@ -382,30 +382,37 @@ __global__ __launch_bounds__(512) void k_conv_dma(const ConvParams p, const void
     const int b_bytes = BN * p.K * 2;
     int tap_r = 0, tap_s = 0, cg = 0;
 
-#define RCV_DMA_ISSUE(stage)                                                                                   \
+// the pieces [LO, HI) of the next K step (0..3: A rows, 4..5: B rows) into `stage`; ADV: advance the K position
+#define RCV_DMA_ISSUE(stage, LO, HI, ADV)                                                                      \
     {                                                                                                          \
         unsigned char *As_ = smem + (stage) * DMA_STAGE_BYTES;                                                 \
         unsigned char *Bs_ = As_ + BM * 128;                                                                   \
         const bool first_ = cg < p.C0;                                                                         \
         const int Cs_ = first_ ? p.C0 : p.C1, c_ = first_ ? cg : cg - p.C0;                                    \
         const int tap_ = tap_r * p.KS + tap_s;                                                                 \
-        const long long disp_ = ((long long)((tap_r - p.pad) * p.Win + (tap_s - p.pad)) * Cs_ + c_) * 2;      \
-        const char *abase_ = (const char *)(first_ ? src0 : src1) + disp_;                                     \
-        const __amdgpu_buffer_rsrc_t ra_ = __builtin_amdgcn_make_buffer_rsrc((void *)abase_, 0, first_ ? a_bytes0 : a_bytes1, 0x00020000); \
-        const __amdgpu_buffer_rsrc_t rb_ = __builtin_amdgcn_make_buffer_rsrc((void *)(b_base + (long long)(tap_ * Ctot + cg) * 2), 0, b_bytes, 0x00020000); \
-        _Pragma("unroll") for (int c = 0; c < 4; c++) {                                                        \
-            const int off_ = ((a_ok[c] >> tap_) & 1u) ? (first_ ? a_off0[c] : a_off1[c]) : OOB;                \
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra_, (__attribute__((address_space(3))) void *)(As_ + (wave * 32 + c * 8) * 128), 16, off_, 0, 0, 0); \
+        if ((LO) < 4) {                                                                                        \
+            const long long disp_ = ((long long)((tap_r - p.pad) * p.Win + (tap_s - p.pad)) * Cs_ + c_) * 2;  \
+            const char *abase_ = (const char *)(first_ ? src0 : src1) + disp_;                                 \
+            const __amdgpu_buffer_rsrc_t ra_ = __builtin_amdgcn_make_buffer_rsrc((void *)abase_, 0, first_ ? a_bytes0 : a_bytes1, 0x00020000); \
+            _Pragma("unroll") for (int c = (LO); c < ((HI) < 4 ? (HI) : 4); c++) {                             \
+                const int off_ = ((a_ok[c] >> tap_) & 1u) ? (first_ ? a_off0[c] : a_off1[c]) : OOB;            \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(ra_, (__attribute__((address_space(3))) void *)(As_ + (wave * 32 + c * 8) * 128), 16, off_, 0, 0, 0); \
+            }                                                                                                  \
         }                                                                                                      \
-        _Pragma("unroll") for (int c = 0; c < 2; c++)                                                          \
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rb_, (__attribute__((address_space(3))) void *)(Bs_ + (wave * 16 + c * 8) * 128), 16, b_off[c], 0, 0, 0); \
-        cg += KE;                                                                                              \
-        const bool wrap_ = cg == Ctot;                                                                         \
-        cg = wrap_ ? 0 : cg;                                                                                   \
-        tap_s += wrap_ ? 1 : 0;                                                                                \
-        const bool wrap2_ = tap_s == p.KS;                                                                     \
-        tap_s = wrap2_ ? 0 : tap_s;                                                                            \
-        tap_r += wrap2_ ? 1 : 0;                                                                               \
+        if ((HI) > 4) {                                                                                        \
+            const __amdgpu_buffer_rsrc_t rb_ = __builtin_amdgcn_make_buffer_rsrc((void *)(b_base + (long long)(tap_ * Ctot + cg) * 2), 0, b_bytes, 0x00020000); \
+            _Pragma("unroll") for (int c = ((LO) > 4 ? (LO) - 4 : 0); c < (HI) - 4; c++)                       \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rb_, (__attribute__((address_space(3))) void *)(Bs_ + (wave * 16 + c * 8) * 128), 16, b_off[c], 0, 0, 0); \
+        }                                                                                                      \
+        if (ADV) {                                                                                             \
+            cg += KE;                                                                                          \
+            const bool wrap_ = cg == Ctot;                                                                     \
+            cg = wrap_ ? 0 : cg;                                                                               \
+            tap_s += wrap_ ? 1 : 0;                                                                            \
+            const bool wrap2_ = tap_s == p.KS;                                                                 \
+            tap_s = wrap2_ ? 0 : tap_s;                                                                        \
+            tap_r += wrap2_ ? 1 : 0;                                                                           \
+        }                                                                                                      \
     }
 
     f32x4 acc[MT][NT];
@@ -416,59 +423,64 @@ __global__ __launch_bounds__(512) void k_conv_dma(const ConvParams p, const void
     const int r16 = lane & 15, kq = lane >> 4;
     const int ch0 = ((0 * 4 + kq) ^ ((r16 >> 1) & 7)) << 4, ch1 = ((1 * 4 + kq) ^ ((r16 >> 1) & 7)) << 4;
 
-// One K step.  All 16 fragment reads, the six LDS-DMA pieces of tile kt+2 (ISSUE) and the 32 MFMAs sit in one basic
-// block; the sched_group_barrier sequence asks for: the kk=0 fragments, then MFMAs with the kk=1 fragment reads
-// and the DMA pieces (with their address arithmetic) slotted between them, one memory instruction per MFMA.
-#define RCV_DMA_STEP(ISSUE, LASTWAIT)                                                                          \
+// A K step is four phases separated by workgroup barriers: load (fragments of the first 32 K columns + three DMA
+// pieces of step kt+2), 16 MFMAs, load (second 32 columns + the other three pieces), 16 MFMAs.  The two waves of
+// a SIMD (wave w and w+4) run the same sequence one barrier apart, so that on every SIMD one wave is in its
+// MFMA phase while the other issues LDS reads and DMA pieces (and their waits).
+//   data of step kt+1 is waited for (counted vmcnt) at the end of the second load phase of step kt by every wave,
+//   which is at least one barrier before any wave reads it; the stage that step kt+2 goes to was last read in the
+//   second load phase of step kt-1, at least one barrier before the first piece is issued.
+#define RCV_DMA_STEP(ISSUE)                                                                                    \
     {                                                                                                          \
-        if (LASTWAIT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                         \
-        else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                                                  \
-        __builtin_amdgcn_s_barrier();                                                                          \
         const unsigned char *Ab = smem + stage * DMA_STAGE_BYTES + (wm * 64 + r16) * 128;                      \
         const unsigned char *Bb = smem + stage * DMA_STAGE_BYTES + BM * 128 + (wn * 64 + r16) * 128;           \
-        bf16x8 af0[MT], bf0[NT], af1[MT], bf1[NT];                                                             \
-        _Pragma("unroll") for (int i = 0; i < MT; i++) af0[i] = *(const bf16x8 *)(Ab + i * 16 * 128 + ch0);    \
-        _Pragma("unroll") for (int j = 0; j < NT; j++) bf0[j] = *(const bf16x8 *)(Bb + j * 16 * 128 + ch0);    \
-        _Pragma("unroll") for (int i = 0; i < MT; i++) af1[i] = *(const bf16x8 *)(Ab + i * 16 * 128 + ch1);    \
-        _Pragma("unroll") for (int j = 0; j < NT; j++) bf1[j] = *(const bf16x8 *)(Bb + j * 16 * 128 + ch1);    \
-        if (ISSUE) {                                                                                           \
-            const int st2 = stage + 2 >= DMA_STAGES ? stage + 2 - DMA_STAGES : stage + 2;                      \
-            RCV_DMA_ISSUE(st2);                                                                                \
-        }                                                                                                      \
-        _Pragma("unroll") for (int i = 0; i < MT; i++)                                                         \
-            _Pragma("unroll") for (int j = 0; j < NT; j++)                                                     \
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af0[i], bf0[j], acc[i][j], 0, 0, 0);       \
-        _Pragma("unroll") for (int i = 0; i < MT; i++)                                                         \
-            _Pragma("unroll") for (int j = 0; j < NT; j++)                                                     \
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af1[i], bf1[j], acc[i][j], 0, 0, 0);       \
-        __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);                                                     \
-        _Pragma("unroll") for (int u = 0; u < 8; u++) {                                                        \
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                 \
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                 \
-        }                                                                                                      \
-        if (ISSUE) {                                                                                           \
-            _Pragma("unroll") for (int u = 0; u < 6; u++) {                                                    \
-                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                             \
-                __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);                                             \
-                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                             \
-            }                                                                                                  \
-            __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);                                                \
-        } else {                                                                                               \
-            __builtin_amdgcn_sched_group_barrier(0x008, 24, 0);                                                \
-        }                                                                                                      \
+        const int st2 = stage + 2 >= DMA_STAGES ? stage + 2 - DMA_STAGES : stage + 2;                          \
+        bf16x8 af[MT], bfr[NT];                                                                                \
+        _Pragma("unroll") for (int i = 0; i < MT; i++) af[i] = *(const bf16x8 *)(Ab + i * 16 * 128 + ch0);     \
+        _Pragma("unroll") for (int j = 0; j < NT; j++) bfr[j] = *(const bf16x8 *)(Bb + j * 16 * 128 + ch0);    \
+        if (ISSUE) RCV_DMA_ISSUE(st2, 0, 3, false);                                                            \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                     \
+        __builtin_amdgcn_s_barrier();                                                                          \
+        __builtin_amdgcn_s_setprio(1);                                                                         \
+        _Pragma("unroll") for (int i = 0; i < MT; i++)                                                         \
+            _Pragma("unroll") for (int j = 0; j < NT; j++)                                                     \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);        \
+        __builtin_amdgcn_s_setprio(0);                                                                         \
+        __builtin_amdgcn_s_barrier();                                                                          \
+        _Pragma("unroll") for (int i = 0; i < MT; i++) af[i] = *(const bf16x8 *)(Ab + i * 16 * 128 + ch1);     \
+        _Pragma("unroll") for (int j = 0; j < NT; j++) bfr[j] = *(const bf16x8 *)(Bb + j * 16 * 128 + ch1);    \
+        if (ISSUE) {                                                                                           \
+            RCV_DMA_ISSUE(st2, 3, 6, true);                                                                    \
+            asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");                                        \
+        } else {                                                                                               \
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                        \
+        }                                                                                                      \
+        __builtin_amdgcn_s_barrier();                                                                          \
+        __builtin_amdgcn_s_setprio(1);                                                                         \
+        _Pragma("unroll") for (int i = 0; i < MT; i++)                                                         \
+            _Pragma("unroll") for (int j = 0; j < NT; j++)                                                     \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);        \
+        __builtin_amdgcn_s_setprio(0);                                                                         \
+        __builtin_amdgcn_s_barrier();                                                                          \
         stage = stage + 1 == DMA_STAGES ? 0 : stage + 1;                                                       \
     }
 
     const int nk = p.K / KE;
-    RCV_DMA_ISSUE(0);
-    if (nk > 1) RCV_DMA_ISSUE(1);
+    const int grp = wave >> 2;  // waves w and w + 4 share a SIMD
+    RCV_DMA_ISSUE(0, 0, 6, true);
+    if (nk > 1) {
+        RCV_DMA_ISSUE(1, 0, 6, true);
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    if (grp == 1) __builtin_amdgcn_s_barrier();  // the second wave of every SIMD runs one phase behind
     int stage = 0;
-    // tile kt has landed once at most the 6 DMAs of tile kt+1 are still outstanding (loads retire in order); every
-    // wave is past its reads of tile kt-1 at the barrier, whose stage is the one tile kt+2 goes to
-    for (int kt = 0; kt + 2 < nk; kt++) RCV_DMA_STEP(true, false);
-    if (nk > 1) RCV_DMA_STEP(false, false);
-    RCV_DMA_STEP(false, true);
+    for (int kt = 0; kt + 2 < nk; kt++) RCV_DMA_STEP(true);
+    if (nk > 1) RCV_DMA_STEP(false);
+    RCV_DMA_STEP(false);
+    if (grp == 0) __builtin_amdgcn_s_barrier();  // match the barrier count of the trailing group
 #undef RCV_DMA_STEP
 #undef RCV_DMA_ISSUE
 
