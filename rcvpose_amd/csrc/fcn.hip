@@ -323,32 +323,20 @@ __global__ __launch_bounds__(512) void k_conv_dma(const ConvParams p, const void
     const T *wg = (const T *)p.w + (long long)g * p.w_gs;
     (void)zero_page;
 
-    // Epilogue layout (see the end of the kernel): this lane ends up with 8 consecutive output channels of pixel
-    // lane & 15 of each of the wave's four 16-pixel groups, twice (channel pairs of 16-channel tiles {0,1} and {2,3}).
-    // The residual and bias values for exactly those positions are requested before anything else: for the short-K
-    // expand convolutions the kernel is a stream of (operand tile, residual tile, output tile).
+    // the residual tile (if any) is requested before anything else: for the short-K expand convolutions the
+    // kernel is a stream of (operand tile, residual tile, output tile) and this overlaps the first two
     const T *res = p.res ? (const T *)p.res + (long long)g * p.res_gs : nullptr;
-    const int e_pix = lane & 15, e_kq = lane >> 4;
-    const int e_ch = n0 + (wave & 1) * 64 + (e_kq & 1) * 16 + (e_kq >> 1) * 8;  // + 32 for the second pair
-    const int e_m0 = m0 + (wave >> 1) * 64 + e_pix;                              // + 16 * i
-    uint4 rres[4][2];
+    constexpr int E_CPR = DMA_BN / 8, E_PER = (64 * E_CPR) / 512;
+    uint4 rres[4][E_PER];
     if (res) {
 #pragma unroll
-        for (int i = 0; i < 4; i++)
+        for (int round = 0; round < 4; round++)
 #pragma unroll
-            for (int pr = 0; pr < 2; pr++) {
-                const int m = e_m0 + i * 16;
-                rres[i][pr] = m < p.M ? *(const uint4 *)(res + (long long)m * p.Cout + e_ch + pr * 32) : make_uint4(0u, 0u, 0u, 0u);
+            for (int q = 0; q < E_PER; q++) {
+                const int c = q * 512 + tid, row = c / E_CPR, cc = c - row * E_CPR;
+                const int m = m0 + round * 64 + row;
+                rres[round][q] = m < p.M ? *(const uint4 *)(res + (long long)m * p.Cout + n0 + cc * 8) : make_uint4(0u, 0u, 0u, 0u);
             }
-    }
-    float4 ebias[2][2];
-    {
-        const float *bias = p.bias + (long long)g * p.bias_gs;
-#pragma unroll
-        for (int pr = 0; pr < 2; pr++) {
-            ebias[pr][0] = *(const float4 *)(bias + e_ch + pr * 32);
-            ebias[pr][1] = *(const float4 *)(bias + e_ch + pr * 32 + 4);
-        }
     }
 
     // loader role of this lane: 4 A rows (wave*32 + c*8 + lane/8) and 2 B rows (wave*16 + c*8 + lane/8), 16-byte
@@ -456,7 +444,7 @@ __global__ __launch_bounds__(512) void k_conv_dma(const ConvParams p, const void
         __builtin_amdgcn_s_setprio(1);                                                                         \
         _Pragma("unroll") for (int i = 0; i < MT; i++)                                                         \
             _Pragma("unroll") for (int j = 0; j < NT; j++)                                                     \
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);        \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);        \
         __builtin_amdgcn_s_setprio(0);                                                                         \
         __builtin_amdgcn_s_barrier();                                                                          \
         _Pragma("unroll") for (int i = 0; i < MT; i++) af[i] = *(const bf16x8 *)(Ab + i * 16 * 128 + ch1);     \
@@ -471,7 +459,7 @@ __global__ __launch_bounds__(512) void k_conv_dma(const ConvParams p, const void
         __builtin_amdgcn_s_setprio(1);                                                                         \
         _Pragma("unroll") for (int i = 0; i < MT; i++)                                                         \
             _Pragma("unroll") for (int j = 0; j < NT; j++)                                                     \
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);        \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);        \
         __builtin_amdgcn_s_setprio(0);                                                                         \
         __builtin_amdgcn_s_barrier();                                                                          \
         stage = stage + 1 == DMA_STAGES ? 0 : stage + 1;                                                       \
@@ -496,29 +484,40 @@ __global__ __launch_bounds__(512) void k_conv_dma(const ConvParams p, const void
 #undef RCV_DMA_STEP
 #undef RCV_DMA_ISSUE
 
-    // epilogue, in registers.  The MFMAs were issued with the operands swapped (weights as A, pixels as B), so
-    // acc[i][j][e] is output channel j*16 + (lane>>4)*4 + e of pixel i*16 + (lane&15): four consecutive channels per
-    // lane.  v_permlane16_swap exchanges, between the lane rows kq = 2t and 2t+1, the values of channel tile j0+1
-    // against those of tile j0; afterwards every lane owns 8 consecutive channels of one pixel (tile j0 + (kq&1),
-    // channels (kq>>1)*8 ..), adds bias and residual in fp32, applies ReLU, rounds once and stores 16 bytes.  No LDS
-    // staging, no barrier; the same arithmetic per element as k_conv (bit-identical results).
+    // epilogue: the whole 256 x 128 fp32 tile fits the (now idle) 144 KB of LDS, so all eight waves stage their
+    // accumulators at once and the tile leaves as 16-byte vectors of contiguous channels after a single barrier
     T *dst = (T *)p.dst + (long long)g * p.dst_gs;
+    const float *bias = p.bias + (long long)g * p.bias_gs;
+    constexpr int SROW = BN + 4, CPR = BN / EPV;
+    float *stg = (float *)smem;
+    __syncthreads();  // every wave is done reading the last operand tile
 #pragma unroll
-    for (int i = 0; i < MT; i++) {
-        const int m = e_m0 + i * 16;
+    for (int j = 0; j < NT; j++) {
+        const int nl = wn * 64 + j * 16 + r16;
+        const float bv = bias[n0 + nl];
 #pragma unroll
-        for (int pr = 0; pr < 2; pr++) {
+        for (int i = 0; i < MT; i++)
+#pragma unroll
+            for (int e = 0; e < 4; e++) stg[(wm * 64 + i * 16 + kq * 4 + e) * SROW + nl] = acc[i][j][e] + bv;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int round = 0; round < 4; round++) {
+#pragma unroll
+        for (int q = 0; q < E_PER; q++) {
+            const int c = q * 512 + tid, row = c / CPR, cc = c - row * CPR;
+            const int m = m0 + round * 64 + row;
+            if (m >= p.M) continue;
+            const long long o = (long long)m * p.Cout + n0 + cc * EPV;
             float v[EPV];
+            const float4 *sp4 = (const float4 *)(stg + (round * 64 + row) * SROW + cc * EPV);
 #pragma unroll
-            for (int e = 0; e < 4; e++) {
-                const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[i][2 * pr][e]), __float_as_uint(acc[i][2 * pr + 1][e]), false, false);
-                v[e] = __uint_as_float(sw[0]);
-                v[4 + e] = __uint_as_float(sw[1]);
+            for (int qq = 0; qq < EPV / 4; qq++) {
+                const float4 t = sp4[qq];
+                v[qq * 4 + 0] = t.x; v[qq * 4 + 1] = t.y; v[qq * 4 + 2] = t.z; v[qq * 4 + 3] = t.w;
             }
-            v[0] += ebias[pr][0].x; v[1] += ebias[pr][0].y; v[2] += ebias[pr][0].z; v[3] += ebias[pr][0].w;
-            v[4] += ebias[pr][1].x; v[5] += ebias[pr][1].y; v[6] += ebias[pr][1].z; v[7] += ebias[pr][1].w;
             if (res) {
-                const T *rp = (const T *)&rres[i][pr];
+                const T *rp = (const T *)&rres[round][q];
 #pragma unroll
                 for (int qq = 0; qq < EPV; qq++) v[qq] += to_f32(rp[qq]);
             }
@@ -530,7 +529,7 @@ __global__ __launch_bounds__(512) void k_conv_dma(const ConvParams p, const void
             T *op = (T *)&outv;
 #pragma unroll
             for (int qq = 0; qq < EPV; qq++) op[qq] = from_f32<T>(v[qq]);
-            if (m < p.M) *(uint4 *)(dst + (long long)m * p.Cout + e_ch + pr * 32) = outv;
+            *(uint4 *)(dst + o) = outv;
         }
     }
 }
