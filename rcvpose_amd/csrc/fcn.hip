@@ -351,23 +351,32 @@ __global__ __launch_bounds__(512) void k_conv_dma(const ConvParams p, const void
     int a_off0[4], a_off1[4];
     unsigned a_ok[4];
     const int HWo = p.Hout * p.Wout;
+    // (image, row, column) of the tile's first output pixel by integer division (once, wave-uniform); the 256 rows
+    // of the tile are then reached with two small float divisions each ((t + 0.5) * (1/d) is exact far beyond the
+    // range 0 .. 256 + Wout that occurs here) instead of eight ~40-instruction integer divisions per lane
+    const int img0 = m0 / HWo, rem0 = m0 - img0 * HWo;
+    const int ho0 = rem0 / p.Wout, wo0 = rem0 - ho0 * p.Wout;
+    const float rW = 1.0f / (float)p.Wout, rH = 1.0f / (float)p.Hout;
 #pragma unroll
     for (int c = 0; c < 4; c++) {
         const int row = wave * 32 + c * 8 + lrow;
-        const int m = m0 + row;
         const int chunk = (lpos ^ ((row >> 1) & 7)) * EPV;
         a_off0[c] = OOB; a_off1[c] = OOB; a_ok[c] = 0u;
-        if (m < p.M) {
-            const int img = m / HWo, rem = m - img * HWo;
-            const int ho = rem / p.Wout, wo = rem - ho * p.Wout;
+        if (m0 + row < p.M) {
+            const int t = wo0 + row;
+            const int q1 = (int)(((float)t + 0.5f) * rW);
+            const int wo = t - q1 * p.Wout, h = ho0 + q1;
+            const int q2 = (int)(((float)h + 0.5f) * rH);
+            const int ho = h - q2 * p.Hout, img = img0 + q2;
             const int hc = ho * p.stride, wc = wo * p.stride;  // the pixel under tap (pad, pad): always inside the image
             const int lin = (img * p.Hin + hc) * p.Win + wc;
             a_off0[c] = (lin * p.C0 + chunk) * 2;
             a_off1[c] = (lin * p.C1 + chunk) * 2;
-            for (int r = 0; r < p.KS; r++)
-                for (int q = 0; q < p.KS; q++)
-                    if ((unsigned)(hc - p.pad + r) < (unsigned)p.Hin && (unsigned)(wc - p.pad + q) < (unsigned)p.Win)
-                        a_ok[c] |= 1u << (r * p.KS + q);
+            // taps inside the image: rows r with 0 <= hc - pad + r < Hin, columns q likewise -> bit r * KS + q
+            const int rlo = max(p.pad - hc, 0), rhi = min(p.Hin - 1 - hc + p.pad, p.KS - 1);
+            const int qlo = max(p.pad - wc, 0), qhi = min(p.Win - 1 - wc + p.pad, p.KS - 1);
+            const unsigned colmask = qhi >= qlo ? ((2u << qhi) - 1u) & ~((1u << qlo) - 1u) : 0u;
+            for (int r = rlo; r <= rhi; r++) a_ok[c] |= colmask << (r * p.KS);
         }
     }
     int b_off[2];
