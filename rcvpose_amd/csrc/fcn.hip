@@ -544,6 +544,141 @@ __global__ __launch_bounds__(512) void k_conv_dma(const ConvParams p, const void
 }
 
 // ---------------------------------------------------------------------------------------------
+// k_stem_mfma (bf16): the same 7x7/2 stem as an MFMA GEMM.  A workgroup owns 8 x 32 output pixels of one image and
+// serves every group (keypoint network) from one im2col image:
+//   1. the fp32 input patch (3 x 21 x 69) is staged in LDS,
+//   2. every thread expands its pixel's 147 taps to bf16 into the A tile [256 px][160 k] (k = (r*7+s)*3+c, the
+//      weight order; k 147..159 zero) -- built once, used by all groups,
+//   3. per group the [64][147] weights are laid into the B tile [64][160] (zero padded), 4 waves x (64 px x 64 ch)
+//      run 80 MFMAs (16x16x32, operands swapped so that a lane holds consecutive channels), and the result leaves
+//      through v_permlane16_swap as 16-byte NHWC vectors after bias + ReLU.
+// The input is rounded to bf16 (the fp32 path keeps k_stem<float>); accumulation is fp32.
+// ---------------------------------------------------------------------------------------------
+constexpr int STEM_TH = 8, STEM_TW = 32, STEM_KP = 160, STEM_PITCH = 336;  // bytes per LDS row: 160 bf16 + 16 (bank spread)
+constexpr int STEM_IH = STEM_TH * 2 + 5, STEM_IW = STEM_TW * 2 + 5;
+constexpr int STEM_LDS = 256 * STEM_PITCH + 64 * STEM_PITCH + 3 * STEM_IH * (STEM_IW + 1) * 4 + STEM_KP * 4;
+
+__global__ __launch_bounds__(256) void k_stem_mfma(const float *x, const __bf16 *w, const float *bias, __bf16 *dst, int H, int W,
+                                                   int Ho, int Wo, int groups, long long w_gs, int bias_gs, long long dst_gs)
+{
+    using T = __bf16;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char *sA = smem;                                   // [256][STEM_PITCH]
+    unsigned char *sB = smem + 256 * STEM_PITCH;                // [64][STEM_PITCH]
+    float(*s_in)[STEM_IH][STEM_IW + 1] = (float(*)[STEM_IH][STEM_IW + 1])(smem + 320 * STEM_PITCH);
+    int *s_koff = (int *)(smem + 320 * STEM_PITCH + 3 * STEM_IH * (STEM_IW + 1) * 4);  // [STEM_KP]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tiles_x = (Wo + STEM_TW - 1) / STEM_TW;
+    const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+    const int img = blockIdx.y;
+    const int ho0 = ty * STEM_TH, wo0 = tx * STEM_TW;
+    const int hi0 = ho0 * 2 - 3, wi0 = wo0 * 2 - 3;
+    for (int i = tid; i < 3 * STEM_IH * STEM_IW; i += 256) {
+        const int c = i / (STEM_IH * STEM_IW), rem = i - c * (STEM_IH * STEM_IW);
+        const int r = rem / STEM_IW, q = rem - r * STEM_IW;
+        const int hi = hi0 + r, wi = wi0 + q;
+        float v = 0.f;
+        if ((unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W) v = x[((long long)(img * 3 + c) * H + hi) * W + wi];
+        s_in[c][r][q] = v;
+    }
+    if (tid < STEM_KP) {  // patch offset of tap k = (r*7 + s)*3 + c; the padding taps point at element 0 and are zeroed
+        const int k = tid < 147 ? tid : 0;
+        const int c = k % 3, rs = k / 3, r = rs / 7, q = rs - r * 7;
+        s_koff[tid] = (c * STEM_IH + r) * (STEM_IW + 1) + q;
+    }
+    __syncthreads();
+    {
+        // im2col row of pixel tid: 8 bf16 (16 bytes) at a time
+        const int py = tid >> 5, px = tid & 31;
+        unsigned char *row = sA + tid * STEM_PITCH;
+        const float *base = &s_in[0][py * 2][px * 2];
+#pragma unroll 4
+        for (int k0 = 0; k0 < STEM_KP; k0 += 8) {
+            uint4 pack;
+            T *pv = (T *)&pack;
+#pragma unroll
+            for (int e = 0; e < 8; e++) pv[e] = (T)(k0 + e < 147 ? base[s_koff[k0 + e]] : 0.f);
+            *(uint4 *)(row + k0 * 2) = pack;
+        }
+    }
+    const int r16 = lane & 15, kq = lane >> 4;
+    const int e_ch = (kq & 1) * 16 + (kq >> 1) * 8;  // + 32 for the second channel-tile pair
+    for (int g = 0; g < groups; g++) {
+        __syncthreads();  // A tile complete (g = 0) / every wave is done with the previous group's B tile
+        const T *wg = w + (long long)g * w_gs;  // [64][147]
+        {
+            // 64 x 147 contiguous weights: all of a thread's loads are issued before the first LDS write
+            constexpr int PER = (64 * 147 + 255) / 256;
+            T wv[PER];
+#pragma unroll
+            for (int u = 0; u < PER; u++) {
+                const int i = u * 256 + tid;
+                wv[u] = wg[i < 64 * 147 ? i : 0];
+            }
+#pragma unroll
+            for (int u = 0; u < PER; u++) {
+                const int i = u * 256 + tid;
+                if (i < 64 * 147) {
+                    const int co = i / 147, k = i - co * 147;
+                    *(T *)(sB + co * STEM_PITCH + k * 2) = wv[u];
+                }
+            }
+            if (g == 0)  // the padding columns stay zero for every group
+                for (int i = tid; i < 64 * (STEM_KP - 147); i += 256) {
+                    const int co = i / (STEM_KP - 147), k = 147 + i - co * (STEM_KP - 147);
+                    *(T *)(sB + co * STEM_PITCH + k * 2) = (T)0.f;
+                }
+        }
+        __syncthreads();
+        f32x4 acc[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < STEM_KP / 32; ks++) {
+            bf16x8 af[4], bfr[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) af[i] = *(const bf16x8 *)(sA + (wave * 64 + i * 16 + r16) * STEM_PITCH + (ks * 32 + kq * 8) * 2);
+#pragma unroll
+            for (int j = 0; j < 4; j++) bfr[j] = *(const bf16x8 *)(sB + (j * 16 + r16) * STEM_PITCH + (ks * 32 + kq * 8) * 2);
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+        }
+        // acc[i][j][e] = channel j*16 + kq*4 + e of pixel wave*64 + i*16 + r16 (operands swapped); see k_conv_dma's
+        // notes on the permlane16 swap: afterwards the lane owns 8 consecutive channels
+        const float *bg = bias + (long long)g * bias_gs;
+        T *out = dst + (long long)g * dst_gs;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int pix = wave * 64 + i * 16 + r16;
+            const int ho = ho0 + (pix >> 5), wo = wo0 + (pix & 31);
+#pragma unroll
+            for (int pr = 0; pr < 2; pr++) {
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[i][2 * pr][e]), __float_as_uint(acc[i][2 * pr + 1][e]), false, false);
+                    v[e] = __uint_as_float(sw[0]);
+                    v[4 + e] = __uint_as_float(sw[1]);
+                }
+                const int ch = e_ch + pr * 32;
+                const float4 b0 = *(const float4 *)(bg + ch), b1 = *(const float4 *)(bg + ch + 4);
+                v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w;
+                v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+                uint4 outv;
+                T *op = (T *)&outv;
+#pragma unroll
+                for (int qq = 0; qq < 8; qq++) op[qq] = (T)fmaxf(v[qq], 0.f);
+                if (ho < Ho && wo < Wo) *(uint4 *)(out + ((long long)(img * Ho + ho) * Wo + wo) * 64 + ch) = outv;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // stem: conv1 7x7 stride 2 pad 3 (3 -> 64, no bias) + BN (folded) + ReLU; NCHW fp32 image -> NHWC T
 // one workgroup = 16 x 16 output pixels x 64 channels of one (group, image)
 // ---------------------------------------------------------------------------------------------
@@ -736,6 +871,7 @@ struct rcv_fcn {
     int dtype = RCV_BF16;
     const void *weights = nullptr;
     const float *bias = nullptr;
+    bool use_mfma_stem = true;
     bool profiling = false;
     std::vector<hipEvent_t> events;  // 2 per op when profiling
     bool events_valid = false;
@@ -819,6 +955,17 @@ int run_op(rcv_fcn *h, const rcv_op &op, const float *x, int B, float *seg, floa
     switch (op.kind) {
     case RCV_OP_STEM: {
         if (op.cout != 64 || op.ksize != 7 || op.stride != 2 || op.pad != 3) return RCV_E_UNSUPPORTED;
+        if constexpr (sizeof(T) == 2) {
+            if (h->use_mfma_stem) {  // MFMA stem (bf16); option 2 = 0 selects the direct fp32-input kernel
+                if (!h->attrs_set)
+                    RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_stem_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, STEM_LDS));
+                dim3 grid(((op.hout + STEM_TH - 1) / STEM_TH) * ((op.wout + STEM_TW - 1) / STEM_TW), B);
+                hipLaunchKernelGGL(k_stem_mfma, grid, dim3(256), STEM_LDS, st, x, (const __bf16 *)w, bias, (__bf16 *)slot(op.dst), op.hin,
+                                   op.win, op.hout, op.wout, G, (long long)64 * 147, 64, gstride(op.dst));
+                RCV_LAUNCH_CHECK();
+                return RCV_OK;
+            }
+        }
         dim3 grid(((op.hout + 15) / 16) * ((op.wout + 15) / 16), B, G);
         hipLaunchKernelGGL((k_stem<T>), grid, dim3(256), 0, st, x, w, bias, slot(op.dst), B, op.hin, op.win, op.hout,
                            op.wout, (long long)64 * 147, 64, gstride(op.dst));
@@ -981,6 +1128,7 @@ int rcv_fcn_set_option(rcv_fcn *h, int key, int value)
 {
     if (!h) return RCV_E_INVALID;
     if (key == 1) { h->use_dma = value != 0; h->attrs_set = false; return RCV_OK; }
+    if (key == 2) { h->use_mfma_stem = value != 0; h->attrs_set = false; return RCV_OK; }
     return RCV_E_INVALID;
 }
 

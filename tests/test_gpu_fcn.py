@@ -102,6 +102,27 @@ def test_bf16_full_size_both_conv_kernels(shapes, state_dict, golden_dir):
     assert err <= REL_BF16
 
 
+def test_mfma_stem_matches_direct_stem(shapes, state_dict):
+    """bf16 engine: the MFMA stem (input rounded to bf16, fp32 accumulation) against the direct stem kernel (fp32 input) at
+    the stem's own output, and the effect on the network output."""
+    from rcvpose_amd.fcn_engine import FcnEngine
+
+    x = torch.from_numpy(fcn_weights.make_input(5, (2, 3, 64, 96))).cuda()
+    eng = FcnEngine([state_dict, _sd(shapes, 1)], 64, 96, dtype="bf16", reuse_slots=False)
+    seg_a, rad_a = [t.clone() for t in eng.forward(x)]
+    stem_a = [eng.debug_stage(2, g, "bn1").clone() for g in range(2)]
+    eng.set_option(2, 0)
+    seg_b, rad_b = [t.clone() for t in eng.forward(x)]
+    stem_b = [eng.debug_stage(2, g, "bn1").clone() for g in range(2)]
+    for a, b in zip(stem_a, stem_b):
+        assert a.shape == b.shape and a.shape[1] == 64
+        err = (a - b).abs().max().item() / b.abs().max().item()
+        print("stem relative difference %.3e" % err)
+        assert err <= 2e-2  # bf16 rounding of the input (2^-9 relative per tap) and of the output
+        assert (a - b).abs().mean().item() / b.abs().mean().item() <= 4e-3
+    assert _rel(rad_a.cpu().numpy(), rad_b.cpu().numpy()) <= REL_BF16
+
+
 def test_groups_and_batch(shapes, state_dict):
     """3 networks x 2 images in one launch sequence == the six single runs (blockIdx.z / batch indexing)."""
     from rcvpose_amd.fcn_engine import FcnEngine
