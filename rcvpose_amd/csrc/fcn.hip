@@ -678,6 +678,22 @@ __global__ __launch_bounds__(256) void k_stem_mfma(const float *x, const __bf16 
     }
 }
 
+// bilinear blend shared by k_upsample2 and the fused tail kernel (one expression, so both round identically)
+__device__ __forceinline__ float bilerp(float hy, float hx, float ly, float lx, float p00, float p01, float p10, float p11)
+{
+    return hy * (hx * p00 + lx * p01) + ly * (hx * p10 + lx * p11);
+}
+// source row/column and weights of destination index d for the 2x upsampling: ATen's area_pixel_compute_source_index
+// (align_corners = False): s = max(0.5 * (d + 0.5) - 0.5, 0)
+__device__ __forceinline__ void up2_src(int d, int n_in, int &i0, int &i1, float &l, float &h)
+{
+    const float sf = fmaxf(0.5f * (d + 0.5f) - 0.5f, 0.f);
+    i0 = (int)sf;
+    i1 = i0 + (i0 < n_in - 1 ? 1 : 0);
+    l = sf - i0;
+    h = 1.f - l;
+}
+
 // ---------------------------------------------------------------------------------------------
 // stem: conv1 7x7 stride 2 pad 3 (3 -> 64, no bias) + BN (folded) + ReLU; NCHW fp32 image -> NHWC T
 // one workgroup = 16 x 16 output pixels x 64 channels of one (group, image)
@@ -800,8 +816,7 @@ __global__ __launch_bounds__(256) void k_upsample2(const T *src, T *dst, int C, 
         T *po = (T *)&o;
 #pragma unroll
         for (int e = 0; e < EPV; e++) {
-            const float v = hy * (hx * to_f32(p00[e]) + lx * to_f32(p01[e])) + ly * (hx * to_f32(p10[e]) + lx * to_f32(p11[e]));
-            po[e] = from_f32<T>(v);
+            po[e] = from_f32<T>(bilerp(hy, hx, ly, lx, to_f32(p00[e]), to_f32(p01[e]), to_f32(p10[e]), to_f32(p11[e])));
         }
         *(uint4 *)(dst + (long long)g * dst_gs + pix * C + c * EPV) = o;
     }
@@ -850,6 +865,152 @@ __global__ __launch_bounds__(256) void k_preprocess(const uint8_t *rgb, float *x
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// k_tail (bf16): the last three layers in one kernel -- 2x bilinear upsampling of the 64-channel map, conv7
+// (3x3, 64 -> 32, folded BN, ReLU) and the 1x1 head (32 -> 2) -- so that neither the 480x640x64 upsampled map nor
+// the 480x640x32 conv7 output ever reaches HBM.  A workgroup walks one strip of 8 x 32-pixel tiles of one
+// (group, image); its waves keep the conv7 weights as MFMA fragments in registers for the whole strip.  Per tile:
+//   source patch (6 x 18 px) -> LDS;  upsampled patch U (10 x 34 px, zero outside the image: conv padding) built
+//   with k_upsample2's arithmetic and rounding;  18 K steps of MFMAs with the A fragments read from U at shifted
+//   pixel addresses (one per tap);  bias + ReLU + bf16 rounding into LDS;  one thread per pixel runs the head's
+//   sequential fp32 FMA chain.  Same operations in the same order as k_upsample2 -> k_conv -> k_head: identical
+//   outputs (tests/test_gpu_fcn.py).
+// ---------------------------------------------------------------------------------------------
+constexpr int TAIL_TH = 8, TAIL_TW = 32, TAIL_UW = TAIL_TW + 2, TAIL_UH = TAIL_TH + 2;
+constexpr int TAIL_SH = TAIL_TH / 2 + 2, TAIL_SW = TAIL_TW / 2 + 2;
+constexpr int TAIL_HP = 80;  // bytes per pixel of the conv7 staging rows (64 + bank spread)
+constexpr int TAIL_LDS = TAIL_UH * TAIL_UW * 128 + TAIL_SH * TAIL_SW * 128 + 256 * TAIL_HP + 64 * 4;
+
+__global__ __launch_bounds__(256, 2) void k_tail(const __bf16 *src, const __bf16 *w7, const float *b7, const __bf16 *w8, const float *b8,
+                                                 float *seg, float *radial, int B, int Hin, int Win, long long src_gs, long long w7_gs,
+                                                 int b7_gs, long long w8_gs, int b8_gs)
+{
+    using T = __bf16;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char *sU = smem;                                        // [340][128 B], chunk swizzled by (pixel >> 1) & 7
+    unsigned char *sS = smem + TAIL_UH * TAIL_UW * 128;              // [6][18][128 B] source patch
+    unsigned char *sH = sS + TAIL_SH * TAIL_SW * 128;                // [256][TAIL_HP] conv7 output (bf16)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r16 = lane & 15, kq = lane >> 4;
+    const int Ho = Hin * 2, Wo = Win * 2;
+    const int ty = blockIdx.x, img = blockIdx.y, g = blockIdx.z;
+    const int ho0 = ty * TAIL_TH;
+    const T *sg = src + (long long)g * src_gs + (long long)img * Hin * Win * 64;
+    // wave = (pixel half ph, channel tile j): 128 pixels x 16 output channels.  Its conv7 weights stay in registers
+    // as MFMA fragments for the whole strip: lane (co = j*16 + r16, k = tap*64 + kk*32 + kq*8)
+    const int ph = wave >> 1, j = wave & 1;
+    bf16x8 bw[9][2];
+    {
+        const T *wg = w7 + (long long)g * w7_gs;
+#pragma unroll
+        for (int t = 0; t < 9; t++)
+#pragma unroll
+            for (int kk = 0; kk < 2; kk++) bw[t][kk] = *(const bf16x8 *)(wg + (j * 16 + r16) * 576 + t * 64 + kk * 32 + kq * 8);
+    }
+    float bias7[4];
+#pragma unroll
+    for (int e = 0; e < 4; e++) bias7[e] = b7[(long long)g * b7_gs + j * 16 + kq * 4 + e];
+    float *sW8 = (float *)(sH + 256 * TAIL_HP);  // head weights [2][32] as float (kept out of the register file)
+    if (tid < 64) sW8[tid] = (float)w8[(long long)g * w8_gs + tid];
+    const float hb0 = b8[(long long)g * b8_gs], hb1 = b8[(long long)g * b8_gs + 1];
+    // pixel of this lane in each of the wave's eight 16-pixel groups, as index into U (tap (0,0))
+    int ubase[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const int m = ph * 128 + i * 16 + r16;
+        ubase[i] = (m >> 5) * TAIL_UW + (m & 31);
+    }
+    const int sy0 = ho0 / 2 - 1;
+    for (int tx = 0; tx * TAIL_TW < Wo; tx++) {
+        const int wo0 = tx * TAIL_TW, sx0 = wo0 / 2 - 1;
+        __syncthreads();  // previous tile: every thread is done with sS / sU / sH
+        // ---- source patch, rows/columns clamped into the image (only clamped positions are ever referenced)
+#pragma unroll 1
+        for (int v = tid; v < TAIL_SH * TAIL_SW * 8; v += 256) {
+            const int c = v & 7, pp = v >> 3, a = pp / TAIL_SW, b = pp - a * TAIL_SW;
+            const int ys = min(max(sy0 + a, 0), Hin - 1), xs = min(max(sx0 + b, 0), Win - 1);
+            *(uint4 *)(sS + pp * 128 + c * 16) = *(const uint4 *)(sg + ((long long)ys * Win + xs) * 64 + c * 8);
+        }
+        __syncthreads();
+        // ---- upsampled patch
+#pragma unroll 1
+        for (int v = tid; v < TAIL_UH * TAIL_UW * 8; v += 256) {
+            const int c = v & 7, u = v >> 3, uy = u / TAIL_UW, ux = u - uy * TAIL_UW;
+            const int y = ho0 - 1 + uy, x = wo0 - 1 + ux;
+            uint4 o = make_uint4(0u, 0u, 0u, 0u);
+            if ((unsigned)y < (unsigned)Ho && (unsigned)x < (unsigned)Wo) {
+                int y0, y1, x0, x1;
+                float ly, hy, lx, hx;
+                up2_src(y, Hin, y0, y1, ly, hy);
+                up2_src(x, Win, x0, x1, lx, hx);
+                const unsigned char *r0 = sS + ((y0 - sy0) * TAIL_SW) * 128 + c * 16, *r1 = sS + ((y1 - sy0) * TAIL_SW) * 128 + c * 16;
+                const uint4 q00 = *(const uint4 *)(r0 + (x0 - sx0) * 128), q01 = *(const uint4 *)(r0 + (x1 - sx0) * 128);
+                const uint4 q10 = *(const uint4 *)(r1 + (x0 - sx0) * 128), q11 = *(const uint4 *)(r1 + (x1 - sx0) * 128);
+                const T *p00 = (const T *)&q00, *p01 = (const T *)&q01, *p10 = (const T *)&q10, *p11 = (const T *)&q11;
+                T *po = (T *)&o;
+#pragma unroll
+                for (int e = 0; e < 8; e++) po[e] = (T)bilerp(hy, hx, ly, lx, (float)p00[e], (float)p01[e], (float)p10[e], (float)p11[e]);
+            }
+            *(uint4 *)(sU + u * 128 + ((c ^ ((u >> 1) & 7)) << 4)) = o;
+        }
+        __syncthreads();
+        // ---- conv7: K = 9 taps x 64 channels, in k_conv's order (tap-major, 32 channels per MFMA)
+        f32x4 acc[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        int uz = 0;
+        asm volatile("" : "+v"(uz));  // opaque zero: keeps the 144 fragment addresses from being hoisted out of the tile loop
+#pragma unroll
+        for (int t = 0; t < 9; t++) {
+            const int toff = (t / 3) * TAIL_UW + (t % 3);
+#pragma unroll
+            for (int kk = 0; kk < 2; kk++) {
+                bf16x8 af[8];
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    const int u = ubase[i] + toff + uz;
+                    af[i] = *(const bf16x8 *)(sU + u * 128 + (((kk * 4 + kq) ^ ((u >> 1) & 7)) << 4));
+                }
+#pragma unroll
+                for (int i = 0; i < 8; i++) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bw[t][kk], af[i], acc[i], 0, 0, 0);
+                asm volatile("" ::: "memory");  // keep the fragment reads of later K steps from being hoisted (registers)
+            }
+        }
+        // ---- bias + ReLU, rounded to bf16 as the stored conv7 activation would be; operands were swapped, so
+        // acc[i][e] is channel j*16 + kq*4 + e of pixel ph*128 + i*16 + r16
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            uint2 pk;
+            T *pv = (T *)&pk;
+#pragma unroll
+            for (int e = 0; e < 4; e++) pv[e] = (T)fmaxf(acc[i][e] + bias7[e], 0.f);
+            *(uint2 *)(sH + (ph * 128 + i * 16 + r16) * TAIL_HP + (j * 16 + kq * 4) * 2) = pk;
+        }
+        __syncthreads();
+        // ---- head: thread = pixel, the sequential FMA chain of k_head
+        {
+            const int ho = ho0 + (tid >> 5), wo = wo0 + (tid & 31);
+            float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+            for (int c = 0; c < 32; c += 8) {
+                const uint4 raw = *(const uint4 *)(sH + tid * TAIL_HP + c * 2);
+                const T *pv = (const T *)&raw;
+#pragma unroll
+                for (int e = 0; e < 8; e++) {
+                    const float v = (float)pv[e];
+                    a0 = fmaf(v, sW8[c + e], a0);
+                    a1 = fmaf(v, sW8[32 + c + e], a1);
+                }
+            }
+            if (ho < Ho && wo < Wo) {
+                const long long o = ((long long)(g * B + img) * Ho + ho) * Wo + wo;
+                seg[o] = a0 + hb0;
+                radial[o] = a1 + hb1;
+            }
+        }
+    }
+}
+
 template <typename T>
 __global__ void k_slot_to_f32(const T *src, float *dst, long long n)
 {
@@ -872,6 +1033,7 @@ struct rcv_fcn {
     const void *weights = nullptr;
     const float *bias = nullptr;
     bool use_mfma_stem = true;
+    bool use_tail = true;  // fused upsample + conv7 + head kernel (bf16)
     bool profiling = false;
     std::vector<hipEvent_t> events;  // 2 per op when profiling
     bool events_valid = false;
@@ -1028,6 +1190,37 @@ int forward_impl(rcv_fcn *h, const float *x, int B, float *seg, float *radial, c
         for (auto &e : h->events) RCV_HIP_CHECK(hipEventCreate(&e));
     }
     for (size_t i = 0; i < h->ops.size(); i++) {
+        if constexpr (sizeof(T) == 2) {
+            // upsample x2 -> conv7 (3x3, 64 -> 32, ReLU) -> head (1x1, 32 -> 2): one fused kernel (option 3)
+            if (h->use_tail && i + 2 < h->ops.size() + 0 && h->ops[i].kind == RCV_OP_UPSAMPLE2 && h->ops[i + 1].kind == RCV_OP_CONV &&
+                h->ops[i + 2].kind == RCV_OP_HEAD) {
+                const rcv_op &u = h->ops[i], &c = h->ops[i + 1], &d = h->ops[i + 2];
+                if (u.c0 == 64 && c.src0 == u.dst && c.src1 < 0 && c.res < 0 && c.c0 == 64 && c.cout == 32 && c.ksize == 3 &&
+                    c.stride == 1 && c.pad == 1 && c.relu && d.src0 == c.dst && d.c0 == 32 && d.cout == 2 && u.hout == 2 * u.hin &&
+                    u.wout == 2 * u.win && c.hin == u.hout && c.win == u.wout) {
+                    if (!h->attrs_set)
+                        RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_tail, hipFuncAttributeMaxDynamicSharedMemorySize, TAIL_LDS));
+                    if (h->profiling) {  // the fused kernel's time is booked on the convolution
+                        RCV_HIP_CHECK(hipEventRecord(h->events[2 * i], st));
+                        RCV_HIP_CHECK(hipEventRecord(h->events[2 * i + 1], st));
+                        RCV_HIP_CHECK(hipEventRecord(h->events[2 * i + 2], st));
+                    }
+                    dim3 grid((u.hout + TAIL_TH - 1) / TAIL_TH, B, h->groups);
+                    hipLaunchKernelGGL(k_tail, grid, dim3(256), TAIL_LDS, st, (const __bf16 *)(ws + off[u.src0]),
+                                       (const __bf16 *)h->weights + c.w_off, h->bias + c.b_off, (const __bf16 *)h->weights + d.w_off,
+                                       h->bias + d.b_off, seg, radial, B, u.hin, u.win, (long long)h->slot_elems[u.src0] * B,
+                                       (long long)32 * 576, 32, (long long)64, 2);
+                    RCV_LAUNCH_CHECK();
+                    if (h->profiling) {
+                        RCV_HIP_CHECK(hipEventRecord(h->events[2 * i + 3], st));
+                        RCV_HIP_CHECK(hipEventRecord(h->events[2 * i + 4], st));
+                        RCV_HIP_CHECK(hipEventRecord(h->events[2 * i + 5], st));
+                    }
+                    i += 2;
+                    continue;
+                }
+            }
+        }
         if (h->profiling) RCV_HIP_CHECK(hipEventRecord(h->events[2 * i], st));
         int rc = run_op<T>(h, h->ops[i], x, B, seg, radial, ws, off, st);
         if (rc != RCV_OK) return rc;
@@ -1129,6 +1322,7 @@ int rcv_fcn_set_option(rcv_fcn *h, int key, int value)
     if (!h) return RCV_E_INVALID;
     if (key == 1) { h->use_dma = value != 0; h->attrs_set = false; return RCV_OK; }
     if (key == 2) { h->use_mfma_stem = value != 0; h->attrs_set = false; return RCV_OK; }
+    if (key == 3) { h->use_tail = value != 0; h->attrs_set = false; return RCV_OK; }
     return RCV_E_INVALID;
 }
 

@@ -123,6 +123,20 @@ def test_mfma_stem_matches_direct_stem(shapes, state_dict):
     assert _rel(rad_a.cpu().numpy(), rad_b.cpu().numpy()) <= REL_BF16
 
 
+def test_fused_tail_identical_to_three_kernels(shapes, state_dict):
+    """upsample x2 + conv7 + head in one kernel (option 3, default on) gives bit-identical outputs to the three separate
+    kernels (same arithmetic in the same order), full size and a size with partial tiles."""
+    from rcvpose_amd.fcn_engine import FcnEngine
+
+    for (H, W, B) in ((480, 640, 2), (64, 96, 3), (96, 160, 1)):
+        x = torch.from_numpy(fcn_weights.make_input(11, (B, 3, H, W))).cuda()
+        eng = FcnEngine([state_dict, _sd(shapes, 1)], H, W, dtype="bf16")
+        seg_a, rad_a = [t.clone() for t in eng.forward(x)]
+        eng.set_option(3, 0)
+        seg_b, rad_b = [t.clone() for t in eng.forward(x)]
+        assert torch.equal(seg_a, seg_b) and torch.equal(rad_a, rad_b), (H, W)
+
+
 def test_groups_and_batch(shapes, state_dict):
     """3 networks x 2 images in one launch sequence == the six single runs (blockIdx.z / batch indexing)."""
     from rcvpose_amd.fcn_engine import FcnEngine
