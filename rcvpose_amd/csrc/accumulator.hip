@@ -1310,50 +1310,42 @@ __device__ __forceinline__ void d_bb_climb(AccHeader *hdr, const double *Q, cons
     }
 }
 
-// Voxel level of the wide search: the 8 children of a 2^3 parent are single voxels, their "bound" is the exact
-// reference count.  Same streaming structure as k_bb_wide, float64 throughout: d2 = ((i-x)^2 + (j-y)^2) + (k-z)^2 in
-// the reference's order, vote <=> T_lo <= d2 < T_hi, decided on the signs of the two float64 differences (a
-// floating-point subtraction has the sign of the exact difference, and x - x is +0).
+// Exact counts of the candidate voxels.  The last wide level (2^3 parents, single-voxel children) leaves the voxels
+// whose float32 upper bound reaches the best exact count: a few dozen around the peak.  Here every candidate gets
+// the reference predicate itself, float64 throughout: d2 = ((i-x)^2 + (j-y)^2) + (k-z)^2 in the reference's order,
+// vote <=> T_lo <= d2 < T_hi, decided on the signs of the two float64 differences (a floating-point subtraction has
+// the sign of the exact difference, and x - x is +0).  A workgroup scores 8 candidates per pass over the point list
+// (streamed through LDS) and writes the counts back into their list entries (ub = lb = votes).
 constexpr int BBL_THREADS = 256;
 constexpr int BBL_CHUNK = 1024;
+constexpr int BBL_NV = 8;
 
-__device__ __forceinline__ void d_bb_last(AccHeader *hdr, const double *Q, const double *P, int cap, const BBEntry *in_list,
-                                          const uint32_t *in_count, int in_cap, BBEntry *out_list, uint32_t *out_count,
-                                          int out_cap)
+__device__ __forceinline__ void d_bb_exact(AccHeader *hdr, const double *Q, const double *P, int cap, BBEntry *list,
+                                           const uint32_t *count, int list_cap)
 {
     __shared__ double sx[BBL_CHUNK], sy[BBL_CHUNK], sz[BBL_CHUNK], slo[BBL_CHUNK], shi[BBL_CHUNK];
-    __shared__ int red[BBL_THREADS / 64][8];
-    __shared__ int s_skip;
+    __shared__ int red[BBL_THREADS / 64][BBL_NV];
     const AccHeader H = *hdr;
-    if (H.status != RCV_OK || !H.bb_enabled) return;
+    if (H.status != RCV_OK || !H.bb_enabled || H.bb_overflow) return;
     const int D = H.dim, n = H.n;
-    const unsigned nin = min(*in_count, (uint32_t)in_cap);
+    const unsigned nin = min(*count, (uint32_t)list_cap);
     const double *Qx = Q, *Qy = Q + (size_t)cap, *Qz = Q + 2 * (size_t)cap;
     const double *Plo = P + 3 * (size_t)cap, *Phi = P + 4 * (size_t)cap;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     constexpr int PT = BBL_CHUNK / BBL_THREADS;
-    for (unsigned pi = blockIdx.x; pi < nin; pi += gridDim.x) {
-        const BBEntry e = in_list[pi];
-        __syncthreads();
-        if (tid == 0)
-            s_skip = e.ub < __hip_atomic_load(&hdr->bb_best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ||
-                     __hip_atomic_load(&hdr->bb_overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __syncthreads();
-        if (s_skip) continue;
-        const int org[3] = {e.i, e.j, e.k};
-        double ce[3][2];
-        bool ok[3][2];
+    for (unsigned pp = blockIdx.x; pp * BBL_NV < nin; pp += gridDim.x) {
+        double ci[BBL_NV], cj[BBL_NV], ck[BBL_NV];
 #pragma unroll
-        for (int a = 0; a < 3; a++)
+        for (int v = 0; v < BBL_NV; v++) {
+            const BBEntry e = list[min(pp * BBL_NV + v, nin - 1)];
+            ci[v] = (double)e.i; cj[v] = (double)e.j; ck[v] = (double)e.k;
+        }
+        int cnt[BBL_NV];
+        unsigned hist[BBL_NV];  // vote bits of the last <= 32 points, as in k_bb_wide
 #pragma unroll
-            for (int h = 0; h < 2; h++) {
-                ok[a][h] = org[a] + h <= D - 1;
-                ce[a][h] = (double)(org[a] + h);
-            }
-        int cnt[8];
-#pragma unroll
-        for (int c = 0; c < 8; c++) cnt[c] = 0;
-        for (int base = 0; base < n; base += BBL_CHUNK) {
+        for (int v = 0; v < BBL_NV; v++) { cnt[v] = 0; hist[v] = 0u; }
+        int chunk_no = 0;
+        for (int base = 0; base < n; base += BBL_CHUNK, chunk_no++) {
             __syncthreads();
             {
                 double rx[PT], ry[PT], rz[PT], rl[PT], rh[PT];
@@ -1375,56 +1367,39 @@ __device__ __forceinline__ void d_bb_last(AccHeader *hdr, const double *Q, const
 #pragma unroll 1
             for (int t = 0; t < PT; t++) {
                 const int li = t * BBL_THREADS + tid;
-                const double q[3] = {sx[li], sy[li], sz[li]};
+                const double qx = sx[li], qy = sy[li], qz = sz[li];
                 const double tlo = slo[li], thi = shi[li];
-                double c2[3][2];
 #pragma unroll
-                for (int a = 0; a < 3; a++)
-#pragma unroll
-                    for (int h = 0; h < 2; h++) {
-                        const double dc = ce[a][h] - q[a];  // (i - x), reference operand order (:337)
-                        c2[a][h] = dc * dc;
-                    }
-                double xy[4];
-#pragma unroll
-                for (int c = 0; c < 4; c++) xy[c] = c2[0][c >> 1] + c2[1][c & 1];
-#pragma unroll
-                for (int c = 0; c < 8; c++) {
-                    const double d2 = xy[c >> 1] + c2[2][c & 1];
+                for (int v = 0; v < BBL_NV; v++) {
+                    const double dx = ci[v] - qx, dy = cj[v] - qy, dz = ck[v] - qz;  // (i - x), reference operand order (:337)
+                    const double d2 = (dx * dx + dy * dy) + dz * dz;
                     const int below = (int)(__double_as_longlong(d2 - thi) >> 32);   // negative <=> d2 < T_hi
                     const int reach = ~(int)(__double_as_longlong(d2 - tlo) >> 32);  // sign set <=> d2 >= T_lo
-                    cnt[c] += (int)((unsigned)(below & reach) >> 31);
+                    hist[v] = __builtin_amdgcn_alignbit(hist[v], (unsigned)(below & reach), 31);
                 }
+            }
+            if ((chunk_no & (32 / PT - 1)) == 32 / PT - 1) {
+#pragma unroll
+                for (int v = 0; v < BBL_NV; v++) { cnt[v] += __popc(hist[v]); hist[v] = 0u; }
             }
         }
 #pragma unroll
-        for (int c = 0; c < 8; c++) {
-            const int u = wave_sum_i32(cnt[c]);
-            if (lane == 0) red[wv][c] = u;
+        for (int v = 0; v < BBL_NV; v++) {
+            const int u = wave_sum_i32(cnt[v] + __popc(hist[v]));
+            if (lane == 0) red[wv][v] = u;
         }
         __syncthreads();
-        if (tid < 8) {
-            const int c = tid, hx = (c >> 2) & 1, hy = (c >> 1) & 1, hz = c & 1;
+        if (tid < BBL_NV && pp * BBL_NV + tid < nin) {
             int u = 0;
-            for (int w = 0; w < BBL_THREADS / 64; w++) u += red[w][c];
-            if (ok[0][hx] && ok[1][hy] && ok[2][hz]) {
-                const int best = max(atomicMax(&hdr->bb_best, u), u);
-                const unsigned long long flat = ((unsigned long long)(org[0] + hx) * D + (unsigned long long)(org[1] + hy)) * D +
-                                                (unsigned long long)(org[2] + hz);
-                atomicMax(&hdr->bb_best_key, ((unsigned long long)u << 32) | flat);
-                if (u > 0 && u >= best) {
-                    const unsigned slot = atomicAdd(out_count, 1u);
-                    if (slot < (unsigned)out_cap) {
-                        BBEntry o;
-                        o.i = (uint16_t)(org[0] + hx); o.j = (uint16_t)(org[1] + hy); o.k = (uint16_t)(org[2] + hz);
-                        o.pad_ = 0; o.ub = u; o.lb = u;
-                        out_list[slot] = o;
-                    } else {
-                        atomicExch(&hdr->bb_overflow, 1);
-                    }
-                }
-            }
+            for (int w = 0; w < BBL_THREADS / 64; w++) u += red[w][tid];
+            BBEntry e = list[pp * BBL_NV + tid];
+            e.ub = u; e.lb = u;
+            list[pp * BBL_NV + tid] = e;
+            atomicMax(&hdr->bb_best, u);
+            const unsigned long long flat = ((unsigned long long)e.i * D + (unsigned long long)e.j) * D + (unsigned long long)e.k;
+            atomicMax(&hdr->bb_best_key, ((unsigned long long)u << 32) | flat);
         }
+        __syncthreads();  // red[] is rewritten by the next pass
     }
 }
 
@@ -1694,13 +1669,12 @@ __global__ __launch_bounds__(256) void k_bb_climb(int cap, SP<unsigned char> ws,
     unsigned char *w = ws.get();
     d_bb_climb((AccHeader *)(w + L.header), (const double *)(w + L.Q), (const double *)(w + L.P), cap);
 }
-__global__ __launch_bounds__(BBL_THREADS) void k_bb_last(int cap, SP<unsigned char> ws, Layout L)
+__global__ __launch_bounds__(BBL_THREADS) void k_bb_exact(int cap, SP<unsigned char> ws, Layout L)
 {
     unsigned char *w = ws.get();
-    const BBEntry *in; const uint32_t *in_count; int in_cap; BBEntry *out; uint32_t *out_count; int out_cap;
-    bb_resolve(w, L, BB_LEVELS - 1, BBIo{0, 0}, in, in_count, in_cap, out, out_count, out_cap);
-    d_bb_last((AccHeader *)(w + L.header), (const double *)(w + L.Q), (const double *)(w + L.P), cap, in, in_count, in_cap, out,
-              out_count, out_cap);
+    AccHeader *hdr = (AccHeader *)(w + L.header);
+    BBEntry *la = (BBEntry *)(w + L.bb_lists), *lb = la + BB_CAP;
+    d_bb_exact(hdr, (const double *)(w + L.Q), (const double *)(w + L.P), cap, (BB_LEVELS & 1) ? lb : la, &hdr->bb_count[BB_LEVELS], BB_CAP);
 }
 // probe selection before level `level`: from the breadth-first list (level 1) or the previous probe children
 __global__ __launch_bounds__(1024) void k_bb_topk(int level, SP<unsigned char> ws, Layout L)
@@ -1875,11 +1849,13 @@ static int accumulate_batch(rcv_strided xyz, rcv_strided radial, int radial_is_f
         }
         // the lower bound now sits at (or next to) the peak: the wide levels only need upper bounds
         const int wide_grid = n_items >= 8 ? 256 : 2048 / n_items;
-        for (int level = 1; level < BB_LEVELS - 1; level++) {
+        // (the last of them, on 2^3 parents, bounds single voxels)
+        for (int level = 1; level < BB_LEVELS; level++) {
             hipLaunchKernelGGL(k_bb_wide, grid3(wide_grid), dim3(BBW_THREADS), 0, st, cap, level, sws, L);
             RCV_LAUNCH_CHECK();
         }
-        hipLaunchKernelGGL(k_bb_last, grid3(wide_grid), dim3(BBL_THREADS), 0, st, cap, sws, L);
+        // exact counts of the surviving voxels (float32 bound >= best exact count): typically a few dozen
+        hipLaunchKernelGGL(k_bb_exact, grid3(n_items >= 8 ? 32 : 256 / n_items), dim3(BBL_THREADS), 0, st, cap, sws, L);
         RCV_LAUNCH_CHECK();
         hipLaunchKernelGGL(k_bb_final, items, dim3(1024), 0, st, sres, sws, L);
         RCV_LAUNCH_CHECK();
