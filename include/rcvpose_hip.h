@@ -147,6 +147,46 @@ int rcv_accumulate_3d_batch(rcv_strided xyz_m, rcv_strided radial_dm, int radial
 int rcv_horn_pose_batch(const double *model_kpts_dev, rcv_strided est_kpts, int n_points, int n_frames, double *rt_out_dev,
                         void *stream);
 
+/*
+ * Depth map restricted to the union of the point masks of the keypoints of one frame -- the pixels behind the scene cloud
+ * `xyz_mm_icp` that the reference hands to ICP (AccumulatorSpace.py:621-626).  seg / radial: n_keypoints float32 [H,W]
+ * maps, kp_stride elements apart (seg may be NULL for mode 1); masks as rcv_seam_compact modes 0 / 1;
+ * rmax_dm_dev: float64 [n_keypoints] on the device.  rcv_seam_compact(mode 2) on depth_out_dev yields the cloud (mm).
+ */
+int rcv_union_depth(const float *seg_dev, const float *radial_dev, long long kp_stride, const uint16_t *depth_dev, int H, int W,
+                    float seg_thr, const double *rmax_dm_dev, int mode, int n_keypoints, uint16_t *depth_out_dev, void *stream);
+
+/*
+ * Nearest-neighbour distances and point-to-point ICP, the two Open3D 0.14.1 calls of the evaluation that follows the
+ * keypoints.  Open3D is not part of the reference tree (rcvpose.yml:176 pins it); these entry
+ * points restate its published algorithm (see rcvpose_amd/csrc/icp.hip).  Points are float64 [n,3], row-major.
+ *
+ * rcv_nn_distance: open3d.geometry.PointCloud.compute_point_cloud_distance, AccumulatorSpace.py:689,693,719,723:
+ *   dist_dev[i] = min_j |a_i - b_j|; idx_dev (optional) = arg-min (lowest index among equals).  Empty b: RCV_E_EMPTY.
+ */
+int rcv_nn_distance(const double *a_dev, int n_a, const double *b_dev, int n_b, double *dist_dev, int *idx_dev, void *stream);
+
+typedef struct rcv_icp_result {
+    double transformation[16]; /* row-major 4x4, source -> target (open3d RegistrationResult.transformation) */
+    double fitness;            /* correspondences / source points */
+    double inlier_rmse;        /* sqrt(mean squared correspondence distance) */
+    int32_t n_correspondences;
+    int32_t iterations;        /* updates applied */
+    int32_t status;
+    int32_t reserved;
+} rcv_icp_result;
+
+/*
+ * open3d.pipelines.registration.registration_icp(source, target, max_correspondence_distance, init,
+ * TransformationEstimationPointToPoint(), ICPConvergenceCriteria(relative_fitness, relative_rmse, max_iteration)),
+ * AccumulatorSpace.py:706-712 (defaults 1e-6, 1e-6, 30) and :935-943.  Synchronous: the convergence test runs on the
+ * host once per iteration; `out` is host memory.  Workspace: rcv_icp_workspace_bytes(n_src) device bytes.
+ */
+size_t rcv_icp_workspace_bytes(int n_src);
+int rcv_icp_point_to_point(const double *src_dev, int n_src, const double *tgt_dev, int n_tgt, double max_corr_dist,
+                           const double T0[16], double relative_fitness, double relative_rmse, int max_iteration,
+                           rcv_icp_result *out, void *ws, size_t ws_bytes, void *stream);
+
 /* How rcv_accumulate_3d finds the arg-max when no vote_grid_dev is requested (process-wide setting):
  *   0 (default): exact branch-and-bound peak search; the LDS rasteriser takes over when the search gives up
  *   1: LDS rasteriser only (the full VoteMap is accumulated tile by tile in LDS).

@@ -269,11 +269,26 @@ def read_ply_points(path):
         return np.stack([data['x'], data['y'], data['z']], axis=1).astype(np.float64)
 
 
-def _nn_distances(a, b):
-    """open3d PointCloud.compute_point_cloud_distance(a -> b): distance from every point of a to its nearest in b."""
-    from scipy.spatial import cKDTree
+def scene_cloud_of_keypoint_masks(seg_maps, radial_maps, depth_dev, max_radii_dm, K=linemod_K, mode=0):
+    """`xyz_mm_icp` of the reference (AccumulatorSpace.py:621-626): the back-projected pixels that belong to the point
+    mask of at least one keypoint, as a float64 [n,3] CUDA tensor in mm (row-major pixel order).
 
-    return cKDTree(b).query(a)[0]
+    seg_maps / radial_maps: float32 [n_kp,H,W] CUDA tensors (seg_maps None for the pre-computed radial-map branch, mode 1)."""
+    torch = _torch()
+    L = _hip.lib()
+    n_kp, H, W = radial_maps.shape
+    radial_maps = radial_maps.contiguous()
+    if seg_maps is not None:
+        seg_maps = seg_maps.contiguous()
+    rmax = torch.from_numpy(np.ascontiguousarray(max_radii_dm, dtype=np.float64)).to(radial_maps.device)
+    union = torch.empty((H, W), dtype=torch.int16, device=radial_maps.device)
+    _hip.check(L.rcv_union_depth(_hip.ptr(seg_maps), _hip.ptr(radial_maps), H * W, _hip.ptr(depth_dev), H, W, float(SEG_THRESHOLD),
+                                 _hip.ptr(rmax), int(mode), n_kp, _hip.ptr(union), _hip.current_stream()), "rcv_union_depth")
+    ws = AccWorkspace(H * W, device=radial_maps.device)
+    _hip.check(L.rcv_seam_compact(None, None, _hip.ptr(union), H, W, _k4(K), 0.0, 0.0, 2, _hip.ptr(ws.xyz), None, _hip.ptr(ws.counts),
+                                  ws.max_points, _hip.ptr(ws.ws), ws.bytes, _hip.current_stream()), "rcv_seam_compact(mode=2)")
+    n = int(ws.counts[0].item())
+    return ws.xyz[:n].clone()
 
 
 def estimate_6d_pose_lm(opts, return_details=False):
@@ -281,13 +296,15 @@ def estimate_6d_pose_lm(opts, return_details=False):
 
     opts attributes read (as in the reference): root_dataset, model_dir, using_ckpts, demo_mode (ignored), plus the
     optional class_names (default: every LINEMOD class present under root_dataset).  Per frame: 3 keypoints (FCN ->
-    seam -> voting, or pre-computed radial maps when using_ckpts is False) -> Horn pose -> ADD(-S) before ICP.
+    seam -> voting, or pre-computed radial maps when using_ckpts is False) -> Horn pose -> ADD(-S) before ICP ->
+    point-to-point ICP of the CAD model onto the masked scene points -> ADD(-S) after ICP (all on the GPU).
     """
     torch = _torch()
     from . import utils
     from .models.fcnresnet import DenseFCNResNet152
     from .pipeline import FramePipeline
     from .util.horn import horn_batch
+    from .registration import ICPConvergenceCriteria, compute_point_cloud_distance, registration_icp
 
     _hip.lib()
     results = {}
@@ -317,7 +334,7 @@ def estimate_6d_pose_lm(opts, return_details=False):
                 model = DenseFCNResNet152(3, 2)
                 model, _, _, _ = utils.load_checkpoint(model, None, model_path)
                 sds.append(model.state_dict())
-        bf_icp, general_counter = 0, 0
+        bf_icp, af_icp, general_counter = 0, 0, 0
         per_frame = {}
         dataPath = rootpvPath + 'JPEGImages/'
         for filename in sorted(os.listdir(dataPath)):
@@ -339,13 +356,16 @@ def estimate_6d_pose_lm(opts, return_details=False):
                 estimated_kpts, res = pipe.read_results()
                 estimated_kpts = estimated_kpts[0]
                 statuses = [r.status for r in res]
+                seg_maps, rad_maps, mask_mode = pipe.seg[:, 0, 0], pipe.radial[:, 0, 0], 0
             else:
                 estimated_kpts, statuses = np.zeros((3, 3)), []
                 ws = AccWorkspace(H * W)
+                seg_maps, rad_maps, mask_mode = None, torch.empty((3, H, W), dtype=torch.float32, device="cuda"), 1
                 for k in range(1, 4):  # reference :611-618
                     radial_est = np.load(os.path.join(opts.root_dataset + "LINEMOD_ORIG/", 'estRadialMap', class_name,
                                                       "Out_pt" + str(k) + "_dm", stem + '.npy'))
                     rad_dev = torch.from_numpy(np.ascontiguousarray(radial_est, dtype=np.float32)).cuda()
+                    rad_maps[k - 1].copy_(rad_dev)
                     seam_compact(None, rad_dev, depth_dev, max_radii_dm[k - 1], mode=1, workspace=ws)
                     accumulate_on_device(ws.xyz, ws.radial, ws.counts, ws.max_points, ws.max_points, ws)
                     r = ws.read_result()
@@ -359,16 +379,32 @@ def estimate_6d_pose_lm(opts, return_details=False):
             RTGT_mm = np.array(RTGT, dtype=np.float64, copy=True)
             RTGT_mm[:, 3] = RTGT_mm[:, 3] * 1000
             _, gt_model = project(xyz_load * 1000, linemod_K, RTGT_mm)
-            d = _nn_distances(gt_model, est_model)
+            gt_dev = torch.from_numpy(np.ascontiguousarray(gt_model)).cuda()
+            d = compute_point_cloud_distance(gt_dev, est_model)
             dist = d.min() if class_name in lm_syms else d.mean()  # reference :686-694
             if dist <= add_threshold[class_name] * 1000:
                 bf_icp += 1
+            # ICP of the CAD model onto the masked scene points, started from the Horn pose, reach = the distance above
+            # (reference :696-712), then the same metric on the refined model (:717-726)
+            scene = scene_cloud_of_keypoint_masks(seg_maps, rad_maps, depth_dev, max_radii_dm, linemod_K, mask_mode)
+            reg = registration_icp(xyz_load * 1000, scene, float(dist), RT, ICPConvergenceCriteria())
+            T = reg.transformation
+            cad_model = (xyz_load * 1000) @ T[:3, :3].T + T[:3, 3]
+            d2 = compute_point_cloud_distance(gt_dev, cad_model)
+            dist_after = d2.min() if class_name in lm_syms else d2.mean()
+            if dist_after <= add_threshold[class_name] * 1000:
+                af_icp += 1
             general_counter += 1
-            per_frame[stem] = dict(estimated_kpts=estimated_kpts.copy(), RT=RT, add_distance_mm=float(dist))
+            per_frame[stem] = dict(estimated_kpts=estimated_kpts.copy(), RT=RT, add_distance_mm=float(dist), scene_points=int(scene.shape[0]),
+                                   icp_transformation=T, icp_fitness=reg.fitness, icp_inlier_rmse=reg.inlier_rmse,
+                                   icp_iterations=reg.iterations, add_distance_after_icp_mm=float(dist_after))
             print('Current ADD\\(s\\) of ' + class_name + ' before ICP: ', bf_icp / general_counter)
+            print('Currnet ADD\\(s\\) of ' + class_name + ' after ICP: ', af_icp / general_counter)
         if general_counter:
             tag = 'ADDs' if class_name in lm_syms else 'ADD'
             print(tag + ' of ' + class_name + ' before ICP: ', bf_icp / general_counter)
-            results[class_name] = dict(frames=general_counter, add_before_icp=bf_icp / general_counter)
+            print(tag + ' of ' + class_name + ' after ICP: ', af_icp / general_counter)
+            results[class_name] = dict(frames=general_counter, add_before_icp=bf_icp / general_counter,
+                                       add_after_icp=af_icp / general_counter)
             details[class_name] = per_frame
     return (results, details) if return_details else results

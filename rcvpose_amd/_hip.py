@@ -32,6 +32,13 @@ class Strided(ctypes.Structure):
     _fields_ = [("ptr", ctypes.c_void_p), ("stride_frame", ctypes.c_int64), ("stride_kp", ctypes.c_int64)]
 
 
+class IcpResult(ctypes.Structure):
+    """struct rcv_icp_result (include/rcvpose_hip.h)."""
+    _fields_ = [("transformation", ctypes.c_double * 16), ("fitness", ctypes.c_double), ("inlier_rmse", ctypes.c_double),
+                ("n_correspondences", ctypes.c_int32), ("iterations", ctypes.c_int32), ("status", ctypes.c_int32),
+                ("reserved", ctypes.c_int32)]
+
+
 class AccResult(ctypes.Structure):
     _fields_ = [
         ("center_mm", ctypes.c_double * 3),
@@ -101,6 +108,10 @@ SYMBOLS = {
     "rcv_fcn_set_option": (_i, [_vp, _i, _i]),
     "rcv_fcn_get_profile": (_i, [_vp, ctypes.POINTER(_d), ctypes.POINTER(_d), ctypes.POINTER(_d)]),
     "rcv_fcn_get_op_times": (_i, [_vp, ctypes.POINTER(_d), _i]),
+    "rcv_union_depth": (_i, [_vp, _vp, ctypes.c_longlong, _vp, _i, _i, _f, _vp, _i, _i, _vp, _vp]),
+    "rcv_nn_distance": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp]),
+    "rcv_icp_workspace_bytes": (_sz, [_i]),
+    "rcv_icp_point_to_point": (_i, [_vp, _i, _vp, _i, _d, ctypes.POINTER(_d), _d, _d, _i, _vp, _vp, _sz, _vp]),
 }
 
 _lib = None

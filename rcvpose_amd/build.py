@@ -21,6 +21,7 @@ SOURCES = {
     "accumulator.hip": ["-ffp-contract=off"],
     "fcn.hip": [],
     "pose.hip": ["-ffp-contract=off"],
+    "icp.hip": ["-ffp-contract=off"],
 }
 COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC,
           "-Wall", "-Wno-unused-function"]

@@ -218,6 +218,24 @@ __device__ __forceinline__ void seam_flags(const float *seg, const RT *rad, cons
     }
 }
 
+// Depth map restricted to the union of the keypoints' point masks of one frame: the pixels whose back-projection the
+// reference collects into `xyz_mm_icp` (AccumulatorSpace.py:621-626: points of keypoint 1, then the not yet present
+// points of keypoints 2 and 3).  Two pixels back-project to the same point only if they are the same pixel, so the
+// union of points is the union of pixels; rcv_seam_compact(mode 2) on the result gives the scene cloud (row-major).
+__global__ __launch_bounds__(256) void k_union_depth(const float *seg, const float *rad, long long kp_stride, const uint16_t *depth,
+                                                     int HW, float thr, const double *rmax, int mode, int n_kp, uint16_t *out)
+{
+    for (int p = blockIdx.x * 256 + threadIdx.x; p < HW; p += gridDim.x * 256) {
+        bool any = false;
+        for (int k = 0; k < n_kp; k++) {
+            bool mr, mp;
+            seam_flags<float>(seg ? seg + (size_t)k * kp_stride : nullptr, rad + (size_t)k * kp_stride, depth, p, thr, rmax[k], mode, mr, mp);
+            any = any || mp;
+        }
+        out[p] = any ? depth[p] : (uint16_t)0;
+    }
+}
+
 template <typename RT>
 __device__ __forceinline__ void d_seam_count(const float *seg, const RT *rad, const uint16_t *depth, int HW,
                                                     float thr, double rmax, int mode, int2 *blk_counts)
@@ -1877,6 +1895,18 @@ static int accumulate_batch(rcv_strided xyz, rcv_strided radial, int radial_is_f
         RCV_LAUNCH_CHECK();
     }
     hipLaunchKernelGGL(k_final, items, dim3(256), 0, st, grid.ptr != nullptr ? 1 : 0, (unsigned long long)grid_cells, sres, sws, L);
+    RCV_LAUNCH_CHECK();
+    return RCV_OK;
+}
+
+int rcv_union_depth(const float *seg_dev, const float *radial_dev, long long kp_stride, const uint16_t *depth_dev, int H, int W,
+                    float seg_thr, const double *rmax_dm_dev, int mode, int n_keypoints, uint16_t *depth_out_dev, void *stream)
+{
+    if (!radial_dev || !depth_dev || !depth_out_dev || !rmax_dm_dev || H <= 0 || W <= 0 || n_keypoints <= 0) return RCV_E_INVALID;
+    if ((mode != 0 && mode != 1) || (mode == 0 && !seg_dev)) return RCV_E_INVALID;
+    const int HW = H * W;
+    hipLaunchKernelGGL(k_union_depth, dim3(std::min((HW + 255) / 256, 4096)), dim3(256), 0, (hipStream_t)stream,
+                       seg_dev, radial_dev, kp_stride, depth_dev, HW, seg_thr, rmax_dm_dev, mode, n_keypoints, depth_out_dev);
     RCV_LAUNCH_CHECK();
     return RCV_OK;
 }

@@ -79,7 +79,28 @@ def test_driver_with_precomputed_radial_maps(tmp_path, oracle):
         t_gt = poses[stem][:, 3] * 1000
         assert np.abs(d["RT"][:3, 3] - t_gt).max() < 25.0
         assert d["add_distance_mm"] < 15.0
+        # ADD before ICP, the scene cloud, the ICP refinement and ADD after ICP against the CPU restatements
+        from oracle import icp_oracle
+
+        RTGT_mm = np.array(poses[stem], dtype=np.float64)
+        RTGT_mm[:, 3] *= 1000
+        gt_model = model * 1000 @ RTGT_mm[:, :3].T + RTGT_mm[:, 3]
+        est_model = model * 1000 @ d["RT"][:3, :3].T + d["RT"][:3, 3]
+        add0 = icp_oracle.nn_distance(gt_model, est_model)[0].mean()
+        assert abs(d["add_distance_mm"] - add0) < 1e-9
+        union = np.zeros(fr["depth"].shape, dtype=bool)
+        for k in range(3):
+            r = fr["radial"][k]
+            union |= (r.astype(np.float64) <= max_radii_dm[k]) & (r != 0) & (fr["depth"] != 0)
+        scene = oracle.backproject((fr["depth"] * union).astype(np.int64))
+        assert d["scene_points"] == len(scene)
+        ref = icp_oracle.registration_icp(model * 1000, scene, add0, d["RT"])
+        assert d["icp_iterations"] == ref["iterations"]
+        assert np.allclose(d["icp_transformation"], ref["transformation"], rtol=0, atol=1e-6)
+        cad = model * 1000 @ ref["transformation"][:3, :3].T + ref["transformation"][:3, 3]
+        assert abs(d["add_distance_after_icp_mm"] - icp_oracle.nn_distance(gt_model, cad)[0].mean()) < 1e-5
     assert results[cls]["add_before_icp"] == 1.0
+    assert 0.0 <= results[cls]["add_after_icp"] <= 1.0
 
 
 def test_main_entry_runs_the_driver(tmp_path):
