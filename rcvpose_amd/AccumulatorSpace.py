@@ -269,7 +269,7 @@ def read_ply_points(path):
         return np.stack([data['x'], data['y'], data['z']], axis=1).astype(np.float64)
 
 
-def scene_cloud_of_keypoint_masks(seg_maps, radial_maps, depth_dev, max_radii_dm, K=linemod_K, mode=0):
+def scene_cloud_of_keypoint_masks(seg_maps, radial_maps, depth_dev, max_radii_dm, K=linemod_K, mode=0, seg_thr=SEG_THRESHOLD):
     """`xyz_mm_icp` of the reference (AccumulatorSpace.py:621-626): the back-projected pixels that belong to the point
     mask of at least one keypoint, as a float64 [n,3] CUDA tensor in mm (row-major pixel order).
 
@@ -282,13 +282,41 @@ def scene_cloud_of_keypoint_masks(seg_maps, radial_maps, depth_dev, max_radii_dm
         seg_maps = seg_maps.contiguous()
     rmax = torch.from_numpy(np.ascontiguousarray(max_radii_dm, dtype=np.float64)).to(radial_maps.device)
     union = torch.empty((H, W), dtype=torch.int16, device=radial_maps.device)
-    _hip.check(L.rcv_union_depth(_hip.ptr(seg_maps), _hip.ptr(radial_maps), H * W, _hip.ptr(depth_dev), H, W, float(SEG_THRESHOLD),
+    _hip.check(L.rcv_union_depth(_hip.ptr(seg_maps), _hip.ptr(radial_maps), H * W, _hip.ptr(depth_dev), H, W, float(seg_thr),
                                  _hip.ptr(rmax), int(mode), n_kp, _hip.ptr(union), _hip.current_stream()), "rcv_union_depth")
     ws = AccWorkspace(H * W, device=radial_maps.device)
     _hip.check(L.rcv_seam_compact(None, None, _hip.ptr(union), H, W, _k4(K), 0.0, 0.0, 2, _hip.ptr(ws.xyz), None, _hip.ptr(ws.counts),
                                   ws.max_points, _hip.ptr(ws.ws), ws.bytes, _hip.current_stream()), "rcv_seam_compact(mode=2)")
     n = int(ws.counts[0].item())
     return ws.xyz[:n].clone()
+
+
+def _pose_and_add(class_name, xyz_load, keypoints, estimated_kpts, RTGT_mm, seg_maps, rad_maps, depth_dev, max_radii_dm,
+                  mask_mode, criteria, seg_thr=SEG_THRESHOLD):
+    """Horn pose from the three keypoints, ADD(-S) before ICP, ICP of the CAD model onto the masked scene points and
+    ADD(-S) after ICP (reference AccumulatorSpace.py:655-726 / :899-958), everything on the GPU."""
+    torch = _torch()
+    from .registration import compute_point_cloud_distance, registration_icp
+    from .util.horn import horn_batch
+
+    kpts = keypoints[1:4, :] * 1000
+    RT = horn_batch(kpts, torch.from_numpy(np.ascontiguousarray(estimated_kpts[None])).cuda())[0].cpu().numpy()  # :659-661
+    _, est_model = project(xyz_load * 1000, linemod_K, RT[0:3, :])
+    _, gt_model = project(xyz_load * 1000, linemod_K, RTGT_mm)
+    gt_dev = torch.from_numpy(np.ascontiguousarray(gt_model)).cuda()
+    d = compute_point_cloud_distance(gt_dev, est_model)
+    dist = d.min() if class_name in lm_syms else d.mean()  # reference :686-694
+    # ICP of the CAD model onto the masked scene points, started from the Horn pose, reach = the distance above
+    # (reference :696-712), then the same metric on the refined model (:717-726)
+    scene = scene_cloud_of_keypoint_masks(seg_maps, rad_maps, depth_dev, max_radii_dm, linemod_K, mask_mode, seg_thr)
+    reg = registration_icp(xyz_load * 1000, scene, float(dist), RT, criteria)
+    T = reg.transformation
+    cad_model = (xyz_load * 1000) @ T[:3, :3].T + T[:3, 3]
+    d2 = compute_point_cloud_distance(gt_dev, cad_model)
+    dist_after = d2.min() if class_name in lm_syms else d2.mean()
+    return dict(estimated_kpts=estimated_kpts.copy(), RT=RT, add_distance_mm=float(dist), scene_points=int(scene.shape[0]),
+                icp_transformation=T, icp_fitness=reg.fitness, icp_inlier_rmse=reg.inlier_rmse, icp_iterations=reg.iterations,
+                add_distance_after_icp_mm=float(dist_after))
 
 
 def estimate_6d_pose_lm(opts, return_details=False):
@@ -303,8 +331,7 @@ def estimate_6d_pose_lm(opts, return_details=False):
     from . import utils
     from .models.fcnresnet import DenseFCNResNet152
     from .pipeline import FramePipeline
-    from .util.horn import horn_batch
-    from .registration import ICPConvergenceCriteria, compute_point_cloud_distance, registration_icp
+    from .registration import ICPConvergenceCriteria
 
     _hip.lib()
     results = {}
@@ -373,31 +400,16 @@ def estimate_6d_pose_lm(opts, return_details=False):
                     estimated_kpts[k - 1] = r.center_mm[:]
             for st in statuses:
                 _raise_like_reference(st)
-            kpts = keypoints[1:4, :] * 1000
-            RT = horn_batch(kpts, torch.from_numpy(np.ascontiguousarray(estimated_kpts[None])).cuda())[0].cpu().numpy()  # :659-661
-            _, est_model = project(xyz_load * 1000, linemod_K, RT[0:3, :])
             RTGT_mm = np.array(RTGT, dtype=np.float64, copy=True)
             RTGT_mm[:, 3] = RTGT_mm[:, 3] * 1000
-            _, gt_model = project(xyz_load * 1000, linemod_K, RTGT_mm)
-            gt_dev = torch.from_numpy(np.ascontiguousarray(gt_model)).cuda()
-            d = compute_point_cloud_distance(gt_dev, est_model)
-            dist = d.min() if class_name in lm_syms else d.mean()  # reference :686-694
-            if dist <= add_threshold[class_name] * 1000:
+            ev = _pose_and_add(class_name, xyz_load, keypoints, estimated_kpts, RTGT_mm, seg_maps, rad_maps, depth_dev, max_radii_dm,
+                               mask_mode, ICPConvergenceCriteria())
+            if ev["add_distance_mm"] <= add_threshold[class_name] * 1000:
                 bf_icp += 1
-            # ICP of the CAD model onto the masked scene points, started from the Horn pose, reach = the distance above
-            # (reference :696-712), then the same metric on the refined model (:717-726)
-            scene = scene_cloud_of_keypoint_masks(seg_maps, rad_maps, depth_dev, max_radii_dm, linemod_K, mask_mode)
-            reg = registration_icp(xyz_load * 1000, scene, float(dist), RT, ICPConvergenceCriteria())
-            T = reg.transformation
-            cad_model = (xyz_load * 1000) @ T[:3, :3].T + T[:3, 3]
-            d2 = compute_point_cloud_distance(gt_dev, cad_model)
-            dist_after = d2.min() if class_name in lm_syms else d2.mean()
-            if dist_after <= add_threshold[class_name] * 1000:
+            if ev["add_distance_after_icp_mm"] <= add_threshold[class_name] * 1000:
                 af_icp += 1
             general_counter += 1
-            per_frame[stem] = dict(estimated_kpts=estimated_kpts.copy(), RT=RT, add_distance_mm=float(dist), scene_points=int(scene.shape[0]),
-                                   icp_transformation=T, icp_fitness=reg.fitness, icp_inlier_rmse=reg.inlier_rmse,
-                                   icp_iterations=reg.iterations, add_distance_after_icp_mm=float(dist_after))
+            per_frame[stem] = ev
             print('Current ADD\\(s\\) of ' + class_name + ' before ICP: ', bf_icp / general_counter)
             print('Currnet ADD\\(s\\) of ' + class_name + ' after ICP: ', af_icp / general_counter)
         if general_counter:
@@ -405,6 +417,123 @@ def estimate_6d_pose_lm(opts, return_details=False):
             print(tag + ' of ' + class_name + ' before ICP: ', bf_icp / general_counter)
             print(tag + ' of ' + class_name + ' after ICP: ', af_icp / general_counter)
             results[class_name] = dict(frames=general_counter, add_before_icp=bf_icp / general_counter,
+                                       add_after_icp=af_icp / general_counter)
+            details[class_name] = per_frame
+    return (results, details) if return_details else results
+
+
+def estimate_6d_pose_lmo(opts, return_details=False):
+    """The Occlusion-LINEMOD evaluation loop of the reference (AccumulatorSpace.py:742-974) on the MI355X hot path
+    (SURVEY.md section 8 f-4): same kernels as estimate_6d_pose_lm, the LM-O file layout and its own thresholds.
+
+    Layout read (as in the reference): `root_dataset/OCCLUSION_LINEMOD/RGB-D/{rgb_noseg/color_NNNNN.png,
+    depth_noseg/depth_NNNNN.png}`, `.../blender_poses/<class>/pose<N>.npy`, and, when using_ckpts is False,
+    `.../estRadialMap/<class>/Out_pt<k>_dm/_NNNNN.npy`; CAD model and `Outside9.npy` from `root_dataset/LINEMOD/<class>/`.
+    Differences from the LINEMOD loop that are kept: the point mask is `seg >= 0.5` (:836) resp. `0 < radial <= max_radius`
+    (:848-849), the radius list is gathered over the mask and the points over mask-and-depth (:858-860, so lists differ in
+    length where the mask covers a depth hole), a frame without pose file (or radial map) is skipped but still counted
+    in the denominator (:963), ICP runs with `ICPConvergenceCriteria(add_threshold*1000, add_threshold*1000, 30)` (:935).
+    One deliberate deviation: with using_ckpts=True the reference compares the radial map with the whole 3-vector
+    `max_radii_dm` (:837), which numpy cannot broadcast (the branch raises); this build applies the keypoint's own
+    entry, as the LINEMOD loop does.
+    """
+    torch = _torch()
+    import os
+
+    from PIL import Image
+
+    from . import utils
+    from .models.fcnresnet import DenseFCNResNet152
+    from .pipeline import FramePipeline
+    from .registration import ICPConvergenceCriteria
+
+    _hip.lib()
+    results, details = {}, {}
+    names = getattr(opts, 'class_names', None) or lmo_cls_names
+    rootPath = opts.root_dataset + 'OCCLUSION_LINEMOD/'
+    seg_thr = float(np.nextafter(np.float32(0.5), np.float32(0.0)))  # seg > thr  <=>  seg >= 0.5 in float32
+    for class_name in names:
+        print(class_name)
+        modelPath = opts.root_dataset + "LINEMOD/" + class_name + "/"
+        if not os.path.isdir(modelPath):
+            continue
+        pipe, sds = None, []
+        if opts.using_ckpts:
+            for i in range(1, 4):
+                model = DenseFCNResNet152(3, 2)
+                model, _, _, _ = utils.load_checkpoint(model, None, opts.model_dir + class_name + "_pt" + str(i) + ".pth.tar")
+                sds.append(model.state_dict())
+        xyz_load = read_ply_points(modelPath + class_name + ".ply")
+        keypoints = np.load(modelPath + "Outside9.npy")
+        max_radii_dm = np.zeros(3)
+        for i in range(3):  # reference :776-781
+            max_radii_dm[i] = (((xyz_load - keypoints[i + 1]) ** 2).sum(axis=1) ** 0.5).max() * 10
+        jpgPath, depthPath = rootPath + "RGB-D/rgb_noseg/", rootPath + "RGB-D/depth_noseg/"
+        criteria = ICPConvergenceCriteria(add_threshold[class_name] * 1000, add_threshold[class_name] * 1000, 30)
+        bf_icp, af_icp, general_counter = 0, 0, 0
+        per_frame = {}
+        for filename in sorted(os.listdir(jpgPath)):
+            if not filename.endswith(".png"):
+                continue
+            idx = int(os.path.splitext(filename)[0][6:])
+            pose_file = rootPath + "blender_poses/" + class_name + "/pose" + str(idx) + '.npy'
+            rad_files = [os.path.join(rootPath, 'estRadialMap', class_name, 'Out_pt' + str(k) + '_dm', '_' + str(idx).zfill(5) + '.npy')
+                         for k in range(1, 4)]
+            condition = os.path.isfile(pose_file) and (opts.using_ckpts or all(os.path.isfile(f) for f in rad_files))
+            if condition:
+                RTGT = np.load(pose_file)
+                depth_map = np.array(Image.open(depthPath + 'depth_' + str(idx).zfill(5) + '.png'), dtype=np.float64)
+                H, W = depth_map.shape
+                depth_dev = _depth_to_u16(depth_map, "cuda")
+                estimated_kpts, statuses = np.zeros((3, 3)), []
+                if opts.using_ckpts:
+                    if pipe is None:
+                        pipe = FramePipeline(sds, H, W, dtype=getattr(opts, 'dtype', 'bf16'), frames_per_step=1)
+                        pipe.seg_threshold = seg_thr
+                    rgb = np.array(Image.open(jpgPath + filename).convert('RGB'), dtype=np.uint8)
+                    pipe.process(torch.from_numpy(rgb)[None].cuda(), depth_dev[None], max_radii_dm)
+                    kp, res = pipe.read_results()
+                    seg_maps, rad_maps = pipe.seg[:, 0, 0], pipe.radial[:, 0, 0]
+                    for k in range(3):  # `if radial_out.max() != 0` (:857): an empty mask leaves the keypoint at zero
+                        if res[k].status == _hip.RCV_E_EMPTY and res[k].n_radii == 0:
+                            continue
+                        statuses.append(res[k].status)
+                        estimated_kpts[k] = kp[0][k]
+                else:
+                    ws = AccWorkspace(H * W)
+                    rad_maps = torch.empty((3, H, W), dtype=torch.float32, device="cuda")
+                    seg_maps = torch.empty((3, H, W), dtype=torch.float32, device="cuda")
+                    for k in range(3):
+                        rad_maps[k].copy_(torch.from_numpy(np.ascontiguousarray(np.load(rad_files[k]), dtype=np.float32)))
+                        seg_maps[k].copy_((rad_maps[k] > 0).to(torch.float32))  # sem_out = radial_out > 0 after thresholding (:849)
+                        seam_compact(seg_maps[k], rad_maps[k], depth_dev, max_radii_dm[k], mode=0, workspace=ws, seg_thr=0.5)
+                        n_radii = int(ws.counts[1].item())
+                        if n_radii == 0:  # radial_out.max() == 0 (:857)
+                            continue
+                        accumulate_on_device(ws.xyz, ws.radial, ws.counts, ws.max_points, ws.max_points, ws)
+                        r = ws.read_result()
+                        statuses.append(r.status)
+                        estimated_kpts[k] = r.center_mm[:]
+                for st in statuses:
+                    _raise_like_reference(st)
+                RTGT_mm = np.array(RTGT, dtype=np.float64, copy=True)
+                RTGT_mm[:, 3] = RTGT_mm[:, 3] * 1000
+                ev = _pose_and_add(class_name, xyz_load, keypoints, estimated_kpts, RTGT_mm, seg_maps, rad_maps, depth_dev, max_radii_dm,
+                                   0, criteria, seg_thr if opts.using_ckpts else 0.5)
+                if ev["add_distance_mm"] <= add_threshold[class_name] * 1000:
+                    bf_icp += 1
+                if ev["add_distance_after_icp_mm"] <= add_threshold[class_name] * 1000:
+                    af_icp += 1
+                per_frame[os.path.splitext(filename)[0]] = ev
+            general_counter += 1
+            tag = 'ADDs' if class_name in lm_syms else 'ADD'
+            print('Current ' + tag + ' of ' + class_name + ' before ICP: ', bf_icp / general_counter)
+            print('Currnet ' + tag + ' of ' + class_name + ' after ICP: ', af_icp / general_counter)
+        if general_counter:
+            tag = 'ADDs' if class_name in lm_syms else 'ADD'
+            print(tag + ' of ' + class_name + ' before ICP: ', bf_icp / general_counter)
+            print(tag + ' of ' + class_name + ' after ICP: ', af_icp / general_counter)
+            results[class_name] = dict(frames=general_counter, evaluated=len(per_frame), add_before_icp=bf_icp / general_counter,
                                        add_after_icp=af_icp / general_counter)
             details[class_name] = per_frame
     return (results, details) if return_details else results

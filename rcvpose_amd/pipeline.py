@@ -26,6 +26,7 @@ class FramePipeline:
         self.H, self.W, self.B, self.G = H, W, int(frames_per_step), len(state_dicts)
         self.K = np.asarray(K, dtype=np.float64)
         self.acc_unit = float(acc_unit)
+        self.seg_threshold = float(A.SEG_THRESHOLD)  # reference :603 (LINEMOD); the LM-O driver uses >= 0.5 (:836)
         self.device = device
         self.engine = fcn_engine.FcnEngine(state_dicts, H, W, dtype=dtype, device=device)
         self.engine.workspace(self.B)
@@ -85,7 +86,7 @@ class FramePipeline:
         cnt = item(self.counts, 8)
         ws = item(self.ws, self.ws_bytes)
         res = item(self.results, ctypes.sizeof(_hip.AccResult))
-        _hip.check(L.rcv_seam_compact_batch(seg, rad, dep, self.H, self.W, self.k4, float(A.SEG_THRESHOLD), rmx, 0, xyz, rl, cnt,
+        _hip.check(L.rcv_seam_compact_batch(seg, rad, dep, self.H, self.W, self.k4, float(self.seg_threshold), rmx, 0, xyz, rl, cnt,
                                             self.cap, ws, self.ws_bytes, B, G, st), "rcv_seam_compact_batch")
         _hip.check(L.rcv_accumulate_3d_batch(xyz, rl, 0, cnt, self.cap, self.acc_unit, res, ws, self.ws_bytes, B, G, st),
                    "rcv_accumulate_3d_batch")

@@ -4,7 +4,7 @@ Only `Test()` is implemented here -- it dispatches to the evaluation driver exac
 training loop is outside the scope of this build ("OUT OF SCOPE -- not inference").
 Unlike the reference, constructing a Trainer in test mode does not already run the evaluation (the reference runs
 it once in __init__ and once more from main.py)."""
-from .AccumulatorSpace import estimate_6d_pose_lm
+from .AccumulatorSpace import estimate_6d_pose_lm, estimate_6d_pose_lmo
 
 
 class Trainer:
@@ -18,5 +18,5 @@ class Trainer:
 
     def Test(self):
         if getattr(self.opts, 'test_occ', False):
-            raise NotImplementedError("Occlusion-LINEMOD driver (estimate_6d_pose_lmo) is not part of this build yet")
+            return estimate_6d_pose_lmo(self.opts)
         return estimate_6d_pose_lm(self.opts)

@@ -110,3 +110,78 @@ def test_main_entry_runs_the_driver(tmp_path):
     _write_dataset(root, n_frames=1)
     res = main(["--mode", "test", "--root_dataset", root, "--model_dir", root, "--using_ckpts", "false"])
     assert res["ape"]["frames"] == 1
+
+
+def _write_lmo_dataset(root, n_frames=2):
+    """Occlusion-LINEMOD layout (reference AccumulatorSpace.py:745-848) around the same synthetic frames; frame 1 has a depth
+    hole under the mask (radius and point lists of different length), one extra image has no pose file."""
+    cls = "ape"
+    pv = os.path.join(root, "LINEMOD", cls)
+    occ = os.path.join(root, "OCCLUSION_LINEMOD")
+    for d in (pv, os.path.join(occ, "RGB-D", "rgb_noseg"), os.path.join(occ, "RGB-D", "depth_noseg"), os.path.join(occ, "blender_poses", cls)):
+        os.makedirs(d)
+    from PIL import Image
+
+    a, b, c = 0.12, 0.10, 0.08
+    rng = np.random.default_rng(0)
+    u = rng.normal(size=(3000, 3))
+    u /= np.linalg.norm(u, axis=1, keepdims=True)
+    model = u * np.array([a, b, c])
+    with open(os.path.join(pv, cls + ".ply"), "w") as f:
+        f.write("ply\nformat ascii 1.0\nelement vertex %d\nproperty float x\nproperty float y\nproperty float z\nend_header\n" % len(model))
+        for p in model:
+            f.write("%.9f %.9f %.9f\n" % tuple(p))
+    sign = np.array([[1, 1, 1], [-1, 1, -1], [1, -1, -1]], dtype=np.float64)
+    kps_obj = np.zeros((9, 3))
+    kps_obj[1:4] = 2.0 * sign * np.array([a, b, c])
+    np.save(os.path.join(pv, "Outside9.npy"), kps_obj)
+    depths, poses = {}, {}
+    for i in range(n_frames):
+        fr = frames.synthetic_frame(i)
+        depth = fr["depth"].copy()
+        if i == 1:
+            ys, xs = np.nonzero(depth)
+            depth[ys[:40], xs[:40]] = 0
+        depths[i] = depth
+        Image.fromarray(fr["rgb"]).save(os.path.join(occ, "RGB-D", "rgb_noseg", "color_%05d.png" % i))
+        Image.fromarray(depth.astype(np.uint16)).save(os.path.join(occ, "RGB-D", "depth_noseg", "depth_%05d.png" % i))
+        centre = fr["keypoints_m"][0] - kps_obj[1]
+        RT = np.concatenate([np.eye(3), centre[:, None]], axis=1)
+        np.save(os.path.join(occ, "blender_poses", cls, "pose%d.npy" % i), RT)
+        poses[i] = RT
+        for k in range(3):
+            d = os.path.join(occ, "estRadialMap", cls, "Out_pt%d_dm" % (k + 1))
+            os.makedirs(d, exist_ok=True)
+            np.save(os.path.join(d, "_%05d.npy" % i), fr["radial"][k])
+    Image.fromarray(frames.synthetic_frame(0)["rgb"]).save(os.path.join(occ, "RGB-D", "rgb_noseg", "color_%05d.png" % 7))
+    return cls, poses, depths
+
+
+def test_lmo_driver_with_precomputed_radial_maps(tmp_path, oracle):
+    """estimate_6d_pose_lmo, the branch of the reference that runs (using_ckpts=False, :842-849)."""
+    from rcvpose_amd import AccumulatorSpace as A
+    from rcvpose_amd.train import Trainer
+
+    root = str(tmp_path) + "/"
+    cls, poses, depths = _write_lmo_dataset(root)
+    opts = types.SimpleNamespace(root_dataset=root, model_dir=root, using_ckpts=False, demo_mode=False, test_occ=True, class_names=[cls])
+    results, details = A.estimate_6d_pose_lmo(opts, return_details=True)
+    assert results[cls]["frames"] == 3 and results[cls]["evaluated"] == 2  # the image without a pose file still counts (:963)
+    kps_obj = np.load(os.path.join(root, "LINEMOD", cls, "Outside9.npy"))
+    model = A.read_ply_points(os.path.join(root, "LINEMOD", cls, cls + ".ply"))
+    max_radii_dm = [(((model - kps_obj[i + 1]) ** 2).sum(axis=1) ** 0.5).max() * 10 for i in range(3)]
+    for i in range(2):
+        d = details[cls]["color_%05d" % i]
+        fr = frames.synthetic_frame(i)
+        for k in range(3):
+            r = fr["radial"][k]
+            xyz, rl = oracle.seam((r > 0).astype(np.float32), r, depths[i], max_radii_dm[k], seg_thr=0.5)
+            if i == 1 and k == 0:
+                assert len(rl) == len(xyz) + 40  # the depth hole: lists of different length, paired like the reference
+            ref = oracle.accumulator_3d(xyz, rl, sparse=True)
+            assert np.array_equal(d["estimated_kpts"][k], ref[0]), (i, k)
+        assert np.array_equal(d["RT"], oracle.horn(kps_obj[1:4] * 1000, d["estimated_kpts"]))
+        assert d["icp_iterations"] == 1  # the LM-O criteria (:935) accept the first update
+    # frame 0 passes ADD; frame 1 pairs radii and points with an offset of up to 40 (the depth hole), like the reference would
+    assert details[cls]["color_00000"]["add_distance_mm"] < 15.0 and results[cls]["add_before_icp"] >= 1 / 3 - 1e-12
+    assert Trainer([None, None], opts).Test()[cls]["frames"] == 3
