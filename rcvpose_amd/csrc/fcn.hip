@@ -678,10 +678,14 @@ __global__ __launch_bounds__(256) void k_stem_mfma(const float *x, const __bf16 
     }
 }
 
-// bilinear blend shared by k_upsample2 and the fused tail kernel (one expression, so both round identically)
+// bilinear blend shared by k_upsample2 and the fused tail kernel: hy * (hx * p00 + lx * p01) + ly * (hx * p10 + lx * p11)
+// with the fusion of multiplies and adds written out, so that every caller rounds identically whatever the compiler
+// would contract in its context
 __device__ __forceinline__ float bilerp(float hy, float hx, float ly, float lx, float p00, float p01, float p10, float p11)
 {
-    return hy * (hx * p00 + lx * p01) + ly * (hx * p10 + lx * p11);
+    const float t0 = __fmaf_rn(lx, p01, __fmul_rn(hx, p00));
+    const float t1 = __fmaf_rn(lx, p11, __fmul_rn(hx, p10));
+    return __fmaf_rn(hy, t0, __fmul_rn(ly, t1));
 }
 // source row/column and weights of destination index d for the 2x upsampling: ATen's area_pixel_compute_source_index
 // (align_corners = False): s = max(0.5 * (d + 0.5) - 0.5, 0)
@@ -794,31 +798,52 @@ template <typename T>
 __global__ __launch_bounds__(256) void k_upsample2(const T *src, T *dst, int C, int Hin, int Win, long long total_vec,
                                                    long long src_gs, long long dst_gs)
 {
+    // One thread = one source cell (a, b) (a in [-1, Hin-1], b in [-1, Win-1]) and one 16-byte channel chunk: the up to
+    // four destination pixels rows {2a+1, 2a+2} x columns {2b+1, 2b+2} all interpolate between source rows (a, a+1) and
+    // columns (b, b+1) (clamped at the borders, where the weight of the clamped neighbour is zero or both neighbours are
+    // the same pixel), so the four source vectors are loaded once for four outputs.  Weights per destination index:
+    // up2_src (ATen's area_pixel_compute_source_index, align_corners = False).
     constexpr int EPV = Traits<T>::EPV;
     const int g = blockIdx.y;
     const int cv = C / EPV, Hout = Hin * 2, Wout = Win * 2;
+    const int cells_w = Win + 1, cells_h = Hin + 1;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total_vec; i += (long long)gridDim.x * 256) {
         const int c = (int)(i % cv);
-        const long long pix = i / cv;
-        const int wo = (int)(pix % Wout), ho = (int)((pix / Wout) % Hout), img = (int)(pix / ((long long)Wout * Hout));
-        // source index = 0.5 * (dst + 0.5) - 0.5, clamped at 0 (ATen area_pixel_compute_source_index)
-        const float sy = fmaxf(0.5f * (ho + 0.5f) - 0.5f, 0.f), sx = fmaxf(0.5f * (wo + 0.5f) - 0.5f, 0.f);
-        const int y0 = (int)sy, x0 = (int)sx;
-        const int y1 = y0 + (y0 < Hin - 1 ? 1 : 0), x1 = x0 + (x0 < Win - 1 ? 1 : 0);
-        const float ly = sy - y0, lx = sx - x0, hy = 1.f - ly, hx = 1.f - lx;
+        const long long cell = i / cv;
+        const int b = (int)(cell % cells_w) - 1, a = (int)((cell / cells_w) % cells_h) - 1;
+        const int img = (int)(cell / ((long long)cells_w * cells_h));
+        const int r0 = max(a, 0), r1 = min(a + 1, Hin - 1), c0 = max(b, 0), c1 = min(b + 1, Win - 1);
         const T *base = src + (long long)g * src_gs + (long long)img * Hin * Win * C + c * EPV;
-        const uint4 r00 = *(const uint4 *)(base + ((long long)y0 * Win + x0) * C);
-        const uint4 r01 = *(const uint4 *)(base + ((long long)y0 * Win + x1) * C);
-        const uint4 r10 = *(const uint4 *)(base + ((long long)y1 * Win + x0) * C);
-        const uint4 r11 = *(const uint4 *)(base + ((long long)y1 * Win + x1) * C);
-        const T *p00 = (const T *)&r00, *p01 = (const T *)&r01, *p10 = (const T *)&r10, *p11 = (const T *)&r11;
-        uint4 o;
-        T *po = (T *)&o;
+        const uint4 q00 = *(const uint4 *)(base + ((long long)r0 * Win + c0) * C);
+        const uint4 q01 = *(const uint4 *)(base + ((long long)r0 * Win + c1) * C);
+        const uint4 q10 = *(const uint4 *)(base + ((long long)r1 * Win + c0) * C);
+        const uint4 q11 = *(const uint4 *)(base + ((long long)r1 * Win + c1) * C);
+        const T *p00 = (const T *)&q00, *p01 = (const T *)&q01, *p10 = (const T *)&q10, *p11 = (const T *)&q11;
+        float f00[EPV], f01[EPV], f10[EPV], f11[EPV];
 #pragma unroll
-        for (int e = 0; e < EPV; e++) {
-            po[e] = from_f32<T>(bilerp(hy, hx, ly, lx, to_f32(p00[e]), to_f32(p01[e]), to_f32(p10[e]), to_f32(p11[e])));
+        for (int e = 0; e < EPV; e++) { f00[e] = to_f32(p00[e]); f01[e] = to_f32(p01[e]); f10[e] = to_f32(p10[e]); f11[e] = to_f32(p11[e]); }
+        T *out = dst + (long long)g * dst_gs + (long long)img * Hout * Wout * C + c * EPV;
+#pragma unroll
+        for (int dy = 1; dy <= 2; dy++) {
+            const int y = 2 * a + dy;
+            if ((unsigned)y >= (unsigned)Hout) continue;
+            int y0, y1;
+            float ly, hy;
+            up2_src(y, Hin, y0, y1, ly, hy);
+#pragma unroll
+            for (int dx = 1; dx <= 2; dx++) {
+                const int x = 2 * b + dx;
+                if ((unsigned)x >= (unsigned)Wout) continue;
+                int x0, x1;
+                float lx, hx;
+                up2_src(x, Win, x0, x1, lx, hx);
+                uint4 o;
+                T *po = (T *)&o;
+#pragma unroll
+                for (int e = 0; e < EPV; e++) po[e] = from_f32<T>(bilerp(hy, hx, ly, lx, f00[e], f01[e], f10[e], f11[e]));
+                *(uint4 *)(out + ((long long)y * Wout + x) * C) = o;
+            }
         }
-        *(uint4 *)(dst + (long long)g * dst_gs + pix * C + c * EPV) = o;
     }
 }
 
@@ -1143,7 +1168,7 @@ int run_op(rcv_fcn *h, const rcv_op &op, const float *x, int B, float *seg, floa
         return RCV_OK;
     }
     case RCV_OP_UPSAMPLE2: {
-        const long long tv = (long long)B * op.hout * op.wout * (op.c0 / Traits<T>::EPV);
+        const long long tv = (long long)B * (op.hin + 1) * (op.win + 1) * (op.c0 / Traits<T>::EPV);  // source cells x chunks
         dim3 grid((unsigned)std::min<long long>((tv + 255) / 256, 65535), G);
         hipLaunchKernelGGL((k_upsample2<T>), grid, dim3(256), 0, st, slot(op.src0), slot(op.dst), op.c0, op.hin, op.win,
                            tv, gstride(op.src0), gstride(op.dst));
