@@ -957,26 +957,40 @@ __global__ __launch_bounds__(256, 2) void k_tail(const __bf16 *src, const __bf16
             *(uint4 *)(sS + pp * 128 + c * 16) = *(const uint4 *)(sg + ((long long)ys * Win + xs) * 64 + c * 8);
         }
         __syncthreads();
-        // ---- upsampled patch
+        // ---- upsampled patch: one task = one source cell (rows ai, ai+1; columns bi, bi+1 of the source patch) and one
+        // channel chunk -> the 2 x 2 patch pixels (2ai.., 2bi..) that interpolate inside that cell (k_upsample2's scheme;
+        // the patch rows / columns pair up with the cells because ho0 and wo0 are even)
 #pragma unroll 1
-        for (int v = tid; v < TAIL_UH * TAIL_UW * 8; v += 256) {
-            const int c = v & 7, u = v >> 3, uy = u / TAIL_UW, ux = u - uy * TAIL_UW;
-            const int y = ho0 - 1 + uy, x = wo0 - 1 + ux;
-            uint4 o = make_uint4(0u, 0u, 0u, 0u);
-            if ((unsigned)y < (unsigned)Ho && (unsigned)x < (unsigned)Wo) {
-                int y0, y1, x0, x1;
-                float ly, hy, lx, hx;
-                up2_src(y, Hin, y0, y1, ly, hy);
-                up2_src(x, Win, x0, x1, lx, hx);
-                const unsigned char *r0 = sS + ((y0 - sy0) * TAIL_SW) * 128 + c * 16, *r1 = sS + ((y1 - sy0) * TAIL_SW) * 128 + c * 16;
-                const uint4 q00 = *(const uint4 *)(r0 + (x0 - sx0) * 128), q01 = *(const uint4 *)(r0 + (x1 - sx0) * 128);
-                const uint4 q10 = *(const uint4 *)(r1 + (x0 - sx0) * 128), q11 = *(const uint4 *)(r1 + (x1 - sx0) * 128);
-                const T *p00 = (const T *)&q00, *p01 = (const T *)&q01, *p10 = (const T *)&q10, *p11 = (const T *)&q11;
-                T *po = (T *)&o;
+        for (int v = tid; v < (TAIL_UH / 2) * (TAIL_UW / 2) * 8; v += 256) {
+            const int c = v & 7, cell = v >> 3, ai = cell / (TAIL_UW / 2), bi = cell - ai * (TAIL_UW / 2);
+            const unsigned char *r0 = sS + (ai * TAIL_SW + bi) * 128 + c * 16, *r1 = r0 + TAIL_SW * 128;
+            const uint4 q00 = *(const uint4 *)r0, q01 = *(const uint4 *)(r0 + 128), q10 = *(const uint4 *)r1, q11 = *(const uint4 *)(r1 + 128);
+            const T *p00 = (const T *)&q00, *p01 = (const T *)&q01, *p10 = (const T *)&q10, *p11 = (const T *)&q11;
+            float f00[8], f01[8], f10[8], f11[8];
 #pragma unroll
-                for (int e = 0; e < 8; e++) po[e] = (T)bilerp(hy, hx, ly, lx, (float)p00[e], (float)p01[e], (float)p10[e], (float)p11[e]);
+            for (int e = 0; e < 8; e++) { f00[e] = (float)p00[e]; f01[e] = (float)p01[e]; f10[e] = (float)p10[e]; f11[e] = (float)p11[e]; }
+#pragma unroll
+            for (int dy = 0; dy < 2; dy++) {
+                const int uy = 2 * ai + dy, y = ho0 - 1 + uy;
+                int y0, y1;
+                float ly, hy;
+                up2_src(y, Hin, y0, y1, ly, hy);
+#pragma unroll
+                for (int dx = 0; dx < 2; dx++) {
+                    const int ux = 2 * bi + dx, x = wo0 - 1 + ux;
+                    int x0, x1;
+                    float lx, hx;
+                    up2_src(x, Win, x0, x1, lx, hx);
+                    uint4 o = make_uint4(0u, 0u, 0u, 0u);
+                    if ((unsigned)y < (unsigned)Ho && (unsigned)x < (unsigned)Wo) {
+                        T *po = (T *)&o;
+#pragma unroll
+                        for (int e = 0; e < 8; e++) po[e] = (T)bilerp(hy, hx, ly, lx, f00[e], f01[e], f10[e], f11[e]);
+                    }
+                    const int u = uy * TAIL_UW + ux;
+                    *(uint4 *)(sU + u * 128 + ((c ^ ((u >> 1) & 7)) << 4)) = o;
+                }
             }
-            *(uint4 *)(sU + u * 128 + ((c ^ ((u >> 1) & 7)) << 4)) = o;
         }
         __syncthreads();
         // ---- conv7: K = 9 taps x 64 channels, in k_conv's order (tap-major, 32 channels per MFMA)
