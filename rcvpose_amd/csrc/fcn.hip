@@ -935,8 +935,9 @@ __global__ __launch_bounds__(256, 2) void k_tail(const __bf16 *src, const __bf16
     float bias7[4];
 #pragma unroll
     for (int e = 0; e < 4; e++) bias7[e] = b7[(long long)g * b7_gs + j * 16 + kq * 4 + e];
-    float *sW8 = (float *)(sH + 256 * TAIL_HP);  // head weights [2][32] as float (kept out of the register file)
-    if (tid < 64) sW8[tid] = (float)w8[(long long)g * w8_gs + tid];
+    float hw[64];  // head weights [2][32]
+#pragma unroll
+    for (int q = 0; q < 64; q++) hw[q] = (float)w8[(long long)g * w8_gs + q];
     const float hb0 = b8[(long long)g * b8_gs], hb1 = b8[(long long)g * b8_gs + 1];
     // pixel of this lane in each of the wave's eight 16-pixel groups, as index into U (tap (0,0))
     int ubase[8];
@@ -1037,8 +1038,8 @@ __global__ __launch_bounds__(256, 2) void k_tail(const __bf16 *src, const __bf16
 #pragma unroll
                 for (int e = 0; e < 8; e++) {
                     const float v = (float)pv[e];
-                    a0 = fmaf(v, sW8[c + e], a0);
-                    a1 = fmaf(v, sW8[32 + c + e], a1);
+                    a0 = fmaf(v, hw[c + e], a0);
+                    a1 = fmaf(v, hw[32 + c + e], a1);
                 }
             }
             if (ho < Ho && wo < Wo) {
