@@ -904,7 +904,8 @@ __global__ __launch_bounds__(256) void k_preprocess(const uint8_t *rgb, float *x
 constexpr int TAIL_TH = 8, TAIL_TW = 32, TAIL_UW = TAIL_TW + 2, TAIL_UH = TAIL_TH + 2;
 constexpr int TAIL_SH = TAIL_TH / 2 + 2, TAIL_SW = TAIL_TW / 2 + 2;
 constexpr int TAIL_HP = 80;  // bytes per pixel of the conv7 staging rows (64 + bank spread)
-constexpr int TAIL_LDS = TAIL_UH * TAIL_UW * 128 + TAIL_SH * TAIL_SW * 128 + 256 * TAIL_HP + 64 * 4;
+constexpr int TAIL_UP = 144;  // bytes per pixel of the upsampled patch: 128 + 16, which spreads 16 consecutive pixels over all banks
+constexpr int TAIL_LDS = TAIL_UH * TAIL_UW * TAIL_UP + (256 * TAIL_HP > TAIL_SH * TAIL_SW * 128 ? 256 * TAIL_HP : TAIL_SH * TAIL_SW * 128);
 
 __global__ __launch_bounds__(256, 2) void k_tail(const __bf16 *src, const __bf16 *w7, const float *b7, const __bf16 *w8, const float *b8,
                                                  float *seg, float *radial, int B, int Hin, int Win, long long src_gs, long long w7_gs,
@@ -912,9 +913,9 @@ __global__ __launch_bounds__(256, 2) void k_tail(const __bf16 *src, const __bf16
 {
     using T = __bf16;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char *sU = smem;                                        // [340][128 B], chunk swizzled by (pixel >> 1) & 7
-    unsigned char *sS = smem + TAIL_UH * TAIL_UW * 128;              // [6][18][128 B] source patch
-    unsigned char *sH = sS + TAIL_SH * TAIL_SW * 128;                // [256][TAIL_HP] conv7 output (bf16)
+    unsigned char *sU = smem;                                        // [340][TAIL_UP] upsampled patch
+    unsigned char *sS = smem + TAIL_UH * TAIL_UW * TAIL_UP;          // [6][18][128 B] source patch ...
+    unsigned char *sH = sS;                                          // ... later [256][TAIL_HP] conv7 output (bf16)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r16 = lane & 15, kq = lane >> 4;
     const int Ho = Hin * 2, Wo = Win * 2;
@@ -989,7 +990,7 @@ __global__ __launch_bounds__(256, 2) void k_tail(const __bf16 *src, const __bf16
                         for (int e = 0; e < 8; e++) po[e] = (T)bilerp(hy, hx, ly, lx, f00[e], f01[e], f10[e], f11[e]);
                     }
                     const int u = uy * TAIL_UW + ux;
-                    *(uint4 *)(sU + u * 128 + ((c ^ ((u >> 1) & 7)) << 4)) = o;
+                    *(uint4 *)(sU + u * TAIL_UP + c * 16) = o;
                 }
             }
         }
@@ -998,8 +999,6 @@ __global__ __launch_bounds__(256, 2) void k_tail(const __bf16 *src, const __bf16
         f32x4 acc[8];
 #pragma unroll
         for (int i = 0; i < 8; i++) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-        int uz = 0;
-        asm volatile("" : "+v"(uz));  // opaque zero: keeps the 144 fragment addresses from being hoisted out of the tile loop
 #pragma unroll
         for (int t = 0; t < 9; t++) {
             const int toff = (t / 3) * TAIL_UW + (t % 3);
@@ -1007,10 +1006,8 @@ __global__ __launch_bounds__(256, 2) void k_tail(const __bf16 *src, const __bf16
             for (int kk = 0; kk < 2; kk++) {
                 bf16x8 af[8];
 #pragma unroll
-                for (int i = 0; i < 8; i++) {
-                    const int u = ubase[i] + toff + uz;
-                    af[i] = *(const bf16x8 *)(sU + u * 128 + (((kk * 4 + kq) ^ ((u >> 1) & 7)) << 4));
-                }
+                for (int i = 0; i < 8; i++)  // constant offset from the lane's pixel: folds into the ds_read immediate
+                    af[i] = *(const bf16x8 *)(sU + ubase[i] * TAIL_UP + kq * 16 + (toff * TAIL_UP + kk * 64));
 #pragma unroll
                 for (int i = 0; i < 8; i++) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bw[t][kk], af[i], acc[i], 0, 0, 0);
                 asm volatile("" ::: "memory");  // keep the fragment reads of later K steps from being hoisted (registers)
