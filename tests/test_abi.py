@@ -38,6 +38,7 @@ def test_struct_layouts_match_header():
 
     assert ctypes.sizeof(_hip.AccResult) == 96      # 7 doubles + 10 int32
     assert ctypes.sizeof(_hip.Op) == 16 * 4 + 2 * 8
+    assert ctypes.sizeof(_hip.IcpResult) == 16 * 8 + 2 * 8 + 4 * 4  # rcv_icp_result
     assert _hip.AccResult.status.offset == 92
 
 
@@ -58,6 +59,12 @@ def test_product_path_fails_loudly_without_gpu():
     m = DenseFCNResNet152(3, 2).eval()
     with pytest.raises(RuntimeError):
         m(torch.zeros(1, 3, 64, 96))
+    from rcvpose_amd import registration
+
+    with pytest.raises(_hip.HipLibraryError):
+        registration.compute_point_cloud_distance(np.zeros((4, 3)), np.ones((5, 3)))
+    with pytest.raises(_hip.HipLibraryError):
+        registration.registration_icp(np.zeros((4, 3)), np.ones((5, 3)), 1.0)
 
 
 def test_product_never_imports_oracle():
