@@ -4,11 +4,14 @@
 //   rcv_accumulate_3d  : Accumulator_3D + fast_for + arg-max (reference AccumulatorSpace.py:373-419, :325-341)
 //
 // Design (MI355X-first, not a translation of the reference's N x D^3 loop):
-//   * the vote grid never has to live in HBM: it is cut into column tiles (TI x TJ x TK voxels) that
-//     fit the 160 KB LDS of a CU as packed 16-bit counters; one 512-thread workgroup owns a tile,
-//     culls the point list against the tile footprint, and rasterises, per (point, column), only the
-//     few voxels of the spherical shell that cross that column.  Votes are LDS atomics; no global
-//     atomics exist anywhere on the path.
+//   * the hot path only needs argwhere(votes == votes.max()), so the default engine is an exact branch-and-bound
+//     peak search (k_bb_*): box upper bounds in float32 over a point list streamed through LDS by LDS-DMA, exact
+//     float64 counts for the probe / hill-climb lower bound and for the few surviving voxels.
+//   * the general engine (and the one that materialises the grid) never needs the vote grid in HBM either: the
+//     grid is cut into column tiles (TI x TJ x TK voxels) that fit the 160 KB LDS of a CU as packed 16-bit
+//     counters; one 1024-thread workgroup owns a tile, culls the point list against the tile footprint, and
+//     rasterises, per (point, column), only the few voxels of the spherical shell that cross that column.
+//     Votes are LDS atomics; no global atomics exist anywhere on the path.
 //   * the arg-max is taken per tile straight out of LDS with a wavefront reduction on the packed key
 //     (votes << 32 | ~flat_index), so ties resolve to the first voxel in C order like np.argwhere.
 //   * exactness: the reference decides `0 < round(r) - sqrt(d2) < sqrt(3)/4` in float64.  sqrt and the

@@ -16,8 +16,12 @@
 //                    BatchNorm is folded into w / bias on the host; ReLU and the residual add are fused
 //                    into the epilogue.  blockIdx.z walks the `groups` networks (one per keypoint) that
 //                    share the input image.
-//   k_stem           conv1 7x7/2 + BN + ReLU from the NCHW fp32 image (K = 147 is too ragged for the GEMM path)
-//   k_maxpool, k_upsample2 (bilinear, align_corners=False), k_head (conv8 1x1 -> seg / radial planes)
+//   k_conv_dma       the same GEMM for bf16 layers with Cout % 128 == 0: 256 x 128 x 64 tiles, operands by buffer-load
+//                    LDS-DMA, four-phase K steps with the two waves of a SIMD staggered (see the kernel)
+//   k_tail           bf16: last 2x upsampling + conv7 + head (conv8) fused; bit-identical to the separate kernels
+//   k_stem_mfma      bf16: conv1 7x7/2 + BN + ReLU as an MFMA GEMM over an im2col tile shared by the networks
+//   k_stem           the same layer computed directly from the NCHW fp32 image (fp32 mode)
+//   k_maxpool, k_upsample2 (bilinear, align_corners=False), k_head (conv8 1x1 -> seg / radial planes; fp32 mode)
 //   k_preprocess     FCResBackbone's uint8 -> normalised fp32 image (reference AccumulatorSpace.py:140-151)
 #include <string.h>
 
@@ -288,25 +292,19 @@ __global__ __launch_bounds__(256) void k_conv(const ConvParams p)
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_conv_dma: the same implicit GEMM with the operand tiles brought in by LDS-DMA (global_load_lds,
+// k_conv_dma: the same implicit GEMM with the operand tiles brought in by LDS-DMA (buffer_load_dwordx4 ... lds,
 // 16 bytes per lane, 1 KB per wave-instruction) instead of through registers.  bf16 only.
-//   tile 256 x 128 x 64, 512 threads = 4 x 2 waves of 64 x 64, three LDS stages of 48 KB: the loads of tile
-//   t+2 are issued right after the barrier that starts tile t and stay in flight across the next barrier
-//   (counted s_waitcnt vmcnt, raw s_barrier), one barrier per K step, no staging VGPRs, no ds_write.
+//   tile 256 x 128 x 64, 512 threads = 4 x 2 waves of 64 x 64, three LDS stages of 48 KB: the pieces of K step
+//   kt+2 are issued during the two load phases of step kt and stay in flight across barriers (counted
+//   s_waitcnt vmcnt, raw s_barrier); no staging VGPRs, no ds_write.
 //   The LDS image is lane-linear per DMA ([8 rows][8 x 16 B]); the bank swizzle is applied to the per-lane
 //   SOURCE chunk (chunk ^= (row>>1)&7) and undone by the same XOR on the fragment reads.
-//   Padding taps / rows beyond M read a 16-byte zero page.
+//   Padding taps / rows beyond M use an out-of-range buffer offset: the hardware writes zeros.
 // ---------------------------------------------------------------------------------------------
 constexpr int DMA_BM = 256, DMA_BN = 128, DMA_STAGES = 3;
 constexpr int DMA_STAGE_BYTES = (DMA_BM + DMA_BN) * 128;
 
-__device__ __forceinline__ void glds16(const void *gptr, unsigned char *lds_wave_base)
-{
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gptr,
-                                     (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
-}
-
-__global__ __launch_bounds__(512) void k_conv_dma(const ConvParams p, const void *zero_page)
+__global__ __launch_bounds__(512) void k_conv_dma(const ConvParams p)
 {
     using T = __bf16;
     constexpr int KE = 64, EPV = 8, BM = DMA_BM, BN = DMA_BN;
@@ -321,7 +319,6 @@ __global__ __launch_bounds__(512) void k_conv_dma(const ConvParams p, const void
     const T *src0 = (const T *)p.src0 + (long long)g * p.src0_gs;
     const T *src1 = p.src1 ? (const T *)p.src1 + (long long)g * p.src1_gs : nullptr;
     const T *wg = (const T *)p.w + (long long)g * p.w_gs;
-    (void)zero_page;
 
     // the residual tile (if any) is requested before anything else: for the short-K expand convolutions the
     // kernel is a stream of (operand tile, residual tile, output tile) and this overlaps the first two
@@ -1080,7 +1077,6 @@ struct rcv_fcn {
 
 namespace {
 
-void *g_zero_page = nullptr;  // 256 zero bytes: source of padding taps for the LDS-DMA loader
 
 size_t esize(int dtype) { return dtype == RCV_F32 ? 4 : 2; }
 
@@ -1113,7 +1109,7 @@ int launch_conv_dma(const ConvParams &p, int groups, hipStream_t st, bool set_at
     if (set_attr)
         RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_conv_dma, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     dim3 grid(p.Cout / DMA_BN, (p.M + DMA_BM - 1) / DMA_BM, groups);
-    hipLaunchKernelGGL(k_conv_dma, grid, dim3(512), lds, st, p, (const void *)g_zero_page);
+    hipLaunchKernelGGL(k_conv_dma, grid, dim3(512), lds, st, p);
     RCV_LAUNCH_CHECK();
     return RCV_OK;
 }
@@ -1123,7 +1119,7 @@ int launch_conv(const ConvParams &p, int groups, hipStream_t st, bool set_attr, 
 {
     constexpr int KE = Traits<T>::KE;
     if (p.C0 % KE || p.C1 % KE || p.Cout % 32 || p.K % KE) return RCV_E_UNSUPPORTED;
-    if (sizeof(T) == 2 && allow_dma && g_zero_page && p.Cout % DMA_BN == 0 &&
+    if (sizeof(T) == 2 && allow_dma && p.Cout % DMA_BN == 0 &&
         (long long)((p.M + DMA_BM - 1) / DMA_BM) * (p.Cout / DMA_BN) * groups >= 192)
         return launch_conv_dma(p, groups, st, set_attr);
     const int BN = p.Cout % 128 == 0 ? 128 : (p.Cout % 64 == 0 ? 64 : 32);
@@ -1293,12 +1289,6 @@ int rcv_fcn_create(const rcv_op *ops, int n_ops, int n_slots, const int64_t *slo
         const int slots[4] = {o.src0, o.src1, o.res, o.dst};
         for (int s : slots)
             if (s >= n_slots || s < -3) return RCV_E_INVALID;
-    }
-    if (!g_zero_page) {
-        void *z = nullptr;
-        RCV_HIP_CHECK(hipMalloc(&z, 256));
-        RCV_HIP_CHECK(hipMemset(z, 0, 256));
-        g_zero_page = z;
     }
     rcv_fcn *h = new rcv_fcn();
     h->ops.assign(ops, ops + n_ops);
