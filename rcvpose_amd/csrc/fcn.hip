@@ -696,6 +696,319 @@ __device__ __forceinline__ void up2_src(int d, int n_in, int &i0, int &i1, float
 }
 
 // ---------------------------------------------------------------------------------------------
+// k_conv_block (bf16): the second and third convolution of a bottleneck block in one kernel --
+//     mid = relu(conv3x3(src) + b1)            (Cmid = 256 channels, BN folded)
+//     dst = relu(conv1x1(mid) + b2 + res)      (Cout = 1024)
+// -- so that `mid` never leaves the CU (reference models/fcnresnet.py:27-43).  A workgroup owns 128 output pixels:
+//   phase 1  [128 x 256] = A(128 x K1) * W1^T: k_conv_dma's loader and four-phase K step with the tile roles swapped
+//            (two A pieces + four B pieces per wave and step, 8 waves = 2 x 4 of 64 x 64, three 48 KB stages);
+//   hand-over: bias + ReLU, rounded to bf16 exactly like the stored activation, written into LDS as the A operand of
+//            phase 2 (four K slabs of [128 rows][128 B], the same chunk swizzle as the DMA tiles);
+//   phase 2  eight column chunks of [128 x 128] = mid(128 x 256) * W2^T: the weights stream through a ring of three 16 KB
+//            LDS slots (two DMA pieces per wave and K step, issued two steps ahead), the residual tile of a chunk is
+//            DMA'd into LDS during the chunk's K steps, the result leaves through v_permlane16_swap as 16-byte vectors.
+// Same MFMA sequence per output element as k_conv_dma on the two layers: bit-identical results.
+// ---------------------------------------------------------------------------------------------
+struct BlockParams {
+    const void *src, *w1, *w2, *res;
+    void *dst;
+    const float *b1, *b2;
+    long long src_gs, w1_gs, w2_gs, res_gs, dst_gs;
+    int b1_gs, b2_gs;
+    int C0, Hin, Win, Hout, Wout, stride, M;
+};
+constexpr int BLK_BM = 128, BLK_CMID = 256, BLK_COUT = 1024;
+constexpr int BLK_STAGE = (BLK_BM + BLK_CMID) * 128;  // 48 KB
+constexpr int BLK_A2 = BLK_BM * BLK_CMID * 2;          // 64 KB: phase-2 A operand
+constexpr int BLK_RING = 3, BLK_SLOT = 128 * 128;      // 16 KB per weight slot
+constexpr int BLK_LDS = 3 * BLK_STAGE;
+
+__device__ __forceinline__ void blk_dma16(const void *base, int num_bytes, unsigned char *lds_wave_base, int voffset)
+{
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, num_bytes, 0x00020000);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void *)lds_wave_base, 16, voffset, 0, 0, 0);
+}
+
+__global__ __launch_bounds__(512) void k_conv_block(const BlockParams p)
+{
+    using T = __bf16;
+    constexpr int KE = 64, EPV = 8, BM = BLK_BM, KS = 3, PAD = 1;
+    constexpr int OOB = (int)0x80000000;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int g = blockIdx.z, m0 = blockIdx.x * BM;
+    const int lrow = lane >> 3, lpos = lane & 7;
+    const int r16 = lane & 15, kq = lane >> 4;
+    const T *src = (const T *)p.src + (long long)g * p.src_gs;
+    const T *w1 = (const T *)p.w1 + (long long)g * p.w1_gs;
+    const T *w2 = (const T *)p.w2 + (long long)g * p.w2_gs;
+    const T *res = (const T *)p.res + (long long)g * p.res_gs;
+    T *dst = (T *)p.dst + (long long)g * p.dst_gs;
+    const int K1 = KS * KS * p.C0;
+
+    // biases in registers, in the layouts of the two epilogues; touched right away so that the compiler's wait for these
+    // (ordinary) loads happens here and not in the middle of the DMA streams
+    float bias1[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+#pragma unroll
+        for (int e = 0; e < 4; e++) bias1[j][e] = p.b1[(long long)g * p.b1_gs + wn * 64 + j * 16 + kq * 4 + e];
+    float bias2[8][8];
+#pragma unroll
+    for (int nc = 0; nc < 8; nc++)
+#pragma unroll
+        for (int e = 0; e < 8; e++) bias2[nc][e] = p.b2[(long long)g * p.b2_gs + nc * 128 + wn * 32 + (kq & 1) * 16 + (kq >> 1) * 8 + e];
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+#pragma unroll
+        for (int e = 0; e < 4; e++) asm volatile("" : "+v"(bias1[j][e]));
+#pragma unroll
+    for (int nc = 0; nc < 8; nc++)
+#pragma unroll
+        for (int e = 0; e < 8; e++) asm volatile("" : "+v"(bias2[nc][e]));
+
+    // ---- phase 1 loader: 2 A rows (wave*16 + c*8 + lrow) and 4 B rows (wave*32 + c*8 + lrow) per lane
+    int a_off[2];
+    unsigned a_ok[2];
+    const int HWo = p.Hout * p.Wout;
+    const int img0 = m0 / HWo, rem0 = m0 - img0 * HWo;
+    const int ho0 = rem0 / p.Wout, wo0 = rem0 - ho0 * p.Wout;
+    const float rW = 1.0f / (float)p.Wout, rH = 1.0f / (float)p.Hout;
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+        const int row = wave * 16 + c * 8 + lrow;
+        const int chunk = (lpos ^ ((row >> 1) & 7)) * EPV;
+        a_off[c] = OOB; a_ok[c] = 0u;
+        if (m0 + row < p.M) {
+            const int t = wo0 + row;
+            const int q1 = (int)(((float)t + 0.5f) * rW);
+            const int wo = t - q1 * p.Wout, h = ho0 + q1;
+            const int q2 = (int)(((float)h + 0.5f) * rH);
+            const int ho = h - q2 * p.Hout, img = img0 + q2;
+            const int hc = ho * p.stride, wc = wo * p.stride;
+            a_off[c] = (((img * p.Hin + hc) * p.Win + wc) * p.C0 + chunk) * 2;
+            const int rlo = max(PAD - hc, 0), rhi = min(p.Hin - 1 - hc + PAD, KS - 1);
+            const int qlo = max(PAD - wc, 0), qhi = min(p.Win - 1 - wc + PAD, KS - 1);
+            const unsigned colmask = qhi >= qlo ? ((2u << qhi) - 1u) & ~((1u << qlo) - 1u) : 0u;
+            for (int r = rlo; r <= rhi; r++) a_ok[c] |= colmask << (r * KS);
+        }
+    }
+    int b_off[4];
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        const int row = wave * 32 + c * 8 + lrow;
+        b_off[c] = (row * K1 + (lpos ^ ((row >> 1) & 7)) * EPV) * 2;
+    }
+    const int n_img = __builtin_amdgcn_readfirstlane(p.M / HWo);
+    const int a_bytes = (int)((long long)p.C0 * p.Hin * p.Win * n_img * 2);
+    const int b_bytes = BLK_CMID * K1 * 2;
+    int tap_r = 0, tap_s = 0, cg = 0;
+
+// pieces [LO, HI) of the next K step (0..1: A rows, 2..5: B rows) into `stage`
+#define RCV_BLK_ISSUE(stage, LO, HI, ADV)                                                                      \
+    {                                                                                                          \
+        unsigned char *As_ = smem + (stage) * BLK_STAGE;                                                       \
+        unsigned char *Bs_ = As_ + BM * 128;                                                                   \
+        const int tap_ = tap_r * KS + tap_s;                                                                   \
+        if ((LO) < 2) {                                                                                        \
+            const long long disp_ = ((long long)((tap_r - PAD) * p.Win + (tap_s - PAD)) * p.C0 + cg) * 2;     \
+            const char *abase_ = (const char *)src + disp_;                                                    \
+            _Pragma("unroll") for (int c = (LO); c < ((HI) < 2 ? (HI) : 2); c++) {                             \
+                const int off_ = ((a_ok[c] >> tap_) & 1u) ? a_off[c] : OOB;                                    \
+                blk_dma16(abase_, a_bytes, As_ + (wave * 16 + c * 8) * 128, off_);                             \
+            }                                                                                                  \
+        }                                                                                                      \
+        if ((HI) > 2) {                                                                                        \
+            const char *bbase_ = (const char *)w1 + (long long)(tap_ * p.C0 + cg) * 2;                         \
+            _Pragma("unroll") for (int c = ((LO) > 2 ? (LO) - 2 : 0); c < (HI) - 2; c++)                       \
+                blk_dma16(bbase_, b_bytes, Bs_ + (wave * 32 + c * 8) * 128, b_off[c]);                         \
+        }                                                                                                      \
+        if (ADV) {                                                                                             \
+            cg += KE;                                                                                          \
+            const bool wrap_ = cg == p.C0;                                                                     \
+            cg = wrap_ ? 0 : cg;                                                                               \
+            tap_s += wrap_ ? 1 : 0;                                                                            \
+            const bool wrap2_ = tap_s == KS;                                                                   \
+            tap_s = wrap2_ ? 0 : tap_s;                                                                        \
+            tap_r += wrap2_ ? 1 : 0;                                                                           \
+        }                                                                                                      \
+    }
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int ch0 = ((0 * 4 + kq) ^ ((r16 >> 1) & 7)) << 4, ch1 = ((1 * 4 + kq) ^ ((r16 >> 1) & 7)) << 4;
+
+// four phases per K step, the two waves of a SIMD one barrier apart (see k_conv_dma); operands swapped so that a lane
+// accumulates four consecutive channels of one pixel
+#define RCV_BLK_STEP(ISSUE)                                                                                    \
+    {                                                                                                          \
+        const unsigned char *Ab = smem + stage * BLK_STAGE + (wm * 64 + r16) * 128;                            \
+        const unsigned char *Bb = smem + stage * BLK_STAGE + BM * 128 + (wn * 64 + r16) * 128;                 \
+        const int st2 = stage + 2 >= 3 ? stage + 2 - 3 : stage + 2;                                            \
+        bf16x8 af[4], bfr[4];                                                                                  \
+        _Pragma("unroll") for (int i = 0; i < 4; i++) af[i] = *(const bf16x8 *)(Ab + i * 16 * 128 + ch0);      \
+        _Pragma("unroll") for (int j = 0; j < 4; j++) bfr[j] = *(const bf16x8 *)(Bb + j * 16 * 128 + ch0);     \
+        if (ISSUE) RCV_BLK_ISSUE(st2, 0, 3, false);                                                            \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                     \
+        __builtin_amdgcn_s_barrier();                                                                          \
+        __builtin_amdgcn_s_setprio(1);                                                                         \
+        _Pragma("unroll") for (int i = 0; i < 4; i++)                                                          \
+            _Pragma("unroll") for (int j = 0; j < 4; j++)                                                      \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);        \
+        __builtin_amdgcn_s_setprio(0);                                                                         \
+        __builtin_amdgcn_s_barrier();                                                                          \
+        _Pragma("unroll") for (int i = 0; i < 4; i++) af[i] = *(const bf16x8 *)(Ab + i * 16 * 128 + ch1);      \
+        _Pragma("unroll") for (int j = 0; j < 4; j++) bfr[j] = *(const bf16x8 *)(Bb + j * 16 * 128 + ch1);     \
+        if (ISSUE) {                                                                                           \
+            RCV_BLK_ISSUE(st2, 3, 6, true);                                                                    \
+            asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");                                        \
+        } else {                                                                                               \
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                        \
+        }                                                                                                      \
+        __builtin_amdgcn_s_barrier();                                                                          \
+        __builtin_amdgcn_s_setprio(1);                                                                         \
+        _Pragma("unroll") for (int i = 0; i < 4; i++)                                                          \
+            _Pragma("unroll") for (int j = 0; j < 4; j++)                                                      \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);        \
+        __builtin_amdgcn_s_setprio(0);                                                                         \
+        __builtin_amdgcn_s_barrier();                                                                          \
+        stage = stage + 1 == 3 ? 0 : stage + 1;                                                                \
+    }
+
+    const int nk = K1 / KE;  // >= 9
+    const int grp = wave >> 2;
+    RCV_BLK_ISSUE(0, 0, 6, true);
+    RCV_BLK_ISSUE(1, 0, 6, true);
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (grp == 1) __builtin_amdgcn_s_barrier();
+    int stage = 0;
+    for (int kt = 0; kt + 2 < nk; kt++) RCV_BLK_STEP(true);
+    RCV_BLK_STEP(false);
+    RCV_BLK_STEP(false);
+    if (grp == 0) __builtin_amdgcn_s_barrier();
+#undef RCV_BLK_STEP
+#undef RCV_BLK_ISSUE
+    __syncthreads();  // every wave is done with the operand stages; no DMA is in flight
+
+    // ---- hand-over: mid = bf16(relu(acc + b1)) into the phase-2 A operand.  acc[i][j][e] = channel wn*64 + j*16 + kq*4 + e
+    // of pixel wm*64 + i*16 + r16: K slab wn, 16-byte chunk j*2 + (kq>>1), upper / lower half by kq & 1
+    unsigned char *sA2 = smem;
+    unsigned char *sW = smem + BLK_A2;                     // ring of BLK_RING weight slots
+    unsigned char *sR = smem + BLK_A2 + BLK_RING * BLK_SLOT;  // residual tile of the current chunk: [128][256 B]
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int row = wm * 64 + i * 16 + r16;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            uint2 pk;
+            T *pv = (T *)&pk;
+#pragma unroll
+            for (int e = 0; e < 4; e++) pv[e] = (T)fmaxf(acc[i][j][e] + bias1[j][e], 0.f);
+            const int chunk = j * 2 + (kq >> 1);
+            *(uint2 *)(sA2 + wn * (BM * 128) + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4) + (kq & 1) * 8) = pk;
+        }
+    }
+
+    // ---- phase 2 loaders.  Weights of stream step s = (chunk nc = s / 4, K slice ks = s % 4): 128 rows (out channels) x 128 B
+    // -> 2 pieces per wave; residual of chunk nc: 128 pixels x 256 B -> 4 pieces per wave (4 rows each)
+    int w_off[2];
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+        const int row = wave * 16 + c * 8 + lrow;
+        w_off[c] = (row * BLK_CMID + (lpos ^ ((row >> 1) & 7)) * EPV) * 2;
+    }
+    int r_off[4];
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        const int row = wave * 16 + c * 4 + (lane >> 4), slot = lane & 15;  // 4 rows x 16 chunks per piece
+        r_off[c] = m0 + row < p.M ? (int)(((long long)(m0 + row) * BLK_COUT + (slot ^ (row & 15)) * EPV) * 2) : OOB;
+    }
+    const int w_bytes = 128 * BLK_CMID * 2;
+    const long long res_bytes_ll = (long long)p.M * BLK_COUT * 2;
+    const int res_bytes = res_bytes_ll > 0x7fffffffLL ? 0x7fffffff : (int)res_bytes_ll;
+#define RCV_BLK_W(s_)                                                                                          \
+    {                                                                                                          \
+        const int nc_ = (s_) >> 2, ks_ = (s_) & 3;                                                             \
+        const char *wb_ = (const char *)w2 + ((long long)nc_ * 128 * BLK_CMID + ks_ * KE) * 2;                 \
+        unsigned char *slot_ = sW + ((s_) % BLK_RING) * BLK_SLOT;                                              \
+        _Pragma("unroll") for (int c = 0; c < 2; c++) blk_dma16(wb_, w_bytes, slot_ + (wave * 16 + c * 8) * 128, w_off[c]); \
+    }
+#define RCV_BLK_R(nc_)                                                                                         \
+    {                                                                                                          \
+        const char *rb_ = (const char *)res + (long long)(nc_) * 128 * 2;                                      \
+        _Pragma("unroll") for (int c = 0; c < 4; c++) blk_dma16(rb_, res_bytes, sR + (wave * 16 + c * 4) * 256, r_off[c]); \
+    }
+    // order of issue per wave: [R(nc) at the first step of a chunk,] W(s + 2) at step s.  At the top of step s the pieces
+    // issued after W(s) are W(s + 1) and, when step s - 1 opened a chunk, R of that chunk: vmcnt 2 or 6.
+    RCV_BLK_W(0);
+    RCV_BLK_W(1);
+    const int e_pix = r16, e_ch = wn * 32 + (kq & 1) * 16 + (kq >> 1) * 8;
+#pragma unroll
+    for (int nc = 0; nc < 8; nc++) {
+        f32x4 a2[4][2];
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int j = 0; j < 2; j++) a2[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 4; ks++) {
+            const int s_ = nc * 4 + ks;
+            if (ks == 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else if (s_ == 31) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();  // step s_ has landed for everybody; slot (s_ + 2) % 3 and (ks == 0) sR are free
+            if (ks == 0) RCV_BLK_R(nc);
+            if (s_ + 2 < 32) RCV_BLK_W(s_ + 2);
+            const unsigned char *Ab = sA2 + ks * (BM * 128) + (wm * 64 + r16) * 128;
+            const unsigned char *Bb = sW + (s_ % BLK_RING) * BLK_SLOT + (wn * 32 + r16) * 128;
+#pragma unroll
+            for (int kk = 0; kk < 2; kk++) {
+                bf16x8 af[4], bfr[2];
+                const int ch = kk ? ch1 : ch0;
+#pragma unroll
+                for (int i = 0; i < 4; i++) af[i] = *(const bf16x8 *)(Ab + i * 16 * 128 + ch);
+#pragma unroll
+                for (int j = 0; j < 2; j++) bfr[j] = *(const bf16x8 *)(Bb + j * 16 * 128 + ch);
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+#pragma unroll
+                    for (int j = 0; j < 2; j++) a2[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], a2[i][j], 0, 0, 0);
+            }
+        }
+        // epilogue of the chunk.  R(nc) was issued at the chunk's first step: every wave has waited for it at the top of the
+        // fourth step (vmcnt 2 leaves only W pieces) and passed that step's barrier.
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int row = wm * 64 + i * 16 + e_pix, m = m0 + row;
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(a2[i][0][e]), __float_as_uint(a2[i][1][e]), false, false);
+                v[e] = __uint_as_float(sw[0]);
+                v[4 + e] = __uint_as_float(sw[1]);
+            }
+            const uint4 rq = *(const uint4 *)(sR + row * 256 + ((((e_ch >> 3)) ^ (row & 15)) << 4));
+            const T *rp = (const T *)&rq;
+#pragma unroll
+            for (int e = 0; e < 8; e++) v[e] = fmaxf((v[e] + bias2[nc][e]) + (float)rp[e], 0.f);
+            uint4 outv;
+            T *op = (T *)&outv;
+#pragma unroll
+            for (int e = 0; e < 8; e++) op[e] = (T)v[e];
+            if (m < p.M) *(uint4 *)(dst + (long long)m * BLK_COUT + nc * 128 + e_ch) = outv;
+        }
+    }
+#undef RCV_BLK_W
+#undef RCV_BLK_R
+}
+
+// ---------------------------------------------------------------------------------------------
 // stem: conv1 7x7 stride 2 pad 3 (3 -> 64, no bias) + BN (folded) + ReLU; NCHW fp32 image -> NHWC T
 // one workgroup = 16 x 16 output pixels x 64 channels of one (group, image)
 // ---------------------------------------------------------------------------------------------
@@ -1068,6 +1381,7 @@ struct rcv_fcn {
     const float *bias = nullptr;
     bool use_mfma_stem = true;
     bool use_tail = true;  // fused upsample + conv7 + head kernel (bf16)
+    bool use_block = true;  // fused 3x3 + expand 1x1 kernel for the 256 -> 256 -> 1024 bottleneck halves (bf16)
     bool profiling = false;
     std::vector<hipEvent_t> events;  // 2 per op when profiling
     bool events_valid = false;
@@ -1224,6 +1538,41 @@ int forward_impl(rcv_fcn *h, const float *x, int B, float *seg, float *radial, c
     }
     for (size_t i = 0; i < h->ops.size(); i++) {
         if constexpr (sizeof(T) == 2) {
+            // 3x3 (-> 256 channels, ReLU) followed by the 1x1 expand to 1024 channels with residual and ReLU: the second
+            // half of a layer-3 bottleneck block as one kernel (option 4)
+            if (h->use_block && i + 1 < h->ops.size() && h->ops[i].kind == RCV_OP_CONV && h->ops[i + 1].kind == RCV_OP_CONV) {
+                const rcv_op &a = h->ops[i], &b = h->ops[i + 1];
+                const long long M = (long long)B * a.hout * a.wout;
+                if (a.ksize == 3 && a.pad == 1 && a.cout == BLK_CMID && a.c0 % 64 == 0 && a.src1 < 0 && a.res < 0 && a.relu &&
+                    b.ksize == 1 && b.stride == 1 && b.pad == 0 && b.c0 == BLK_CMID && b.cout == BLK_COUT && b.src0 == a.dst &&
+                    b.src1 < 0 && b.res >= 0 && b.relu && b.hout == a.hout && b.wout == a.wout &&
+                    (M + BLK_BM - 1) / BLK_BM * h->groups >= 192 && M * BLK_COUT * 2 < 0x7fffffffLL) {
+                    if (!h->attrs_set)
+                        RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_conv_block, hipFuncAttributeMaxDynamicSharedMemorySize, BLK_LDS));
+                    auto gs = [&](int s) -> long long { return (long long)h->slot_elems[s] * B; };
+                    BlockParams q;
+                    memset(&q, 0, sizeof(q));
+                    q.src = ws + off[a.src0]; q.res = ws + off[b.res]; q.dst = ws + off[b.dst];
+                    q.w1 = (const __bf16 *)h->weights + a.w_off; q.w2 = (const __bf16 *)h->weights + b.w_off;
+                    q.b1 = h->bias + a.b_off; q.b2 = h->bias + b.b_off;
+                    q.src_gs = gs(a.src0); q.res_gs = gs(b.res); q.dst_gs = gs(b.dst);
+                    q.w1_gs = (long long)a.cout * 9 * a.c0; q.w2_gs = (long long)b.cout * b.c0;
+                    q.b1_gs = a.cout; q.b2_gs = b.cout;
+                    q.C0 = a.c0; q.Hin = a.hin; q.Win = a.win; q.Hout = a.hout; q.Wout = a.wout; q.stride = a.stride; q.M = (int)M;
+                    if (h->profiling) {  // the fused kernel's time is booked on the 3x3 convolution
+                        RCV_HIP_CHECK(hipEventRecord(h->events[2 * i], st));
+                    }
+                    hipLaunchKernelGGL(k_conv_block, dim3((unsigned)((M + BLK_BM - 1) / BLK_BM), 1, h->groups), dim3(512), BLK_LDS, st, q);
+                    RCV_LAUNCH_CHECK();
+                    if (h->profiling) {
+                        RCV_HIP_CHECK(hipEventRecord(h->events[2 * i + 1], st));
+                        RCV_HIP_CHECK(hipEventRecord(h->events[2 * i + 2], st));
+                        RCV_HIP_CHECK(hipEventRecord(h->events[2 * i + 3], st));
+                    }
+                    i += 1;
+                    continue;
+                }
+            }
             // upsample x2 -> conv7 (3x3, 64 -> 32, ReLU) -> head (1x1, 32 -> 2): one fused kernel (option 3)
             if (h->use_tail && i + 2 < h->ops.size() + 0 && h->ops[i].kind == RCV_OP_UPSAMPLE2 && h->ops[i + 1].kind == RCV_OP_CONV &&
                 h->ops[i + 2].kind == RCV_OP_HEAD) {
@@ -1350,6 +1699,7 @@ int rcv_fcn_set_option(rcv_fcn *h, int key, int value)
     if (key == 1) { h->use_dma = value != 0; h->attrs_set = false; return RCV_OK; }
     if (key == 2) { h->use_mfma_stem = value != 0; h->attrs_set = false; return RCV_OK; }
     if (key == 3) { h->use_tail = value != 0; h->attrs_set = false; return RCV_OK; }
+    if (key == 4) { h->use_block = value != 0; h->attrs_set = false; return RCV_OK; }
     return RCV_E_INVALID;
 }
 

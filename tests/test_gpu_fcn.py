@@ -137,6 +137,21 @@ def test_fused_tail_identical_to_three_kernels(shapes, state_dict):
         assert torch.equal(seg_a, seg_b) and torch.equal(rad_a, rad_b), (H, W)
 
 
+def test_fused_bottleneck_half_identical_to_two_kernels(shapes, state_dict):
+    """3x3 (-> 256, ReLU) + 1x1 expand (-> 1024, + residual, ReLU) of the layer-3 blocks as one kernel (option 4, default on)
+    gives bit-identical network outputs to the two separate convolution kernels; batch sizes with full and ragged tiles."""
+    from rcvpose_amd.fcn_engine import FcnEngine
+
+    # the fused kernel is used from 192 tiles of 128 pixels on: 7 images x 30 x 40 pixels x 3 networks = 198 (last tile ragged)
+    for (H, W, B) in ((480, 640, 7), (480, 640, 8), (352, 480, 14)):
+        x = torch.from_numpy(fcn_weights.make_input(13, (B, 3, H, W))).cuda()
+        eng = FcnEngine([state_dict, _sd(shapes, 1), _sd(shapes, 2)], H, W, dtype="bf16")
+        seg_a, rad_a = [t.clone() for t in eng.forward(x)]
+        eng.set_option(4, 0)
+        seg_b, rad_b = [t.clone() for t in eng.forward(x)]
+        assert torch.equal(seg_a, seg_b) and torch.equal(rad_a, rad_b), (H, W, B)
+
+
 def test_groups_and_batch(shapes, state_dict):
     """3 networks x 2 images in one launch sequence == the six single runs (blockIdx.z / batch indexing)."""
     from rcvpose_amd.fcn_engine import FcnEngine
