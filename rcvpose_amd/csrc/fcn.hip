@@ -721,7 +721,7 @@ constexpr int BLK_BM = 128, BLK_CMID = 256, BLK_COUT = 1024;
 constexpr int BLK_STAGE = (BLK_BM + BLK_CMID) * 128;  // 48 KB
 constexpr int BLK_A2 = BLK_BM * BLK_CMID * 2;          // 64 KB: phase-2 A operand
 constexpr int BLK_RING = 3, BLK_SLOT = 128 * 128;      // 16 KB per weight slot
-constexpr int BLK_LDS = 3 * BLK_STAGE;
+constexpr int BLK_LDS = 3 * BLK_STAGE + BLK_COUT * 4;  // + the expand layer's bias (fp32) behind the stages
 
 __device__ __forceinline__ void blk_dma16(const void *base, int num_bytes, unsigned char *lds_wave_base, int voffset)
 {
@@ -747,26 +747,23 @@ __global__ __launch_bounds__(512) void k_conv_block(const BlockParams p)
     T *dst = (T *)p.dst + (long long)g * p.dst_gs;
     const int K1 = KS * KS * p.C0;
 
-    // biases in registers, in the layouts of the two epilogues; touched right away so that the compiler's wait for these
-    // (ordinary) loads happens here and not in the middle of the DMA streams
+    // biases: the 3x3 layer's in registers (epilogue layout), the expand layer's in LDS; both fetched right away so that
+    // the compiler's wait for these (ordinary) loads happens here and not in the middle of the DMA streams
     float bias1[4][4];
 #pragma unroll
     for (int j = 0; j < 4; j++)
 #pragma unroll
         for (int e = 0; e < 4; e++) bias1[j][e] = p.b1[(long long)g * p.b1_gs + wn * 64 + j * 16 + kq * 4 + e];
-    float bias2[8][8];
-#pragma unroll
-    for (int nc = 0; nc < 8; nc++)
-#pragma unroll
-        for (int e = 0; e < 8; e++) bias2[nc][e] = p.b2[(long long)g * p.b2_gs + nc * 128 + wn * 32 + (kq & 1) * 16 + (kq >> 1) * 8 + e];
+    float *sB2 = (float *)(smem + 3 * BLK_STAGE);  // [1024] bias of the expand layer
+    {
+        const float b2a = p.b2[(long long)g * p.b2_gs + tid], b2b = p.b2[(long long)g * p.b2_gs + 512 + tid];
+        sB2[tid] = b2a;
+        sB2[512 + tid] = b2b;
+    }
 #pragma unroll
     for (int j = 0; j < 4; j++)
 #pragma unroll
         for (int e = 0; e < 4; e++) asm volatile("" : "+v"(bias1[j][e]));
-#pragma unroll
-    for (int nc = 0; nc < 8; nc++)
-#pragma unroll
-        for (int e = 0; e < 8; e++) asm volatile("" : "+v"(bias2[nc][e]));
 
     // ---- phase 1 loader: 2 A rows (wave*16 + c*8 + lrow) and 4 B rows (wave*32 + c*8 + lrow) per lane
     int a_off[2];
@@ -947,14 +944,16 @@ __global__ __launch_bounds__(512) void k_conv_block(const BlockParams p)
     // issued after W(s) are W(s + 1) and, when step s - 1 opened a chunk, R of that chunk: vmcnt 2 or 6.
     RCV_BLK_W(0);
     RCV_BLK_W(1);
-    const int e_pix = r16, e_ch = wn * 32 + (kq & 1) * 16 + (kq >> 1) * 8;
+    // phase-2 wave tile: 32 pixels x 64 channels (8 waves = 4 x 2), so that the two 16-byte stores a lane makes per pixel
+    // group complete a 128-byte line (64 channels) of the output row
+    const int wm2 = wave >> 1, wn2 = wave & 1;
 #pragma unroll
     for (int nc = 0; nc < 8; nc++) {
-        f32x4 a2[4][2];
+        f32x4 a2[2][4];
 #pragma unroll
-        for (int i = 0; i < 4; i++)
+        for (int i = 0; i < 2; i++)
 #pragma unroll
-            for (int j = 0; j < 2; j++) a2[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < 4; j++) a2[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ks = 0; ks < 4; ks++) {
             const int s_ = nc * 4 + ks;
@@ -965,43 +964,49 @@ __global__ __launch_bounds__(512) void k_conv_block(const BlockParams p)
             __builtin_amdgcn_s_barrier();  // step s_ has landed for everybody; slot (s_ + 2) % 3 and (ks == 0) sR are free
             if (ks == 0) RCV_BLK_R(nc);
             if (s_ + 2 < 32) RCV_BLK_W(s_ + 2);
-            const unsigned char *Ab = sA2 + ks * (BM * 128) + (wm * 64 + r16) * 128;
-            const unsigned char *Bb = sW + (s_ % BLK_RING) * BLK_SLOT + (wn * 32 + r16) * 128;
+            const unsigned char *Ab = sA2 + ks * (BM * 128) + (wm2 * 32 + r16) * 128;
+            const unsigned char *Bb = sW + (s_ % BLK_RING) * BLK_SLOT + (wn2 * 64 + r16) * 128;
 #pragma unroll
             for (int kk = 0; kk < 2; kk++) {
-                bf16x8 af[4], bfr[2];
+                bf16x8 af[2], bfr[4];
                 const int ch = kk ? ch1 : ch0;
 #pragma unroll
-                for (int i = 0; i < 4; i++) af[i] = *(const bf16x8 *)(Ab + i * 16 * 128 + ch);
+                for (int i = 0; i < 2; i++) af[i] = *(const bf16x8 *)(Ab + i * 16 * 128 + ch);
 #pragma unroll
-                for (int j = 0; j < 2; j++) bfr[j] = *(const bf16x8 *)(Bb + j * 16 * 128 + ch);
+                for (int j = 0; j < 4; j++) bfr[j] = *(const bf16x8 *)(Bb + j * 16 * 128 + ch);
 #pragma unroll
-                for (int i = 0; i < 4; i++)
+                for (int i = 0; i < 2; i++)
 #pragma unroll
-                    for (int j = 0; j < 2; j++) a2[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], a2[i][j], 0, 0, 0);
+                    for (int j = 0; j < 4; j++) a2[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], a2[i][j], 0, 0, 0);
             }
         }
         // epilogue of the chunk.  R(nc) was issued at the chunk's first step: every wave has waited for it at the top of the
         // fourth step (vmcnt 2 leaves only W pieces) and passed that step's barrier.
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const int row = wm * 64 + i * 16 + e_pix, m = m0 + row;
-            float v[8];
+        for (int i = 0; i < 2; i++) {
+            const int row = wm2 * 32 + i * 16 + r16, m = m0 + row;
 #pragma unroll
-            for (int e = 0; e < 4; e++) {
-                const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(a2[i][0][e]), __float_as_uint(a2[i][1][e]), false, false);
-                v[e] = __uint_as_float(sw[0]);
-                v[4 + e] = __uint_as_float(sw[1]);
+            for (int pr = 0; pr < 2; pr++) {
+                const int e_ch = wn2 * 64 + (2 * pr + (kq & 1)) * 16 + (kq >> 1) * 8;  // first of this lane's 8 channels in the chunk
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(a2[i][2 * pr][e]), __float_as_uint(a2[i][2 * pr + 1][e]), false, false);
+                    v[e] = __uint_as_float(sw[0]);
+                    v[4 + e] = __uint_as_float(sw[1]);
+                }
+                const float4 bA = *(const float4 *)(sB2 + nc * 128 + e_ch), bB = *(const float4 *)(sB2 + nc * 128 + e_ch + 4);
+                const float bb[8] = {bA.x, bA.y, bA.z, bA.w, bB.x, bB.y, bB.z, bB.w};
+                const uint4 rq = *(const uint4 *)(sR + row * 256 + (((e_ch >> 3) ^ (row & 15)) << 4));
+                const T *rp = (const T *)&rq;
+#pragma unroll
+                for (int e = 0; e < 8; e++) v[e] = fmaxf((v[e] + bb[e]) + (float)rp[e], 0.f);
+                uint4 outv;
+                T *op = (T *)&outv;
+#pragma unroll
+                for (int e = 0; e < 8; e++) op[e] = (T)v[e];
+                if (m < p.M) *(uint4 *)(dst + (long long)m * BLK_COUT + nc * 128 + e_ch) = outv;
             }
-            const uint4 rq = *(const uint4 *)(sR + row * 256 + ((((e_ch >> 3)) ^ (row & 15)) << 4));
-            const T *rp = (const T *)&rq;
-#pragma unroll
-            for (int e = 0; e < 8; e++) v[e] = fmaxf((v[e] + bias2[nc][e]) + (float)rp[e], 0.f);
-            uint4 outv;
-            T *op = (T *)&outv;
-#pragma unroll
-            for (int e = 0; e < 8; e++) op[e] = (T)v[e];
-            if (m < p.M) *(uint4 *)(dst + (long long)m * BLK_COUT + nc * 128 + e_ch) = outv;
         }
     }
 #undef RCV_BLK_W
