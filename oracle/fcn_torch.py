@@ -89,6 +89,39 @@ def forward(state_dict, x, return_stages=False):
     return seg, radial
 
 
+def forward_res(state_dict, x, return_stages=False):
+    """`ResFCNResNet152.forward` (reference models/fcnresnet.py:263-318): the same encoder, additive skips
+    `conv_upK(up + conv_upK_1(skip))`, a final x2 upsampling before conv7.  Pinned by tests/golden/resfcn1_64x96.npz."""
+    sd = {k[7:] if k.startswith("module.") else k: v for k, v in state_dict.items()}
+    st = {}
+    with torch.no_grad():
+        x = F.relu(_bn(sd, "bn1", F.conv2d(x, sd["conv1.weight"], stride=2, padding=3)))  # in-place ReLU: `x` is post-ReLU (:266-267)
+        h = F.max_pool2d(x, kernel_size=3, stride=2, padding=1)
+        skips = []
+        for first, rest, count, stride in _STAGES:
+            h = _bottleneck(sd, first, h, stride, True)
+            for i in range(count):
+                h = _bottleneck(sd, "%s.%d" % (rest, i), h, 1, False)
+            skips.append(h)
+            st[rest] = h
+        x2s, x4s, x8s, x16s = skips
+        up = x16s
+        for name, skip in (("4", x8s), ("3", x4s), ("2", x2s), ("1", x)):
+            up = _up2(up)
+            lat = F.conv2d(skip, sd["conv_up%s_1.weight" % name], sd["conv_up%s_1.bias" % name])
+            up = _cbr(sd, "conv_up" + name, up + lat)
+            st["conv_up" + name] = up
+        up = _up2(up)  # `self.up1` a second time (:308)
+        up = _cbr(sd, "conv7", up)
+        st["conv7"] = up
+        out = F.conv2d(up, sd["conv8.weight"], sd["conv8.bias"])
+        st["conv8"] = out
+    seg, radial = out[:, :1], out[:, 1:]
+    if return_stages:
+        return seg, radial, st
+    return seg, radial
+
+
 def preprocess(rgb_u8):
     """FCResBackbone's image preparation, AccumulatorSpace.py:140-151: uint8 HWC -> float64
     /255, -mean, /std -> CHW float32 [1,3,H,W]."""

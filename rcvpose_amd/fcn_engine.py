@@ -47,11 +47,18 @@ class _Builder:
         return op
 
 
-def build_program(H, W):
-    """The op list of one DenseFCNResNet152 forward on an HxW image (H, W multiples of 32)."""
-    if H % 32 or W % 32 or H <= 0 or W <= 0:
-        raise ValueError("DenseFCNResNet152 needs H and W to be positive multiples of 32 (skip concatenations)")
-    b = _Builder()
+def _conv_op(b, src0, c0, cout, hin, win, k, stride, relu, wspec, src1=-1, c1=0, res=-1):
+    pad = 1 if k == 3 else 0
+    hout, wout = (hin + 2 * pad - k) // stride + 1, (win + 2 * pad - k) // stride + 1
+    dst = b.tensor(hout, wout, cout)
+    b.add(_hip.OP_CONV, wspec, src0=src0, src1=src1, res=res, dst=dst, c0=c0, c1=c1, cout=cout, hin=hin, win=win,
+          hout=hout, wout=wout, ksize=k, stride=stride, pad=pad, relu=relu)
+    return dst, hout, wout
+
+
+def _encoder(b, H, W):
+    """Stem, max-pool and the four ResNet-152 stages shared by both FCN variants (reference models/fcnresnet.py:54-83,
+    :200-228).  Returns (stem tensor at H/2, [(tensor, channels, h, w) of block1..block4])."""
     h2, w2 = H // 2, W // 2
     x = b.tensor(h2, w2, 64)
     b.add(_hip.OP_STEM, dict(conv="conv1", bn="bn1", bias=False), src0=_hip.SLOT_INPUT, dst=x, c0=3, cout=64, hin=H,
@@ -64,24 +71,16 @@ def build_program(H, W):
     cin, hh, ww = 64, h4, w4
     skips = []
 
-    def conv(src0, c0, cout, hin, win, k, stride, relu, wspec, src1=-1, c1=0, res=-1):
-        pad = 1 if k == 3 else 0
-        hout, wout = (hin + 2 * pad - k) // stride + 1, (win + 2 * pad - k) // stride + 1
-        dst = b.tensor(hout, wout, cout)
-        b.add(_hip.OP_CONV, wspec, src0=src0, src1=src1, res=res, dst=dst, c0=c0, c1=c1, cout=cout, hin=hin, win=win,
-              hout=hout, wout=wout, ksize=k, stride=stride, pad=pad, relu=relu)
-        return dst, hout, wout
-
     def bottleneck(prefix, src, cin, width, hin, win, stride, project):
-        t1, _, _ = conv(src, cin, width, hin, win, 1, 1, 1, dict(conv=prefix + ".conv1", bn=prefix + ".bn1", bias=False))
-        t2, ho, wo = conv(t1, width, width, hin, win, 3, stride, 1,
-                          dict(conv=prefix + ".conv2", bn=prefix + ".bn2", bias=True))
+        t1, _, _ = _conv_op(b, src, cin, width, hin, win, 1, 1, 1, dict(conv=prefix + ".conv1", bn=prefix + ".bn1", bias=False))
+        t2, ho, wo = _conv_op(b, t1, width, width, hin, win, 3, stride, 1,
+                              dict(conv=prefix + ".conv2", bn=prefix + ".bn2", bias=True))
         res = src
         if project:  # `upsample_` is applied only where upsample=True (reference :35-36)
-            res, _, _ = conv(src, cin, 4 * width, hin, win, 1, stride, 0,
-                             dict(conv=prefix + ".upsample_.0", bn=prefix + ".upsample_.1", bias=False))
-        out, _, _ = conv(t2, width, 4 * width, ho, wo, 1, 1, 1,
-                         dict(conv=prefix + ".conv3", bn=prefix + ".bn3", bias=False), res=res)
+            res, _, _ = _conv_op(b, src, cin, 4 * width, hin, win, 1, stride, 0,
+                                 dict(conv=prefix + ".upsample_.0", bn=prefix + ".upsample_.1", bias=False))
+        out, _, _ = _conv_op(b, t2, width, 4 * width, ho, wo, 1, 1, 1,
+                             dict(conv=prefix + ".conv3", bn=prefix + ".bn3", bias=False), res=res)
         return out, ho, wo
 
     for first, rest, count, width, stride in STAGES:
@@ -91,6 +90,47 @@ def build_program(H, W):
             cur, hh, ww = bottleneck("%s.%d" % (rest, i), cur, cin, width, hh, ww, 1, False)
         skips.append((cur, cin, hh, ww))
         b.name(rest, cur)
+    return x, skips
+
+
+def build_program_res(H, W):
+    """The op list of one ResFCNResNet152 forward (reference models/fcnresnet.py:263-318): additive skips
+    `conv_upK(up(x) + conv_upK_1(skip))` -- the 1x1 lateral convolution takes the upsampled tensor as its residual --
+    and a last x2 upsampling in front of conv7 (128 -> 64) and the head (64 -> 2)."""
+    if H % 32 or W % 32 or H <= 0 or W <= 0:
+        raise ValueError("ResFCNResNet152 needs H and W to be positive multiples of 32")
+    b = _Builder()
+    x, skips = _encoder(b, H, W)
+    (x2s, c2, _, _), (x4s, c4, _, _), (x8s, c8, _, _), (x16s, c16, hh, ww) = skips
+    up, cup = x16s, c16
+    for name, (skip, cskip), cout in (("4", (x8s, c8), 1024), ("3", (x4s, c4), 512), ("2", (x2s, c2), 256), ("1", (x, 64), 128)):
+        dst = b.tensor(hh * 2, ww * 2, cup)
+        b.add(_hip.OP_UPSAMPLE2, src0=up, dst=dst, c0=cup, cout=cup, hin=hh, win=ww, hout=hh * 2, wout=ww * 2)
+        hh, ww = hh * 2, ww * 2
+        lat, _, _ = _conv_op(b, skip, cskip, cup, hh, ww, 1, 1, 0, dict(conv="conv_up%s_1" % name, bn=None, bias=True), res=dst)
+        up, _, _ = _conv_op(b, lat, cup, cout, hh, ww, 3, 1, 1, dict(conv="conv_up%s.0" % name, bn="conv_up%s.1" % name, bias=True))
+        b.name("conv_up" + name, up)
+        cup = cout
+    dst = b.tensor(hh * 2, ww * 2, cup)
+    b.add(_hip.OP_UPSAMPLE2, src0=up, dst=dst, c0=cup, cout=cup, hin=hh, win=ww, hout=hh * 2, wout=ww * 2)
+    hh, ww = hh * 2, ww * 2
+    up, _, _ = _conv_op(b, dst, cup, 64, hh, ww, 3, 1, 1, dict(conv="conv7.0", bn="conv7.1", bias=True))
+    b.name("conv7", up)
+    b.add(_hip.OP_HEAD, dict(conv="conv8", bn=None, bias=True), src0=up, dst=_hip.SLOT_OUTPUT, c0=64, cout=2, hin=hh,
+          win=ww, hout=hh, wout=ww)
+    return b
+
+
+def build_program(H, W):
+    """The op list of one DenseFCNResNet152 forward on an HxW image (H, W multiples of 32)."""
+    if H % 32 or W % 32 or H <= 0 or W <= 0:
+        raise ValueError("DenseFCNResNet152 needs H and W to be positive multiples of 32 (skip concatenations)")
+    b = _Builder()
+    x, skips = _encoder(b, H, W)
+
+    def conv(src0, c0, cout, hin, win, k, stride, relu, wspec, src1=-1, c1=0, res=-1):
+        return _conv_op(b, src0, c0, cout, hin, win, k, stride, relu, wspec, src1=src1, c1=c1, res=res)
+
     (x2s, c2, _, _), (x4s, c4, _, _), (x8s, c8, _, _), (x16s, c16, h16, w16) = skips
     up, _, _ = conv(x16s, c16, 1024, h16, w16, 3, 1, 1, dict(conv="conv6", bn="bn6", bias=True))
     b.name("bn6", up)
@@ -218,7 +258,7 @@ class FcnEngine:
     forward(x): x float32 [B,3,H,W] on the GPU -> (seg, radial), each float32 [G,B,1,H,W].
     """
 
-    def __init__(self, state_dicts, H, W, dtype="bf16", device="cuda", reuse_slots=True):
+    def __init__(self, state_dicts, H, W, dtype="bf16", device="cuda", reuse_slots=True, arch="dense"):
         import torch
 
         self.lib = _hip.lib()
@@ -226,7 +266,10 @@ class FcnEngine:
         self.groups = len(state_dicts)
         self.dtype = {"bf16": _hip.RCV_BF16, "fp32": _hip.RCV_F32, "f32": _hip.RCV_F32}[dtype]
         self.dtype_name = "bf16" if self.dtype == _hip.RCV_BF16 else "fp32"
-        builder = build_program(self.H, self.W)
+        if arch not in ("dense", "res"):
+            raise ValueError("arch must be 'dense' (DenseFCNResNet152) or 'res' (ResFCNResNet152)")
+        self.arch = arch
+        builder = build_program(self.H, self.W) if arch == "dense" else build_program_res(self.H, self.W)
         ops, slot_sizes = assign_slots(builder, reuse=reuse_slots)
         self.stages = builder.named if not reuse_slots else {}
         w, b, ops = pack_weights(state_dicts, builder, ops, self.dtype)

@@ -4,6 +4,7 @@ Public surface kept from the reference (reference models/fcnresnet.py:6-45, :48-
 
     Bottleneck(in_channels, channels, stride=1, upsample=False)
     DenseFCNResNet152(input_channels=3, output_channels=2).forward(x) -> (seg_pred, radial_pred)
+    ResFCNResNet152(input_channels=3, output_channels=2).forward(x)   -> (seg_pred, radial_pred)   (:194-318)
 
 The modules hold parameters under exactly the reference's 1 307 state-dict keys (including the
 `upsample_` branches the reference constructs in every Bottleneck but applies in only four, and the
@@ -52,6 +53,7 @@ def _decoder_stage(cin, cout):
 class DenseFCNResNet152(nn.Module):
     # width, number of plain bottlenecks after the projecting one, stride of the projecting one
     _encoder = ((64, 2, 1), (128, 7, 2), (256, 35, 2), (512, 2, 2))
+    _arch = "dense"
 
     def __init__(self, input_channels=3, output_channels=2):
         super().__init__()
@@ -96,7 +98,7 @@ class DenseFCNResNet152(nn.Module):
     def engine(self, H, W):
         key = (H, W, self.compute_dtype, self._stamp())
         if self._engine is None or self._engine_key != key:
-            self._engine = fcn_engine.FcnEngine([self.state_dict()], H, W, dtype=self.compute_dtype)
+            self._engine = fcn_engine.FcnEngine([self.state_dict()], H, W, dtype=self.compute_dtype, arch=self._arch)
             self._engine_key = key
         return self._engine
 
@@ -112,3 +114,35 @@ class DenseFCNResNet152(nn.Module):
             eng = self.engine(int(x.shape[2]), int(x.shape[3]))
             seg, radial = eng.forward(x.float())
         return seg[0], radial[0]
+
+
+class ResFCNResNet152(DenseFCNResNet152):
+    """The additive-skip variant of the reference (models/fcnresnet.py:194-318): same encoder, decoder stages
+    `conv_upK(upK(x) + conv_upK_1(skip))`, a second `up1` in front of conv7 (128 -> 64) and conv8 (64 -> 2).  The reference
+    imports it next to DenseFCNResNet152 but none of its drivers instantiates it.  Same 1 301 state-dict keys."""
+
+    _arch = "res"
+
+    def __init__(self, input_channels=3, output_channels=2):
+        nn.Module.__init__(self)
+        if input_channels != 3:
+            raise ValueError("the RCVPose FCN takes 3 input channels")
+        self.input_channels = input_channels
+        self.output_channels = output_channels
+        self.conv1, self.bn1 = _conv_bn(3, 64, 7, stride=2, padding=3)
+        self.relu = nn.ReLU(inplace=True)
+        self.maxpool = nn.MaxPool2d(kernel_size=3, stride=2, padding=1)
+        cin = 64
+        for idx, (width, plain, stride) in enumerate(self._encoder, start=1):
+            setattr(self, "block%dup" % idx, Bottleneck(cin, width, stride=stride, upsample=True))
+            cin = width * Bottleneck.expansion
+            setattr(self, "block%d" % idx, nn.Sequential(*[Bottleneck(cin, width) for _ in range(plain)]))
+        for name, cskip, cup, cout in (("4", 1024, 2048, 1024), ("3", 512, 1024, 512), ("2", 256, 512, 256), ("1", 64, 256, 128)):
+            setattr(self, "conv_up%s_1" % name, nn.Conv2d(cskip, cup, kernel_size=1))
+            setattr(self, "conv_up" + name, _decoder_stage(cup, cout))
+            setattr(self, "up" + name, nn.Upsample(scale_factor=2, mode="bilinear", align_corners=False))
+        self.conv7 = _decoder_stage(128, 64)
+        self.conv8 = nn.Conv2d(64, output_channels, kernel_size=1, stride=1)
+        self.compute_dtype = "fp32"
+        self._engine = None
+        self._engine_key = None

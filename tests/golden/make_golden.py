@@ -367,6 +367,44 @@ def gen_fcn(A):
 
 
 # --------------------------------------------------------------------------------------
+# RESFCN-1: models/fcnresnet.py:194-323 (ResFCNResNet152: additive skips `up + conv_upK_1(skip)`), imported by the
+# reference but never instantiated by its drivers
+# --------------------------------------------------------------------------------------
+def gen_resfcn(A):
+    import torch
+
+    import fcn_weights
+    from models.fcnresnet import ResFCNResNet152
+
+    torch.manual_seed(0)
+    model = ResFCNResNet152(3, 2)
+    sd = fcn_weights.make_state_dict(model, seed=7)
+    model.load_state_dict(sd, strict=True)
+    model.eval()
+    keys = {k: list(v.shape) for k, v in model.state_dict().items()}
+    with open(os.path.join(HERE, "resfcn_state_dict_keys.json"), "w") as f:
+        json.dump(keys, f)
+    print("  resfcn: %d state-dict keys, %d params" % (len(keys), sum(p.numel() for p in model.parameters())))
+    stages = {}
+
+    def hook(name):
+        def fn(mod, inp, out):
+            stages[name] = out.detach().clone()
+        return fn
+
+    names = ["block1", "block2", "block3", "block4", "conv_up4", "conv_up3", "conv_up2", "conv_up1", "conv7", "conv8"]
+    handles = [getattr(model, n).register_forward_hook(hook(n)) for n in names]
+    x = torch.from_numpy(fcn_weights.make_input(3, (1, 3, 64, 96)))
+    with torch.no_grad():
+        seg, rad = model(x)
+    np.savez_compressed(os.path.join(HERE, "resfcn1_64x96.npz"), input_seed=3, weight_seed=7, seg=seg.numpy(), radial=rad.numpy(),
+                        **{"stage_" + n: stages[n].numpy() for n in names if stages[n].numel() <= 50000})
+    print("  resfcn1 |radial|max %.3f |seg|max %.3f" % (float(rad.abs().max()), float(seg.abs().max())))
+    for h in handles:
+        h.remove()
+
+
+# --------------------------------------------------------------------------------------
 # HORN-*: util/horn.py:75-181 (HornPoseFitting.lmshorn), called at AccumulatorSpace.py:659-661
 # --------------------------------------------------------------------------------------
 def gen_horn(A):
@@ -396,7 +434,7 @@ def gen_horn(A):
 
 
 def main():
-    which = set(sys.argv[1:]) or {"acc", "seam", "fcn", "horn"}
+    which = set(sys.argv[1:]) or {"acc", "seam", "fcn", "horn", "resfcn"}
     A = _import_reference()
     if "acc" in which:
         print("ACC cases (reference fast_for runs as pure Python, ~1 us per point*voxel test)")
@@ -407,6 +445,8 @@ def main():
         gen_fcn(A)
     if "horn" in which:
         gen_horn(A)
+    if "resfcn" in which:
+        gen_resfcn(A)
 
 
 if __name__ == "__main__":
