@@ -717,12 +717,18 @@ struct BlockParams {
     long long src_gs, w1_gs, w2_gs, res_gs, dst_gs;
     int b1_gs, b2_gs;
     int C0, Hin, Win, Hout, Wout, stride, M;
+    // chained variant: the next block's 1x1 reduce (1024 -> 256, ReLU) on the tile just produced
+    const void *w3;
+    void *dst3;
+    const float *b3;
+    long long w3_gs, dst3_gs;
+    int b3_gs;
 };
 constexpr int BLK_BM = 128, BLK_CMID = 256, BLK_COUT = 1024;
 constexpr int BLK_STAGE = (BLK_BM + BLK_CMID) * 128;  // 48 KB
 constexpr int BLK_A2 = BLK_BM * BLK_CMID * 2;          // 64 KB: phase-2 A operand
 constexpr int BLK_RING = 3, BLK_SLOT = 128 * 128;      // 16 KB per weight slot
-constexpr int BLK_LDS = 3 * BLK_STAGE + BLK_COUT * 4;  // + the expand layer's bias (fp32) behind the stages
+constexpr int BLK_LDS = 3 * BLK_STAGE + BLK_COUT * 4 + BLK_CMID * 4;  // + the expand and the chained reduce layer's bias (fp32)
 
 __device__ __forceinline__ void blk_dma16(const void *base, int num_bytes, unsigned char *lds_wave_base, int voffset)
 {
@@ -730,6 +736,7 @@ __device__ __forceinline__ void blk_dma16(const void *base, int num_bytes, unsig
     __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void *)lds_wave_base, 16, voffset, 0, 0, 0);
 }
 
+template <bool CHAIN>
 __global__ __launch_bounds__(512) void k_conv_block(const BlockParams p)
 {
     using T = __bf16;
@@ -760,6 +767,7 @@ __global__ __launch_bounds__(512) void k_conv_block(const BlockParams p)
         const float b2a = p.b2[(long long)g * p.b2_gs + tid], b2b = p.b2[(long long)g * p.b2_gs + 512 + tid];
         sB2[tid] = b2a;
         sB2[512 + tid] = b2b;
+        if (CHAIN && tid < BLK_CMID) sB2[BLK_COUT + tid] = p.b3[(long long)g * p.b3_gs + tid];
     }
 #pragma unroll
     for (int j = 0; j < 4; j++)
@@ -895,9 +903,13 @@ __global__ __launch_bounds__(512) void k_conv_block(const BlockParams p)
 
     // ---- hand-over: mid = bf16(relu(acc + b1)) into the phase-2 A operand.  acc[i][j][e] = channel wn*64 + j*16 + kq*4 + e
     // of pixel wm*64 + i*16 + r16: K slab wn, 16-byte chunk j*2 + (kq>>1), upper / lower half by kq & 1
+    // LDS map of phase 2.  Plain: A2 [0, 64K), W ring [64K, 112K), residual [112K, 144K).  Chained: A2 only lives in LDS
+    // until every wave has copied its rows into registers as MFMA fragments; then W ring [0, 48K), residual / output chunk
+    // [48K, 80K), two 32 KB slots for the reduce layer's weights [80K, 144K).
     unsigned char *sA2 = smem;
-    unsigned char *sW = smem + BLK_A2;                     // ring of BLK_RING weight slots
-    unsigned char *sR = smem + BLK_A2 + BLK_RING * BLK_SLOT;  // residual tile of the current chunk: [128][256 B]
+    unsigned char *sW = CHAIN ? smem : smem + BLK_A2;
+    unsigned char *sR = CHAIN ? smem + BLK_RING * BLK_SLOT : smem + BLK_A2 + BLK_RING * BLK_SLOT;
+    unsigned char *sW3 = smem + BLK_RING * BLK_SLOT + BLK_BM * 256;  // CHAIN only
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         const int row = wm * 64 + i * 16 + r16;
@@ -911,9 +923,24 @@ __global__ __launch_bounds__(512) void k_conv_block(const BlockParams p)
             *(uint2 *)(sA2 + wn * (BM * 128) + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4) + (kq & 1) * 8) = pk;
         }
     }
+    // phase-2 wave tile: 32 pixels x 64 channels (8 waves = 4 x 2), so that the two 16-byte stores a lane makes per pixel
+    // group complete a 128-byte line (64 channels) of the output row
+    const int wm2 = wave >> 1, wn2 = wave & 1;
+    bf16x8 a2f[2][8];  // CHAIN: this wave's 32 rows of `mid` as fragments, [pixel group][K chunk of 32]
+    if (CHAIN) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int k8 = 0; k8 < 8; k8++)
+                a2f[i][k8] = *(const bf16x8 *)(sA2 + (k8 >> 1) * (BM * 128) + (wm2 * 32 + i * 16 + r16) * 128 + ((k8 & 1) ? ch1 : ch0));
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __syncthreads();  // A2's LDS is free for the weight ring
+    }
 
     // ---- phase 2 loaders.  Weights of stream step s = (chunk nc = s / 4, K slice ks = s % 4): 128 rows (out channels) x 128 B
-    // -> 2 pieces per wave; residual of chunk nc: 128 pixels x 256 B -> 4 pieces per wave (4 rows each)
+    // -> 2 pieces per wave; residual of chunk nc: 128 pixels x 256 B -> 4 pieces per wave (4 rows each); chained reduce layer:
+    // two K slices of 64 per chunk, 256 rows (out channels) x 128 B each -> 4 pieces per wave and slice
     int w_off[2];
 #pragma unroll
     for (int c = 0; c < 2; c++) {
@@ -926,7 +953,14 @@ __global__ __launch_bounds__(512) void k_conv_block(const BlockParams p)
         const int row = wave * 16 + c * 4 + (lane >> 4), slot = lane & 15;  // 4 rows x 16 chunks per piece
         r_off[c] = m0 + row < p.M ? (int)(((long long)(m0 + row) * BLK_COUT + (slot ^ (row & 15)) * EPV) * 2) : OOB;
     }
-    const int w_bytes = 128 * BLK_CMID * 2;
+    int w3_off[4];
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        const int row = wave * 32 + c * 8 + lrow;
+        w3_off[c] = (row * BLK_COUT + (lpos ^ ((row >> 1) & 7)) * EPV) * 2;
+    }
+    const T *w3 = CHAIN ? (const T *)p.w3 + (long long)g * p.w3_gs : nullptr;
+    const int w_bytes = 128 * BLK_CMID * 2, w3_bytes = BLK_CMID * BLK_COUT * 2;
     const long long res_bytes_ll = (long long)p.M * BLK_COUT * 2;
     const int res_bytes = res_bytes_ll > 0x7fffffffLL ? 0x7fffffff : (int)res_bytes_ll;
 #define RCV_BLK_W(s_)                                                                                          \
@@ -941,13 +975,26 @@ __global__ __launch_bounds__(512) void k_conv_block(const BlockParams p)
         const char *rb_ = (const char *)res + (long long)(nc_) * 128 * 2;                                      \
         _Pragma("unroll") for (int c = 0; c < 4; c++) blk_dma16(rb_, res_bytes, sR + (wave * 16 + c * 4) * 256, r_off[c]); \
     }
-    // order of issue per wave: [R(nc) at the first step of a chunk,] W(s + 2) at step s.  At the top of step s the pieces
-    // issued after W(s) are W(s + 1) and, when step s - 1 opened a chunk, R of that chunk: vmcnt 2 or 6.
+#define RCV_BLK_W3(nc_)                                                                                        \
+    {                                                                                                          \
+        _Pragma("unroll") for (int h = 0; h < 2; h++) {                                                        \
+            const char *wb_ = (const char *)w3 + ((long long)(nc_) * 128 + h * KE) * 2;                        \
+            _Pragma("unroll") for (int c = 0; c < 4; c++)                                                      \
+                blk_dma16(wb_, w3_bytes, sW3 + h * (BLK_CMID * 128) + (wave * 32 + c * 8) * 128, w3_off[c]);   \
+        }                                                                                                      \
+    }
+    // order of issue per wave: at the first step of a chunk R(nc) [4 pieces] and, chained, both reduce-weight slices [8]; then
+    // W(s + 2) [2] at every step s.  At the top of step s the pieces issued after W(s) are W(s + 1) and, when step s - 1
+    // opened a chunk, that chunk's R (and W3): vmcnt 2, or 6 / 14.
     RCV_BLK_W(0);
     RCV_BLK_W(1);
-    // phase-2 wave tile: 32 pixels x 64 channels (8 waves = 4 x 2), so that the two 16-byte stores a lane makes per pixel
-    // group complete a 128-byte line (64 channels) of the output row
-    const int wm2 = wave >> 1, wn2 = wave & 1;
+    f32x4 acc3[2][8];  // CHAIN: [pixel group][16-channel tile of this wave's 128 reduce outputs]
+    if (CHAIN) {
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int j = 0; j < 8; j++) acc3[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
 #pragma unroll
     for (int nc = 0; nc < 8; nc++) {
         f32x4 a2[2][4];
@@ -958,12 +1005,17 @@ __global__ __launch_bounds__(512) void k_conv_block(const BlockParams p)
 #pragma unroll
         for (int ks = 0; ks < 4; ks++) {
             const int s_ = nc * 4 + ks;
-            if (ks == 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-            else if (s_ == 31) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (ks == 1) {
+                if (CHAIN) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            } else if (s_ == 31) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();  // step s_ has landed for everybody; slot (s_ + 2) % 3 and (ks == 0) sR are free
-            if (ks == 0) RCV_BLK_R(nc);
+            __builtin_amdgcn_s_barrier();  // step s_ has landed for everybody; slot (s_ + 2) % 3 and (ks == 0) sR / sW3 are free
+            if (ks == 0) {
+                RCV_BLK_R(nc);
+                if (CHAIN) RCV_BLK_W3(nc);
+            }
             if (s_ + 2 < 32) RCV_BLK_W(s_ + 2);
             const unsigned char *Ab = sA2 + ks * (BM * 128) + (wm2 * 32 + r16) * 128;
             const unsigned char *Bb = sW + (s_ % BLK_RING) * BLK_SLOT + (wn2 * 64 + r16) * 128;
@@ -972,7 +1024,7 @@ __global__ __launch_bounds__(512) void k_conv_block(const BlockParams p)
                 bf16x8 af[2], bfr[4];
                 const int ch = kk ? ch1 : ch0;
 #pragma unroll
-                for (int i = 0; i < 2; i++) af[i] = *(const bf16x8 *)(Ab + i * 16 * 128 + ch);
+                for (int i = 0; i < 2; i++) af[i] = CHAIN ? a2f[i][ks * 2 + kk] : *(const bf16x8 *)(Ab + i * 16 * 128 + ch);
 #pragma unroll
                 for (int j = 0; j < 4; j++) bfr[j] = *(const bf16x8 *)(Bb + j * 16 * 128 + ch);
 #pragma unroll
@@ -982,7 +1034,8 @@ __global__ __launch_bounds__(512) void k_conv_block(const BlockParams p)
             }
         }
         // epilogue of the chunk.  R(nc) was issued at the chunk's first step: every wave has waited for it at the top of the
-        // fourth step (vmcnt 2 leaves only W pieces) and passed that step's barrier.
+        // fourth step (vmcnt 2 leaves only W pieces) and passed that step's barrier.  Chained: the rounded outputs go back
+        // into the residual's LDS slot, where they are the A operand (K = this chunk's 128 channels) of the reduce layer.
 #pragma unroll
         for (int i = 0; i < 2; i++) {
             const int row = wm2 * 32 + i * 16 + r16, m = m0 + row;
@@ -998,7 +1051,8 @@ __global__ __launch_bounds__(512) void k_conv_block(const BlockParams p)
                 }
                 const float4 bA = *(const float4 *)(sB2 + nc * 128 + e_ch), bB = *(const float4 *)(sB2 + nc * 128 + e_ch + 4);
                 const float bb[8] = {bA.x, bA.y, bA.z, bA.w, bB.x, bB.y, bB.z, bB.w};
-                const uint4 rq = *(const uint4 *)(sR + row * 256 + (((e_ch >> 3) ^ (row & 15)) << 4));
+                unsigned char *rslot = sR + row * 256 + (((e_ch >> 3) ^ (row & 15)) << 4);
+                const uint4 rq = *(const uint4 *)rslot;
                 const T *rp = (const T *)&rq;
 #pragma unroll
                 for (int e = 0; e < 8; e++) v[e] = fmaxf((v[e] + bb[e]) + (float)rp[e], 0.f);
@@ -1007,9 +1061,66 @@ __global__ __launch_bounds__(512) void k_conv_block(const BlockParams p)
 #pragma unroll
                 for (int e = 0; e < 8; e++) op[e] = (T)v[e];
                 if (m < p.M) *(uint4 *)(dst + (long long)m * BLK_COUT + nc * 128 + e_ch) = outv;
+                if (CHAIN) *(uint4 *)rslot = outv;
+            }
+        }
+        if (CHAIN) {
+            // reduce layer, K slab of this chunk: acc3 += Y[32 px x 128] * W3[128 out x 128]^T.  Both weight slices were
+            // issued at the chunk's first step and are older than everything the later steps waited for.
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();  // every wave's part of Y is in LDS
+#pragma unroll
+            for (int h = 0; h < 2; h++)
+#pragma unroll
+                for (int kk = 0; kk < 2; kk++) {
+                    bf16x8 yf[2];
+#pragma unroll
+                    for (int i = 0; i < 2; i++) {
+                        const int row = wm2 * 32 + i * 16 + r16;
+                        yf[i] = *(const bf16x8 *)(sR + row * 256 + (((h * 8 + kk * 4 + kq) ^ (row & 15)) << 4));
+                    }
+                    const unsigned char *Bb = sW3 + h * (BLK_CMID * 128) + (wn2 * 128 + r16) * 128 + (kk ? ch1 : ch0);
+#pragma unroll
+                    for (int jh = 0; jh < 2; jh++) {
+                        bf16x8 bfr[4];
+#pragma unroll
+                        for (int j = 0; j < 4; j++) bfr[j] = *(const bf16x8 *)(Bb + (jh * 4 + j) * 16 * 128);
+#pragma unroll
+                        for (int i = 0; i < 2; i++)
+#pragma unroll
+                            for (int j = 0; j < 4; j++)
+                                acc3[i][jh * 4 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], yf[i], acc3[i][jh * 4 + j], 0, 0, 0);
+                    }
+                }
+        }
+    }
+    if (CHAIN) {
+        // the next block's first activation: relu(acc3 + b3) rounded to bf16, 16-byte vectors of 8 channels
+        T *dst3 = (T *)p.dst3 + (long long)g * p.dst3_gs;
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const int row = wm2 * 32 + i * 16 + r16, m = m0 + row;
+#pragma unroll
+            for (int pr = 0; pr < 4; pr++) {
+                const int e_ch = wn2 * 128 + (2 * pr + (kq & 1)) * 16 + (kq >> 1) * 8;
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc3[i][2 * pr][e]), __float_as_uint(acc3[i][2 * pr + 1][e]), false, false);
+                    v[e] = __uint_as_float(sw[0]);
+                    v[4 + e] = __uint_as_float(sw[1]);
+                }
+                const float4 bA = *(const float4 *)(sB2 + BLK_COUT + e_ch), bB = *(const float4 *)(sB2 + BLK_COUT + e_ch + 4);
+                const float bb[8] = {bA.x, bA.y, bA.z, bA.w, bB.x, bB.y, bB.z, bB.w};
+                uint4 outv;
+                T *op = (T *)&outv;
+#pragma unroll
+                for (int e = 0; e < 8; e++) op[e] = (T)fmaxf(v[e] + bb[e], 0.f);
+                if (m < p.M) *(uint4 *)(dst3 + (long long)m * BLK_CMID + e_ch) = outv;
             }
         }
     }
+#undef RCV_BLK_W3
 #undef RCV_BLK_W
 #undef RCV_BLK_R
 }
@@ -1388,6 +1499,7 @@ struct rcv_fcn {
     bool use_mfma_stem = true;
     bool use_tail = true;  // fused upsample + conv7 + head kernel (bf16)
     bool use_block = true;  // fused 3x3 + expand 1x1 kernel for the 256 -> 256 -> 1024 bottleneck halves (bf16)
+    bool use_chain = true;  // ... with the next block's 1x1 reduce chained in where it follows directly
     bool profiling = false;
     std::vector<hipEvent_t> events;  // 2 per op when profiling
     bool events_valid = false;
@@ -1553,8 +1665,10 @@ int forward_impl(rcv_fcn *h, const float *x, int B, float *seg, float *radial, c
                     b.ksize == 1 && b.stride == 1 && b.pad == 0 && b.c0 == BLK_CMID && b.cout == BLK_COUT && b.src0 == a.dst &&
                     b.src1 < 0 && b.res >= 0 && b.relu && b.hout == a.hout && b.wout == a.wout &&
                     (M + BLK_BM - 1) / BLK_BM * h->groups >= 192 && M * BLK_COUT * 2 < 0x7fffffffLL) {
-                    if (!h->attrs_set)
-                        RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_conv_block, hipFuncAttributeMaxDynamicSharedMemorySize, BLK_LDS));
+                    if (!h->attrs_set) {
+                        RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_conv_block<false>, hipFuncAttributeMaxDynamicSharedMemorySize, BLK_LDS));
+                        RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_conv_block<true>, hipFuncAttributeMaxDynamicSharedMemorySize, BLK_LDS));
+                    }
                     auto gs = [&](int s) -> long long { return (long long)h->slot_elems[s] * B; };
                     BlockParams q;
                     memset(&q, 0, sizeof(q));
@@ -1565,17 +1679,26 @@ int forward_impl(rcv_fcn *h, const float *x, int B, float *seg, float *radial, c
                     q.w1_gs = (long long)a.cout * 9 * a.c0; q.w2_gs = (long long)b.cout * b.c0;
                     q.b1_gs = a.cout; q.b2_gs = b.cout;
                     q.C0 = a.c0; q.Hin = a.hin; q.Win = a.win; q.Hout = a.hout; q.Wout = a.wout; q.stride = a.stride; q.M = (int)M;
-                    if (h->profiling) {  // the fused kernel's time is booked on the 3x3 convolution
-                        RCV_HIP_CHECK(hipEventRecord(h->events[2 * i], st));
+                    // the next block's 1x1 reduce (1024 -> 256, ReLU) reads exactly the tile this kernel produces: chained in
+                    bool chain = false;
+                    if (h->use_chain && i + 2 < h->ops.size() && h->ops[i + 2].kind == RCV_OP_CONV) {
+                        const rcv_op &c = h->ops[i + 2];
+                        chain = c.ksize == 1 && c.stride == 1 && c.pad == 0 && c.c0 == BLK_COUT && c.cout == BLK_CMID && c.src0 == b.dst &&
+                                c.src1 < 0 && c.res < 0 && c.relu && c.hout == b.hout && c.wout == b.wout;
+                        if (chain) {
+                            q.w3 = (const __bf16 *)h->weights + c.w_off; q.b3 = h->bias + c.b_off; q.dst3 = ws + off[c.dst];
+                            q.w3_gs = (long long)c.cout * c.c0; q.b3_gs = c.cout; q.dst3_gs = gs(c.dst);
+                        }
                     }
-                    hipLaunchKernelGGL(k_conv_block, dim3((unsigned)((M + BLK_BM - 1) / BLK_BM), 1, h->groups), dim3(512), BLK_LDS, st, q);
+                    const int fused = chain ? 3 : 2;
+                    if (h->profiling) RCV_HIP_CHECK(hipEventRecord(h->events[2 * i], st));  // time booked on the 3x3 convolution
+                    const dim3 grid((unsigned)((M + BLK_BM - 1) / BLK_BM), 1, h->groups);
+                    if (chain) hipLaunchKernelGGL(k_conv_block<true>, grid, dim3(512), BLK_LDS, st, q);
+                    else hipLaunchKernelGGL(k_conv_block<false>, grid, dim3(512), BLK_LDS, st, q);
                     RCV_LAUNCH_CHECK();
-                    if (h->profiling) {
-                        RCV_HIP_CHECK(hipEventRecord(h->events[2 * i + 1], st));
-                        RCV_HIP_CHECK(hipEventRecord(h->events[2 * i + 2], st));
-                        RCV_HIP_CHECK(hipEventRecord(h->events[2 * i + 3], st));
-                    }
-                    i += 1;
+                    if (h->profiling)
+                        for (int e = 1; e < 2 * fused; e++) RCV_HIP_CHECK(hipEventRecord(h->events[2 * i + e], st));
+                    i += fused - 1;
                     continue;
                 }
             }
@@ -1706,6 +1829,7 @@ int rcv_fcn_set_option(rcv_fcn *h, int key, int value)
     if (key == 2) { h->use_mfma_stem = value != 0; h->attrs_set = false; return RCV_OK; }
     if (key == 3) { h->use_tail = value != 0; h->attrs_set = false; return RCV_OK; }
     if (key == 4) { h->use_block = value != 0; h->attrs_set = false; return RCV_OK; }
+    if (key == 5) { h->use_chain = value != 0; h->attrs_set = false; return RCV_OK; }
     return RCV_E_INVALID;
 }
 

@@ -147,6 +147,9 @@ def test_fused_bottleneck_half_identical_to_two_kernels(shapes, state_dict):
         x = torch.from_numpy(fcn_weights.make_input(13, (B, 3, H, W))).cuda()
         eng = FcnEngine([state_dict, _sd(shapes, 1), _sd(shapes, 2)], H, W, dtype="bf16")
         seg_a, rad_a = [t.clone() for t in eng.forward(x)]
+        eng.set_option(5, 0)  # without chaining the next block's 1x1 reduce into the kernel
+        seg_c, rad_c = [t.clone() for t in eng.forward(x)]
+        assert torch.equal(seg_a, seg_c) and torch.equal(rad_a, rad_c), (H, W, B)
         eng.set_option(4, 0)
         seg_b, rad_b = [t.clone() for t in eng.forward(x)]
         assert torch.equal(seg_a, seg_b) and torch.equal(rad_a, rad_b), (H, W, B)
