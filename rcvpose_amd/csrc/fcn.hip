@@ -1663,7 +1663,7 @@ int forward_impl(rcv_fcn *h, const float *x, int B, float *seg, float *radial, c
                 const long long M = (long long)B * a.hout * a.wout;
                 if (a.ksize == 3 && a.pad == 1 && a.cout == BLK_CMID && a.c0 % 64 == 0 && a.src1 < 0 && a.res < 0 && a.relu &&
                     b.ksize == 1 && b.stride == 1 && b.pad == 0 && b.c0 == BLK_CMID && b.cout == BLK_COUT && b.src0 == a.dst &&
-                    b.src1 < 0 && b.res >= 0 && b.relu && b.hout == a.hout && b.wout == a.wout &&
+                    b.src1 < 0 && b.res >= 0 && b.relu && b.hout == a.hout && b.wout == a.wout && b.dst != a.src0 && b.dst != b.res &&
                     (M + BLK_BM - 1) / BLK_BM * h->groups >= 192 && M * BLK_COUT * 2 < 0x7fffffffLL) {
                     if (!h->attrs_set) {
                         RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_conv_block<false>, hipFuncAttributeMaxDynamicSharedMemorySize, BLK_LDS));
@@ -1683,8 +1683,10 @@ int forward_impl(rcv_fcn *h, const float *x, int B, float *seg, float *radial, c
                     bool chain = false;
                     if (h->use_chain && i + 2 < h->ops.size() && h->ops[i + 2].kind == RCV_OP_CONV) {
                         const rcv_op &c = h->ops[i + 2];
+                        // (its output must not share a slot with anything the kernel still reads: other tiles are in flight)
                         chain = c.ksize == 1 && c.stride == 1 && c.pad == 0 && c.c0 == BLK_COUT && c.cout == BLK_CMID && c.src0 == b.dst &&
-                                c.src1 < 0 && c.res < 0 && c.relu && c.hout == b.hout && c.wout == b.wout;
+                                c.src1 < 0 && c.res < 0 && c.relu && c.hout == b.hout && c.wout == b.wout && c.dst != a.src0 &&
+                                c.dst != b.res && c.dst != b.dst;
                         if (chain) {
                             q.w3 = (const __bf16 *)h->weights + c.w_off; q.b3 = h->bias + c.b_off; q.dst3 = ws + off[c.dst];
                             q.w3_gs = (long long)c.cout * c.c0; q.b3_gs = c.cout; q.dst3_gs = gs(c.dst);

@@ -20,6 +20,7 @@ STAGES = (
     ("block4up", "block4", 2, 512, 2),
 )
 BN_EPS = 1e-5
+FUSE_SPAN = 3  # the executor fuses at most this many consecutive ops into one kernel (slot liveness, assign_slots)
 
 
 class _Builder:
@@ -176,10 +177,16 @@ def assign_slots(builder, reuse=True):
                 s = len(slot_size)
                 slot_size.append(size)
             slot_of[t] = s
-        for key in ("src0", "src1", "res"):
-            t = op[key]
-            if t >= 0 and last_use[t] == i and slot_of[t] not in free:
-                free.append(slot_of[t])
+        # A slot is released two ops after the last reader: the executor may run up to three consecutive ops as one kernel
+        # (3x3 -> expand -> next reduce, upsample -> conv7 -> head), in which later tiles still read an input while earlier
+        # tiles already write the outputs of the following ops.
+        for j in range(max(0, i - FUSE_SPAN + 1), i - FUSE_SPAN + 2):
+            if j < 0:
+                continue
+            for key in ("src0", "src1", "res"):
+                t = builder.ops[j][key]
+                if t >= 0 and last_use[t] == j and slot_of[t] not in free:
+                    free.append(slot_of[t])
     ops = []
     for op in builder.ops:
         o = dict(op)

@@ -93,3 +93,18 @@ def test_weight_packing_layout(golden_dir):
     assert torch.equal(w[o["w_off"]:o["w_off"] + n], w[o["w_off"] + n:o["w_off"] + 2 * n])
     wf, bf = fcn_engine.fold_conv_bn(sd, dict(conv="block2up.conv2", bn="block2up.bn2", bias=True), o["cout"])
     assert torch.equal(w[o["w_off"]:o["w_off"] + n], wf.reshape(-1).float())
+
+
+def test_slots_are_not_recycled_inside_a_fusion_window():
+    """The executor may run up to FUSE_SPAN consecutive ops as one kernel whose tiles read an input while other tiles
+    already write the outputs of the following ops: no output may share a slot with an input of the ops in its window."""
+    from rcvpose_amd import fcn_engine
+
+    for builder in (fcn_engine.build_program(480, 640), fcn_engine.build_program_res(96, 128)):
+        ops, slots = fcn_engine.assign_slots(builder)
+        for i, o in enumerate(ops):
+            for j in range(max(0, i - fcn_engine.FUSE_SPAN + 1), i + 1):
+                for key in ("src0", "src1", "res"):
+                    if ops[j][key] >= 0:
+                        assert ops[j][key] != o["dst"], (i, j, key)
+        assert len(slots) <= 24

@@ -143,7 +143,8 @@ def test_fused_bottleneck_half_identical_to_two_kernels(shapes, state_dict):
     from rcvpose_amd.fcn_engine import FcnEngine
 
     # the fused kernel is used from 192 tiles of 128 pixels on: 7 images x 30 x 40 pixels x 3 networks = 198 (last tile ragged)
-    for (H, W, B) in ((480, 640, 7), (480, 640, 8), (352, 480, 14)):
+    # ... and more tiles than CUs from 9 images on (second-round tiles read inputs while first-round tiles write outputs)
+    for (H, W, B) in ((480, 640, 7), (480, 640, 8), (352, 480, 14), (480, 640, 16)):
         x = torch.from_numpy(fcn_weights.make_input(13, (B, 3, H, W))).cuda()
         eng = FcnEngine([state_dict, _sd(shapes, 1), _sd(shapes, 2)], H, W, dtype="bf16")
         seg_a, rad_a = [t.clone() for t in eng.forward(x)]
