@@ -717,18 +717,23 @@ struct BlockParams {
     long long src_gs, w1_gs, w2_gs, res_gs, dst_gs;
     int b1_gs, b2_gs;
     int C0, Hin, Win, Hout, Wout, stride, M;
-    // chained variant: the next block's 1x1 reduce (1024 -> 256, ReLU) on the tile just produced
+    // chained variant: the next block's 1x1 reduce (4*CMID -> CMID, ReLU) on the tile just produced
     const void *w3;
     void *dst3;
     const float *b3;
     long long w3_gs, dst3_gs;
     int b3_gs;
 };
-constexpr int BLK_BM = 128, BLK_CMID = 256, BLK_COUT = 1024;
-constexpr int BLK_STAGE = (BLK_BM + BLK_CMID) * 128;  // 48 KB
-constexpr int BLK_A2 = BLK_BM * BLK_CMID * 2;          // 64 KB: phase-2 A operand
-constexpr int BLK_RING = 3, BLK_SLOT = 128 * 128;      // 16 KB per weight slot
-constexpr int BLK_LDS = 3 * BLK_STAGE + BLK_COUT * 4 + BLK_CMID * 4;  // + the expand and the chained reduce layer's bias (fp32)
+constexpr int BLK_BM = 128;
+constexpr int BLK_RING = 3, BLK_SLOT = 128 * 128;  // expand-weight ring: 16 KB slots (128 out channels x 64 K)
+// LDS bytes of k_conv_block<CMID, .>: the larger of phase 1 (three operand stages) and phase 2 (weight ring, residual /
+// output chunk, and either the `mid` tile or the two reduce-weight slices), plus the fp32 biases of the 1x1 layers
+constexpr int blk_lds(int cmid)
+{
+    const int p1 = 3 * (BLK_BM + cmid) * 128;
+    const int p2 = BLK_RING * BLK_SLOT + BLK_BM * 256 + (2 * cmid * 128 > BLK_BM * cmid * 2 ? 2 * cmid * 128 : BLK_BM * cmid * 2);
+    return (p1 > p2 ? p1 : p2) + 5 * cmid * 4;
+}
 
 __device__ __forceinline__ void blk_dma16(const void *base, int num_bytes, unsigned char *lds_wave_base, int voffset)
 {
@@ -736,15 +741,27 @@ __device__ __forceinline__ void blk_dma16(const void *base, int num_bytes, unsig
     __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void *)lds_wave_base, 16, voffset, 0, 0, 0);
 }
 
-template <bool CHAIN>
+template <int CMID, bool CHAIN>
 __global__ __launch_bounds__(512) void k_conv_block(const BlockParams p)
 {
     using T = __bf16;
     constexpr int KE = 64, EPV = 8, BM = BLK_BM, KS = 3, PAD = 1;
+    constexpr int COUT = 4 * CMID;
     constexpr int OOB = (int)0x80000000;
+    // phase 1: 8 waves = WM1 x WN1 over the [128 x CMID] tile
+    constexpr int WN1 = CMID >= 128 ? 4 : 2, WM1 = 8 / WN1;
+    constexpr int MT1 = BM / WM1 / 16, NT1 = CMID / WN1 / 16;
+    constexpr int STAGE = (BM + CMID) * 128;
+    constexpr int BPW1 = CMID / 64;           // B pieces (8 rows x 128 B) per wave and K step; A: 2
+    constexpr int NP1 = 2 + BPW1, H1 = (NP1 + 1) / 2;
+    constexpr int A2_BYTES = BM * CMID * 2;
+    // phase 2: COUT / 128 chunks of 128 output channels, KS2 K steps of 64 each
+    constexpr int NCH = COUT / 128, KS2 = CMID / 64, S2 = NCH * KS2;
+    constexpr int W3P = CMID / 64;            // reduce-weight pieces per wave and K slice (two slices per chunk)
+    constexpr int NT3 = CMID / 32;            // 16-channel tiles of a wave's CMID / 2 reduce outputs
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 2, wn = wave & 3;
+    const int wm = wave / WN1, wn = wave % WN1;
     const int g = blockIdx.z, m0 = blockIdx.x * BM;
     const int lrow = lane >> 3, lpos = lane & 7;
     const int r16 = lane & 15, kq = lane >> 4;
@@ -755,26 +772,22 @@ __global__ __launch_bounds__(512) void k_conv_block(const BlockParams p)
     T *dst = (T *)p.dst + (long long)g * p.dst_gs;
     const int K1 = KS * KS * p.C0;
 
-    // biases: the 3x3 layer's in registers (epilogue layout), the expand layer's in LDS; both fetched right away so that
-    // the compiler's wait for these (ordinary) loads happens here and not in the middle of the DMA streams
-    float bias1[4][4];
+    // biases: the 3x3 layer's in registers (epilogue layout), the 1x1 layers' in LDS; all fetched right away so that the
+    // compiler's wait for these (ordinary) loads happens here and not in the middle of the DMA streams
+    float bias1[NT1][4];
 #pragma unroll
-    for (int j = 0; j < 4; j++)
+    for (int j = 0; j < NT1; j++)
 #pragma unroll
-        for (int e = 0; e < 4; e++) bias1[j][e] = p.b1[(long long)g * p.b1_gs + wn * 64 + j * 16 + kq * 4 + e];
-    float *sB2 = (float *)(smem + 3 * BLK_STAGE);  // [1024] bias of the expand layer
-    {
-        const float b2a = p.b2[(long long)g * p.b2_gs + tid], b2b = p.b2[(long long)g * p.b2_gs + 512 + tid];
-        sB2[tid] = b2a;
-        sB2[512 + tid] = b2b;
-        if (CHAIN && tid < BLK_CMID) sB2[BLK_COUT + tid] = p.b3[(long long)g * p.b3_gs + tid];
-    }
+        for (int e = 0; e < 4; e++) bias1[j][e] = p.b1[(long long)g * p.b1_gs + wn * (CMID / WN1) + j * 16 + kq * 4 + e];
+    float *sB2 = (float *)(smem + blk_lds(CMID) - 5 * CMID * 4);  // [COUT] expand bias, [CMID] reduce bias
+    for (int q = tid; q < COUT; q += 512) sB2[q] = p.b2[(long long)g * p.b2_gs + q];
+    if (CHAIN && tid < CMID) sB2[COUT + tid] = p.b3[(long long)g * p.b3_gs + tid];
 #pragma unroll
-    for (int j = 0; j < 4; j++)
+    for (int j = 0; j < NT1; j++)
 #pragma unroll
         for (int e = 0; e < 4; e++) asm volatile("" : "+v"(bias1[j][e]));
 
-    // ---- phase 1 loader: 2 A rows (wave*16 + c*8 + lrow) and 4 B rows (wave*32 + c*8 + lrow) per lane
+    // ---- phase 1 loader: 2 A rows (wave*16 + c*8 + lrow) and BPW1 B rows (wave*8*BPW1 + c*8 + lrow) per lane
     int a_off[2];
     unsigned a_ok[2];
     const int HWo = p.Hout * p.Wout;
@@ -800,21 +813,21 @@ __global__ __launch_bounds__(512) void k_conv_block(const BlockParams p)
             for (int r = rlo; r <= rhi; r++) a_ok[c] |= colmask << (r * KS);
         }
     }
-    int b_off[4];
+    int b_off[BPW1];
 #pragma unroll
-    for (int c = 0; c < 4; c++) {
-        const int row = wave * 32 + c * 8 + lrow;
+    for (int c = 0; c < BPW1; c++) {
+        const int row = wave * (8 * BPW1) + c * 8 + lrow;
         b_off[c] = (row * K1 + (lpos ^ ((row >> 1) & 7)) * EPV) * 2;
     }
     const int n_img = __builtin_amdgcn_readfirstlane(p.M / HWo);
     const int a_bytes = (int)((long long)p.C0 * p.Hin * p.Win * n_img * 2);
-    const int b_bytes = BLK_CMID * K1 * 2;
+    const int b_bytes = CMID * K1 * 2;
     int tap_r = 0, tap_s = 0, cg = 0;
 
-// pieces [LO, HI) of the next K step (0..1: A rows, 2..5: B rows) into `stage`
+// pieces [LO, HI) of the next K step (0..1: A rows, 2..: B rows) into `stage`
 #define RCV_BLK_ISSUE(stage, LO, HI, ADV)                                                                      \
     {                                                                                                          \
-        unsigned char *As_ = smem + (stage) * BLK_STAGE;                                                       \
+        unsigned char *As_ = smem + (stage) * STAGE;                                                           \
         unsigned char *Bs_ = As_ + BM * 128;                                                                   \
         const int tap_ = tap_r * KS + tap_s;                                                                   \
         if ((LO) < 2) {                                                                                        \
@@ -828,7 +841,7 @@ __global__ __launch_bounds__(512) void k_conv_block(const BlockParams p)
         if ((HI) > 2) {                                                                                        \
             const char *bbase_ = (const char *)w1 + (long long)(tap_ * p.C0 + cg) * 2;                         \
             _Pragma("unroll") for (int c = ((LO) > 2 ? (LO) - 2 : 0); c < (HI) - 2; c++)                       \
-                blk_dma16(bbase_, b_bytes, Bs_ + (wave * 32 + c * 8) * 128, b_off[c]);                         \
+                blk_dma16(bbase_, b_bytes, Bs_ + (wave * (8 * BPW1) + c * 8) * 128, b_off[c]);                 \
         }                                                                                                      \
         if (ADV) {                                                                                             \
             cg += KE;                                                                                          \
@@ -840,45 +853,52 @@ __global__ __launch_bounds__(512) void k_conv_block(const BlockParams p)
             tap_r += wrap2_ ? 1 : 0;                                                                           \
         }                                                                                                      \
     }
+#define RCV_BLK_VMWAIT(N)                                                                                      \
+    {                                                                                                          \
+        if constexpr ((N) == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                               \
+        else if constexpr ((N) == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                          \
+        else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");                                                  \
+    }
 
-    f32x4 acc[4][4];
+    f32x4 acc[MT1][NT1];
 #pragma unroll
-    for (int i = 0; i < 4; i++)
+    for (int i = 0; i < MT1; i++)
 #pragma unroll
-        for (int j = 0; j < 4; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < NT1; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int ch0 = ((0 * 4 + kq) ^ ((r16 >> 1) & 7)) << 4, ch1 = ((1 * 4 + kq) ^ ((r16 >> 1) & 7)) << 4;
 
 // four phases per K step, the two waves of a SIMD one barrier apart (see k_conv_dma); operands swapped so that a lane
 // accumulates four consecutive channels of one pixel
 #define RCV_BLK_STEP(ISSUE)                                                                                    \
     {                                                                                                          \
-        const unsigned char *Ab = smem + stage * BLK_STAGE + (wm * 64 + r16) * 128;                            \
-        const unsigned char *Bb = smem + stage * BLK_STAGE + BM * 128 + (wn * 64 + r16) * 128;                 \
+        const unsigned char *Ab = smem + stage * STAGE + (wm * (BM / WM1) + r16) * 128;                        \
+        const unsigned char *Bb = smem + stage * STAGE + BM * 128 + (wn * (CMID / WN1) + r16) * 128;           \
         const int st2 = stage + 2 >= 3 ? stage + 2 - 3 : stage + 2;                                            \
-        bf16x8 af[4], bfr[4];                                                                                  \
-        _Pragma("unroll") for (int i = 0; i < 4; i++) af[i] = *(const bf16x8 *)(Ab + i * 16 * 128 + ch0);      \
-        _Pragma("unroll") for (int j = 0; j < 4; j++) bfr[j] = *(const bf16x8 *)(Bb + j * 16 * 128 + ch0);     \
-        if (ISSUE) RCV_BLK_ISSUE(st2, 0, 3, false);                                                            \
+        bf16x8 af[MT1], bfr[NT1];                                                                              \
+        _Pragma("unroll") for (int i = 0; i < MT1; i++) af[i] = *(const bf16x8 *)(Ab + i * 16 * 128 + ch0);    \
+        _Pragma("unroll") for (int j = 0; j < NT1; j++) bfr[j] = *(const bf16x8 *)(Bb + j * 16 * 128 + ch0);   \
+        if (ISSUE) RCV_BLK_ISSUE(st2, 0, H1, false);                                                           \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                     \
         __builtin_amdgcn_s_barrier();                                                                          \
         __builtin_amdgcn_s_setprio(1);                                                                         \
-        _Pragma("unroll") for (int i = 0; i < 4; i++)                                                          \
-            _Pragma("unroll") for (int j = 0; j < 4; j++)                                                      \
+        _Pragma("unroll") for (int i = 0; i < MT1; i++)                                                        \
+            _Pragma("unroll") for (int j = 0; j < NT1; j++)                                                    \
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);        \
         __builtin_amdgcn_s_setprio(0);                                                                         \
         __builtin_amdgcn_s_barrier();                                                                          \
-        _Pragma("unroll") for (int i = 0; i < 4; i++) af[i] = *(const bf16x8 *)(Ab + i * 16 * 128 + ch1);      \
-        _Pragma("unroll") for (int j = 0; j < 4; j++) bfr[j] = *(const bf16x8 *)(Bb + j * 16 * 128 + ch1);     \
+        _Pragma("unroll") for (int i = 0; i < MT1; i++) af[i] = *(const bf16x8 *)(Ab + i * 16 * 128 + ch1);    \
+        _Pragma("unroll") for (int j = 0; j < NT1; j++) bfr[j] = *(const bf16x8 *)(Bb + j * 16 * 128 + ch1);   \
         if (ISSUE) {                                                                                           \
-            RCV_BLK_ISSUE(st2, 3, 6, true);                                                                    \
-            asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");                                        \
+            RCV_BLK_ISSUE(st2, H1, NP1, true);                                                                 \
+            RCV_BLK_VMWAIT(NP1);                                                                               \
         } else {                                                                                               \
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                        \
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                   \
         }                                                                                                      \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                     \
         __builtin_amdgcn_s_barrier();                                                                          \
         __builtin_amdgcn_s_setprio(1);                                                                         \
-        _Pragma("unroll") for (int i = 0; i < 4; i++)                                                          \
-            _Pragma("unroll") for (int j = 0; j < 4; j++)                                                      \
+        _Pragma("unroll") for (int i = 0; i < MT1; i++)                                                        \
+            _Pragma("unroll") for (int j = 0; j < NT1; j++)                                                    \
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);        \
         __builtin_amdgcn_s_setprio(0);                                                                         \
         __builtin_amdgcn_s_barrier();                                                                          \
@@ -887,9 +907,9 @@ __global__ __launch_bounds__(512) void k_conv_block(const BlockParams p)
 
     const int nk = K1 / KE;  // >= 9
     const int grp = wave >> 2;
-    RCV_BLK_ISSUE(0, 0, 6, true);
-    RCV_BLK_ISSUE(1, 0, 6, true);
-    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    RCV_BLK_ISSUE(0, 0, NP1, true);
+    RCV_BLK_ISSUE(1, 0, NP1, true);
+    RCV_BLK_VMWAIT(NP1);
     __builtin_amdgcn_s_barrier();
     if (grp == 1) __builtin_amdgcn_s_barrier();
     int stage = 0;
@@ -899,74 +919,76 @@ __global__ __launch_bounds__(512) void k_conv_block(const BlockParams p)
     if (grp == 0) __builtin_amdgcn_s_barrier();
 #undef RCV_BLK_STEP
 #undef RCV_BLK_ISSUE
+#undef RCV_BLK_VMWAIT
     __syncthreads();  // every wave is done with the operand stages; no DMA is in flight
 
-    // ---- hand-over: mid = bf16(relu(acc + b1)) into the phase-2 A operand.  acc[i][j][e] = channel wn*64 + j*16 + kq*4 + e
-    // of pixel wm*64 + i*16 + r16: K slab wn, 16-byte chunk j*2 + (kq>>1), upper / lower half by kq & 1
-    // LDS map of phase 2.  Plain: A2 [0, 64K), W ring [64K, 112K), residual [112K, 144K).  Chained: A2 only lives in LDS
-    // until every wave has copied its rows into registers as MFMA fragments; then W ring [0, 48K), residual / output chunk
-    // [48K, 80K), two 32 KB slots for the reduce layer's weights [80K, 144K).
+    // ---- hand-over: mid = bf16(relu(acc + b1)) into the phase-2 A operand (K slabs of [128 rows][128 B], the DMA tiles'
+    // chunk swizzle).  acc[i][j][e] = channel wn*(CMID/WN1) + j*16 + kq*4 + e of pixel wm*(128/WM1) + i*16 + r16
+    // LDS map of phase 2.  Plain: A2, then the W ring, then the residual tile.  Chained: A2 only lives in LDS until every wave
+    // has copied its rows into registers as MFMA fragments; then W ring [0, 48K), residual / output chunk [48K, 80K), two
+    // slots of CMID x 128 B for the reduce layer's weights behind it.
     unsigned char *sA2 = smem;
-    unsigned char *sW = CHAIN ? smem : smem + BLK_A2;
-    unsigned char *sR = CHAIN ? smem + BLK_RING * BLK_SLOT : smem + BLK_A2 + BLK_RING * BLK_SLOT;
-    unsigned char *sW3 = smem + BLK_RING * BLK_SLOT + BLK_BM * 256;  // CHAIN only
+    unsigned char *sW = CHAIN ? smem : smem + A2_BYTES;
+    unsigned char *sR = sW + BLK_RING * BLK_SLOT;
+    unsigned char *sW3 = sR + BM * 256;  // CHAIN only
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const int row = wm * 64 + i * 16 + r16;
+    for (int i = 0; i < MT1; i++) {
+        const int row = wm * (BM / WM1) + i * 16 + r16;
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
+        for (int j = 0; j < NT1; j++) {
             uint2 pk;
             T *pv = (T *)&pk;
 #pragma unroll
             for (int e = 0; e < 4; e++) pv[e] = (T)fmaxf(acc[i][j][e] + bias1[j][e], 0.f);
-            const int chunk = j * 2 + (kq >> 1);
-            *(uint2 *)(sA2 + wn * (BM * 128) + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4) + (kq & 1) * 8) = pk;
+            const int chn = wn * (CMID / WN1) + j * 16 + kq * 4;  // first of the four channels
+            const int slab = chn >> 6, chunk = (chn & 63) >> 3;
+            *(uint2 *)(sA2 + slab * (BM * 128) + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4) + (kq & 1) * 8) = pk;
         }
     }
     // phase-2 wave tile: 32 pixels x 64 channels (8 waves = 4 x 2), so that the two 16-byte stores a lane makes per pixel
     // group complete a 128-byte line (64 channels) of the output row
     const int wm2 = wave >> 1, wn2 = wave & 1;
-    bf16x8 a2f[2][8];  // CHAIN: this wave's 32 rows of `mid` as fragments, [pixel group][K chunk of 32]
+    bf16x8 a2f[2][CMID / 32];  // CHAIN: this wave's 32 rows of `mid` as fragments, [pixel group][K chunk of 32]
     if (CHAIN) {
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < 2; i++)
 #pragma unroll
-            for (int k8 = 0; k8 < 8; k8++)
+            for (int k8 = 0; k8 < CMID / 32; k8++)
                 a2f[i][k8] = *(const bf16x8 *)(sA2 + (k8 >> 1) * (BM * 128) + (wm2 * 32 + i * 16 + r16) * 128 + ((k8 & 1) ? ch1 : ch0));
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __syncthreads();  // A2's LDS is free for the weight ring
     }
+    __syncthreads();  // `mid` is complete (plain) / its LDS is free for the weight ring (chained)
 
-    // ---- phase 2 loaders.  Weights of stream step s = (chunk nc = s / 4, K slice ks = s % 4): 128 rows (out channels) x 128 B
-    // -> 2 pieces per wave; residual of chunk nc: 128 pixels x 256 B -> 4 pieces per wave (4 rows each); chained reduce layer:
-    // two K slices of 64 per chunk, 256 rows (out channels) x 128 B each -> 4 pieces per wave and slice
+    // ---- phase 2 loaders.  Weights of stream step s = (chunk nc = s / KS2, K slice ks = s % KS2): 128 rows (out channels) x
+    // 128 B -> 2 pieces per wave; residual of chunk nc: 128 pixels x 256 B -> 4 pieces per wave (4 rows each); chained reduce
+    // layer: two K slices of 64 per chunk, CMID rows (out channels) x 128 B each -> W3P pieces per wave and slice
     int w_off[2];
 #pragma unroll
     for (int c = 0; c < 2; c++) {
         const int row = wave * 16 + c * 8 + lrow;
-        w_off[c] = (row * BLK_CMID + (lpos ^ ((row >> 1) & 7)) * EPV) * 2;
+        w_off[c] = (row * CMID + (lpos ^ ((row >> 1) & 7)) * EPV) * 2;
     }
     int r_off[4];
 #pragma unroll
     for (int c = 0; c < 4; c++) {
         const int row = wave * 16 + c * 4 + (lane >> 4), slot = lane & 15;  // 4 rows x 16 chunks per piece
-        r_off[c] = m0 + row < p.M ? (int)(((long long)(m0 + row) * BLK_COUT + (slot ^ (row & 15)) * EPV) * 2) : OOB;
+        r_off[c] = m0 + row < p.M ? (int)(((long long)(m0 + row) * COUT + (slot ^ (row & 15)) * EPV) * 2) : OOB;
     }
-    int w3_off[4];
+    int w3_off[W3P];
 #pragma unroll
-    for (int c = 0; c < 4; c++) {
-        const int row = wave * 32 + c * 8 + lrow;
-        w3_off[c] = (row * BLK_COUT + (lpos ^ ((row >> 1) & 7)) * EPV) * 2;
+    for (int c = 0; c < W3P; c++) {
+        const int row = wave * (8 * W3P) + c * 8 + lrow;
+        w3_off[c] = (row * COUT + (lpos ^ ((row >> 1) & 7)) * EPV) * 2;
     }
     const T *w3 = CHAIN ? (const T *)p.w3 + (long long)g * p.w3_gs : nullptr;
-    const int w_bytes = 128 * BLK_CMID * 2, w3_bytes = BLK_CMID * BLK_COUT * 2;
-    const long long res_bytes_ll = (long long)p.M * BLK_COUT * 2;
+    const int w_bytes = 128 * CMID * 2, w3_bytes = CMID * COUT * 2;
+    const long long res_bytes_ll = (long long)p.M * COUT * 2;
     const int res_bytes = res_bytes_ll > 0x7fffffffLL ? 0x7fffffff : (int)res_bytes_ll;
 #define RCV_BLK_W(s_)                                                                                          \
     {                                                                                                          \
-        const int nc_ = (s_) >> 2, ks_ = (s_) & 3;                                                             \
-        const char *wb_ = (const char *)w2 + ((long long)nc_ * 128 * BLK_CMID + ks_ * KE) * 2;                 \
+        const int nc_ = (s_) / KS2, ks_ = (s_) % KS2;                                                          \
+        const char *wb_ = (const char *)w2 + ((long long)nc_ * 128 * CMID + ks_ * KE) * 2;                     \
         unsigned char *slot_ = sW + ((s_) % BLK_RING) * BLK_SLOT;                                              \
         _Pragma("unroll") for (int c = 0; c < 2; c++) blk_dma16(wb_, w_bytes, slot_ + (wave * 16 + c * 8) * 128, w_off[c]); \
     }
@@ -979,44 +1001,51 @@ __global__ __launch_bounds__(512) void k_conv_block(const BlockParams p)
     {                                                                                                          \
         _Pragma("unroll") for (int h = 0; h < 2; h++) {                                                        \
             const char *wb_ = (const char *)w3 + ((long long)(nc_) * 128 + h * KE) * 2;                        \
-            _Pragma("unroll") for (int c = 0; c < 4; c++)                                                      \
-                blk_dma16(wb_, w3_bytes, sW3 + h * (BLK_CMID * 128) + (wave * 32 + c * 8) * 128, w3_off[c]);   \
+            _Pragma("unroll") for (int c = 0; c < W3P; c++)                                                    \
+                blk_dma16(wb_, w3_bytes, sW3 + h * (CMID * 128) + (wave * (8 * W3P) + c * 8) * 128, w3_off[c]); \
         }                                                                                                      \
     }
-    // order of issue per wave: at the first step of a chunk R(nc) [4 pieces] and, chained, both reduce-weight slices [8]; then
-    // W(s + 2) [2] at every step s.  At the top of step s the pieces issued after W(s) are W(s + 1) and, when step s - 1
-    // opened a chunk, that chunk's R (and W3): vmcnt 2, or 6 / 14.
+    // order of issue per wave: at the first step of a chunk R(nc) [4 pieces] and, chained, both reduce-weight slices
+    // [2 * W3P]; then W(s + 2) [2] at every step s < S2 - 2.  At the top of step s the pieces issued after W(s) are those
+    // of step s - 1: W(s + 1) and, when step s - 1 opened a chunk, that chunk's R (and W3).
+    constexpr int OPEN_PIECES = 4 + (CHAIN ? 2 * W3P : 0);
     RCV_BLK_W(0);
-    RCV_BLK_W(1);
-    f32x4 acc3[2][8];  // CHAIN: [pixel group][16-channel tile of this wave's 128 reduce outputs]
+    if (S2 > 1) RCV_BLK_W(1);
+    f32x4 acc3[2][NT3];  // CHAIN: [pixel group][16-channel tile of this wave's CMID / 2 reduce outputs]
     if (CHAIN) {
 #pragma unroll
         for (int i = 0; i < 2; i++)
 #pragma unroll
-            for (int j = 0; j < 8; j++) acc3[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < NT3; j++) acc3[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
 #pragma unroll
-    for (int nc = 0; nc < 8; nc++) {
+    for (int nc = 0; nc < NCH; nc++) {
         f32x4 a2[2][4];
 #pragma unroll
         for (int i = 0; i < 2; i++)
 #pragma unroll
             for (int j = 0; j < 4; j++) a2[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int ks = 0; ks < 4; ks++) {
-            const int s_ = nc * 4 + ks;
-            if (ks == 1) {
-                if (CHAIN) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+        for (int ks = 0; ks < KS2; ks++) {
+            const int s_ = nc * KS2 + ks;
+            // younger pieces: W(s_ + 1) and the chunk-opening pieces of step s_ - 1; the last step simply drains
+            if (s_ + 1 >= S2) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            } else if (s_ >= 1 && (s_ - 1) % KS2 == 0) {
+                if constexpr (OPEN_PIECES + 2 == 14) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+                else if constexpr (OPEN_PIECES + 2 == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+                else if constexpr (OPEN_PIECES + 2 == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
                 else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-            } else if (s_ == 31) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();  // step s_ has landed for everybody; slot (s_ + 2) % 3 and (ks == 0) sR / sW3 are free
             if (ks == 0) {
                 RCV_BLK_R(nc);
                 if (CHAIN) RCV_BLK_W3(nc);
             }
-            if (s_ + 2 < 32) RCV_BLK_W(s_ + 2);
+            if (s_ + 2 < S2) RCV_BLK_W(s_ + 2);
             const unsigned char *Ab = sA2 + ks * (BM * 128) + (wm2 * 32 + r16) * 128;
             const unsigned char *Bb = sW + (s_ % BLK_RING) * BLK_SLOT + (wn2 * 64 + r16) * 128;
 #pragma unroll
@@ -1033,9 +1062,16 @@ __global__ __launch_bounds__(512) void k_conv_block(const BlockParams p)
                     for (int j = 0; j < 4; j++) a2[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], a2[i][j], 0, 0, 0);
             }
         }
-        // epilogue of the chunk.  R(nc) was issued at the chunk's first step: every wave has waited for it at the top of the
-        // fourth step (vmcnt 2 leaves only W pieces) and passed that step's barrier.  Chained: the rounded outputs go back
-        // into the residual's LDS slot, where they are the A operand (K = this chunk's 128 channels) of the reduce layer.
+        // epilogue of the chunk.  R(nc) (and the reduce weights) were issued at the chunk's first step; with four K steps per
+        // chunk the later waits (vmcnt 2) already cover them, with one or two steps they are waited for here.
+        if (KS2 <= 2) {
+            // (after them only W(s + 2) of the opening step and W(s + 3) of the next were issued: four pieces, none at the end)
+            if (KS2 == 1 || nc == NCH - 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+        // Chained: the rounded outputs go back into the residual's LDS slot, where they are the A operand (K = this chunk's
+        // 128 channels) of the reduce layer.
 #pragma unroll
         for (int i = 0; i < 2; i++) {
             const int row = wm2 * 32 + i * 16 + r16, m = m0 + row;
@@ -1060,12 +1096,12 @@ __global__ __launch_bounds__(512) void k_conv_block(const BlockParams p)
                 T *op = (T *)&outv;
 #pragma unroll
                 for (int e = 0; e < 8; e++) op[e] = (T)v[e];
-                if (m < p.M) *(uint4 *)(dst + (long long)m * BLK_COUT + nc * 128 + e_ch) = outv;
+                if (m < p.M) *(uint4 *)(dst + (long long)m * COUT + nc * 128 + e_ch) = outv;
                 if (CHAIN) *(uint4 *)rslot = outv;
             }
         }
         if (CHAIN) {
-            // reduce layer, K slab of this chunk: acc3 += Y[32 px x 128] * W3[128 out x 128]^T.  Both weight slices were
+            // reduce layer, K slab of this chunk: acc3 += Y[32 px x 128] * W3[CMID/2 out x 128]^T.  Both weight slices were
             // issued at the chunk's first step and are older than everything the later steps waited for.
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();  // every wave's part of Y is in LDS
@@ -1079,17 +1115,18 @@ __global__ __launch_bounds__(512) void k_conv_block(const BlockParams p)
                         const int row = wm2 * 32 + i * 16 + r16;
                         yf[i] = *(const bf16x8 *)(sR + row * 256 + (((h * 8 + kk * 4 + kq) ^ (row & 15)) << 4));
                     }
-                    const unsigned char *Bb = sW3 + h * (BLK_CMID * 128) + (wn2 * 128 + r16) * 128 + (kk ? ch1 : ch0);
+                    const unsigned char *Bb = sW3 + h * (CMID * 128) + (wn2 * (CMID / 2) + r16) * 128 + (kk ? ch1 : ch0);
+                    constexpr int JG = NT3 < 4 ? NT3 : 4;
 #pragma unroll
-                    for (int jh = 0; jh < 2; jh++) {
-                        bf16x8 bfr[4];
+                    for (int jh = 0; jh < NT3 / JG; jh++) {
+                        bf16x8 bfr[JG];
 #pragma unroll
-                        for (int j = 0; j < 4; j++) bfr[j] = *(const bf16x8 *)(Bb + (jh * 4 + j) * 16 * 128);
+                        for (int j = 0; j < JG; j++) bfr[j] = *(const bf16x8 *)(Bb + (jh * JG + j) * 16 * 128);
 #pragma unroll
                         for (int i = 0; i < 2; i++)
 #pragma unroll
-                            for (int j = 0; j < 4; j++)
-                                acc3[i][jh * 4 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], yf[i], acc3[i][jh * 4 + j], 0, 0, 0);
+                            for (int j = 0; j < JG; j++)
+                                acc3[i][jh * JG + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], yf[i], acc3[i][jh * JG + j], 0, 0, 0);
                     }
                 }
         }
@@ -1101,8 +1138,8 @@ __global__ __launch_bounds__(512) void k_conv_block(const BlockParams p)
         for (int i = 0; i < 2; i++) {
             const int row = wm2 * 32 + i * 16 + r16, m = m0 + row;
 #pragma unroll
-            for (int pr = 0; pr < 4; pr++) {
-                const int e_ch = wn2 * 128 + (2 * pr + (kq & 1)) * 16 + (kq >> 1) * 8;
+            for (int pr = 0; pr < NT3 / 2; pr++) {
+                const int e_ch = wn2 * (CMID / 2) + (2 * pr + (kq & 1)) * 16 + (kq >> 1) * 8;
                 float v[8];
 #pragma unroll
                 for (int e = 0; e < 4; e++) {
@@ -1110,13 +1147,13 @@ __global__ __launch_bounds__(512) void k_conv_block(const BlockParams p)
                     v[e] = __uint_as_float(sw[0]);
                     v[4 + e] = __uint_as_float(sw[1]);
                 }
-                const float4 bA = *(const float4 *)(sB2 + BLK_COUT + e_ch), bB = *(const float4 *)(sB2 + BLK_COUT + e_ch + 4);
+                const float4 bA = *(const float4 *)(sB2 + COUT + e_ch), bB = *(const float4 *)(sB2 + COUT + e_ch + 4);
                 const float bb[8] = {bA.x, bA.y, bA.z, bA.w, bB.x, bB.y, bB.z, bB.w};
                 uint4 outv;
                 T *op = (T *)&outv;
 #pragma unroll
                 for (int e = 0; e < 8; e++) op[e] = (T)fmaxf(v[e] + bb[e], 0.f);
-                if (m < p.M) *(uint4 *)(dst3 + (long long)m * BLK_CMID + e_ch) = outv;
+                if (m < p.M) *(uint4 *)(dst3 + (long long)m * CMID + e_ch) = outv;
             }
         }
     }
@@ -1661,13 +1698,18 @@ int forward_impl(rcv_fcn *h, const float *x, int B, float *seg, float *radial, c
             if (h->use_block && i + 1 < h->ops.size() && h->ops[i].kind == RCV_OP_CONV && h->ops[i + 1].kind == RCV_OP_CONV) {
                 const rcv_op &a = h->ops[i], &b = h->ops[i + 1];
                 const long long M = (long long)B * a.hout * a.wout;
-                if (a.ksize == 3 && a.pad == 1 && a.cout == BLK_CMID && a.c0 % 64 == 0 && a.src1 < 0 && a.res < 0 && a.relu &&
-                    b.ksize == 1 && b.stride == 1 && b.pad == 0 && b.c0 == BLK_CMID && b.cout == BLK_COUT && b.src0 == a.dst &&
+                const int cmid = a.cout;
+                if (a.ksize == 3 && a.pad == 1 && (cmid == 64 || cmid == 128 || cmid == 256) && a.c0 == cmid && a.src1 < 0 && a.res < 0 &&
+                    a.relu && b.ksize == 1 && b.stride == 1 && b.pad == 0 && b.c0 == cmid && b.cout == 4 * cmid && b.src0 == a.dst &&
                     b.src1 < 0 && b.res >= 0 && b.relu && b.hout == a.hout && b.wout == a.wout && b.dst != a.src0 && b.dst != b.res &&
-                    (M + BLK_BM - 1) / BLK_BM * h->groups >= 192 && M * BLK_COUT * 2 < 0x7fffffffLL) {
+                    (M + BLK_BM - 1) / BLK_BM * h->groups >= 192 && M * 4 * cmid * 2 < 0x7fffffffLL) {
                     if (!h->attrs_set) {
-                        RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_conv_block<false>, hipFuncAttributeMaxDynamicSharedMemorySize, BLK_LDS));
-                        RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_conv_block<true>, hipFuncAttributeMaxDynamicSharedMemorySize, BLK_LDS));
+                        RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_conv_block<64, false>, hipFuncAttributeMaxDynamicSharedMemorySize, blk_lds(64)));
+                        RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_conv_block<64, true>, hipFuncAttributeMaxDynamicSharedMemorySize, blk_lds(64)));
+                        RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_conv_block<128, false>, hipFuncAttributeMaxDynamicSharedMemorySize, blk_lds(128)));
+                        RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_conv_block<128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, blk_lds(128)));
+                        RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_conv_block<256, false>, hipFuncAttributeMaxDynamicSharedMemorySize, blk_lds(256)));
+                        RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_conv_block<256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, blk_lds(256)));
                     }
                     auto gs = [&](int s) -> long long { return (long long)h->slot_elems[s] * B; };
                     BlockParams q;
@@ -1684,7 +1726,7 @@ int forward_impl(rcv_fcn *h, const float *x, int B, float *seg, float *radial, c
                     if (h->use_chain && i + 2 < h->ops.size() && h->ops[i + 2].kind == RCV_OP_CONV) {
                         const rcv_op &c = h->ops[i + 2];
                         // (its output must not share a slot with anything the kernel still reads: other tiles are in flight)
-                        chain = c.ksize == 1 && c.stride == 1 && c.pad == 0 && c.c0 == BLK_COUT && c.cout == BLK_CMID && c.src0 == b.dst &&
+                        chain = c.ksize == 1 && c.stride == 1 && c.pad == 0 && c.c0 == 4 * cmid && c.cout == cmid && c.src0 == b.dst &&
                                 c.src1 < 0 && c.res < 0 && c.relu && c.hout == b.hout && c.wout == b.wout && c.dst != a.src0 &&
                                 c.dst != b.res && c.dst != b.dst;
                         if (chain) {
@@ -1695,8 +1737,16 @@ int forward_impl(rcv_fcn *h, const float *x, int B, float *seg, float *radial, c
                     const int fused = chain ? 3 : 2;
                     if (h->profiling) RCV_HIP_CHECK(hipEventRecord(h->events[2 * i], st));  // time booked on the 3x3 convolution
                     const dim3 grid((unsigned)((M + BLK_BM - 1) / BLK_BM), 1, h->groups);
-                    if (chain) hipLaunchKernelGGL(k_conv_block<true>, grid, dim3(512), BLK_LDS, st, q);
-                    else hipLaunchKernelGGL(k_conv_block<false>, grid, dim3(512), BLK_LDS, st, q);
+                    if (cmid == 256) {
+                        if (chain) hipLaunchKernelGGL((k_conv_block<256, true>), grid, dim3(512), blk_lds(256), st, q);
+                        else hipLaunchKernelGGL((k_conv_block<256, false>), grid, dim3(512), blk_lds(256), st, q);
+                    } else if (cmid == 128) {
+                        if (chain) hipLaunchKernelGGL((k_conv_block<128, true>), grid, dim3(512), blk_lds(128), st, q);
+                        else hipLaunchKernelGGL((k_conv_block<128, false>), grid, dim3(512), blk_lds(128), st, q);
+                    } else {
+                        if (chain) hipLaunchKernelGGL((k_conv_block<64, true>), grid, dim3(512), blk_lds(64), st, q);
+                        else hipLaunchKernelGGL((k_conv_block<64, false>), grid, dim3(512), blk_lds(64), st, q);
+                    }
                     RCV_LAUNCH_CHECK();
                     if (h->profiling)
                         for (int e = 1; e < 2 * fused; e++) RCV_HIP_CHECK(hipEventRecord(h->events[2 * i + e], st));
