@@ -268,7 +268,7 @@ int rcv_fcn_debug_slot(rcv_fcn *h, const void *ws, int B, int g, int slot, float
 int rcv_fcn_set_profiling(rcv_fcn *h, int enable);
 /* Engine options (A-B tests; all default 1, bf16 engines only): key 1 = LDS-DMA convolution kernel where it applies
  * (k_conv_dma), key 2 = MFMA stem (k_stem_mfma; 0: direct kernel with fp32 input), key 3 = fused last upsampling + conv7
- * + head (k_tail; 0: three kernels, bit-identical output), key 4 = fused 3x3 + expand 1x1 of the layer-3 bottleneck blocks
+ * + head (k_tail; 0: three kernels, bit-identical output), key 4 = fused 3x3 + expand 1x1 of the stride-1 bottleneck blocks (layers 1-3)
  * (k_conv_block; 0: two kernels, bit-identical output), key 5 = chain the next block's 1x1 reduce into k_conv_block where it
  * follows directly (0: separate kernel, bit-identical output). */
 int rcv_fcn_set_option(rcv_fcn *h, int key, int value);
