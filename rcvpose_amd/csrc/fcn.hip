@@ -1680,6 +1680,45 @@ int run_op(rcv_fcn *h, const rcv_op &op, const float *x, int B, float *seg, floa
     }
 }
 
+// The kernels with more than 64 KB of dynamic LDS need their limit raised once per process.  Done for every variant
+// up front (rcv_fcn_create): which variant a layer uses depends on the batch size of the call, not only on the engine.
+template <typename T, int BM, int BN>
+int register_conv_variant()
+{
+    RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_conv<T, BM, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (BM + BN) * 128 * 2));
+    return RCV_OK;
+}
+template <typename T>
+int register_conv_variants()
+{
+    int rc;
+    if ((rc = register_conv_variant<T, 128, 128>()) != RCV_OK) return rc;
+    if ((rc = register_conv_variant<T, 64, 128>()) != RCV_OK) return rc;
+    if ((rc = register_conv_variant<T, 128, 64>()) != RCV_OK) return rc;
+    if ((rc = register_conv_variant<T, 64, 64>()) != RCV_OK) return rc;
+    if ((rc = register_conv_variant<T, 128, 32>()) != RCV_OK) return rc;
+    return register_conv_variant<T, 64, 32>();
+}
+int register_kernel_attributes()
+{
+    static bool done = false;
+    if (done) return RCV_OK;
+    int rc;
+    if ((rc = register_conv_variants<float>()) != RCV_OK) return rc;
+    if ((rc = register_conv_variants<__bf16>()) != RCV_OK) return rc;
+    RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_conv_dma, hipFuncAttributeMaxDynamicSharedMemorySize, DMA_STAGES * DMA_STAGE_BYTES));
+    RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_stem_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, STEM_LDS));
+    RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_tail, hipFuncAttributeMaxDynamicSharedMemorySize, TAIL_LDS));
+    RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_conv_block<64, false>, hipFuncAttributeMaxDynamicSharedMemorySize, blk_lds(64)));
+    RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_conv_block<64, true>, hipFuncAttributeMaxDynamicSharedMemorySize, blk_lds(64)));
+    RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_conv_block<128, false>, hipFuncAttributeMaxDynamicSharedMemorySize, blk_lds(128)));
+    RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_conv_block<128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, blk_lds(128)));
+    RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_conv_block<256, false>, hipFuncAttributeMaxDynamicSharedMemorySize, blk_lds(256)));
+    RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_conv_block<256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, blk_lds(256)));
+    done = true;
+    return RCV_OK;
+}
+
 template <typename T>
 int forward_impl(rcv_fcn *h, const float *x, int B, float *seg, float *radial, char *ws, hipStream_t st)
 {
@@ -1819,6 +1858,10 @@ int rcv_fcn_create(const rcv_op *ops, int n_ops, int n_slots, const int64_t *slo
         const int slots[4] = {o.src0, o.src1, o.res, o.dst};
         for (int s : slots)
             if (s >= n_slots || s < -3) return RCV_E_INVALID;
+    }
+    {
+        const int rc = register_kernel_attributes();
+        if (rc != RCV_OK) return rc;
     }
     rcv_fcn *h = new rcv_fcn();
     h->ops.assign(ops, ops + n_ops);

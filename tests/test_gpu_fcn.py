@@ -246,3 +246,15 @@ def test_resfcn_model_vs_golden(golden_dir):
     er, es = _rel(rad_b.cpu().numpy(), g["radial"]), _rel(seg_b.cpu().numpy(), g["seg"])
     print("resfcn bf16 relative error: radial %.3e seg %.3e" % (er, es))
     assert er <= REL_BF16 and es <= REL_BF16
+
+
+def test_batch_size_may_grow_between_calls(shapes, state_dict):
+    """One engine, first a small batch (register-staged kernels only), then a large one (LDS-DMA and fused kernels with
+    > 64 KB of dynamic LDS): the large-LDS kernels are registered at engine creation, not by the first forward."""
+    from rcvpose_amd.fcn_engine import FcnEngine
+
+    eng = FcnEngine([state_dict, _sd(shapes, 1), _sd(shapes, 2)], 480, 640, dtype="bf16")
+    x = torch.from_numpy(fcn_weights.make_input(17, (9, 3, 480, 640))).cuda()
+    seg1, rad1 = [t.clone() for t in eng.forward(x[:1])]
+    seg9, rad9 = [t.clone() for t in eng.forward(x)]
+    assert torch.equal(seg9[:, :1], seg1) and torch.equal(rad9[:, :1], rad1)
