@@ -6,7 +6,8 @@
 //
 //   k_conv<T,BM,BN>  implicit-GEMM convolution on the matrix cores, im2col-free:
 //                    out[m, n] = act( sum_{tap,c} in[pixel(m) + tap, c] * w[n, tap, c] + bias[n] (+ res[m, n]) )
-//                    M = B*Hout*Wout pixels, N = Cout, K = KH*KW*(C0+C1).  The A operand is gathered on the
+//                    M = B*Hout*Wout pixels, N = Cout, K = KH*KW*(C0+C1), walked 64-channel slice by slice with the taps
+//                    innermost (L2 reuse of the shifted reads).  The A operand is gathered on the
 //                    fly from one or two channel-concatenated sources (torch.cat is never materialised),
 //                    zero-filled at the borders, staged through XOR-swizzled LDS tiles (16-byte chunk ^= (row>>1)&7:
 //                    the 16 lanes of a ds_read_b128 group land on 16 distinct slots of the 256-byte bank row) with register
@@ -142,8 +143,7 @@ __global__ __launch_bounds__(256) void k_conv(const ConvParams p)
             if (LIVE) w_ = *(const uint4 *)(wg + (long long)(n0 + rowb + 32 * q) * p.K + kcol_);             \
             RB[q] = w_;                                                                                      \
         }                                                                                                    \
-        cg += KE;                                                                                            \
-        if (cg == Ctot) { cg = 0; if (++tap_s == p.KS) { tap_s = 0; ++tap_r; } }                             \
+        if (++tap_s == p.KS) { tap_s = 0; if (++tap_r == p.KS) { tap_r = 0; cg += KE; } }                    \
     }
 // registers -> XOR-swizzled LDS tile
 #define RCV_STASH(buf, RA, RB)                                                                                     \
@@ -412,13 +412,13 @@ __global__ __launch_bounds__(512) void k_conv_dma(const ConvParams p)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rb_, (__attribute__((address_space(3))) void *)(Bs_ + (wave * 16 + c * 8) * 128), 16, b_off[c], 0, 0, 0); \
         }                                                                                                      \
         if (ADV) {                                                                                             \
-            cg += KE;                                                                                          \
-            const bool wrap_ = cg == Ctot;                                                                     \
-            cg = wrap_ ? 0 : cg;                                                                               \
-            tap_s += wrap_ ? 1 : 0;                                                                            \
-            const bool wrap2_ = tap_s == p.KS;                                                                 \
-            tap_s = wrap2_ ? 0 : tap_s;                                                                        \
-            tap_r += wrap2_ ? 1 : 0;                                                                           \
+            tap_s += 1;                                                                                        \
+            const bool wrap_ = tap_s == p.KS;                                                                  \
+            tap_s = wrap_ ? 0 : tap_s;                                                                         \
+            tap_r += wrap_ ? 1 : 0;                                                                            \
+            const bool wrap2_ = tap_r == p.KS;                                                                 \
+            tap_r = wrap2_ ? 0 : tap_r;                                                                        \
+            cg += wrap2_ ? KE : 0;                                                                             \
         }                                                                                                      \
     }
 
@@ -844,13 +844,13 @@ __global__ __launch_bounds__(512) void k_conv_block(const BlockParams p)
                 blk_dma16(bbase_, b_bytes, Bs_ + (wave * (8 * BPW1) + c * 8) * 128, b_off[c]);                 \
         }                                                                                                      \
         if (ADV) {                                                                                             \
-            cg += KE;                                                                                          \
-            const bool wrap_ = cg == p.C0;                                                                     \
-            cg = wrap_ ? 0 : cg;                                                                               \
-            tap_s += wrap_ ? 1 : 0;                                                                            \
-            const bool wrap2_ = tap_s == KS;                                                                   \
-            tap_s = wrap2_ ? 0 : tap_s;                                                                        \
-            tap_r += wrap2_ ? 1 : 0;                                                                           \
+            tap_s += 1;                                                                                        \
+            const bool wrap_ = tap_s == KS;                                                                    \
+            tap_s = wrap_ ? 0 : tap_s;                                                                         \
+            tap_r += wrap_ ? 1 : 0;                                                                            \
+            const bool wrap2_ = tap_r == KS;                                                                   \
+            tap_r = wrap2_ ? 0 : tap_r;                                                                        \
+            cg += wrap2_ ? KE : 0;                                                                             \
         }                                                                                                      \
     }
 #define RCV_BLK_VMWAIT(N)                                                                                      \
