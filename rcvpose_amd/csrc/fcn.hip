@@ -762,7 +762,14 @@ __global__ __launch_bounds__(512) void k_conv_block(const BlockParams p)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN1, wn = wave % WN1;
-    const int g = blockIdx.z, m0 = blockIdx.x * BM;
+    // consecutive pixel tiles (which share their halo rows) on the same XCD: bijective remap of the round-robin dispatch
+    int tile_;
+    {
+        const unsigned total = gridDim.x, id = blockIdx.x;
+        const unsigned q = total / 8, r = total % 8, xcd = id % 8;
+        tile_ = (int)((xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + id / 8);
+    }
+    const int g = blockIdx.z, m0 = tile_ * BM;
     const int lrow = lane >> 3, lpos = lane & 7;
     const int r16 = lane & 15, kq = lane >> 4;
     const T *src = (const T *)p.src + (long long)g * p.src_gs;
