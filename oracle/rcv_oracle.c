@@ -7,7 +7,7 @@
  *
  * Every function restates (in plain C, own code) the arithmetic of the reference
  * aaronWool/rcvpose, file AccumulatorSpace.py, and cites the lines it follows.  It is pinned
- * to the reference by tests/golden/*.npz, which were produced by running the reference's own
+ * to the reference by the .npz files of tests/golden, which were produced by running the reference's own
  * source (tests/golden/make_golden.py): exact vote grids, exact tie lists, centres.
  *
  * Arithmetic contract (all IEEE-754 binary64 unless noted, no FMA contraction: build with
