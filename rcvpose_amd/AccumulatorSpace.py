@@ -23,7 +23,13 @@ linemod_K = np.array([[572.4114, 0., 325.2611],
 lm_cls_names = ['ape', 'benchvise', 'cam', 'can', 'cat', 'duck', 'driller', 'eggbox', 'glue', 'holepuncher', 'iron', 'lamp',
                 'phone']
 lmo_cls_names = ['ape', 'can', 'cat', 'duck', 'driller', 'eggbox', 'glue', 'holepuncher']
+ycb_cls_names = {1: '002_master_chef_can', 2: '003_cracker_box', 3: '004_sugar_box', 4: '005_tomato_soup_can', 5: '006_mustard_bottle',
+                 6: '007_tuna_fish_can', 7: '008_pudding_box', 8: '009_gelatin_box', 9: '010_potted_meat_can', 10: '011_banana',
+                 11: '019_pitcher_base', 12: '021_bleach_cleanser', 13: '024_bowl', 14: '025_mug', 15: '035_power_drill',
+                 16: '036_wood_block', 17: '037_scissors', 18: '040_large_marker', 19: '051_large_clamp', 20: '052_extra_large_clamp',
+                 21: '061_foam_brick'}
 lm_syms = ['eggbox', 'glue']
+ycb_syms = ['024_bowl', '036_wood_block', '051_large_clamp', '052_extra_large_clamp', '061_foam_brick']
 add_threshold = {
     'eggbox': 0.019735770122546523, 'ape': 0.01421240983190395, 'cat': 0.018594838977253875, 'cam': 0.02222763033276377,
     'duck': 0.015569664208967385, 'glue': 0.01930723067998101, 'can': 0.028415044264086586, 'driller': 0.031877906042,
@@ -213,9 +219,10 @@ def FCResBackbone(model, input_img_path, normalized_depth=None):
 
 
 # ---------------------------------------------------------------------------------------------------
-# Dataset ingest + the evaluation driver: reference AccumulatorSpace.py:64-75, :482-490,
-# :495-740.  The hot loop runs in rcvpose_amd.pipeline.FramePipeline; the Horn fit on the device (f-1).
-# Not reproduced: Open3D ICP refinement and the ADD(-S) after ICP (f-3, third-party C++ in the reference).
+# Dataset ingest + the evaluation drivers: reference AccumulatorSpace.py:64-75, :482-490,
+# :495-740 (LINEMOD), :742-974 (Occlusion LINEMOD), :976-1197 (YCB-Video), :1202-1227 (command line).  The hot loop runs in
+# rcvpose_amd.pipeline.FramePipeline; the Horn fit (f-1), ADD(-S) and the ICP refinement (f-3, rcvpose_amd.registration)
+# on the device.
 # ---------------------------------------------------------------------------------------------------
 def project(xyz, K, RT):
     """reference AccumulatorSpace.py:64-75: xyz [N,3], K [3,3], RT [3,4] -> (pixel xy [N,2], camera-frame xyz [N,3])."""
@@ -292,9 +299,12 @@ def scene_cloud_of_keypoint_masks(seg_maps, radial_maps, depth_dev, max_radii_dm
 
 
 def _pose_and_add(class_name, xyz_load, keypoints, estimated_kpts, RTGT_mm, seg_maps, rad_maps, depth_dev, max_radii_dm,
-                  mask_mode, criteria, seg_thr=SEG_THRESHOLD):
+                  mask_mode, criteria, seg_thr=SEG_THRESHOLD, K=linemod_K, syms=lm_syms, scene_scale=1.0, reach_is_mean=False):
     """Horn pose from the three keypoints, ADD(-S) before ICP, ICP of the CAD model onto the masked scene points and
-    ADD(-S) after ICP (reference AccumulatorSpace.py:655-726 / :899-958), everything on the GPU."""
+    ADD(-S) after ICP (reference AccumulatorSpace.py:655-726 / :899-958 / :1115-1190), everything on the GPU.
+
+    scene_scale: millimetres per depth unit (1 for LINEMOD; 1000 / factor_depth for YCB-Video).  reach_is_mean: the
+    YCB loop hands the mean distance to ICP even for symmetric classes (:1160), the LINEMOD loops the metric itself."""
     torch = _torch()
     from .registration import compute_point_cloud_distance, registration_icp
     from .util.horn import horn_batch
@@ -305,15 +315,17 @@ def _pose_and_add(class_name, xyz_load, keypoints, estimated_kpts, RTGT_mm, seg_
     _, gt_model = project(xyz_load * 1000, linemod_K, RTGT_mm)
     gt_dev = torch.from_numpy(np.ascontiguousarray(gt_model)).cuda()
     d = compute_point_cloud_distance(gt_dev, est_model)
-    dist = d.min() if class_name in lm_syms else d.mean()  # reference :686-694
+    dist = d.min() if class_name in syms else d.mean()  # reference :686-694
     # ICP of the CAD model onto the masked scene points, started from the Horn pose, reach = the distance above
     # (reference :696-712), then the same metric on the refined model (:717-726)
-    scene = scene_cloud_of_keypoint_masks(seg_maps, rad_maps, depth_dev, max_radii_dm, linemod_K, mask_mode, seg_thr)
-    reg = registration_icp(xyz_load * 1000, scene, float(dist), RT, criteria)
+    scene = scene_cloud_of_keypoint_masks(seg_maps, rad_maps, depth_dev, max_radii_dm, K, mask_mode, seg_thr)
+    if scene_scale != 1.0:
+        scene = scene * float(scene_scale)
+    reg = registration_icp(xyz_load * 1000, scene, float(d.mean() if reach_is_mean else dist), RT, criteria)
     T = reg.transformation
     cad_model = (xyz_load * 1000) @ T[:3, :3].T + T[:3, 3]
     d2 = compute_point_cloud_distance(gt_dev, cad_model)
-    dist_after = d2.min() if class_name in lm_syms else d2.mean()
+    dist_after = d2.min() if class_name in syms else d2.mean()
     return dict(estimated_kpts=estimated_kpts.copy(), RT=RT, add_distance_mm=float(dist), scene_points=int(scene.shape[0]),
                 icp_transformation=T, icp_fitness=reg.fitness, icp_inlier_rmse=reg.inlier_rmse, icp_iterations=reg.iterations,
                 add_distance_after_icp_mm=float(dist_after))
@@ -537,3 +549,160 @@ def estimate_6d_pose_lmo(opts, return_details=False):
                                        add_after_icp=af_icp / general_counter)
             details[class_name] = per_frame
     return (results, details) if return_details else results
+
+
+def oriented_bbox_extent(points):
+    """Edge lengths of `open3d.geometry.PointCloud.get_oriented_bounding_box().extent` as the YCB loop uses it
+    (reference AccumulatorSpace.py:1119-1120): the box aligned with the principal axes of the convex hull's vertices.
+    Once per class, on the host (scipy's Qhull).  Parity unpinned: Open3D is not installed here."""
+    from scipy.spatial import ConvexHull
+
+    pts = np.asarray(points, dtype=np.float64)
+    hull = pts[ConvexHull(pts).vertices]
+    c = hull - hull.mean(axis=0)
+    _, vec = np.linalg.eigh(c.T @ c / len(hull))
+    q = c @ vec
+    return (q.max(axis=0) - q.min(axis=0))[::-1]
+
+
+def _auc(x, y):
+    """sklearn.metrics.auc (trapezoidal rule), reference AccumulatorSpace.py:1192-1193."""
+    x, y = np.asarray(x, dtype=np.float64), np.asarray(y, dtype=np.float64)
+    return float(((x[1:] - x[:-1]) * (y[1:] + y[:-1]) / 2).sum())
+
+
+def estimate_6d_pose_ycb(opts, return_details=False):
+    """The YCB-Video evaluation loop of the reference (AccumulatorSpace.py:976-1197) on the MI355X hot path (SURVEY.md
+    section 8 f-4): the same kernels as the LINEMOD loops behind the YCB-Video file layout.
+
+    Layout read: `root_dataset/Split/<class>/val.txt` (names `<cycle>_<idx>`), `models/<class>/{points.xyz, Outside9.npy}`,
+    `data/<cycle>/<idx>{-color.png, -depth.png, .mat}` with `poses`, `cls_indexes`, `factor_depth`, `intrinsic_matrix` in the
+    `.mat`, checkpoints `model_dir/<class>_pt<k>.pth.tar` saved from `nn.DataParallel` (`module.` keys, :1005).
+    Kept from the reference: the point mask is `seg > 0.8` alone (:1051, no radius bound), depth is divided by `factor_depth`
+    (:1053), ADD(-S) passes at 1 % of the CAD model's oriented-bounding-box diagonal (:1119-1131), the ADD(-S) AUC is taken
+    over the thresholds 0 ... 0.1 m (:978,1132-1140,1192), ICP runs with reach = mean distance and
+    `ICPConvergenceCriteria(max_iteration=2000000)` (:1160-1165).
+
+    The reference's loop cannot run as written; this build follows its evident intent and says where:
+      * `keypoint_count` is read before it is assigned (:1003) and then indexes `model_list` and `estimated_kpts` from 1 to 3
+        (:1044,1090) -- here network k (1..3) estimates `Outside9[k]` into row k-1, and Horn pairs rows 0..2 with
+        `Outside9[1:4]`, as the LINEMOD loop does (the reference pairs `Outside9[0:3]`, :1115);
+      * `poses[:, :, np.where(cls_indexes == class_id)]` (:1017) indexes with both coordinate arrays of `np.where`; the pose
+        of the class is meant;
+      * the frame names come from `<class>.hdf5` through h5py (:1012-1013), which only lists them: here the names of
+        `val.txt` in sorted order (what h5py's key order is);
+      * the summary is printed once after the class loop with counters that were reset per class (:1192-1195): here per class.
+    """
+    torch = _torch()
+    import os
+
+    import scipy.io
+    from PIL import Image
+
+    from . import utils
+    from .models.fcnresnet import DenseFCNResNet152
+    from .pipeline import FramePipeline
+    from .registration import ICPConvergenceCriteria
+
+    _hip.lib()
+    auc_threshold = [0, 0.02, 0.04, 0.06, 0.08, 0.1]
+    results, details = {}, {}
+    wanted = getattr(opts, 'class_names', None)
+    for class_id in ycb_cls_names:
+        class_name = ycb_cls_names[class_id]
+        if (wanted and class_name not in wanted) or not os.path.isdir(opts.root_dataset + "models/" + class_name):
+            continue
+        print(class_name)
+        test_list = [s.replace('\n', '') for s in open(opts.root_dataset + "Split/" + class_name + "/val.txt", "r").readlines()]
+        xyz_load = np.loadtxt(opts.root_dataset + "models/" + class_name + "/points.xyz", ndmin=2)[:, :3]
+        keypoints = np.load(opts.root_dataset + "models/" + class_name + "/Outside9.npy")
+        sds = []
+        for i in range(1, 4):
+            model_path = opts.model_dir + class_name + "_pt" + str(i) + ".pth.tar"
+            if not os.path.exists(model_path):
+                raise ValueError(model_path + " not found")  # reference :1029-1030
+            model = DenseFCNResNet152(3, 2)
+            model, _, _, _ = utils.load_checkpoint(model, None, model_path)
+            sds.append(model.state_dict())
+        w, h, d = oriented_bbox_extent(xyz_load)
+        bbox_diagonal = (w ** 2 + h ** 2 + d ** 2) ** 0.5
+        criteria = ICPConvergenceCriteria(max_iteration=2000000)
+        no_bound = np.full(3, np.inf)
+        auc_adds_count = np.zeros((2, 6))
+        bf_icp, af_icp, general_counter = 0, 0, 0
+        per_frame = {}
+        pipe, ws = None, None
+        for filename in sorted(s for s in test_list if s):
+            cycle, idx = filename.split('_')
+            print(filename)
+            sceneInfo = scipy.io.loadmat(opts.root_dataset + 'data/' + cycle + "/" + idx)
+            hit = np.nonzero(np.asarray(sceneInfo['cls_indexes']).reshape(-1) == class_id)[0]
+            if len(hit) == 0:
+                raise ValueError(class_name + " is not annotated in " + filename)
+            RTGT = np.asarray(sceneInfo['poses'], dtype=np.float64)[:, :, hit[0]]
+            K = np.asarray(sceneInfo['intrinsic_matrix'], dtype=np.float64)
+            depth_unit_mm = 1000.0 / float(np.asarray(sceneInfo['factor_depth']).reshape(-1)[0])
+            rgb = np.array(Image.open(opts.root_dataset + 'data/' + cycle + "/" + idx + '-color.png').convert('RGB'), dtype=np.uint8)
+            depth_map1 = np.array(Image.open(opts.root_dataset + 'data/' + cycle + "/" + idx + '-depth.png'))
+            H, W = depth_map1.shape
+            depth_dev = _depth_to_u16(depth_map1, "cuda")
+            if pipe is None:
+                pipe = FramePipeline(sds, H, W, dtype=getattr(opts, 'dtype', 'bf16'), frames_per_step=1)
+                ws = AccWorkspace(H * W)
+            pipe.forward_fcn(torch.from_numpy(rgb)[None].cuda())
+            seg_maps, rad_maps = pipe.seg[:, 0, 0], pipe.radial[:, 0, 0]
+            estimated_kpts = np.zeros((3, 3))
+            for k in range(3):
+                # the seam back-projects depth units as millimetres; one device multiply turns them into the metres of
+                # depth / factor_depth (:1053-1059)
+                seam_compact(seg_maps[k], rad_maps[k], depth_dev, np.inf, K=K, mode=0, workspace=ws)
+                ws.xyz.mul_(depth_unit_mm)
+                accumulate_on_device(ws.xyz, ws.radial, ws.counts, ws.max_points, ws.max_points, ws)
+                r = ws.read_result()
+                _raise_like_reference(r.status)
+                estimated_kpts[k] = r.center_mm[:]
+            RTGT_mm = np.array(RTGT, dtype=np.float64, copy=True)
+            RTGT_mm[:, 3] = RTGT_mm[:, 3] * 1000
+            ev = _pose_and_add(class_name, xyz_load, keypoints, estimated_kpts, RTGT_mm, seg_maps, rad_maps, depth_dev, no_bound,
+                               0, criteria, SEG_THRESHOLD, K=K, syms=ycb_syms, scene_scale=depth_unit_mm, reach_is_mean=True)
+            if ev["add_distance_mm"] <= bbox_diagonal * 0.01 * 1000:
+                bf_icp += 1
+            if ev["add_distance_after_icp_mm"] <= bbox_diagonal * 0.01 * 1000:
+                af_icp += 1
+            for i, thre in enumerate(auc_threshold):
+                auc_adds_count[0, i] += ev["add_distance_mm"] <= thre * 1000
+                auc_adds_count[1, i] += ev["add_distance_after_icp_mm"] <= thre * 1000
+            general_counter += 1
+            per_frame[filename] = ev
+        if general_counter:
+            auc_before = _auc(auc_threshold, auc_adds_count[0] / general_counter) / 0.1
+            auc_after = _auc(auc_threshold, auc_adds_count[1] / general_counter) / 0.1
+            print('ADD\\(s\\) AUC of ' + class_name + ' before ICP: ', auc_before)
+            print('ADD\\(s\\) AUC of ' + class_name + ' after ICP: ', auc_after)
+            print('ADD\\(s\\) of ' + class_name + ' before ICP: ', bf_icp / general_counter)
+            print('ADD\\(s\\) of ' + class_name + ' after ICP: ', af_icp / general_counter)
+            results[class_name] = dict(frames=general_counter, add_before_icp=bf_icp / general_counter,
+                                       add_after_icp=af_icp / general_counter, auc_before_icp=auc_before, auc_after_icp=auc_after,
+                                       bbox_diagonal_m=float(bbox_diagonal))
+            details[class_name] = per_frame
+    return (results, details) if return_details else results
+
+
+def main(argv=None):
+    """The module's own command line (reference AccumulatorSpace.py:1202-1227): --dataset lm | lmo | ycb."""
+    import argparse
+
+    from .utils import str2bool
+
+    parser = argparse.ArgumentParser()
+    parser.add_argument('--root_dataset', type=str, default='Datasets/LINEMOD/')
+    parser.add_argument('--model_dir', type=str, default='ckpts/')
+    parser.add_argument('--demo_mode', type=str2bool, default=False)
+    parser.add_argument('--using_ckpts', type=str2bool, default=False)
+    parser.add_argument('--dataset', type=str, default='lm', choices=['lm', 'lmo', 'ycb'])
+    opts = parser.parse_args(argv)
+    return {'lm': estimate_6d_pose_lm, 'lmo': estimate_6d_pose_lmo, 'ycb': estimate_6d_pose_ycb}[opts.dataset](opts)
+
+
+if __name__ == "__main__":
+    main()

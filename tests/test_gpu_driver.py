@@ -110,6 +110,11 @@ def test_main_entry_runs_the_driver(tmp_path):
     _write_dataset(root, n_frames=1)
     res = main(["--mode", "test", "--root_dataset", root, "--model_dir", root, "--using_ckpts", "false"])
     assert res["ape"]["frames"] == 1
+    # the module's own command line (reference AccumulatorSpace.py:1202-1227)
+    from rcvpose_amd import AccumulatorSpace as A
+
+    assert A.main(["--dataset", "lm", "--root_dataset", root, "--model_dir", root]) == res
+    assert A.main(["--dataset", "ycb", "--root_dataset", root, "--model_dir", root]) == {}   # no YCB classes under this root
 
 
 def _write_lmo_dataset(root, n_frames=2):
@@ -185,3 +190,102 @@ def test_lmo_driver_with_precomputed_radial_maps(tmp_path, oracle):
     # frame 0 passes ADD; frame 1 pairs radii and points with an offset of up to 40 (the depth hole), like the reference would
     assert details[cls]["color_00000"]["add_distance_mm"] < 15.0 and results[cls]["add_before_icp"] >= 1 / 3 - 1e-12
     assert Trainer([None, None], opts).Test()[cls]["frames"] == 3
+
+
+def _write_ycb_dataset(root, golden_dir, radii_dm=(2.0, 2.5, 3.0)):
+    """YCB-Video layout (reference AccumulatorSpace.py:986-1057) around the YCB-shaped synthetic frames.  The three
+    checkpoints carry a zeroed last layer, so every network answers seg = 1 and radial = its own constant: known maps
+    through the real FCN path.  Saved with `module.` keys, as `nn.DataParallel` checkpoints are (:1005)."""
+    import json
+
+    import scipy.io
+    import torch
+    from PIL import Image
+
+    import fcn_weights
+
+    cls, cls_id = "003_cracker_box", 2
+    for d in (os.path.join(root, "Split", cls), os.path.join(root, "models", cls), os.path.join(root, "data", "0048")):
+        os.makedirs(d)
+    a, b, c = 0.0975, 0.079, 0.065
+    rng = np.random.default_rng(0)
+    u = rng.normal(size=(2000, 3))
+    u /= np.linalg.norm(u, axis=1, keepdims=True)
+    model = u * np.array([a, b, c])
+    np.savetxt(os.path.join(root, "models", cls, "points.xyz"), model, fmt="%.9f")
+    model = np.loadtxt(os.path.join(root, "models", cls, "points.xyz"))     # the rounded text is what the driver sees
+    sign = np.array([[1, 1, 1], [-1, 1, -1], [1, -1, -1]], dtype=np.float64)
+    kps_obj = np.zeros((9, 3))
+    kps_obj[1:4] = 2.0 * sign * np.array([a, b, c])
+    np.save(os.path.join(root, "models", cls, "Outside9.npy"), kps_obj)
+    fr = frames.synthetic_frame(0, shape="ycb")
+    raw = (fr["depth"].astype(np.uint32) * 10).astype(np.uint16)       # factor_depth 10000: units of 0.1 mm
+    Image.fromarray(fr["rgb"]).save(os.path.join(root, "data", "0048", "000001-color.png"))
+    Image.fromarray(raw).save(os.path.join(root, "data", "0048", "000001-depth.png"))
+    centre = fr["keypoints_m"][0] - kps_obj[1]
+    RT = np.concatenate([np.eye(3), centre[:, None]], axis=1)
+    poses = np.stack([np.concatenate([np.eye(3), np.ones((3, 1))], axis=1), RT], axis=2)   # another object first
+    fx, fy, cx, cy = frames.YCB_K
+    Kmat = np.array([[fx, 0, cx], [0, fy, cy], [0, 0, 1.0]])
+    scipy.io.savemat(os.path.join(root, "data", "0048", "000001.mat"),
+                     dict(poses=poses, cls_indexes=np.array([[5], [cls_id]], dtype=np.uint8), factor_depth=np.array([[10000]], dtype=np.uint16),
+                          intrinsic_matrix=Kmat))
+    with open(os.path.join(root, "Split", cls, "val.txt"), "w") as f:
+        f.write("0048_000001\n")
+    shapes = json.load(open(os.path.join(golden_dir, "fcn_state_dict_keys.json")))
+    for k in range(3):
+        sd = {n: torch.from_numpy(v) for n, v in fcn_weights.make_state_dict_numpy(shapes, seed=k).items()}
+        sd["conv8.weight"] = torch.zeros_like(sd["conv8.weight"])
+        sd["conv8.bias"] = torch.tensor([1.0, radii_dm[k]], dtype=torch.float32)
+        torch.save(dict(epoch=1, model_state_dict={"module." + n: v for n, v in sd.items()}, loss=[]),
+                   os.path.join(root, cls + "_pt%d.pth.tar" % (k + 1)))
+    return cls, model, kps_obj, RT, raw, Kmat
+
+
+def test_ycb_driver_end_to_end(tmp_path, golden_dir, oracle):
+    """estimate_6d_pose_ycb: checkpoints -> FCN -> seam (seg > 0.8, depth / factor_depth, the frame's own K)
+    -> voting -> Horn -> ADD / ICP / AUC, against the CPU restatements on the same files."""
+    from oracle import icp_oracle
+    from rcvpose_amd import AccumulatorSpace as A
+
+    root = str(tmp_path) + "/"
+    radii = (2.0, 2.5, 3.0)
+    cls, model, kps_obj, RT_gt, raw, Kmat = _write_ycb_dataset(root, golden_dir, radii)
+    opts = types.SimpleNamespace(root_dataset=root, model_dir=root, using_ckpts=True, demo_mode=False, class_names=[cls])
+    results, details = A.estimate_6d_pose_ycb(opts, return_details=True)
+    assert results[cls]["frames"] == 1
+    d = details[cls]["0048_000001"]
+    # the reference's seam for this loop (:1051-1059): every pixel is in the mask, depth in metres = raw / factor_depth
+    depth_m = raw.astype(np.float64) / 10000.0
+    vs, us = depth_m.nonzero()
+    zs = depth_m[vs, us]
+    xyz = np.stack([(us - Kmat[0, 2]) * zs / Kmat[0, 0], (vs - Kmat[1, 2]) * zs / Kmat[1, 1], zs], axis=1)
+    assert len(xyz) > 45000
+    for k in range(3):
+        ref = oracle.accumulator_3d(xyz, np.full(raw.size, radii[k], dtype=np.float32), sparse=True)
+        assert np.abs(d["estimated_kpts"][k] - ref[0]).max() <= 5.0, k    # 1 voxel (the two seams round differently by ~1 ulp)
+    # constant-radius maps put the three peaks nearly on one line: the rotation about it is ill-conditioned, so the pose is
+    # checked through what Horn minimises rather than element by element
+    kp_mm = kps_obj[1:4] * 1000
+    fit = lambda T: np.linalg.norm(kp_mm @ T[:3, :3].T + T[:3, 3] - d["estimated_kpts"])
+    assert fit(d["RT"]) <= fit(oracle.horn(kp_mm, d["estimated_kpts"])) + 1e-6
+    assert abs(np.linalg.det(d["RT"][:3, :3]) - 1.0) < 1e-9
+    gt_model = model * 1000 @ RT_gt[:, :3].T + RT_gt[:, 3] * 1000
+    est_model = model * 1000 @ d["RT"][:3, :3].T + d["RT"][:3, 3]
+    add0 = icp_oracle.nn_distance(gt_model, est_model)[0].mean()
+    assert abs(d["add_distance_mm"] - add0) < 1e-9
+    assert d["scene_points"] == len(xyz)
+    ref = icp_oracle.registration_icp(model * 1000, xyz * 1000, add0, d["RT"], max_iteration=2000000)
+    assert d["icp_iterations"] == ref["iterations"]
+    assert np.allclose(d["icp_transformation"], ref["transformation"], rtol=0, atol=1e-5)
+    cad = model * 1000 @ ref["transformation"][:3, :3].T + ref["transformation"][:3, 3]
+    add1 = icp_oracle.nn_distance(gt_model, cad)[0].mean()
+    assert abs(d["add_distance_after_icp_mm"] - add1) < 1e-4
+    # summary figures: 1 % of the bounding-box diagonal, AUC over 0 ... 0.1 m
+    diag = results[cls]["bbox_diagonal_m"]
+    assert abs(diag - 2 * np.linalg.norm([0.0975, 0.079, 0.065])) < 0.01
+    thr = np.array([0, 0.02, 0.04, 0.06, 0.08, 0.1]) * 1000
+    for key, val in (("auc_before_icp", add0), ("auc_after_icp", add1)):
+        y = (val <= thr).astype(np.float64)
+        assert abs(results[cls][key] - np.trapezoid(y, thr / 1000) / 0.1) < 1e-12
+    assert results[cls]["add_before_icp"] == float(add0 <= diag * 10)
