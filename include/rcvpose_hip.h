@@ -270,7 +270,8 @@ int rcv_fcn_set_profiling(rcv_fcn *h, int enable);
  * (k_conv_dma), key 2 = MFMA stem (k_stem_mfma; 0: direct kernel with fp32 input), key 3 = fused last upsampling + conv7
  * + head (k_tail; 0: three kernels, bit-identical output), key 4 = fused 3x3 + expand 1x1 of the stride-1 bottleneck blocks (layers 1-3)
  * (k_conv_block; 0: two kernels, bit-identical output), key 5 = chain the next block's 1x1 reduce into k_conv_block where it
- * follows directly (0: separate kernel, bit-identical output). */
+ * follows directly (0: separate kernel, bit-identical output), key 6 = staggered schedule of the 1x1 phases of the chained
+ * 256-wide block (0: all waves in lockstep, bit-identical output). */
 int rcv_fcn_set_option(rcv_fcn *h, int key, int value);
 int rcv_fcn_get_profile(rcv_fcn *h, double *conv_ms, double *other_ms, double *conv_flop);
 /* Per-op device times (ms) of the last profiled forward; ms_out has room for n_ops doubles. */

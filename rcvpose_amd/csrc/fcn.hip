@@ -36,6 +36,7 @@ namespace {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 
 template <typename T> struct Traits;
 template <> struct Traits<float> {
@@ -710,6 +711,20 @@ __device__ __forceinline__ void up2_src(int d, int n_in, int &i0, int &i1, float
 //            DMA'd into LDS during the chunk's K steps, the result leaves through v_permlane16_swap as 16-byte vectors.
 // Same MFMA sequence per output element as k_conv_dma on the two layers: bit-identical results.
 // ---------------------------------------------------------------------------------------------
+#ifdef RCV_BLK_STAMPS
+// diagnostic build only (tools/blk_stamps.py): cycle stamps of one chunk of the staggered schedule, two waves of one workgroup
+__device__ unsigned g_blk_stamps[2][80];
+#define RCV_STAMP(idx)                                                                                         \
+    if (nc == 3) {                                                                                             \
+        unsigned long long t_;                                                                                 \
+        __builtin_amdgcn_sched_barrier(0);                                                                     \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                          \
+        __builtin_amdgcn_sched_barrier(0);                                                                     \
+        stamps[idx] = (unsigned)t_;                                                                            \
+    }
+#else
+#define RCV_STAMP(idx)
+#endif
 struct BlockParams {
     const void *src, *w1, *w2, *res;
     void *dst;
@@ -741,9 +756,10 @@ __device__ __forceinline__ void blk_dma16(const void *base, int num_bytes, unsig
     __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void *)lds_wave_base, 16, voffset, 0, 0, 0);
 }
 
-template <int CMID, bool CHAIN>
+template <int CMID, bool CHAIN, bool STAG = false>
 __global__ __launch_bounds__(512) void k_conv_block(const BlockParams p)
 {
+    static_assert(!STAG || (CHAIN && CMID == 256), "the staggered schedule is written for the chained 256-wide block");
     using T = __bf16;
     constexpr int KE = 64, EPV = 8, BM = BLK_BM, KS = 3, PAD = 1;
     constexpr int COUT = 4 * CMID;
@@ -1012,12 +1028,17 @@ __global__ __launch_bounds__(512) void k_conv_block(const BlockParams p)
                 blk_dma16(wb_, w3_bytes, sW3 + h * (CMID * 128) + (wave * (8 * W3P) + c * 8) * 128, w3_off[c]); \
         }                                                                                                      \
     }
+#define RCV_BLK_W3H(nc_, h_)                                                                                   \
+    {                                                                                                          \
+        const char *wb_ = (const char *)w3 + ((long long)(nc_) * 128 + (h_) * KE) * 2;                         \
+        _Pragma("unroll") for (int c = 0; c < W3P; c++)                                                        \
+            blk_dma16(wb_, w3_bytes, sW3 + (h_) * (CMID * 128) + (wave * (8 * W3P) + c * 8) * 128, w3_off[c]); \
+    }
     // order of issue per wave: at the first step of a chunk R(nc) [4 pieces] and, chained, both reduce-weight slices
     // [2 * W3P]; then W(s + 2) [2] at every step s < S2 - 2.  At the top of step s the pieces issued after W(s) are those
     // of step s - 1: W(s + 1) and, when step s - 1 opened a chunk, that chunk's R (and W3).
     constexpr int OPEN_PIECES = 4 + (CHAIN ? 2 * W3P : 0);
-    RCV_BLK_W(0);
-    if (S2 > 1) RCV_BLK_W(1);
+    constexpr bool STAGGER = STAG;
     f32x4 acc3[2][NT3];  // CHAIN: [pixel group][16-channel tile of this wave's CMID / 2 reduce outputs]
     if (CHAIN) {
 #pragma unroll
@@ -1025,6 +1046,158 @@ __global__ __launch_bounds__(512) void k_conv_block(const BlockParams p)
 #pragma unroll
             for (int j = 0; j < NT3; j++) acc3[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
+    if constexpr (STAGGER) {
+        // Staggered schedule (CMID = 256, chained).  Every chunk is a chain of 17 segments, each closed by one s_barrier:
+        //     Le0 Me0 Le1 Me1 Le2 Me2 Le3 Me3 | P | Lr0 Mr0 Lr1 Mr1 Lr2 Mr2 Lr3 Mr3
+        // L = DMA issue + fragment reads (whole K step into registers), M = 16 MFMAs, P = the chunk's epilogue.  Waves 4..7
+        // run one barrier behind waves 0..3 (one extra barrier at the start, waves 0..3 one at the end), so that the MFMAs
+        // of one wave of a SIMD cover the LDS / DMA / epilogue work of the other.  With that lag a buffer may be read two
+        // barriers after the owner's wait for it, and overwritten two barriers after its last read (sR, whose rows are
+        // private to a pair of waves of the same group: one barrier).  Per wave and chunk (s0 = first stream step):
+        //     Le0: R(nc) [4], W(s0+2) [2]            Le1: W3(nc, h=1) [4], W(s0+3) [2]; vmcnt(6) -> W(s0+2), R, W3(nc, 0)
+        //     Le2: W(s0+4) [2]; vmcnt(2) -> W(s0+3), W3(nc, 1)               Le3: W(s0+5) [2]
+        //     Lr2: W3(nc+1, h=0) [4]                 Lr3: vmcnt(4) -> W(s0+4), W(s0+5) (and the chunk's stores)
+        const int grp2 = wave >> 2;
+        RCV_BLK_W(0);
+        RCV_BLK_W(1);
+        RCV_BLK_W3H(0, 0);
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (grp2 == 1) __builtin_amdgcn_s_barrier();
+        const unsigned sB2a = (unsigned)(size_t)sB2, sRa = (unsigned)(size_t)sR;
+#ifdef RCV_BLK_STAMPS
+        unsigned stamps[80];
+#pragma unroll
+        for (int k = 0; k < 80; k++) stamps[k] = 0u;
+#endif
+#pragma unroll
+        for (int nc = 0; nc < NCH; nc++) {
+            constexpr int KS2c = 4;
+            const int s0 = nc * KS2c;
+            const bool more = nc + 1 < NCH;
+            f32x4 a2[2][4];
+#pragma unroll
+            for (int i = 0; i < 2; i++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) a2[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KS2c; ks++) {
+                // ---- Le(ks)
+                RCV_STAMP(4 * ks);
+                if (ks == 0) { RCV_BLK_R(nc); RCV_BLK_W(s0 + 2); }
+                if (ks == 1) { RCV_BLK_W3H(nc, 1); RCV_BLK_W(s0 + 3); }
+                if (ks == 2 && more) RCV_BLK_W(s0 + 4);
+                if (ks == 3 && more) RCV_BLK_W(s0 + 5);
+                const unsigned char *Bb = sW + ((s0 + ks) % BLK_RING) * BLK_SLOT + (wn2 * 64 + r16) * 128;
+                bf16x8 bfr[2][4];
+#pragma unroll
+                for (int kk = 0; kk < 2; kk++)
+#pragma unroll
+                    for (int j = 0; j < 4; j++) bfr[kk][j] = *(const bf16x8 *)(Bb + j * 16 * 128 + (kk ? ch1 : ch0));
+                RCV_STAMP(40 + ks);
+                if (ks == 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                if (ks == 2) {
+                    if (more) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                RCV_STAMP(4 * ks + 1);
+                __builtin_amdgcn_s_barrier();
+                // ---- Me(ks)
+                RCV_STAMP(4 * ks + 2);
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int kk = 0; kk < 2; kk++)
+#pragma unroll
+                    for (int i = 0; i < 2; i++)
+#pragma unroll
+                        for (int j = 0; j < 4; j++)
+                            a2[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[kk][j], a2f[i][ks * 2 + kk], a2[i][j], 0, 0, 0);
+                __builtin_amdgcn_s_setprio(0);
+                RCV_STAMP(4 * ks + 3);
+                __builtin_amdgcn_s_barrier();
+            }
+            RCV_STAMP(16);
+            // ---- P: bias + residual + ReLU; 16-byte stores; the rounded tile back into sR as the reduce layer's A operand.
+            // LDS traffic through inline asm: compiler-visible LDS accesses here make hipcc drain vmcnt for the DMAs in flight.
+#pragma unroll
+            for (int i = 0; i < 2; i++) {
+                const int row = wm2 * 32 + i * 16 + r16, m = m0 + row;
+#pragma unroll
+                for (int pr = 0; pr < 2; pr++) {
+                    const int e_ch = wn2 * 64 + (2 * pr + (kq & 1)) * 16 + (kq >> 1) * 8;
+                    float v[8];
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(a2[i][2 * pr][e]), __float_as_uint(a2[i][2 * pr + 1][e]), false, false);
+                        v[e] = __uint_as_float(sw[0]);
+                        v[4 + e] = __uint_as_float(sw[1]);
+                    }
+                    const unsigned baddr = sB2a + (nc * 128 + e_ch) * 4;
+                    const unsigned raddr = sRa + row * 256 + (((e_ch >> 3) ^ (row & 15)) << 4);
+                    f32x4 bA, bB;
+                    u32x4 rq;
+                    asm volatile("ds_read_b128 %0, %3\n\tds_read_b128 %1, %3 offset:16\n\tds_read_b128 %2, %4\n\ts_waitcnt lgkmcnt(0)"
+                                 : "=&v"(bA), "=&v"(bB), "=&v"(rq) : "v"(baddr), "v"(raddr) : "memory");
+                    const float bb[8] = {bA[0], bA[1], bA[2], bA[3], bB[0], bB[1], bB[2], bB[3]};
+                    const T *rp = (const T *)&rq;
+#pragma unroll
+                    for (int e = 0; e < 8; e++) v[e] = fmaxf((v[e] + bb[e]) + (float)rp[e], 0.f);
+                    u32x4 outv;
+                    T *op = (T *)&outv;
+#pragma unroll
+                    for (int e = 0; e < 8; e++) op[e] = (T)v[e];
+                    if (m < p.M) *(u32x4 *)(dst + (long long)m * COUT + nc * 128 + e_ch) = outv;
+                    asm volatile("ds_write_b128 %0, %1" :: "v"(raddr), "v"(outv) : "memory");
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            RCV_STAMP(17);
+            __builtin_amdgcn_s_barrier();
+            // ---- reduce layer on the chunk: acc3 += Y[32 px x 128] * W3[128 out x 128]^T, four K steps of 32
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                const int h = t >> 1, kk = t & 1;
+                // ---- Lr(t)
+                RCV_STAMP(18 + 4 * t);
+                if (t == 2 && more) RCV_BLK_W3H(nc + 1, 0);
+                bf16x8 yf[2], bf3[NT3];
+#pragma unroll
+                for (int i = 0; i < 2; i++) {
+                    const int row = wm2 * 32 + i * 16 + r16;
+                    yf[i] = *(const bf16x8 *)(sR + row * 256 + (((h * 8 + kk * 4 + kq) ^ (row & 15)) << 4));
+                }
+                const unsigned char *B3 = sW3 + h * (CMID * 128) + (wn2 * (CMID / 2) + r16) * 128 + (kk ? ch1 : ch0);
+#pragma unroll
+                for (int j = 0; j < NT3; j++) bf3[j] = *(const bf16x8 *)(B3 + j * 16 * 128);
+                if (t == 3) {
+                    if (more) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                RCV_STAMP(18 + 4 * t + 1);
+                __builtin_amdgcn_s_barrier();
+                // ---- Mr(t)
+                RCV_STAMP(18 + 4 * t + 2);
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int i = 0; i < 2; i++)
+#pragma unroll
+                    for (int j = 0; j < NT3; j++) acc3[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf3[j], yf[i], acc3[i][j], 0, 0, 0);
+                __builtin_amdgcn_s_setprio(0);
+                RCV_STAMP(18 + 4 * t + 3);
+                __builtin_amdgcn_s_barrier();
+            }
+            RCV_STAMP(34);
+        }
+        if (grp2 == 0) __builtin_amdgcn_s_barrier();
+#ifdef RCV_BLK_STAMPS
+        if (lane == 0 && (wave & 3) == 0 && blockIdx.x == 100 && g == 0)
+            for (int k = 0; k < 80; k++) g_blk_stamps[wave >> 2][k] = stamps[k];
+#endif
+    } else {
+    RCV_BLK_W(0);
+    if (S2 > 1) RCV_BLK_W(1);
 #pragma unroll
     for (int nc = 0; nc < NCH; nc++) {
         f32x4 a2[2][4];
@@ -1138,6 +1311,7 @@ __global__ __launch_bounds__(512) void k_conv_block(const BlockParams p)
                 }
         }
     }
+    }  // !STAGGER
     if (CHAIN) {
         // the next block's first activation: relu(acc3 + b3) rounded to bf16, 16-byte vectors of 8 channels
         T *dst3 = (T *)p.dst3 + (long long)g * p.dst3_gs;
@@ -1165,6 +1339,7 @@ __global__ __launch_bounds__(512) void k_conv_block(const BlockParams p)
         }
     }
 #undef RCV_BLK_W3
+#undef RCV_BLK_W3H
 #undef RCV_BLK_W
 #undef RCV_BLK_R
 }
@@ -1544,6 +1719,7 @@ struct rcv_fcn {
     bool use_tail = true;  // fused upsample + conv7 + head kernel (bf16)
     bool use_block = true;  // fused 3x3 + expand 1x1 kernel for the 256 -> 256 -> 1024 bottleneck halves (bf16)
     bool use_chain = true;  // ... with the next block's 1x1 reduce chained in where it follows directly
+    bool use_stagger = true;  // ... and, for the 256-wide chained block, the staggered schedule of the 1x1 phases
     bool profiling = false;
     std::vector<hipEvent_t> events;  // 2 per op when profiling
     bool events_valid = false;
@@ -1722,6 +1898,7 @@ int register_kernel_attributes()
     RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_conv_block<128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, blk_lds(128)));
     RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_conv_block<256, false>, hipFuncAttributeMaxDynamicSharedMemorySize, blk_lds(256)));
     RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_conv_block<256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, blk_lds(256)));
+    RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_conv_block<256, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, blk_lds(256)));
     done = true;
     return RCV_OK;
 }
@@ -1756,6 +1933,7 @@ int forward_impl(rcv_fcn *h, const float *x, int B, float *seg, float *radial, c
                         RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_conv_block<128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, blk_lds(128)));
                         RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_conv_block<256, false>, hipFuncAttributeMaxDynamicSharedMemorySize, blk_lds(256)));
                         RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_conv_block<256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, blk_lds(256)));
+                        RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_conv_block<256, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, blk_lds(256)));
                     }
                     auto gs = [&](int s) -> long long { return (long long)h->slot_elems[s] * B; };
                     BlockParams q;
@@ -1784,7 +1962,8 @@ int forward_impl(rcv_fcn *h, const float *x, int B, float *seg, float *radial, c
                     if (h->profiling) RCV_HIP_CHECK(hipEventRecord(h->events[2 * i], st));  // time booked on the 3x3 convolution
                     const dim3 grid((unsigned)((M + BLK_BM - 1) / BLK_BM), 1, h->groups);
                     if (cmid == 256) {
-                        if (chain) hipLaunchKernelGGL((k_conv_block<256, true>), grid, dim3(512), blk_lds(256), st, q);
+                        if (chain && h->use_stagger) hipLaunchKernelGGL((k_conv_block<256, true, true>), grid, dim3(512), blk_lds(256), st, q);
+                        else if (chain) hipLaunchKernelGGL((k_conv_block<256, true>), grid, dim3(512), blk_lds(256), st, q);
                         else hipLaunchKernelGGL((k_conv_block<256, false>), grid, dim3(512), blk_lds(256), st, q);
                     } else if (cmid == 128) {
                         if (chain) hipLaunchKernelGGL((k_conv_block<128, true>), grid, dim3(512), blk_lds(128), st, q);
@@ -1924,6 +2103,14 @@ int rcv_fcn_debug_slot(rcv_fcn *h, const void *ws, int B, int g, int slot, float
     return RCV_OK;
 }
 
+#ifdef RCV_BLK_STAMPS
+extern "C" int rcv_debug_blk_stamps(unsigned *out160)
+{
+    RCV_HIP_CHECK(hipDeviceSynchronize());
+    RCV_HIP_CHECK(hipMemcpyFromSymbol(out160, HIP_SYMBOL(g_blk_stamps), sizeof(unsigned) * 160));
+    return RCV_OK;
+}
+#endif
 int rcv_fcn_set_option(rcv_fcn *h, int key, int value)
 {
     if (!h) return RCV_E_INVALID;
@@ -1932,6 +2119,7 @@ int rcv_fcn_set_option(rcv_fcn *h, int key, int value)
     if (key == 3) { h->use_tail = value != 0; h->attrs_set = false; return RCV_OK; }
     if (key == 4) { h->use_block = value != 0; h->attrs_set = false; return RCV_OK; }
     if (key == 5) { h->use_chain = value != 0; h->attrs_set = false; return RCV_OK; }
+    if (key == 6) { h->use_stagger = value != 0; h->attrs_set = false; return RCV_OK; }
     return RCV_E_INVALID;
 }
 

@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--no-dma", action="store_true", help="disable the LDS-DMA conv kernel")
+    ap.add_argument("--off", type=int, action="append", default=[], help="engine option key to switch off (repeatable)")
     ap.add_argument("--all", action="store_true", help="print every op, not the per-shape summary")
     args = ap.parse_args()
     shapes = json.load(open(os.path.join(ROOT, "tests", "golden", "fcn_state_dict_keys.json")))
@@ -36,6 +37,8 @@ def main():
     eng = FcnEngine(sds, 480, 640, dtype=args.dtype)
     if args.no_dma:
         eng.set_option(1, 0)
+    for key in args.off:
+        eng.set_option(key, 0)
     x = torch.randn(args.batch, 3, 480, 640, device="cuda")
     for _ in range(2):
         eng.forward(x)
