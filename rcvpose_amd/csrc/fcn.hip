@@ -1034,6 +1034,12 @@ __global__ __launch_bounds__(512) void k_conv_block(const BlockParams p)
         _Pragma("unroll") for (int c = 0; c < W3P; c++)                                                        \
             blk_dma16(wb_, w3_bytes, sW3 + (h_) * (CMID * 128) + (wave * (8 * W3P) + c * 8) * 128, w3_off[c]); \
     }
+#define RCV_BLK_W3Q(nc_, h_, q_)                                                                               \
+    {                                                                                                          \
+        const char *wb_ = (const char *)w3 + ((long long)(nc_) * 128 + (h_) * KE) * 2;                         \
+        _Pragma("unroll") for (int c = (q_) * (W3P / 2); c < ((q_) + 1) * (W3P / 2); c++)                      \
+            blk_dma16(wb_, w3_bytes, sW3 + (h_) * (CMID * 128) + (wave * (8 * W3P) + c * 8) * 128, w3_off[c]); \
+    }
     // order of issue per wave: at the first step of a chunk R(nc) [4 pieces] and, chained, both reduce-weight slices
     // [2 * W3P]; then W(s + 2) [2] at every step s < S2 - 2.  At the top of step s the pieces issued after W(s) are those
     // of step s - 1: W(s + 1) and, when step s - 1 opened a chunk, that chunk's R (and W3).
@@ -1047,24 +1053,42 @@ __global__ __launch_bounds__(512) void k_conv_block(const BlockParams p)
             for (int j = 0; j < NT3; j++) acc3[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     if constexpr (STAGGER) {
-        // Staggered schedule (CMID = 256, chained).  Every chunk is a chain of 17 segments, each closed by one s_barrier:
-        //     Le0 Me0 Le1 Me1 Le2 Me2 Le3 Me3 | P | Lr0 Mr0 Lr1 Mr1 Lr2 Mr2 Lr3 Mr3
+        // Staggered schedule (CMID = 256, chained).  Every chunk is a chain of 18 segments, each closed by one s_barrier:
+        //     Le0 Me0 Le1 Me1 Le2 Me2 Le3 Me3 | (-) P | P (-) | Lr0 Mr0 Lr1 Mr1 Lr2 Mr2 Lr3 Mr3      (-): an empty segment
         // L = DMA issue + fragment reads (whole K step into registers), M = 16 MFMAs, P = the chunk's epilogue.  Waves 4..7
         // run one barrier behind waves 0..3 (one extra barrier at the start, waves 0..3 one at the end), so that the MFMAs
-        // of one wave of a SIMD cover the LDS / DMA / epilogue work of the other.  With that lag a buffer may be read two
-        // barriers after the owner's wait for it, and overwritten two barriers after its last read (sR, whose rows are
-        // private to a pair of waves of the same group: one barrier).  Per wave and chunk (s0 = first stream step):
-        //     Le0: R(nc) [4], W(s0+2) [2]            Le1: W3(nc, h=1) [4], W(s0+3) [2]; vmcnt(6) -> W(s0+2), R, W3(nc, 0)
-        //     Le2: W(s0+4) [2]; vmcnt(2) -> W(s0+3), W3(nc, 1)               Le3: W(s0+5) [2]
-        //     Lr2: W3(nc+1, h=0) [4]                 Lr3: vmcnt(4) -> W(s0+4), W(s0+5) (and the chunk's stores)
+        // of one wave of a SIMD cover the LDS / DMA work of the other; around P the groups are level (the epilogue is
+        // latency-bound, two of them side by side cost little more than one).  With the lag a buffer may be read two
+        // barriers after the owner's wait for it and overwritten two barriers after its last read (sR holds only the
+        // rounded output tile, whose rows are private to a pair of waves of one group).  The residual does not pass through
+        // LDS here: its HBM latency would hold up every DMA piece issued after it (in-order return), so each lane loads its
+        // own 4 x 16 B for the next chunk into registers right after the epilogue, where the DMA queue is quiet.
+        // Issue order per wave and chunk (s0 = first stream step), [pieces]; no segment carries more than four:
+        //     Le0: W(s0+2) [2], W3(nc, h=1) first half [2]     Le1: W(s0+3) [2], W3(nc, 1) second half [2]
+        //     Le2: W(s0+4) [2]     Le3: W(s0+5) [2]             Lr0: residual of chunk nc+1 [4 loads]
+        //     Lr2: W3(nc+1, h=0) first half [2]                 Lr3: W3(nc+1, 0) second half [2]
+        // Waits: Le1 vmcnt(6) -> W(s0+2);  Le2 vmcnt(4) -> W(s0+3);  Lr0 (before the loads) vmcnt(4) -> W3(nc, 1);
+        //        Lr3 vmcnt(8) -> W(s0+4), W(s0+5).  Stores are never counted as younger pieces (a wave may skip them).
         const int grp2 = wave >> 2;
+        const int e_base = wn2 * 64 + (kq & 1) * 16 + (kq >> 1) * 8;  // first of this lane's 8 channels (pr adds 32)
+        const T *rrow[2];
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const int m = m0 + wm2 * 32 + i * 16 + r16;
+            rrow[i] = res + (long long)(m < p.M ? m : p.M - 1) * COUT + e_base;
+        }
+        u32x4 rg[2][2];  // residual of the coming chunk: [pixel group][pr]
         RCV_BLK_W(0);
         RCV_BLK_W(1);
         RCV_BLK_W3H(0, 0);
-        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int pr = 0; pr < 2; pr++) rg[i][pr] = *(const u32x4 *)(rrow[i] + pr * 32);
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         if (grp2 == 1) __builtin_amdgcn_s_barrier();
-        const unsigned sB2a = (unsigned)(size_t)sB2, sRa = (unsigned)(size_t)sR;
+        const unsigned sB2a = (unsigned)(size_t)sB2 + e_base * 4, sRa = (unsigned)(size_t)sR;
 #ifdef RCV_BLK_STAMPS
         unsigned stamps[80];
 #pragma unroll
@@ -1084,8 +1108,8 @@ __global__ __launch_bounds__(512) void k_conv_block(const BlockParams p)
             for (int ks = 0; ks < KS2c; ks++) {
                 // ---- Le(ks)
                 RCV_STAMP(4 * ks);
-                if (ks == 0) { RCV_BLK_R(nc); RCV_BLK_W(s0 + 2); }
-                if (ks == 1) { RCV_BLK_W3H(nc, 1); RCV_BLK_W(s0 + 3); }
+                if (ks == 0) { RCV_BLK_W(s0 + 2); RCV_STAMP(44); RCV_BLK_W3Q(nc, 1, 0); RCV_STAMP(45); }
+                if (ks == 1) { RCV_BLK_W(s0 + 3); RCV_STAMP(46); RCV_BLK_W3Q(nc, 1, 1); RCV_STAMP(47); }
                 if (ks == 2 && more) RCV_BLK_W(s0 + 4);
                 if (ks == 3 && more) RCV_BLK_W(s0 + 5);
                 const unsigned char *Bb = sW + ((s0 + ks) % BLK_RING) * BLK_SLOT + (wn2 * 64 + r16) * 128;
@@ -1097,9 +1121,10 @@ __global__ __launch_bounds__(512) void k_conv_block(const BlockParams p)
                 RCV_STAMP(40 + ks);
                 if (ks == 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
                 if (ks == 2) {
-                    if (more) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    if (more) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
                 }
+                if (ks == 3 && !more) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // W3(nc, 1), before the last stores
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 RCV_STAMP(4 * ks + 1);
                 __builtin_amdgcn_s_barrier();
@@ -1117,50 +1142,64 @@ __global__ __launch_bounds__(512) void k_conv_block(const BlockParams p)
                 RCV_STAMP(4 * ks + 3);
                 __builtin_amdgcn_s_barrier();
             }
+            if (grp2 == 0) __builtin_amdgcn_s_barrier();
             RCV_STAMP(16);
-            // ---- P: bias + residual + ReLU; 16-byte stores; the rounded tile back into sR as the reduce layer's A operand.
+            // ---- P: bias + residual + ReLU; 16-byte stores; the rounded tile into sR as the reduce layer's A operand.
             // LDS traffic through inline asm: compiler-visible LDS accesses here make hipcc drain vmcnt for the DMAs in flight.
+            {
+                f32x4 bq[2][2];  // bias: [pr][first / second four channels]
+                asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:16\n\tds_read_b128 %2, %4 offset:128\n\tds_read_b128 %3, %4 offset:144"
+                             : "=&v"(bq[0][0]), "=&v"(bq[0][1]), "=&v"(bq[1][0]), "=&v"(bq[1][1]) : "v"(sB2a + nc * 128 * 4) : "memory");
+                float v[2][2][8];
 #pragma unroll
-            for (int i = 0; i < 2; i++) {
-                const int row = wm2 * 32 + i * 16 + r16, m = m0 + row;
+                for (int i = 0; i < 2; i++)
 #pragma unroll
-                for (int pr = 0; pr < 2; pr++) {
-                    const int e_ch = wn2 * 64 + (2 * pr + (kq & 1)) * 16 + (kq >> 1) * 8;
-                    float v[8];
+                    for (int pr = 0; pr < 2; pr++)
 #pragma unroll
-                    for (int e = 0; e < 4; e++) {
-                        const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(a2[i][2 * pr][e]), __float_as_uint(a2[i][2 * pr + 1][e]), false, false);
-                        v[e] = __uint_as_float(sw[0]);
-                        v[4 + e] = __uint_as_float(sw[1]);
+                        for (int e = 0; e < 4; e++) {
+                            const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(a2[i][2 * pr][e]), __float_as_uint(a2[i][2 * pr + 1][e]), false, false);
+                            v[i][pr][e] = __uint_as_float(sw[0]);
+                            v[i][pr][4 + e] = __uint_as_float(sw[1]);
+                        }
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bq[0][0]), "+v"(bq[0][1]), "+v"(bq[1][0]), "+v"(bq[1][1])::"memory");
+#pragma unroll
+                for (int i = 0; i < 2; i++) {
+                    const int row = wm2 * 32 + i * 16 + r16, m = m0 + row;
+#pragma unroll
+                    for (int pr = 0; pr < 2; pr++) {
+                        const int e_ch = e_base + pr * 32;
+                        const float bb[8] = {bq[pr][0][0], bq[pr][0][1], bq[pr][0][2], bq[pr][0][3], bq[pr][1][0], bq[pr][1][1], bq[pr][1][2], bq[pr][1][3]};
+                        const u32x4 rq = rg[i][pr];
+                        const T *rp = (const T *)&rq;
+                        u32x4 outv;
+                        T *op = (T *)&outv;
+#pragma unroll
+                        for (int e = 0; e < 8; e++) op[e] = (T)fmaxf((v[i][pr][e] + bb[e]) + (float)rp[e], 0.f);
+                        if (m < p.M) *(u32x4 *)(dst + (long long)m * COUT + nc * 128 + e_ch) = outv;
+                        const unsigned yaddr = sRa + row * 256 + (((e_ch >> 3) ^ (row & 15)) << 4);
+                        asm volatile("ds_write_b128 %0, %1" ::"v"(yaddr), "v"(outv) : "memory");
                     }
-                    const unsigned baddr = sB2a + (nc * 128 + e_ch) * 4;
-                    const unsigned raddr = sRa + row * 256 + (((e_ch >> 3) ^ (row & 15)) << 4);
-                    f32x4 bA, bB;
-                    u32x4 rq;
-                    asm volatile("ds_read_b128 %0, %3\n\tds_read_b128 %1, %3 offset:16\n\tds_read_b128 %2, %4\n\ts_waitcnt lgkmcnt(0)"
-                                 : "=&v"(bA), "=&v"(bB), "=&v"(rq) : "v"(baddr), "v"(raddr) : "memory");
-                    const float bb[8] = {bA[0], bA[1], bA[2], bA[3], bB[0], bB[1], bB[2], bB[3]};
-                    const T *rp = (const T *)&rq;
-#pragma unroll
-                    for (int e = 0; e < 8; e++) v[e] = fmaxf((v[e] + bb[e]) + (float)rp[e], 0.f);
-                    u32x4 outv;
-                    T *op = (T *)&outv;
-#pragma unroll
-                    for (int e = 0; e < 8; e++) op[e] = (T)v[e];
-                    if (m < p.M) *(u32x4 *)(dst + (long long)m * COUT + nc * 128 + e_ch) = outv;
-                    asm volatile("ds_write_b128 %0, %1" :: "v"(raddr), "v"(outv) : "memory");
                 }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             RCV_STAMP(17);
             __builtin_amdgcn_s_barrier();
+            if (grp2 == 1) __builtin_amdgcn_s_barrier();
             // ---- reduce layer on the chunk: acc3 += Y[32 px x 128] * W3[128 out x 128]^T, four K steps of 32
 #pragma unroll
             for (int t = 0; t < 4; t++) {
                 const int h = t >> 1, kk = t & 1;
                 // ---- Lr(t)
                 RCV_STAMP(18 + 4 * t);
-                if (t == 2 && more) RCV_BLK_W3H(nc + 1, 0);
+                if (t == 0 && more) {
+                    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // W3(nc, 1); the youngest four are W(s0+4), W(s0+5) or stores
+#pragma unroll
+                    for (int i = 0; i < 2; i++)
+#pragma unroll
+                        for (int pr = 0; pr < 2; pr++) rg[i][pr] = *(const u32x4 *)(rrow[i] + (nc + 1) * 128 + pr * 32);
+                }
+                if (t == 2 && more) RCV_BLK_W3Q(nc + 1, 0, 0);
+                if (t == 3 && more) RCV_BLK_W3Q(nc + 1, 0, 1);
                 bf16x8 yf[2], bf3[NT3];
 #pragma unroll
                 for (int i = 0; i < 2; i++) {
@@ -1170,10 +1209,7 @@ __global__ __launch_bounds__(512) void k_conv_block(const BlockParams p)
                 const unsigned char *B3 = sW3 + h * (CMID * 128) + (wn2 * (CMID / 2) + r16) * 128 + (kk ? ch1 : ch0);
 #pragma unroll
                 for (int j = 0; j < NT3; j++) bf3[j] = *(const bf16x8 *)(B3 + j * 16 * 128);
-                if (t == 3) {
-                    if (more) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                }
+                if (t == 3 && more) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 RCV_STAMP(18 + 4 * t + 1);
                 __builtin_amdgcn_s_barrier();
@@ -1340,6 +1376,7 @@ __global__ __launch_bounds__(512) void k_conv_block(const BlockParams p)
     }
 #undef RCV_BLK_W3
 #undef RCV_BLK_W3H
+#undef RCV_BLK_W3Q
 #undef RCV_BLK_W
 #undef RCV_BLK_R
 }

@@ -148,6 +148,9 @@ def test_fused_bottleneck_half_identical_to_two_kernels(shapes, state_dict):
         x = torch.from_numpy(fcn_weights.make_input(13, (B, 3, H, W))).cuda()
         eng = FcnEngine([state_dict, _sd(shapes, 1), _sd(shapes, 2)], H, W, dtype="bf16")
         seg_a, rad_a = [t.clone() for t in eng.forward(x)]
+        eng.set_option(6, 0)  # the 256-wide chained block with all waves in lockstep instead of the staggered schedule
+        seg_d, rad_d = [t.clone() for t in eng.forward(x)]
+        assert torch.equal(seg_a, seg_d) and torch.equal(rad_a, rad_d), (H, W, B)
         eng.set_option(5, 0)  # without chaining the next block's 1x1 reduce into the kernel
         seg_c, rad_c = [t.clone() for t in eng.forward(x)]
         assert torch.equal(seg_a, seg_c) and torch.equal(rad_a, rad_c), (H, W, B)

@@ -13,12 +13,13 @@ from rcvpose_amd import build as B
 LIB = os.path.join(B.HERE, "build", "librcvpose_stamps.so")
 ap = argparse.ArgumentParser()
 ap.add_argument("--build", action="store_true")
+ap.add_argument("--define", action="append", default=[], help="extra -D for the diagnostic build (timing experiments)")
 ap.add_argument("--batch", type=int, default=16)
 args = ap.parse_args()
 if args.build:
     B.build_library()
     obj = os.path.join(B.HERE, "build", "fcn_stamps.o")
-    subprocess.check_call([B._hipcc()] + B.COMMON + ["-DRCV_BLK_STAMPS", "-c", os.path.join(B.CSRC, "fcn.hip"), "-o", obj])
+    subprocess.check_call([B._hipcc()] + B.COMMON + ["-DRCV_BLK_STAMPS"] + ["-D" + d for d in args.define] + ["-c", os.path.join(B.CSRC, "fcn.hip"), "-o", obj])
     objs = [os.path.join(B.HERE, "build", s.replace(".hip", ".o")) for s in B.SOURCES if s != "fcn.hip"] + [obj]
     subprocess.check_call([B._hipcc(), "--offload-arch=" + B.ARCH, "-shared", "-fPIC", "-o", LIB] + objs)
     print("built", LIB)
@@ -53,7 +54,7 @@ print("one chunk (nc = 3) of the last 256-wide chained block launched; cycles of
 for w in range(2):
     s = st[w]
     t0 = s[0]
-    print("wave %d (group %d): chunk = %d cycles" % (4 * w, w, s[34] - s[0]))
+    print("wave %d (group %d): chunk = %d cycles; starts %d cycles after wave 0's chunk" % (4 * w, w, s[34] - s[0], s[0] - st[0][0]))
     print("  %-4s %8s %8s %8s %8s" % ("seg", "start", "work", "(pre-wait)", "barrier"))
     starts = [s[4 * ks + 2 * h] for ks in range(4) for h in range(2)] + [s[16]] + [s[18 + 4 * t + 2 * h] for t in range(4) for h in range(2)]
     ends = [s[4 * ks + 2 * h + 1] for ks in range(4) for h in range(2)] + [s[17]] + [s[18 + 4 * t + 2 * h + 1] for t in range(4) for h in range(2)]
@@ -63,3 +64,5 @@ for w in range(2):
         if nm.startswith("Le"):
             pre = str(s[40 + int(nm[2])] - starts[k])
         print("  %-4s %8d %8d %8s %8d" % (nm, starts[k] - t0, ends[k] - starts[k], pre, nxt[k] - ends[k]))
+    print("  inside Le0: W pieces issued +%d, W3 pieces +%d, fragment reads back +%d" % (s[44] - s[0], s[45] - s[44], s[40] - s[45]))
+    print("  inside Le1: W pieces issued +%d, W3 pieces +%d, fragment reads back +%d" % (s[46] - s[4], s[47] - s[46], s[41] - s[47]))
