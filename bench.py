@@ -186,9 +186,9 @@ def main():
         achieved = conv_flop_step / conv_s / 1e12
         peak = MFMA_PEAK_TFLOPS[args.dtype]
         # HBM bytes of the conv family from the committed PMC passes (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
-        # runs, gfx950 correction applied: profiles/r01j_conv_hbm_traffic.json); only valid for the profiled workload
+        # runs, gfx950 correction applied: profiles/r01l_conv_hbm_traffic.json); only valid for the profiled workload
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01j_conv_hbm_traffic.json")
+        tpath = os.path.join(ROOT, "profiles", "r01l_conv_hbm_traffic.json")
         if os.path.exists(tpath) and args.dtype == "bf16":
             tj = json.load(open(tpath))["conv_family"]
             traffic = tj["hbm_bytes_per_network_forward"] * B * G  # bytes per step on this GPU
