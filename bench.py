@@ -33,7 +33,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--frames-per-step", type=int, default=64, help="frames per GPU per step")
+    ap.add_argument("--frames-per-step", type=int, default=72, help="frames per GPU per step")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--overlap", action="store_true", help="FCN of batch s+1 and voting of batch s on two HIP streams")
     ap.add_argument("--no-cpu-baseline", action="store_true")
