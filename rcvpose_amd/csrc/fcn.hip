@@ -543,6 +543,290 @@ __global__ __launch_bounds__(512) void k_conv_dma(const ConvParams p)
 }
 
 // ---------------------------------------------------------------------------------------------
+// k_conv_halo (bf16): 3x3 / stride 1 / pad 1 convolutions with the A operand read from a halo'd pixel patch.
+// k_conv_dma brings the [256 px][64 ch] A tile of a channel slice in nine times, once per tap (32 KB per K step through
+// the CU's 64 B/clk vector-memory path, next to 16 KB of weights).  Here a workgroup owns a th x tw pixel rectangle of one
+// image (th * tw <= 256) and keeps, per 64-channel slice, the (th+2) x (tw+2) patch around it in LDS (<= 48 rows-of-8 =
+// 48 KB, double buffered, filled by LDS-DMA during the previous slice's nine steps, six pieces per wave); the A fragments of
+// tap (dh, dw) are ds_read_b128 at the patch row of the pixel shifted by (dh-1) * (tw+2) + (dw-1).  Pixels outside the
+// image are out-of-range buffer offsets (zeros), per patch row and independent of the tap.  Weights: k_conv_dma's ring of
+// three 16 KB stages, two pieces per wave and step.  Same K order (channel-slice-major, taps innermost) and MFMA sequence
+// per output element as k_conv_dma: bit-identical results.  Four-phase step, wave groups one barrier apart, as there.
+// Every step issues the same number of pieces (beyond the end: out-of-range offsets), so one counted vmcnt serves all.
+// ---------------------------------------------------------------------------------------------
+struct HaloParams {
+    const void *src0, *src1, *w;
+    void *dst;
+    const float *bias;
+    long long src0_gs, src1_gs, dst_gs, w_gs;
+    int bias_gs;
+    int C0, C1, Cout, H, W, n_img, relu, K;
+    int th, tw, tiles_y, tiles_x;
+};
+constexpr int HALO_PIECES = 48;                               // patch rows / 8 (six pieces per wave)
+constexpr int HALO_PATCH = HALO_PIECES * 1024;                // bytes per patch buffer
+constexpr int halo_lds(int bn) { return 2 * HALO_PATCH + 3 * bn * 128; }  // 144 KB for BN = 128
+
+// (plain function: the buffer builtins are device-only and a template kernel's body is also instantiated for the host)
+__device__ __forceinline__ void halo_dma16(const void *base, int num_bytes, unsigned char *lds_wave_base, int voffset)
+{
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, num_bytes, 0x00020000);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void *)lds_wave_base, 16, voffset, 0, 0, 0);
+}
+
+template <int BN>
+__global__ __launch_bounds__(512) void k_conv_halo(const HaloParams p)
+{
+    using T = __bf16;
+    constexpr int EPV = 8, BM = 256, MT = 4, NT = BN / 32;  // 8 waves = 4 x 2 of 64 px x BN / 2 channels
+    constexpr int BPW = BN / 64;                             // weight pieces per wave and K step
+    constexpr int OOB = (int)0x80000000;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char *sP = smem;                    // [2][HALO_PATCH]
+    unsigned char *sB = smem + 2 * HALO_PATCH;   // [3][BN][128 B]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    int mt_, nt_;
+    tile_of_block(p.Cout / BN, mt_, nt_);
+    const int g = blockIdx.z, n0 = nt_ * BN;
+    const int tpi = p.tiles_y * p.tiles_x;
+    const int img = mt_ / tpi, trem = mt_ - img * tpi;
+    const int ty = trem / p.tiles_x, tx = trem - ty * p.tiles_x;
+    const int y0 = ty * p.th, x0 = tx * p.tw;
+    const int pitch = p.tw + 2, prows = (p.th + 2) * pitch, npx = p.th * p.tw;
+    const int Ctot = p.C0 + p.C1;
+    const T *src0 = (const T *)p.src0 + (long long)g * p.src0_gs;
+    const T *src1 = p.src1 ? (const T *)p.src1 + (long long)g * p.src1_gs : nullptr;
+    const T *wg = (const T *)p.w + (long long)g * p.w_gs;
+    const int lrow = lane >> 3, lpos = lane & 7;
+    const int r16 = lane & 15, kq = lane >> 4;
+    const float rP = 1.0f / (float)pitch, rT = 1.0f / (float)p.tw;
+
+    // loader: patch piece k of this wave = patch rows (k * 8 + wave) * 8 + lrow; pixel index in the image or -1
+    int lin[6];
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+        const int pr = (k * 8 + wave) * 8 + lrow;
+        const int py = (int)(((float)pr + 0.5f) * rP), px = pr - py * pitch;
+        const int y = y0 - 1 + py, x = x0 - 1 + px;
+        lin[k] = (pr < prows && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W) ? (img * p.H + y) * p.W + x : -1;
+    }
+    // (k * 8 + wave) * 8 + lrow: (row >> 1) & 7 = (lrow >> 1) | 4 * (wave & 1)
+    const int pchunk16 = (lpos ^ ((lrow >> 1) | ((wave & 1) << 2))) << 4;
+    int b_off[BPW];
+#pragma unroll
+    for (int c = 0; c < BPW; c++) {
+        const int row = wave * (8 * BPW) + c * 8 + lrow;
+        b_off[c] = (row * p.K + (lpos ^ ((row >> 1) & 7)) * EPV) * 2;
+    }
+    const char *b_base = (const char *)(wg + (long long)n0 * p.K);
+    const int a_bytes0 = (int)((long long)p.C0 * p.H * p.W * p.n_img * 2), a_bytes1 = (int)((long long)p.C1 * p.H * p.W * p.n_img * 2);
+    const int b_bytes = BN * p.K * 2;
+    const int nsl = Ctot >> 6;
+
+    // fragment rows: tile row r = wm * 64 + i * 16 + r16 -> patch row of its pixel (centre tap); rows beyond the rectangle
+    // read pixel 0's (their results are never stored)
+    int pr0[MT];
+#pragma unroll
+    for (int i = 0; i < MT; i++) {
+        int r = wm * 64 + i * 16 + r16;
+        r = r < npx ? r : 0;
+        const int py = (int)(((float)r + 0.5f) * rT), px = r - py * p.tw;
+        pr0[i] = (py + 1) * pitch + px + 1;
+    }
+
+// patch piece k of channel slice sl_ into patch buffer (sl_ & 1); slices beyond the last one: zeros
+#define RCV_HALO_PATCH(sl_, k)                                                                                 \
+    {                                                                                                          \
+        const int cgp_ = (sl_) << 6;                                                                           \
+        const bool first_ = cgp_ < p.C0, live_ = (sl_) < nsl;                                                  \
+        const int Cs_ = first_ ? p.C0 : p.C1;                                                                  \
+        const char *ab_ = (const char *)(first_ ? src0 : src1) + (long long)(first_ ? cgp_ : cgp_ - p.C0) * 2; \
+        const int off_ = (live_ && lin[k] >= 0) ? lin[k] * (Cs_ * 2) + pchunk16 : OOB;                         \
+        halo_dma16(ab_, first_ ? a_bytes0 : a_bytes1, sP + ((sl_) & 1) * HALO_PATCH + ((k) * 8 + wave) * 1024, off_); \
+    }
+// weight piece c of K step (slice sl_, tap t_) into ring stage st_; steps beyond the last one: zeros
+#define RCV_HALO_B(sl_, t_, st_, c)                                                                            \
+    {                                                                                                          \
+        halo_dma16(b_base + (long long)((t_) * Ctot + ((sl_) << 6)) * 2, b_bytes, sB + (st_) * (BN * 128) + (wave * (8 * BPW) + (c) * 8) * 128, \
+                   (sl_) < nsl ? b_off[c] : OOB);                                                              \
+    }
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; i++)
+#pragma unroll
+        for (int j = 0; j < NT; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int ch0 = ((0 * 4 + kq) ^ ((r16 >> 1) & 7)) << 4, ch1 = ((1 * 4 + kq) ^ ((r16 >> 1) & 7)) << 4;
+
+// One K step = (slice sl, tap TAP), four phases as in k_conv_dma.  Pieces issued: first load phase the first weight piece
+// of step + 2, second load phase its second piece and (taps 0..5) one patch piece of slice sl + 1; the counted wait of the
+// second load phase leaves exactly those in flight, so the weights of step + 1 (and by tap 6 the whole next patch) have
+// landed at least one barrier before anybody reads them.  The patch buffer refilled during slice sl was last read in the
+// second load phase of slice sl - 1's last step, two barriers before the first piece goes out.
+#define RCV_HALO_STEP(TAP)                                                                                     \
+    {                                                                                                          \
+        constexpr int T2_ = ((TAP) + 2) % 9, S2_ = ((TAP) + 2) / 9;                                            \
+        const int shift_ = ((TAP) / 3 - 1) * pitch + ((TAP) % 3 - 1);                                          \
+        const unsigned char *Pb = sP + (sl & 1) * HALO_PATCH;                                                  \
+        const unsigned char *Bb = sB + stage * (BN * 128) + (wn * (BN / 2) + r16) * 128;                       \
+        const int st2 = stage + 2 >= 3 ? stage + 2 - 3 : stage + 2;                                            \
+        int ao_[MT];                                                                                           \
+        _Pragma("unroll") for (int i = 0; i < MT; i++) {                                                       \
+            const int prow_ = pr0[i] + shift_;                                                                 \
+            ao_[i] = prow_ * 128 + ((kq ^ ((prow_ >> 1) & 7)) << 4);                                           \
+        }                                                                                                      \
+        bf16x8 af[MT], bfr[NT];                                                                                \
+        _Pragma("unroll") for (int i = 0; i < MT; i++) af[i] = *(const bf16x8 *)(Pb + ao_[i]);                 \
+        _Pragma("unroll") for (int j = 0; j < NT; j++) bfr[j] = *(const bf16x8 *)(Bb + j * 16 * 128 + ch0);    \
+        RCV_HALO_B(sl + S2_, T2_, st2, 0);                                                                     \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                     \
+        __builtin_amdgcn_s_barrier();                                                                          \
+        __builtin_amdgcn_s_setprio(1);                                                                         \
+        _Pragma("unroll") for (int i = 0; i < MT; i++)                                                         \
+            _Pragma("unroll") for (int j = 0; j < NT; j++)                                                     \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);        \
+        __builtin_amdgcn_s_setprio(0);                                                                         \
+        __builtin_amdgcn_s_barrier();                                                                          \
+        _Pragma("unroll") for (int i = 0; i < MT; i++) af[i] = *(const bf16x8 *)(Pb + (ao_[i] ^ 64));          \
+        _Pragma("unroll") for (int j = 0; j < NT; j++) bfr[j] = *(const bf16x8 *)(Bb + j * 16 * 128 + ch1);    \
+        if constexpr (BPW == 2) RCV_HALO_B(sl + S2_, T2_, st2, 1);                                             \
+        if constexpr ((TAP) < 6) {                                                                             \
+            RCV_HALO_PATCH(sl + 1, TAP);                                                                       \
+            if constexpr (BPW == 2) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");                \
+            else asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");                                   \
+        } else {                                                                                               \
+            if constexpr (BPW == 2) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");                \
+            else asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");                                   \
+        }                                                                                                      \
+        __builtin_amdgcn_s_barrier();                                                                          \
+        __builtin_amdgcn_s_setprio(1);                                                                         \
+        _Pragma("unroll") for (int i = 0; i < MT; i++)                                                         \
+            _Pragma("unroll") for (int j = 0; j < NT; j++)                                                     \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);        \
+        __builtin_amdgcn_s_setprio(0);                                                                         \
+        __builtin_amdgcn_s_barrier();                                                                          \
+        stage = stage + 1 == 3 ? 0 : stage + 1;                                                                \
+    }
+
+// BN = 64: half the MFMAs per step, so one load phase (fragments of all 64 K columns) and one MFMA phase per step -- two
+// barriers instead of four.  Same distances: data is waited for in the load phase one step (two barriers) before it is
+// read, a buffer is refilled two barriers after its last read.
+#define RCV_HALO_STEP2(TAP)                                                                                    \
+    {                                                                                                          \
+        constexpr int T2_ = ((TAP) + 2) % 9, S2_ = ((TAP) + 2) / 9;                                            \
+        const int shift_ = ((TAP) / 3 - 1) * pitch + ((TAP) % 3 - 1);                                          \
+        const unsigned char *Pb = sP + (sl & 1) * HALO_PATCH;                                                  \
+        const unsigned char *Bb = sB + stage * (BN * 128) + (wn * (BN / 2) + r16) * 128;                       \
+        const int st2 = stage + 2 >= 3 ? stage + 2 - 3 : stage + 2;                                            \
+        bf16x8 af[2][MT], bfr[2][NT];                                                                          \
+        _Pragma("unroll") for (int i = 0; i < MT; i++) {                                                       \
+            const int prow_ = pr0[i] + shift_;                                                                 \
+            const int ao_ = prow_ * 128 + ((kq ^ ((prow_ >> 1) & 7)) << 4);                                    \
+            af[0][i] = *(const bf16x8 *)(Pb + ao_);                                                            \
+            af[1][i] = *(const bf16x8 *)(Pb + (ao_ ^ 64));                                                     \
+        }                                                                                                      \
+        _Pragma("unroll") for (int j = 0; j < NT; j++) {                                                       \
+            bfr[0][j] = *(const bf16x8 *)(Bb + j * 16 * 128 + ch0);                                            \
+            bfr[1][j] = *(const bf16x8 *)(Bb + j * 16 * 128 + ch1);                                            \
+        }                                                                                                      \
+        RCV_HALO_B(sl + S2_, T2_, st2, 0);                                                                     \
+        if constexpr ((TAP) < 6) {                                                                             \
+            RCV_HALO_PATCH(sl + 1, TAP);                                                                       \
+            asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");                                        \
+        } else {                                                                                               \
+            asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");                                        \
+        }                                                                                                      \
+        __builtin_amdgcn_s_barrier();                                                                          \
+        __builtin_amdgcn_s_setprio(1);                                                                         \
+        _Pragma("unroll") for (int kk = 0; kk < 2; kk++)                                                       \
+            _Pragma("unroll") for (int i = 0; i < MT; i++)                                                     \
+                _Pragma("unroll") for (int j = 0; j < NT; j++)                                                 \
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[kk][i], bfr[kk][j], acc[i][j], 0, 0, 0); \
+        __builtin_amdgcn_s_setprio(0);                                                                         \
+        __builtin_amdgcn_s_barrier();                                                                          \
+        stage = stage + 1 == 3 ? 0 : stage + 1;                                                                \
+    }
+
+    const int grp = wave >> 2;
+#pragma unroll
+    for (int k = 0; k < 6; k++) RCV_HALO_PATCH(0, k);
+    RCV_HALO_B(0, 0, 0, 0);
+    if constexpr (BPW == 2) RCV_HALO_B(0, 0, 0, 1);
+    RCV_HALO_B(0, 1, 1, 0);
+    if constexpr (BPW == 2) RCV_HALO_B(0, 1, 1, 1);
+    if constexpr (BPW == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (grp == 1) __builtin_amdgcn_s_barrier();
+    int stage = 0;
+    if constexpr (BPW == 2) {
+        for (int sl = 0; sl < nsl; sl++) {
+            RCV_HALO_STEP(0); RCV_HALO_STEP(1); RCV_HALO_STEP(2);
+            RCV_HALO_STEP(3); RCV_HALO_STEP(4); RCV_HALO_STEP(5);
+            RCV_HALO_STEP(6); RCV_HALO_STEP(7); RCV_HALO_STEP(8);
+        }
+    } else {
+        for (int sl = 0; sl < nsl; sl++) {
+            RCV_HALO_STEP2(0); RCV_HALO_STEP2(1); RCV_HALO_STEP2(2);
+            RCV_HALO_STEP2(3); RCV_HALO_STEP2(4); RCV_HALO_STEP2(5);
+            RCV_HALO_STEP2(6); RCV_HALO_STEP2(7); RCV_HALO_STEP2(8);
+        }
+    }
+    if (grp == 0) __builtin_amdgcn_s_barrier();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the zero pieces issued past the end
+#undef RCV_HALO_STEP
+#undef RCV_HALO_STEP2
+#undef RCV_HALO_B
+#undef RCV_HALO_PATCH
+
+    // epilogue: k_conv_dma's (fp32 tile staged in LDS, 16-byte vectors of contiguous channels); tile row -> image pixel
+    T *dst = (T *)p.dst + (long long)g * p.dst_gs;
+    const float *bias = p.bias + (long long)g * p.bias_gs;
+    constexpr int SROW = BN + 4, CPR = BN / EPV, E_PER = (64 * CPR) / 512;
+    float *stg = (float *)smem;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < NT; j++) {
+        const int nl = wn * (BN / 2) + j * 16 + r16;
+        const float bv = bias[n0 + nl];
+#pragma unroll
+        for (int i = 0; i < MT; i++)
+#pragma unroll
+            for (int e = 0; e < 4; e++) stg[(wm * 64 + i * 16 + kq * 4 + e) * SROW + nl] = acc[i][j][e] + bv;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int round = 0; round < 4; round++) {
+#pragma unroll
+        for (int q = 0; q < E_PER; q++) {
+            const int c = q * 512 + tid, row = c / CPR, cc = c - row * CPR;
+            const int r = round * 64 + row;
+            const int py = (int)(((float)r + 0.5f) * rT), px = r - py * p.tw;
+            const int y = y0 + py, x = x0 + px;
+            if (r >= npx || y >= p.H || x >= p.W) continue;
+            const long long o = ((long long)(img * p.H + y) * p.W + x) * p.Cout + n0 + cc * EPV;
+            float v[EPV];
+            const float4 *sp4 = (const float4 *)(stg + r * SROW + cc * EPV);
+#pragma unroll
+            for (int qq = 0; qq < EPV / 4; qq++) {
+                const float4 t = sp4[qq];
+                v[qq * 4 + 0] = t.x; v[qq * 4 + 1] = t.y; v[qq * 4 + 2] = t.z; v[qq * 4 + 3] = t.w;
+            }
+            if (p.relu) {
+#pragma unroll
+                for (int qq = 0; qq < EPV; qq++) v[qq] = fmaxf(v[qq], 0.f);
+            }
+            uint4 outv;
+            T *op = (T *)&outv;
+#pragma unroll
+            for (int qq = 0; qq < EPV; qq++) op[qq] = from_f32<T>(v[qq]);
+            *(uint4 *)(dst + o) = outv;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // k_stem_mfma (bf16): the same 7x7/2 stem as an MFMA GEMM.  A workgroup owns 8 x 32 output pixels of one image and
 // serves every group (keypoint network) from one im2col image:
 //   1. the fp32 input patch (3 x 21 x 69) is staged in LDS,
@@ -1757,6 +2041,7 @@ struct rcv_fcn {
     bool use_block = true;  // fused 3x3 + expand 1x1 kernel for the 256 -> 256 -> 1024 bottleneck halves (bf16)
     bool use_chain = true;  // ... with the next block's 1x1 reduce chained in where it follows directly
     bool use_stagger = true;  // ... and, for the 256-wide chained block, the staggered schedule of the 1x1 phases
+    int use_halo = 1;  // halo-patch kernel for the 3x3 / stride-1 layers it covers (k_conv_halo); 2: also at poor tile fits
     bool profiling = false;
     std::vector<hipEvent_t> events;  // 2 per op when profiling
     bool events_valid = false;
@@ -1799,6 +2084,37 @@ int launch_conv_dma(const ConvParams &p, int groups, hipStream_t st, bool set_at
         RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_conv_dma, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     dim3 grid(p.Cout / DMA_BN, (p.M + DMA_BM - 1) / DMA_BM, groups);
     hipLaunchKernelGGL(k_conv_dma, grid, dim3(512), lds, st, p);
+    RCV_LAUNCH_CHECK();
+    return RCV_OK;
+}
+
+// k_conv_halo where it applies: 3x3 / stride 1 / pad 1, bf16, Cout a multiple of 128, a pixel rectangle of <= 256 pixels
+// whose halo'd patch fits 48 DMA pieces and that covers the image with little waste, and enough workgroups
+bool halo_tile(int H, int W, int mode, int &th, int &tw)
+{
+    const int cand[4][2] = {{8, 32}, {6, 40}, {12, 20}, {16, 16}};
+    double best = 0.0;
+    for (auto &c : cand) {
+        if ((c[0] + 2) * (c[1] + 2) > HALO_PIECES * 8) continue;
+        const double util = (double)H * W / ((double)((H + c[0] - 1) / c[0]) * ((W + c[1] - 1) / c[1]) * 256.0);
+        if (util > best) { best = util; th = c[0]; tw = c[1]; }
+    }
+    return best >= (mode == 2 ? 0.3 : 0.9);  // mode 2 (tests): also where rectangles hang over the image edge a lot
+}
+
+int launch_conv_halo(const ConvParams &p, int B, int groups, int mode, hipStream_t st)
+{
+    HaloParams q;
+    memset(&q, 0, sizeof(q));
+    if (!halo_tile(p.Hout, p.Wout, mode, q.th, q.tw)) return RCV_E_UNSUPPORTED;
+    q.src0 = p.src0; q.src1 = p.src1; q.w = p.w; q.dst = p.dst; q.bias = p.bias;
+    q.src0_gs = p.src0_gs; q.src1_gs = p.src1_gs; q.dst_gs = p.dst_gs; q.w_gs = p.w_gs; q.bias_gs = p.bias_gs;
+    q.C0 = p.C0; q.C1 = p.C1; q.Cout = p.Cout; q.H = p.Hout; q.W = p.Wout; q.n_img = B; q.relu = p.relu; q.K = p.K;
+    q.tiles_y = (q.H + q.th - 1) / q.th; q.tiles_x = (q.W + q.tw - 1) / q.tw;
+    const int bn = p.Cout % 128 == 0 ? 128 : 64;
+    dim3 grid(p.Cout / bn, (unsigned)(B * q.tiles_y * q.tiles_x), groups);
+    if (bn == 128) hipLaunchKernelGGL(k_conv_halo<128>, grid, dim3(512), halo_lds(128), st, q);
+    else hipLaunchKernelGGL(k_conv_halo<64>, grid, dim3(512), halo_lds(64), st, q);
     RCV_LAUNCH_CHECK();
     return RCV_OK;
 }
@@ -1894,6 +2210,13 @@ int run_op(rcv_fcn *h, const rcv_op &op, const float *x, int B, float *seg, floa
         p.K = op.ksize * op.ksize * (p.C0 + p.C1);
         p.w_gs = (long long)op.cout * p.K;
         p.bias_gs = op.cout;
+        if constexpr (sizeof(T) == 2) {
+            int th, tw;
+            if (h->use_halo && h->use_dma && op.ksize == 3 && op.stride == 1 && op.pad == 1 && op.res < 0 && p.Cout % 64 == 0 &&
+                p.C0 % 64 == 0 && p.C1 % 64 == 0 && op.hin == op.hout && op.win == op.wout && halo_tile(op.hout, op.wout, h->use_halo, th, tw) &&
+                (long long)B * ((op.hout + th - 1) / th) * ((op.wout + tw - 1) / tw) * (p.Cout / (p.Cout % 128 == 0 ? 128 : 64)) * G >= 192)
+                return launch_conv_halo(p, B, G, h->use_halo, st);
+        }
         return launch_conv<T>(p, G, st, !h->attrs_set, h->use_dma);
     }
     default: return RCV_E_UNSUPPORTED;
@@ -1927,6 +2250,8 @@ int register_kernel_attributes()
     if ((rc = register_conv_variants<float>()) != RCV_OK) return rc;
     if ((rc = register_conv_variants<__bf16>()) != RCV_OK) return rc;
     RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_conv_dma, hipFuncAttributeMaxDynamicSharedMemorySize, DMA_STAGES * DMA_STAGE_BYTES));
+    RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_conv_halo<128>, hipFuncAttributeMaxDynamicSharedMemorySize, halo_lds(128)));
+    RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_conv_halo<64>, hipFuncAttributeMaxDynamicSharedMemorySize, halo_lds(64)));
     RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_stem_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, STEM_LDS));
     RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_tail, hipFuncAttributeMaxDynamicSharedMemorySize, TAIL_LDS));
     RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_conv_block<64, false>, hipFuncAttributeMaxDynamicSharedMemorySize, blk_lds(64)));
@@ -2157,6 +2482,7 @@ int rcv_fcn_set_option(rcv_fcn *h, int key, int value)
     if (key == 4) { h->use_block = value != 0; h->attrs_set = false; return RCV_OK; }
     if (key == 5) { h->use_chain = value != 0; h->attrs_set = false; return RCV_OK; }
     if (key == 6) { h->use_stagger = value != 0; h->attrs_set = false; return RCV_OK; }
+    if (key == 7) { h->use_halo = value; h->attrs_set = false; return RCV_OK; }
     return RCV_E_INVALID;
 }
 

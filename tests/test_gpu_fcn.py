@@ -159,6 +159,22 @@ def test_fused_bottleneck_half_identical_to_two_kernels(shapes, state_dict):
         assert torch.equal(seg_a, seg_b) and torch.equal(rad_a, rad_b), (H, W, B)
 
 
+def test_halo_patch_convolution_identical_to_dma_kernel(shapes, state_dict):
+    """k_conv_halo (option 7, default on: the 3x3 / stride-1 decoder layers read their A operand from a halo'd pixel patch in LDS)
+    gives bit-identical network outputs to k_conv_dma; with option 7 = 2 also at image sizes whose pixel rectangles hang over
+    the image edges (ragged rectangles, masked stores) and for both channel-tile widths (128 and 64 output channels)."""
+    from rcvpose_amd.fcn_engine import FcnEngine
+
+    for (H, W, B, mode) in ((480, 640, 3, 1), (480, 640, 9, 1), (416, 544, 5, 2), (352, 480, 6, 2), (64, 96, 40, 2)):
+        x = torch.from_numpy(fcn_weights.make_input(17, (B, 3, H, W))).cuda()
+        eng = FcnEngine([state_dict, _sd(shapes, 1), _sd(shapes, 2)], H, W, dtype="bf16")
+        eng.set_option(7, 0)
+        seg_a, rad_a = [t.clone() for t in eng.forward(x)]
+        eng.set_option(7, mode)
+        seg_b, rad_b = [t.clone() for t in eng.forward(x)]
+        assert torch.equal(seg_a, seg_b) and torch.equal(rad_a, rad_b), (H, W, B, mode)
+
+
 def test_groups_and_batch(shapes, state_dict):
     """3 networks x 2 images in one launch sequence == the six single runs (blockIdx.z / batch indexing)."""
     from rcvpose_amd.fcn_engine import FcnEngine

@@ -17,10 +17,10 @@ sds = [{k: torch.from_numpy(v) for k, v in synthetic_weights.make_state_dict_num
 eng = FcnEngine(sds, 480, 640, dtype="bf16")
 g = torch.Generator().manual_seed(5)
 x = torch.randn((args.batch, 3, 480, 640), generator=g).cuda()
-for key in (1, 3, 4, 5, 6):
+for key in (1, 3, 4, 5, 6, 7):
     eng.set_option(key, 0)
 ref = [t.clone() for t in eng.forward(x)]
-for key in (1, 3, 4, 5, 6):
+for key in (1, 3, 4, 5, 6, 7):
     eng.set_option(key, 1)
 bad = 0
 for r in range(args.reps):
