@@ -186,9 +186,9 @@ def main():
         achieved = conv_flop_step / conv_s / 1e12
         peak = MFMA_PEAK_TFLOPS[args.dtype]
         # HBM bytes of the conv family from the committed PMC passes (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
-        # runs, gfx950 correction applied: profiles/r01l_conv_hbm_traffic.json); only valid for the profiled workload
+        # runs, gfx950 correction applied: profiles/r01n_conv_hbm_traffic.json); only valid for the profiled workload
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01l_conv_hbm_traffic.json")
+        tpath = os.path.join(ROOT, "profiles", "r01n_conv_hbm_traffic.json")
         if os.path.exists(tpath) and args.dtype == "bf16":
             tj = json.load(open(tpath))["conv_family"]
             traffic = tj["hbm_bytes_per_network_forward"] * B * G  # bytes per step on this GPU
@@ -204,7 +204,7 @@ def main():
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                          "traffic": traffic, "traffic_unit": "HBM bytes per step (all conv launches, PMC passes)",
                          "algorithmic_flop_per_step": conv_flop_step,
-                         "kernel": "implicit-GEMM convolution family (k_conv_dma, k_conv<%s,..>, k_tail), %d convolutions per "
+                         "kernel": "implicit-GEMM convolution family (k_conv_block, k_conv_dma, k_conv_halo, k_conv<%s,..>, k_tail), %d convolutions per "
                                    "forward, algorithmic 265.568 GFLOP per network forward" %
                                    (args.dtype, sum(1 for o in pipe.engine.ops if o["kind"] == 3)),
                          "fcn_conv_ms_per_step": prof["conv_ms"], "fcn_other_ms_per_step": prof["other_ms"]},

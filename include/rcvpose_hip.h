@@ -271,7 +271,8 @@ int rcv_fcn_set_profiling(rcv_fcn *h, int enable);
  * + head (k_tail; 0: three kernels, bit-identical output), key 4 = fused 3x3 + expand 1x1 of the stride-1 bottleneck blocks (layers 1-3)
  * (k_conv_block; 0: two kernels, bit-identical output), key 5 = chain the next block's 1x1 reduce into k_conv_block where it
  * follows directly (0: separate kernel, bit-identical output), key 6 = staggered schedule of the 1x1 phases of the chained
- * 256-wide block (0: all waves in lockstep, bit-identical output). */
+ * 256-wide block (0: all waves in lockstep, bit-identical output), key 7 = halo-patch kernel for the 3x3 / stride-1 layers whose
+ * image tiles well (k_conv_halo; 0: k_conv_dma, bit-identical output; 2: also where the pixel rectangles fit the image badly -- tests). */
 int rcv_fcn_set_option(rcv_fcn *h, int key, int value);
 int rcv_fcn_get_profile(rcv_fcn *h, double *conv_ms, double *other_ms, double *conv_flop);
 /* Per-op device times (ms) of the last profiled forward; ms_out has room for n_ops doubles. */
