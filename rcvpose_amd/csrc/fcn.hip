@@ -19,7 +19,10 @@
 //                    share the input image.
 //   k_conv_dma       the same GEMM for bf16 layers with Cout % 128 == 0: 256 x 128 x 64 tiles, operands by buffer-load
 //                    LDS-DMA, four-phase K steps with the two waves of a SIMD staggered (see the kernel)
-//   k_conv_block     bf16: 3x3 (256 -> 256) + 1x1 expand (-> 1024, residual) of a bottleneck block fused; bit-identical
+//   k_conv_halo      bf16: 3x3 / stride-1 layers whose image tiles into <= 256-pixel rectangles: the A operand is a halo'd pixel
+//                    patch kept in LDS per channel slice (one load instead of nine tap tiles); bit-identical to k_conv_dma
+//   k_conv_block     bf16: 3x3 + 1x1 expand (+ residual) of a bottleneck block, and where it follows the next block's 1x1
+//                    reduce, fused in one kernel; staggered wave groups in the 1x1 phases of the 256-wide form; bit-identical
 //   k_tail           bf16: last 2x upsampling + conv7 + head (conv8) fused; bit-identical to the separate kernels
 //   k_stem_mfma      bf16: conv1 7x7/2 + BN + ReLU as an MFMA GEMM over an im2col tile shared by the networks
 //   k_stem           the same layer computed directly from the NCHW fp32 image (fp32 mode)
