@@ -1201,10 +1201,11 @@ __device__ __forceinline__ void d_bb_wide(AccHeader *hdr, const float *F, size_t
                     for (int a = 0; a < 3; a++) {
                         const f32x2 qq = {q[a], q[a]};
                         const f32x2 e1 = lo2[u][a] - qq, e2 = qq - hi2[u][a];
-                        const f32x2 s1 = e1 * e1, s2 = e2 * e2;
                         const f32x2 dmin = {fmaxf(fmaxf(e1.x, e2.x), 0.f), fmaxf(fmaxf(e1.y, e2.y), 0.f)};
+                        // max(e1^2, e2^2) = max(|e1|, |e2|)^2 exactly (the |.| are free source modifiers): one multiply less
+                        const f32x2 dmax = {fmaxf(fabsf(e1.x), fabsf(e2.x)), fmaxf(fabsf(e1.y), fabsf(e2.y))};
                         mn2[a] = dmin * dmin;
-                        mx2[a] = f32x2{fmaxf(s1.x, s2.x), fmaxf(s1.y, s2.y)};
+                        mx2[a] = dmax * dmax;
                     }
                     // (smin < thi) && (smax > tlo) as sign bits; the xy partial sums are shared by the two z halves
                     // and the thresholds are folded into the z terms
