@@ -581,7 +581,7 @@ template <int BN>
 __global__ __launch_bounds__(512) void k_conv_halo(const HaloParams p)
 {
     using T = __bf16;
-    constexpr int EPV = 8, BM = 256, MT = 4, NT = BN / 32;  // 8 waves = 4 x 2 of 64 px x BN / 2 channels
+    constexpr int EPV = 8, MT = 4, NT = BN / 32;   // 8 waves = 4 x 2 of 64 px x BN / 2 channels
     constexpr int BPW = BN / 64;                             // weight pieces per wave and K step
     constexpr int OOB = (int)0x80000000;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
