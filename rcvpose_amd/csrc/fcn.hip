@@ -577,11 +577,11 @@ __device__ __forceinline__ void halo_dma16(const void *base, int num_bytes, unsi
     __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void *)lds_wave_base, 16, voffset, 0, 0, 0);
 }
 
-template <int BN>
+template <int BN, int MT>
 __global__ __launch_bounds__(512) void k_conv_halo(const HaloParams p)
 {
     using T = __bf16;
-    constexpr int EPV = 8, MT = 4, NT = BN / 32;   // 8 waves = 4 x 2 of 64 px x BN / 2 channels
+    constexpr int EPV = 8, NT = BN / 32, RW = 16 * MT;   // 8 waves = 4 x 2 of RW pixels x BN / 2 channels (tile: 4 * RW rows)
     constexpr int BPW = BN / 64;                             // weight pieces per wave and K step
     constexpr int OOB = (int)0x80000000;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -627,12 +627,12 @@ __global__ __launch_bounds__(512) void k_conv_halo(const HaloParams p)
     const int b_bytes = BN * p.K * 2;
     const int nsl = Ctot >> 6;
 
-    // fragment rows: tile row r = wm * 64 + i * 16 + r16 -> patch row of its pixel (centre tap); rows beyond the rectangle
+    // fragment rows: tile row r = wm * RW + i * 16 + r16 -> patch row of its pixel (centre tap); rows beyond the rectangle
     // read pixel 0's (their results are never stored)
     int pr0[MT];
 #pragma unroll
     for (int i = 0; i < MT; i++) {
-        int r = wm * 64 + i * 16 + r16;
+        int r = wm * RW + i * 16 + r16;
         r = r < npx ? r : 0;
         const int py = (int)(((float)r + 0.5f) * rT), px = r - py * p.tw;
         pr0[i] = (py + 1) * pitch + px + 1;
@@ -783,34 +783,37 @@ __global__ __launch_bounds__(512) void k_conv_halo(const HaloParams p)
 #undef RCV_HALO_B
 #undef RCV_HALO_PATCH
 
-    // epilogue: k_conv_dma's (fp32 tile staged in LDS, 16-byte vectors of contiguous channels); tile row -> image pixel
+    // epilogue: k_conv_dma's (fp32 tile staged in LDS, 16-byte vectors of contiguous channels), in two halves of 2 * RW rows
+    // (the 320-row tile would not fit at once); tile row -> image pixel
     T *dst = (T *)p.dst + (long long)g * p.dst_gs;
     const float *bias = p.bias + (long long)g * p.bias_gs;
-    constexpr int SROW = BN + 4, CPR = BN / EPV, E_PER = (64 * CPR) / 512;
+    constexpr int SROW = BN + 4, CPR = BN / EPV, RPR = 512 / CPR;  // rows per pass of the 512 threads
     float *stg = (float *)smem;
     __syncthreads();
 #pragma unroll
-    for (int j = 0; j < NT; j++) {
-        const int nl = wn * (BN / 2) + j * 16 + r16;
-        const float bv = bias[n0 + nl];
+    for (int half = 0; half < 2; half++) {
+        if ((wm >> 1) == half) {
 #pragma unroll
-        for (int i = 0; i < MT; i++)
+            for (int j = 0; j < NT; j++) {
+                const int nl = wn * (BN / 2) + j * 16 + r16;
+                const float bv = bias[n0 + nl];
 #pragma unroll
-            for (int e = 0; e < 4; e++) stg[(wm * 64 + i * 16 + kq * 4 + e) * SROW + nl] = acc[i][j][e] + bv;
-    }
-    __syncthreads();
+                for (int i = 0; i < MT; i++)
 #pragma unroll
-    for (int round = 0; round < 4; round++) {
+                    for (int e = 0; e < 4; e++) stg[((wm & 1) * RW + i * 16 + kq * 4 + e) * SROW + nl] = acc[i][j][e] + bv;
+            }
+        }
+        __syncthreads();
 #pragma unroll
-        for (int q = 0; q < E_PER; q++) {
-            const int c = q * 512 + tid, row = c / CPR, cc = c - row * CPR;
-            const int r = round * 64 + row;
+        for (int pass = 0; pass < (2 * RW + RPR - 1) / RPR; pass++) {
+            const int lr = pass * RPR + tid / CPR, cc = tid % CPR;  // row within the half, 16-byte chunk
+            const int r = half * 2 * RW + lr;
             const int py = (int)(((float)r + 0.5f) * rT), px = r - py * p.tw;
             const int y = y0 + py, x = x0 + px;
-            if (r >= npx || y >= p.H || x >= p.W) continue;
+            if (lr >= 2 * RW || r >= npx || y >= p.H || x >= p.W) continue;
             const long long o = ((long long)(img * p.H + y) * p.W + x) * p.Cout + n0 + cc * EPV;
             float v[EPV];
-            const float4 *sp4 = (const float4 *)(stg + r * SROW + cc * EPV);
+            const float4 *sp4 = (const float4 *)(stg + lr * SROW + cc * EPV);
 #pragma unroll
             for (int qq = 0; qq < EPV / 4; qq++) {
                 const float4 t = sp4[qq];
@@ -826,6 +829,7 @@ __global__ __launch_bounds__(512) void k_conv_halo(const HaloParams p)
             for (int qq = 0; qq < EPV; qq++) op[qq] = from_f32<T>(v[qq]);
             *(uint4 *)(dst + o) = outv;
         }
+        if (half == 0) __syncthreads();
     }
 }
 
@@ -2095,11 +2099,13 @@ int launch_conv_dma(const ConvParams &p, int groups, hipStream_t st, bool set_at
 // whose halo'd patch fits 48 DMA pieces and that covers the image with little waste, and enough workgroups
 bool halo_tile(int H, int W, int mode, int &th, int &tw)
 {
-    const int cand[4][2] = {{8, 32}, {6, 40}, {12, 20}, {16, 16}};
+    // rectangles of <= 256 pixels, and 15 x 20 (a whole 15 x 20 image: the 320-row tile, 128 output channels only)
+    const int cand[5][2] = {{8, 32}, {6, 40}, {12, 20}, {16, 16}, {15, 20}};
     double best = 0.0;
     for (auto &c : cand) {
         if ((c[0] + 2) * (c[1] + 2) > HALO_PIECES * 8) continue;
-        const double util = (double)H * W / ((double)((H + c[0] - 1) / c[0]) * ((W + c[1] - 1) / c[1]) * 256.0);
+        const double rows = c[0] * c[1] > 256 ? 320.0 : 256.0;
+        const double util = (double)H * W / ((double)((H + c[0] - 1) / c[0]) * ((W + c[1] - 1) / c[1]) * rows);
         if (util > best) { best = util; th = c[0]; tw = c[1]; }
     }
     return best >= (mode == 2 ? 0.3 : 0.9);  // mode 2 (tests): also where rectangles hang over the image edge a lot
@@ -2116,8 +2122,11 @@ int launch_conv_halo(const ConvParams &p, int B, int groups, int mode, hipStream
     q.tiles_y = (q.H + q.th - 1) / q.th; q.tiles_x = (q.W + q.tw - 1) / q.tw;
     const int bn = p.Cout % 128 == 0 ? 128 : 64;
     dim3 grid(p.Cout / bn, (unsigned)(B * q.tiles_y * q.tiles_x), groups);
-    if (bn == 128) hipLaunchKernelGGL(k_conv_halo<128>, grid, dim3(512), halo_lds(128), st, q);
-    else hipLaunchKernelGGL(k_conv_halo<64>, grid, dim3(512), halo_lds(64), st, q);
+    if (q.th * q.tw > 256) {
+        if (bn != 128) return RCV_E_UNSUPPORTED;
+        hipLaunchKernelGGL((k_conv_halo<128, 5>), grid, dim3(512), halo_lds(128), st, q);
+    } else if (bn == 128) hipLaunchKernelGGL((k_conv_halo<128, 4>), grid, dim3(512), halo_lds(128), st, q);
+    else hipLaunchKernelGGL((k_conv_halo<64, 4>), grid, dim3(512), halo_lds(64), st, q);
     RCV_LAUNCH_CHECK();
     return RCV_OK;
 }
@@ -2216,7 +2225,7 @@ int run_op(rcv_fcn *h, const rcv_op &op, const float *x, int B, float *seg, floa
         if constexpr (sizeof(T) == 2) {
             int th, tw;
             if (h->use_halo && h->use_dma && op.ksize == 3 && op.stride == 1 && op.pad == 1 && op.res < 0 && p.Cout % 64 == 0 &&
-                p.C0 % 64 == 0 && p.C1 % 64 == 0 && op.hin == op.hout && op.win == op.wout && halo_tile(op.hout, op.wout, h->use_halo, th, tw) &&
+                p.C0 % 64 == 0 && p.C1 % 64 == 0 && op.hin == op.hout && op.win == op.wout && halo_tile(op.hout, op.wout, h->use_halo, th, tw) && (th * tw <= 256 || p.Cout % 128 == 0) &&
                 (long long)B * ((op.hout + th - 1) / th) * ((op.wout + tw - 1) / tw) * (p.Cout / (p.Cout % 128 == 0 ? 128 : 64)) * G >= 192)
                 return launch_conv_halo(p, B, G, h->use_halo, st);
         }
@@ -2253,8 +2262,9 @@ int register_kernel_attributes()
     if ((rc = register_conv_variants<float>()) != RCV_OK) return rc;
     if ((rc = register_conv_variants<__bf16>()) != RCV_OK) return rc;
     RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_conv_dma, hipFuncAttributeMaxDynamicSharedMemorySize, DMA_STAGES * DMA_STAGE_BYTES));
-    RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_conv_halo<128>, hipFuncAttributeMaxDynamicSharedMemorySize, halo_lds(128)));
-    RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_conv_halo<64>, hipFuncAttributeMaxDynamicSharedMemorySize, halo_lds(64)));
+    RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_conv_halo<128, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, halo_lds(128)));
+    RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_conv_halo<128, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, halo_lds(128)));
+    RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_conv_halo<64, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, halo_lds(64)));
     RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_stem_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, STEM_LDS));
     RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_tail, hipFuncAttributeMaxDynamicSharedMemorySize, TAIL_LDS));
     RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_conv_block<64, false>, hipFuncAttributeMaxDynamicSharedMemorySize, blk_lds(64)));
