@@ -1592,19 +1592,24 @@ __global__ __launch_bounds__(512) void k_conv_block(const BlockParams p)
                     v[e] = __uint_as_float(sw[0]);
                     v[4 + e] = __uint_as_float(sw[1]);
                 }
-                const float4 bA = *(const float4 *)(sB2 + nc * 128 + e_ch), bB = *(const float4 *)(sB2 + nc * 128 + e_ch + 4);
-                const float bb[8] = {bA.x, bA.y, bA.z, bA.w, bB.x, bB.y, bB.z, bB.w};
-                unsigned char *rslot = sR + row * 256 + (((e_ch >> 3) ^ (row & 15)) << 4);
-                const uint4 rq = *(const uint4 *)rslot;
+                // (LDS traffic through inline asm: compiler-visible LDS accesses here make hipcc drain vmcnt(0), i.e. wait for
+                // the next chunk's weight pieces that are already in flight)
+                const unsigned baddr = (unsigned)(size_t)(sB2 + nc * 128 + e_ch);
+                const unsigned raddr = (unsigned)(size_t)(sR + row * 256 + (((e_ch >> 3) ^ (row & 15)) << 4));
+                f32x4 bA, bB;
+                u32x4 rq;
+                asm volatile("ds_read_b128 %0, %3\n\tds_read_b128 %1, %3 offset:16\n\tds_read_b128 %2, %4\n\ts_waitcnt lgkmcnt(0)"
+                             : "=&v"(bA), "=&v"(bB), "=&v"(rq) : "v"(baddr), "v"(raddr) : "memory");
+                const float bb[8] = {bA[0], bA[1], bA[2], bA[3], bB[0], bB[1], bB[2], bB[3]};
                 const T *rp = (const T *)&rq;
 #pragma unroll
                 for (int e = 0; e < 8; e++) v[e] = fmaxf((v[e] + bb[e]) + (float)rp[e], 0.f);
-                uint4 outv;
+                u32x4 outv;
                 T *op = (T *)&outv;
 #pragma unroll
                 for (int e = 0; e < 8; e++) op[e] = (T)v[e];
-                if (m < p.M) *(uint4 *)(dst + (long long)m * COUT + nc * 128 + e_ch) = outv;
-                if (CHAIN) *(uint4 *)rslot = outv;
+                if (m < p.M) *(u32x4 *)(dst + (long long)m * COUT + nc * 128 + e_ch) = outv;
+                if (CHAIN) asm volatile("ds_write_b128 %0, %1" ::"v"(raddr), "v"(outv) : "memory");
             }
         }
         if (CHAIN) {
