@@ -335,6 +335,29 @@ class FcnEngine:
                                             ws.numel(), _hip.current_stream()), "rcv_fcn_forward")
         return seg, radial
 
+    def capture(self, x, out=None):
+        """One forward for fixed buffers as a HIP graph (the ~170 launches of a forward are launch-bound at small batches).
+
+        x: the static input tensor (refill it in place before a replay); returns (graph, seg, radial): `graph.replay()`
+        re-runs the captured launches on the current stream and leaves the result in seg / radial.  Per-op profiling must
+        be off; the layer program, options and batch size are frozen into the graph."""
+        import torch
+
+        B = x.shape[0]
+        self.workspace(B)
+        if out is None:
+            out = (torch.empty((self.groups, B, 1, self.H, self.W), dtype=torch.float32, device=x.device),
+                   torch.empty((self.groups, B, 1, self.H, self.W), dtype=torch.float32, device=x.device))
+        side = torch.cuda.Stream(device=x.device)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):  # warm-up outside the capture (kernel attributes are registered on first use)
+            self.forward(x, out=out)
+        torch.cuda.current_stream().wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            self.forward(x, out=out)
+        return graph, out[0], out[1]
+
     def debug_stage(self, B, g, name):
         """Activation of a named stage as float32 [B,C,H,W] (engine must be built with reuse_slots=False)."""
         t, shape = self.stages[name]

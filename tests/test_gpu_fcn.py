@@ -175,6 +175,27 @@ def test_halo_patch_convolution_identical_to_dma_kernel(shapes, state_dict):
         assert torch.equal(seg_a, seg_b) and torch.equal(rad_a, rad_b), (H, W, B, mode)
 
 
+def test_forward_as_hip_graph(shapes, state_dict):
+    """FcnEngine.capture: the forward's launches replayed as one HIP graph give the eager result, also after the static input
+    has been refilled."""
+    from rcvpose_amd.fcn_engine import FcnEngine
+
+    eng = FcnEngine([state_dict, _sd(shapes, 1)], 64, 96, dtype="bf16")
+    x = torch.from_numpy(fcn_weights.make_input(21, (2, 3, 64, 96))).cuda()
+    seg_a, rad_a = [t.clone() for t in eng.forward(x)]
+    graph, seg_g, rad_g = eng.capture(x)
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(seg_a, seg_g) and torch.equal(rad_a, rad_g)
+    x2 = torch.from_numpy(fcn_weights.make_input(22, (2, 3, 64, 96))).cuda()
+    seg_b, rad_b = [t.clone() for t in eng.forward(x2)]
+    x.copy_(x2)
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(seg_b, seg_g) and torch.equal(rad_b, rad_g)
+    assert not torch.equal(seg_a, seg_b)
+
+
 def test_groups_and_batch(shapes, state_dict):
     """3 networks x 2 images in one launch sequence == the six single runs (blockIdx.z / batch indexing)."""
     from rcvpose_amd.fcn_engine import FcnEngine

@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--no-dma", action="store_true", help="disable the LDS-DMA conv kernel")
     ap.add_argument("--off", type=int, action="append", default=[], help="engine option key to switch off (repeatable)")
+    ap.add_argument("--graph", action="store_true", help="also time the forward replayed as one HIP graph")
     ap.add_argument("--all", action="store_true", help="print every op, not the per-shape summary")
     args = ap.parse_args()
     shapes = json.load(open(os.path.join(ROOT, "tests", "golden", "fcn_state_dict_keys.json")))
@@ -74,6 +75,26 @@ def main():
     conv_ms = sum(ms for o, ms in zip(eng.ops, acc) if o["kind"] == 3)
     print("conv total %.3f ms  -> %.1f TFLOP/s ; all ops %.3f ms ; wall per forward %.3f ms (B=%d, G=%d, %s)" %
           (conv_ms, tot_flop / conv_ms / 1e9, acc.sum(), e0.elapsed_time(e1) / args.iters, args.batch, args.groups, args.dtype))
+    if args.graph:
+        eng.set_profiling(False)
+        seg_e, rad_e = [t.clone() for t in eng.forward(x)]
+        t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        t0.record()
+        for _ in range(args.iters):
+            eng.forward(x)
+        t1.record()
+        torch.cuda.synchronize()
+        eager = t0.elapsed_time(t1) / args.iters
+        graph, seg_g, rad_g = eng.capture(x)
+        torch.cuda.synchronize()
+        t0.record()
+        for _ in range(args.iters):
+            graph.replay()
+        t1.record()
+        torch.cuda.synchronize()
+        print("wall per forward without per-op events: %.3f ms launched op by op, %.3f ms replayed as one HIP graph; identical outputs: %s" %
+              (eager, t0.elapsed_time(t1) / args.iters, bool(torch.equal(seg_e, seg_g) and torch.equal(rad_e, rad_g))))
 
 
 if __name__ == "__main__":
