@@ -2227,14 +2227,17 @@ int run_op(rcv_fcn *h, const rcv_op &op, const float *x, int B, float *seg, floa
         p.K = op.ksize * op.ksize * (p.C0 + p.C1);
         p.w_gs = (long long)op.cout * p.K;
         p.bias_gs = op.cout;
+        // the LDS-DMA kernels address a tensor through a buffer descriptor with 32-bit byte offsets: only below 2 GiB per group
+        auto fits32 = [&](int s) { return s < 0 || (long long)h->slot_elems[s] * B * (long long)sizeof(T) < 0x7fffffffLL; };
+        const bool dma_ok = h->use_dma && fits32(op.src0) && fits32(op.src1) && fits32(op.res) && fits32(op.dst);
         if constexpr (sizeof(T) == 2) {
             int th, tw;
-            if (h->use_halo && h->use_dma && op.ksize == 3 && op.stride == 1 && op.pad == 1 && op.res < 0 && p.Cout % 64 == 0 &&
+            if (h->use_halo && dma_ok && op.ksize == 3 && op.stride == 1 && op.pad == 1 && op.res < 0 && p.Cout % 64 == 0 &&
                 p.C0 % 64 == 0 && p.C1 % 64 == 0 && op.hin == op.hout && op.win == op.wout && halo_tile(op.hout, op.wout, h->use_halo, th, tw) && (th * tw <= 256 || p.Cout % 128 == 0) &&
                 (long long)B * ((op.hout + th - 1) / th) * ((op.wout + tw - 1) / tw) * (p.Cout / (p.Cout % 128 == 0 ? 128 : 64)) * G >= 192)
                 return launch_conv_halo(p, B, G, h->use_halo, st);
         }
-        return launch_conv<T>(p, G, st, !h->attrs_set, h->use_dma);
+        return launch_conv<T>(p, G, st, !h->attrs_set, dma_ok);
     }
     default: return RCV_E_UNSUPPORTED;
     }
@@ -2298,7 +2301,8 @@ int forward_impl(rcv_fcn *h, const float *x, int B, float *seg, float *radial, c
         if constexpr (sizeof(T) == 2) {
             // 3x3 (-> 256 channels, ReLU) followed by the 1x1 expand to 1024 channels with residual and ReLU: the second
             // half of a layer-3 bottleneck block as one kernel (option 4)
-            if (h->use_block && i + 1 < h->ops.size() && h->ops[i].kind == RCV_OP_CONV && h->ops[i + 1].kind == RCV_OP_CONV) {
+            if (h->use_block && i + 1 < h->ops.size() && h->ops[i].kind == RCV_OP_CONV && h->ops[i + 1].kind == RCV_OP_CONV &&
+                (long long)h->slot_elems[h->ops[i + 1].dst] * B * 2 < 0x7fffffffLL) {  // (the widest tensor it touches; 32-bit DMA offsets)
                 const rcv_op &a = h->ops[i], &b = h->ops[i + 1];
                 const long long M = (long long)B * a.hout * a.wout;
                 const int cmid = a.cout;

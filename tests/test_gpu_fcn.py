@@ -175,6 +175,20 @@ def test_halo_patch_convolution_identical_to_dma_kernel(shapes, state_dict):
         assert torch.equal(seg_a, seg_b) and torch.equal(rad_a, rad_b), (H, W, B, mode)
 
 
+def test_batch_whose_tensors_exceed_2gib(shapes, state_dict):
+    """At 112 frames the 240 x 320 x 128 activations of one network pass 2 GiB: the LDS-DMA kernels (32-bit buffer offsets) must
+    step aside for those layers, and every image still gets the result it gets in a small batch."""
+    from rcvpose_amd.fcn_engine import FcnEngine
+
+    eng = FcnEngine([state_dict], 480, 640, dtype="bf16")
+    small = torch.from_numpy(fcn_weights.make_input(23, (2, 3, 480, 640))).cuda()
+    seg_s, rad_s = [t.clone() for t in eng.forward(small)]
+    big = small.repeat(56, 1, 1, 1)  # images 0, 1, 0, 1, ...
+    seg_b, rad_b = eng.forward(big)
+    for i in (0, 1, 55, 110, 111):
+        assert torch.equal(seg_b[0, i], seg_s[0, i % 2]) and torch.equal(rad_b[0, i], rad_s[0, i % 2]), i
+
+
 def test_forward_as_hip_graph(shapes, state_dict):
     """FcnEngine.capture: the forward's launches replayed as one HIP graph give the eager result, also after the static input
     has been refilled."""
