@@ -614,8 +614,10 @@ __global__ __launch_bounds__(512) void k_conv_halo(const HaloParams p)
         const int y = y0 - 1 + py, x = x0 - 1 + px;
         lin[k] = (pr < prows && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W) ? (img * p.H + y) * p.W + x : -1;
     }
-    // (k * 8 + wave) * 8 + lrow: (row >> 1) & 7 = (lrow >> 1) | 4 * (wave & 1)
-    const int pchunk16 = (lpos ^ ((lrow >> 1) | ((wave & 1) << 2))) << 4;
+    // The patch is swizzled with chunk ^= row & 7 (= lrow here), not with the tiles' (row >> 1) & 7: the taps read 16 consecutive
+    // patch rows from ANY start row, and under ds_read_b128's lane grouping this key is conflict-free for every start (the
+    // tiles' key is only for starts that are multiples of 4: 2-way conflicts on 12 of 16 offsets)
+    const int pchunk16 = (lpos ^ lrow) << 4;
     int b_off[BPW];
 #pragma unroll
     for (int c = 0; c < BPW; c++) {
@@ -677,7 +679,7 @@ __global__ __launch_bounds__(512) void k_conv_halo(const HaloParams p)
         int ao_[MT];                                                                                           \
         _Pragma("unroll") for (int i = 0; i < MT; i++) {                                                       \
             const int prow_ = pr0[i] + shift_;                                                                 \
-            ao_[i] = prow_ * 128 + ((kq ^ ((prow_ >> 1) & 7)) << 4);                                           \
+            ao_[i] = prow_ * 128 + ((kq ^ (prow_ & 7)) << 4);                                                  \
         }                                                                                                      \
         bf16x8 af[MT], bfr[NT];                                                                                \
         _Pragma("unroll") for (int i = 0; i < MT; i++) af[i] = *(const bf16x8 *)(Pb + ao_[i]);                 \
@@ -725,7 +727,7 @@ __global__ __launch_bounds__(512) void k_conv_halo(const HaloParams p)
         bf16x8 af[2][MT], bfr[2][NT];                                                                          \
         _Pragma("unroll") for (int i = 0; i < MT; i++) {                                                       \
             const int prow_ = pr0[i] + shift_;                                                                 \
-            const int ao_ = prow_ * 128 + ((kq ^ ((prow_ >> 1) & 7)) << 4);                                    \
+            const int ao_ = prow_ * 128 + ((kq ^ (prow_ & 7)) << 4);                                           \
             af[0][i] = *(const bf16x8 *)(Pb + ao_);                                                            \
             af[1][i] = *(const bf16x8 *)(Pb + (ao_ ^ 64));                                                     \
         }                                                                                                      \
