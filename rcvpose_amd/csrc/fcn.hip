@@ -1885,7 +1885,7 @@ __global__ __launch_bounds__(256) void k_preprocess(const uint8_t *rgb, float *x
 constexpr int TAIL_TH = 8, TAIL_TW = 32, TAIL_UW = TAIL_TW + 2, TAIL_UH = TAIL_TH + 2;
 constexpr int TAIL_SH = TAIL_TH / 2 + 2, TAIL_SW = TAIL_TW / 2 + 2;
 constexpr int TAIL_HP = 80;  // bytes per pixel of the conv7 staging rows (64 + bank spread)
-constexpr int TAIL_UP = 144;  // bytes per pixel of the upsampled patch: 128 + 16, which spreads 16 consecutive pixels over all banks
+constexpr int TAIL_UP = 160;  // bytes per pixel of the upsampled patch: 128 + 32 -- conflict-free for ds_read_b128's lane groups (16 consecutive pixels, two 16-byte columns per group; 144 is 2-way)
 constexpr int TAIL_LDS = TAIL_UH * TAIL_UW * TAIL_UP + (256 * TAIL_HP > TAIL_SH * TAIL_SW * 128 ? 256 * TAIL_HP : TAIL_SH * TAIL_SW * 128);
 
 __global__ __launch_bounds__(256, 2) void k_tail(const __bf16 *src, const __bf16 *w7, const float *b7, const __bf16 *w8, const float *b8,
