@@ -12,12 +12,16 @@ Because the weights are random (no checkpoints without a network), the FCN outpu
 object: after the (timed, complete) forward the ideal seg / radial maps of the synthetic frame are copied
 over the output buffers (also timed) and the seam/vote stages run on those.
 
-Usage:  python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
-Prints ONE JSON line on rank 0.
+Usage:  python bench.py --gpus N --steps K --warmup W
+For N > 1 the driver launches one process per GPU through torch.distributed.run; a plain
+`python bench.py --gpus N` starts those N processes itself (fresh children, before this process touches a GPU)
+and relays rank 0's line.  Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -26,9 +30,11 @@ sys.path.insert(0, ROOT)
 
 MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}  # dense peaks, /opt/skills/guides/MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0
+GATE_VOXELS = 1.0          # north_star: keypoints within 1 voxel of the reference's
+TRUTH_GATE_VOXELS = 4.0    # sanity only: recovered keypoint vs the synthetic frame's true keypoint (0.02 dm radial noise)
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -37,14 +43,83 @@ def parse():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--overlap", action="store_true", help="FCN of batch s+1 and voting of batch s on two HIP streams")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU vote sample")
-    return ap.parse_args()
+    ap.add_argument("--no-extras", action="store_true", help="skip the fp32-mode and batch-1 (configs[1]) side measurements")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU vote samples (all frames together)")
+    ap.add_argument("--parity-frames", type=int, default=8, help="frames of the last step checked against the oracle")
+    ap.add_argument("--selftest-launcher", action="store_true",
+                    help="CPU only: exercise the launcher / rendezvous / gather with gloo ranks and no GPU work (tests)")
+    return ap.parse_args(argv)
 
 
-def cpu_baseline(frame, rmax, budget_s):
-    """The oracle (kind "port") timed on this box's host cores on a bounded sample of the same workload:
-    one torch-CPU fp32 FCN forward (all cores) and the brute-force N x D^3 vote on a subset of the frame's
-    points (cost is exactly proportional to the number of points, so it is scaled to the full cloud)."""
+# ---------------------------------------------------------------------------------------------------------
+# launcher: `python bench.py --gpus N` without torch.distributed.run around it
+# ---------------------------------------------------------------------------------------------------------
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def self_launch(args, argv):
+    """Start N fresh ranks of this script (one per GPU) and return their exit code.  Runs before this process has made any
+    HIP call: a process that initialised the GPU must never be replaced or forked into the ranks."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC (RCCL across processes on this pool)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // max(1, args.gpus))))
+    return subprocess.run(cmd, env=env).returncode
+
+
+def selftest(args):
+    """The N > 1 plumbing without a GPU: rendezvous from the torchrun environment, the per-step collective
+    (sharding.gather_keypoints) on deterministic stand-in keypoints, the max-over-ranks timing reduction, rank 0's line."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    from rcvpose_amd import sharding
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="gloo")
+    assert args.gpus == world, "--gpus must equal WORLD_SIZE"
+    B = args.frames_per_step
+
+    def fake(frame):  # stands in for the pipeline's result for global frame `frame`
+        return np.random.default_rng(1000 + frame).normal(size=(3, 3)) * 100
+
+    t0 = time.perf_counter()
+    ok = True
+    for s in range(args.steps):
+        local = torch.from_numpy(np.stack([fake((s * B + i) * world + rank) for i in range(B)]))
+        full = sharding.gather_keypoints(local, B * world)
+        expect = np.stack([fake(s * B * world + f) for f in range(B * world)])
+        ok = ok and np.array_equal(full.numpy(), expect)
+    if world > 1:
+        dist.barrier()
+    tmax = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        print(json.dumps({"selftest": True, "n_gpus": world, "ranks": dist.get_world_size() if world > 1 else 1, "steps": args.steps,
+                          "gather_equals_world1": bool(ok), "seconds": float(tmax.item())}))
+    if world > 1:
+        dist.destroy_process_group()
+    return 0 if ok else 1
+
+
+# ---------------------------------------------------------------------------------------------------------
+# CPU baseline (the oracle timed on the host cores)
+# ---------------------------------------------------------------------------------------------------------
+def cpu_baseline(frames, budget_s):
+    """The oracle (kind "port") timed on this box's host cores on a bounded sample of the same workload, per frame:
+    one torch-CPU fp32 FCN forward (all cores) and the brute-force N x D^3 vote on a subset of the frame's points
+    (cost is exactly proportional to the number of points, so it is scaled to the full cloud).  Median over the frames."""
     import numpy as np
     import torch
 
@@ -53,38 +128,106 @@ def cpu_baseline(frame, rmax, budget_s):
 
     shapes = json.load(open(os.path.join(ROOT, "tests", "golden", "fcn_state_dict_keys.json")))
     sd = {k: torch.from_numpy(v) for k, v in synthetic_weights.make_state_dict_numpy(shapes, seed=0).items()}
-    x = fcn_torch.preprocess(frame["rgb"])
-    fcn_torch.forward(sd, x)  # warm-up
-    ts = []
-    for _ in range(2):
+    fcn_torch.forward(sd, fcn_torch.preprocess(frames[0]["rgb"]))  # warm-up
+    per_frame, notes, rates = [], [], []
+    for f in frames:
+        x = fcn_torch.preprocess(f["rgb"])
         t0 = time.perf_counter()
         fcn_torch.forward(sd, x)
-        ts.append(time.perf_counter() - t0)
-    t_fcn = min(ts)
-    xyz, rl = cpu_oracle.seam(frame["seg"], frame["radial"][0], frame["depth"], rmax[0])
-    pts, rv, info = cpu_oracle.prepare(xyz, rl)
-    n = len(pts)
-    probe = 16
-    t0 = time.perf_counter()
-    cpu_oracle.fast_for(pts[:probe], rv[:probe], info.dim)
-    per_point = (time.perf_counter() - t0) / probe
-    sample = int(max(probe, min(n, budget_s / max(per_point, 1e-9))))
-    idx = np.linspace(0, n - 1, sample).astype(np.int64)
-    t0 = time.perf_counter()
-    cpu_oracle.fast_for(pts[idx], rv[idx], info.dim)
-    t_vote_sample = time.perf_counter() - t0
-    t_vote = t_vote_sample * n / sample
-    fps = 1.0 / (3.0 * t_fcn + 3.0 * t_vote)
+        t_fcn = time.perf_counter() - t0
+        xyz, rl = cpu_oracle.seam(f["seg"], f["radial"][0], f["depth"], f["max_radii_dm"][0])
+        pts, rv, info = cpu_oracle.prepare(xyz, rl)
+        n = len(pts)
+        probe = 16
+        t0 = time.perf_counter()
+        cpu_oracle.fast_for(pts[:probe], rv[:probe], info.dim)
+        per_point = (time.perf_counter() - t0) / probe
+        sample = int(max(probe, min(n, budget_s / len(frames) / max(per_point, 1e-9))))
+        idx = np.linspace(0, n - 1, sample).astype(np.int64)
+        t0 = time.perf_counter()
+        cpu_oracle.fast_for(pts[idx], rv[idx], info.dim)
+        t_vote_sample = time.perf_counter() - t0
+        t_vote = t_vote_sample * n / sample
+        per_frame.append(1.0 / (3.0 * t_fcn + 3.0 * t_vote))
+        rates.append(sample * float(info.dim) ** 3 / t_vote_sample)
+        notes.append("fwd %.2f s, vote %d/%d pts D=%d %.1f s -> %.0f s" % (t_fcn, sample, n, info.dim, t_vote_sample, t_vote))
     return {
-        "value": fps, "unit": "frames/s", "cores": int(max(cpu_oracle.num_threads(), torch.get_num_threads())),
-        "kind": "port",
-        "sample": "1 torch-CPU fp32 FCN forward (%.2f s) x3 + brute-force N*D^3 vote on %d of %d points, D=%d "
-                  "(%.1f s, scaled by N to %.0f s) x3 keypoints" % (t_fcn, sample, n, info.dim, t_vote_sample, t_vote),
+        "value": float(np.median(per_frame)), "unit": "frames/s",
+        "cores": int(max(cpu_oracle.num_threads(), torch.get_num_threads())), "kind": "port",
+        "sample": "median over %d frames of: 1 torch-CPU fp32 FCN forward x3 networks + brute-force N*D^3 vote on a point "
+                  "subset scaled by N, x3 keypoints [%s]" % (len(frames), "; ".join(notes)),
+        "brute_force_tests_per_s": float(np.median(rates)),
     }
 
 
-def main():
-    args = parse()
+# ---------------------------------------------------------------------------------------------------------
+# side measurements that the driver should see (fp32-mode fps, configs[1] batch-1 latency)
+# ---------------------------------------------------------------------------------------------------------
+def extras(sds, frames, H, W):
+    import numpy as np
+    import torch
+
+    from rcvpose_amd.fcn_engine import FcnEngine
+    from rcvpose_amd.pipeline import FramePipeline
+
+    out = {}
+    # configs[1]: one DenseFCNResNet152, bf16, batch 1, 640x480, forward only
+    eng = FcnEngine(sds[:1], H, W, dtype="bf16")
+    x = torch.randn((1, 3, H, W), device="cuda")
+    for _ in range(5):
+        eng.forward(x)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(30):
+        eng.forward(x)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 30
+    out["configs1_batch1_bf16_forward_ms"] = ms
+    out["configs1_batch1_bf16_tflops"] = eng.flops_per_image_group / ms / 1e9
+    del eng
+    # the three networks of one frame at batch 1 (the latency of one frame's forwards)
+    eng = FcnEngine(sds, H, W, dtype="bf16")
+    for _ in range(5):
+        eng.forward(x)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(30):
+        eng.forward(x)
+    e1.record()
+    torch.cuda.synchronize()
+    out["one_frame_3_networks_bf16_forward_ms"] = e0.elapsed_time(e1) / 30
+    del eng
+    # fp32 mode (the precision that meets north_star's 1e-4 on the radial maps): whole path, 8 frames per step
+    B = 8
+    pipe = FramePipeline(sds, H, W, dtype="fp32", frames_per_step=B)
+    rgb = torch.from_numpy(np.stack([f["rgb"] for f in frames[:B]])).cuda()
+    depth = torch.from_numpy(np.stack([f["depth"] for f in frames[:B]]).view(np.int16)).cuda()
+    seg = torch.from_numpy(np.stack([f["seg"] for f in frames[:B]])).cuda()[None].expand(3, B, H, W)[:, :, None]
+    rad = torch.from_numpy(np.stack([f["radial"] for f in frames[:B]])).cuda().permute(1, 0, 2, 3)[:, :, None]
+    rmax = torch.tensor(np.stack([f["max_radii_dm"] for f in frames[:B]]), dtype=torch.float64, device="cuda")
+    pipe.enqueue_step(rgb, depth, rmax, inject=(seg, rad))
+    pipe.finish()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        pipe.enqueue_step(rgb, depth, rmax, inject=(seg, rad))
+    pipe.finish()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    out["fp32_mode_frames_per_s"] = 3 * B / dt
+    out["fp32_mode_frames_per_step"] = B
+    return out
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args, argv))  # nothing in this process has touched a GPU yet
+    if args.selftest_launcher:
+        sys.exit(selftest(args))
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -92,15 +235,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
-    assert args.gpus == world, "--gpus must equal WORLD_SIZE (use torch.distributed.run for N > 1)"
 
-    from rcvpose_amd import synthetic, synthetic_weights
+    from rcvpose_amd import sharding, synthetic, synthetic_weights
     from rcvpose_amd.pipeline import FramePipeline
 
     B, G, H, W = args.frames_per_step, 3, 480, 640
@@ -108,42 +252,47 @@ def main():
     sds = [{k: torch.from_numpy(v) for k, v in synthetic_weights.make_state_dict_numpy(shapes, seed=s).items()}
            for s in range(G)]
     pipe = FramePipeline(sds, H, W, dtype=args.dtype, frames_per_step=B, overlap=args.overlap)
-    del sds
 
-    # frames are sharded over ranks: global frame f -> rank f % world; a pool of distinct
-    # frames per rank is cycled, all resident in HBM before the timed region
+    # frames are sharded over ranks: global frame f -> rank f % world; local frame i of rank r is the
+    # synthetic frame r + world * i.  A pool of distinct frames per rank is cycled, resident in HBM before the timed region.
     pool = max(B, 4)
     fr = [synthetic.synthetic_frame(rank + world * i) for i in range(pool)]
-    rmax = np.max([f["max_radii_dm"] for f in fr], axis=0) + 0.05
-    rgb_pool = torch.from_numpy(np.stack([f["rgb"] for f in fr])).cuda()
-    depth_pool = torch.from_numpy(np.stack([f["depth"] for f in fr]).view(np.int16)).cuda()
-    seg_pool = torch.from_numpy(np.stack([f["seg"] for f in fr])).cuda()            # [P,H,W]
-    rad_pool = torch.from_numpy(np.stack([f["radial"] for f in fr])).cuda()         # [P,3,H,W]
 
-    def batch(step):
-        ids = [(step * B + i) % pool for i in range(B)]
+    def upload(frames):
+        return (torch.from_numpy(np.stack([f["rgb"] for f in frames])).cuda(),
+                torch.from_numpy(np.stack([f["depth"] for f in frames]).view(np.int16)).cuda(),
+                torch.from_numpy(np.stack([f["seg"] for f in frames])).cuda(),                      # [P,H,W]
+                torch.from_numpy(np.stack([f["radial"] for f in frames])).cuda(),                   # [P,3,H,W]
+                torch.tensor(np.stack([f["max_radii_dm"] for f in frames]), dtype=torch.float64, device="cuda"))  # [P,3]
+
+    rgb_pool, depth_pool, seg_pool, rad_pool, rmax_pool = upload(fr)
+
+    def batch_of(pools, ids):
+        rgb_p, depth_p, seg_p, rad_p, rmax_p = pools
         it = torch.tensor(ids, device="cuda")
-        seg = seg_pool[it][None].expand(G, B, H, W)[:, :, None]
-        rad = rad_pool[it].permute(1, 0, 2, 3)[:, :, None]
-        return ids, rgb_pool[it], depth_pool[it], (seg, rad)
+        seg = seg_p[it][None].expand(G, B, H, W)[:, :, None]
+        rad = rad_p[it].permute(1, 0, 2, 3)[:, :, None]
+        return rgb_p[it], depth_p[it], rmax_p[it], (seg, rad)
 
-    from rcvpose_amd import sharding
+    def ids_of(step):
+        return [(step * B + i) % pool for i in range(B)]
 
     # results of every step land in pinned host memory through an async copy on the voting stream
     host_out = [torch.empty((B * world, G, 3), dtype=torch.float64).pin_memory() for _ in range(args.steps + args.warmup)]
-    rmax_dev = torch.tensor(rmax, dtype=torch.float64, device="cuda")
 
     def step_fn(step):
-        """One batch: FCN on one HIP stream; seam + voting + the single collective of the path (one RCCL all_gather of
-        72 B per frame over xGMI, frames back in global order f = i*world + rank) + result copy on another.  Batch s+1's
-        forward overlaps batch s's voting; nothing waits on the host inside the timed region."""
-        ids, rgb, depth, inject = batch(step)
+        """One batch: preprocess + 3 FCN forwards + injection, then seam + voting + the single collective of the path (one
+        RCCL all_gather of 72 B per frame over xGMI, frames back in global order f = i*world + rank) + the result copy.
+        One HIP stream by default; --overlap puts the forward of batch s+1 and the voting of batch s on two streams.
+        Nothing waits on the host inside the timed region."""
+        ids = ids_of(step)
+        rgb, depth, rmax, inject = batch_of((rgb_pool, depth_pool, seg_pool, rad_pool, rmax_pool), ids)
 
         def collect(k):
             out = sharding.gather_keypoints(k, B * world)
             host_out[step].copy_(out, non_blocking=True)
 
-        pipe.enqueue_step(rgb, depth, rmax_dev, inject=inject, collect=collect)
+        pipe.enqueue_step(rgb, depth, rmax, inject=inject, collect=collect)
         return ids
 
     def fence():
@@ -156,6 +305,7 @@ def main():
         step_fn(s)
     fence()
     pipe.engine.set_profiling(True)   # HIP events around every FCN op, on the launch stream
+    pipe.set_stage_timing(True)       # ... and around the stages (net / inject / seam / acc / collect)
     fence()
     t0 = time.perf_counter()
     last_ids = None
@@ -164,67 +314,143 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     prof = pipe.engine.get_profile()
+    stages = pipe.stage_times()
     pipe.engine.set_profiling(False)
+    pipe.set_stage_timing(False)
     tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
     frames_total = args.steps * B * world
     fps = frames_total / dt
-    last = (last_ids, host_out[args.warmup + args.steps - 1])
-
-    # sanity of the last step on rank 0: recovered keypoints within one voxel of the truth
-    ids, out = last
+    out = host_out[args.warmup + args.steps - 1]     # [B*world, G, 3], global frame order f = i*world + rank
+    ids = last_ids
     mine = out[rank::world]
+
+    # sanity of the last step on every rank: recovered keypoints near the synthetic truth
     truth_vox = 0.0
     for i, fid in enumerate(ids):
         truth_vox = max(truth_vox, float(np.abs(mine[i].numpy() - fr[fid]["keypoints_m"] * 1000).max() / 5.0))
 
+    # world-N == world-1: rank 0 recomputes frames of the other ranks on its own GPU and compares the gathered
+    # rows bit for bit (a frame's result must not depend on which rank produced it)
+    sharded_equal, sharded_checked = None, 0
+    if world > 1 and rank == 0:
+        nchk = min(8, B)
+        todo = [(r, i) for r in range(1, world) for i in range(nchk)]
+        sharded_equal = True
+        for c0 in range(0, len(todo), B):
+            chunk = todo[c0:c0 + B]
+            frames = [synthetic.synthetic_frame(r + world * ids[i]) for r, i in chunk]
+            frames += [fr[0]] * (B - len(frames))
+            pools = upload(frames)
+            rgb, depth, rmax, inject = batch_of(pools, list(range(B)))
+            pipe.process(rgb, depth, rmax, inject=inject)
+            torch.cuda.synchronize()
+            kp = pipe.keypoints_tensor().cpu()
+            for j, (r, i) in enumerate(chunk):
+                sharded_equal = sharded_equal and bool(torch.equal(kp[j], out[i * world + r]))
+                sharded_checked += 1
+
+    ok = True
     if rank == 0:
         conv_flop_step = prof["conv_flop_per_image_group"] * B * G
         conv_s = prof["conv_ms"] * 1e-3
         achieved = conv_flop_step / conv_s / 1e12
         peak = MFMA_PEAK_TFLOPS[args.dtype]
-        # HBM bytes of the conv family from the committed PMC passes (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
-        # runs, gfx950 correction applied: profiles/r01n_conv_hbm_traffic.json); only valid for the profiled workload
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01n_conv_hbm_traffic.json")
-        if os.path.exists(tpath) and args.dtype == "bf16":
-            tj = json.load(open(tpath))["conv_family"]
-            traffic = tj["hbm_bytes_per_network_forward"] * B * G  # bytes per step on this GPU
+        # HBM bytes of the conv family: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (gfx950
+        # correction applied), committed under profiles/ with the batch they were taken at
+        traffic, traffic_src = None, None
+        for name in ("r02_conv_hbm_traffic.json", "r01n_conv_hbm_traffic.json"):
+            tpath = os.path.join(ROOT, "profiles", name)
+            if os.path.exists(tpath) and args.dtype == "bf16":
+                tj = json.load(open(tpath))["conv_family"]
+                traffic = tj["hbm_bytes_per_network_forward"] * B * G  # bytes per step on this GPU
+                traffic_src = "profiles/%s (PMC passes at %s frames/step; per-forward bytes x %d forwards)" % (
+                    name, tj.get("frames_per_step", "8"), B * G)
+                break
+        n_steps = float(args.steps)
+        stage_ms = {k: v / n_steps for k, v in stages.items()}
+        # ---- second roofline: seam + voting (HBM-bound by definition) -------------------------------
+        n_pts = [f["n_silhouette"] for f in (fr[i] for i in ids)]
+        alg_bytes = sum(H * W * 10 + 40 * n + 96 for n in n_pts) * G           # per step on this GPU
+        votes = 0.0
+        for i in ids[:8]:                                                       # sum 5.44 r^2 (voxels) over points, 8 frames sampled
+            f = fr[i]
+            for k in range(G):
+                r = f["radial"][k][f["depth"] != 0].astype(np.float64) * 100.0 / 5.0
+                votes += 5.44 * float((r * r).sum())
+        votes = votes / min(8, len(ids)) * B                                    # per step
+        vote_s = (stage_ms.get("seam", 0.0) + stage_ms.get("acc", 0.0)) * 1e-3
+        roof_vote = {
+            "bound": "hbm", "achieved": alg_bytes / vote_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": alg_bytes / vote_s / 1e9 / HBM_PEAK_GBS, "traffic": None,
+            "kernel": "seam + Accumulator_3D (k_seam_*, k_prep, k_setup, k_bb_*; dominant: k_bb_wide), %d (frame, keypoint) items per step" % (B * G),
+            "ms_per_step": vote_s * 1e3, "algorithmic_bytes_per_step": alg_bytes,
+            "algorithmic_bytes_per_item": "H*W*10 B seam read + 40 B/point list written+read + 96 B result (DESIGN 4.2)",
+            "votes_per_s": votes / vote_s,
+        }
+        vp = os.path.join(ROOT, "profiles", "r02_vote_pmc.json")
+        if os.path.exists(vp):
+            roof_vote["pmc"] = json.load(open(vp))
         line = {
             "metric": "end-to-end frames/sec (FCN+3-kpt voting), 640x480 RGB-D",
             "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": args.dtype, "data": "synthetic",
+            "dtype": args.dtype, "data": "synthetic", "rccl_ranks": dist.get_world_size() if world > 1 else 1,
             "config": {"workload": "1-GPU full pipeline: 3x DenseFCNResNet152 forward + seam + LDS radial voting + arg-max, "
                                    "3 keypoints, ~15.5k back-projected pts, 5 mm voxel grid (D~228), 640x480",
                        "frames_per_step_per_gpu": B, "weights": "random (seeded He), ideal maps injected after the forward",
                        "overlap": bool(args.overlap), "parallelism": "frames sharded f%%%d, 1 RCCL all_gather/step" % world},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-                         "traffic": traffic, "traffic_unit": "HBM bytes per step (all conv launches, PMC passes)",
+                         "traffic": traffic, "traffic_unit": "HBM bytes per step (all conv launches)", "traffic_source": traffic_src,
                          "algorithmic_flop_per_step": conv_flop_step,
                          "kernel": "implicit-GEMM convolution family (k_conv_block, k_conv_dma, k_conv_halo, k_conv<%s,..>, k_tail), %d convolutions per "
                                    "forward, algorithmic 265.568 GFLOP per network forward" %
                                    (args.dtype, sum(1 for o in pipe.engine.ops if o["kind"] == 3)),
                          "fcn_conv_ms_per_step": prof["conv_ms"], "fcn_other_ms_per_step": prof["other_ms"]},
-            "sanity": {"max_distance_to_true_keypoint_voxels": truth_vox},
+            "roofline_vote": roof_vote,
+            "stage_ms_per_step": {"net_time (preprocess + 3 forwards)": stage_ms.get("net"), "inject (measurement only)": stage_ms.get("inject"),
+                                  "seam": stage_ms.get("seam"), "acc_time (Accumulator_3D)": stage_ms.get("acc"),
+                                  "collect (gather + D2H)": stage_ms.get("collect")},
+            "sanity": {"max_distance_to_true_keypoint_voxels": truth_vox, "gate_voxels": TRUTH_GATE_VOXELS},
         }
+        ok = ok and truth_vox <= TRUTH_GATE_VOXELS
+        if world > 1:
+            line["sharding"] = {"world_n_equals_world_1_bit_for_bit": sharded_equal, "frames_checked": sharded_checked}
+            ok = ok and bool(sharded_equal)
         if not args.no_cpu_baseline and world == 1:
-            line["cpu_baseline"] = cpu_baseline(fr[0], rmax, args.cpu_seconds)
-            line["speedup_vs_cpu_baseline"] = fps / line["cpu_baseline"]["value"]
-            # parity of the timed path against the oracle (the reference's algorithm) on the last step's first frame
+            # parity of the timed path against the oracle (the reference's algorithm) on frames of the last step
             from oracle import cpu_oracle
 
-            fid, worst = ids[0], 0.0
-            for k in range(G):
-                xyz, rl = cpu_oracle.seam(fr[fid]["seg"], fr[fid]["radial"][k], fr[fid]["depth"], rmax[k])
-                ref = cpu_oracle.accumulator_3d(xyz, rl, sparse=True)[0]
-                worst = max(worst, float(np.abs(mine[0, k].numpy() - ref).max() / 5.0))
-            line["parity"] = {"keypoints_vs_oracle_max_voxels": worst, "gate_voxels": 1.0, "frames_checked": 1}
+            worst, dims, checked = 0.0, [], 0
+            for i in range(min(args.parity_frames, B)):
+                f = fr[ids[i]]
+                for k in range(G):
+                    xyz, rl = cpu_oracle.seam(f["seg"], f["radial"][k], f["depth"], f["max_radii_dm"][k])
+                    ref, _, info, _ = cpu_oracle.accumulator_3d(xyz, rl, sparse=True, return_all=True)
+                    worst = max(worst, float(np.abs(mine[i, k].numpy() - ref[0]).max() / 5.0))
+                    dims.append(info.dim)
+                checked += 1
+            line["parity"] = {"keypoints_vs_oracle_max_voxels": worst, "gate_voxels": GATE_VOXELS, "frames_checked": checked,
+                              "keypoints_checked": checked * G}
+            ok = ok and worst <= GATE_VOXELS
+            d3 = float(np.mean([d ** 3 for d in dims]))
+            roof_vote["brute_force_equivalent_tests_per_s"] = float(np.mean(n_pts)) * d3 * B * G / vote_s
+            line["cpu_baseline"] = cpu_baseline([fr[ids[i]] for i in range(min(3, B))], args.cpu_seconds)
+            line["speedup_vs_cpu_baseline"] = fps / line["cpu_baseline"]["value"]
+        if not args.no_extras and world == 1:
+            del pipe
+            torch.cuda.empty_cache()
+            line["extras"] = extras(sds, fr, H, W)
+        line["ok"] = bool(ok)
         print(json.dumps(line))
     if world > 1:
+        flag = torch.tensor([1 if ok else 0], device="cuda")
+        dist.broadcast(flag, src=0)
+        ok = bool(flag.item())
         dist.destroy_process_group()
+    sys.exit(0 if ok else 1)   # a regressed path must not leave a valid-looking fps line with rc 0
 
 
 if __name__ == "__main__":

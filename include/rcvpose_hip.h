@@ -69,9 +69,20 @@ typedef struct rcv_acc_result {
 
 #define RCV_SEAM_RADIAL_F16 256
 
-/* Bytes of workspace needed by rcv_seam_compact / rcv_accumulate_3d for clouds of up to
- * max_points points (and radii). */
+/* Bytes of workspace for rcv_seam_compact / rcv_accumulate_3d for clouds of up to max_points points (and radii).
+ * rcv_acc_workspace_bytes_min is what every call needs (~45 MB at 640x480); rcv_acc_workspace_bytes adds the replica area
+ * with which the LDS rasteriser splits a tile's point list over up to 8 workgroups (load balance of a SINGLE item;
+ * ~125 MB more).  The calls take whatever lies between the two and size the split from it: batched callers, whose
+ * items already fill the chip, allocate the minimum per item. */
 size_t rcv_acc_workspace_bytes(int max_points);
+size_t rcv_acc_workspace_bytes_min(int max_points);
+
+/* How rcv_accumulate_3d finds the arg-max when no vote_grid_dev is requested (per call; both give the identical peak,
+ * tie count and first index in C order):
+ *   RCV_VOTE_AUTO   exact branch-and-bound peak search; the LDS rasteriser takes over when the search gives up
+ *   RCV_VOTE_RASTER LDS rasteriser only (the full VoteMap is accumulated tile by tile in LDS). */
+#define RCV_VOTE_AUTO 0
+#define RCV_VOTE_RASTER 1
 
 /*
  * The mask / back-projection seam of the per-keypoint loop, reference AccumulatorSpace.py:603-610
@@ -104,13 +115,14 @@ int rcv_seam_compact(const float *seg_dev, const float *radial_dev, const uint16
  *                 rcv_seam_compact); when non-null it overrides n_points / n_radii, which then only
  *                 give upper bounds (cap) so that nothing has to be copied to the host first.
  *   acc_unit_mm   voxel edge in mm (the reference hard-codes 5, AccumulatorSpace.py:374)
+ *   engine        RCV_VOTE_AUTO / RCV_VOTE_RASTER (above)
  *   result_dev    rcv_acc_result on the device
  *   vote_grid_dev optional uint32 [dim^3] copy of VoteMap_3D (tests, tie listing); may be null.
  * The votes are integer counts accumulated in LDS sub-volumes; they are bit-identical to the
  * sequential reference loop.
  */
 int rcv_accumulate_3d(const double *xyz_m_dev, const void *radial_dm_dev, int radial_is_f64,
-                      const int32_t *counts_dev, int n_points, int n_radii, double acc_unit_mm,
+                      const int32_t *counts_dev, int n_points, int n_radii, double acc_unit_mm, int engine,
                       rcv_acc_result *result_dev, uint32_t *vote_grid_dev, size_t vote_grid_cells, void *ws,
                       size_t ws_bytes, void *stream);
 
@@ -133,7 +145,7 @@ int rcv_seam_compact_batch(rcv_strided seg, rcv_strided radial, rcv_strided dept
 /* counts (int32[2] per item, device) give the list lengths; cap bounds them.  radial lists are float32 unless
  * radial_is_f64. */
 int rcv_accumulate_3d_batch(rcv_strided xyz_m, rcv_strided radial_dm, int radial_is_f64, rcv_strided counts, int cap,
-                            double acc_unit_mm, rcv_strided result, rcv_strided ws, size_t ws_bytes, int n_frames,
+                            double acc_unit_mm, int engine, rcv_strided result, rcv_strided ws, size_t ws_bytes, int n_frames,
                             int n_keypoints, void *stream);
 
 /*
@@ -186,12 +198,6 @@ size_t rcv_icp_workspace_bytes(int n_src);
 int rcv_icp_point_to_point(const double *src_dev, int n_src, const double *tgt_dev, int n_tgt, double max_corr_dist,
                            const double T0[16], double relative_fitness, double relative_rmse, int max_iteration,
                            rcv_icp_result *out, void *ws, size_t ws_bytes, void *stream);
-
-/* How rcv_accumulate_3d finds the arg-max when no vote_grid_dev is requested (process-wide setting):
- *   0 (default): exact branch-and-bound peak search; the LDS rasteriser takes over when the search gives up
- *   1: LDS rasteriser only (the full VoteMap is accumulated tile by tile in LDS).
- * Both give the identical result (peak, tie count, first index in C order). */
-int rcv_set_vote_mode(int mode);
 
 /* argwhere(VoteMap_3D == peak) in C order over a grid produced by rcv_accumulate_3d
  * (AccumulatorSpace.py:406): writes up to cap flat indices (ascending) and the total count. */
@@ -256,7 +262,7 @@ size_t rcv_fcn_workspace_bytes(const rcv_fcn *h, int B);
 /*
  * DenseFCNResNet152.forward, reference models/fcnresnet.py:121-191, for all groups:
  *   x_dev    float32 [B,3,H,W] (normalised image, shared by the groups)
- *   seg_dev, radial_dev  float32 [G,B,1,H,W]
+ *   seg_dev, radial_dev  float32 [G,B,1,H,W] (radial_dev float16 under engine option 8)
  */
 int rcv_fcn_forward(rcv_fcn *h, const float *x_dev, int B, float *seg_dev, float *radial_dev, void *ws,
                     size_t ws_bytes, void *stream);
@@ -272,7 +278,10 @@ int rcv_fcn_set_profiling(rcv_fcn *h, int enable);
  * (k_conv_block; 0: two kernels, bit-identical output), key 5 = chain the next block's 1x1 reduce into k_conv_block where it
  * follows directly (0: separate kernel, bit-identical output), key 6 = staggered schedule of the 1x1 phases of the chained
  * 256-wide block (0: all waves in lockstep, bit-identical output), key 7 = halo-patch kernel for the 3x3 / stride-1 layers whose
- * image tiles well (k_conv_halo; 0: k_conv_dma, bit-identical output; 2: also where the pixel rectangles fit the image badly -- tests). */
+ * image tiles well (k_conv_halo; 0: k_conv_dma, bit-identical output; 2: also where the pixel rectangles fit the image badly -- tests).
+ * key 8 (default 0, both dtypes): 1 = the radial plane is written as float16 [G,B,1,H,W] (radial_dev then points at 2-byte
+ * elements; the stress configuration of BASELINE.json; feed it to rcv_seam_compact with RCV_SEAM_RADIAL_F16).  The value is
+ * the float32 head output rounded to nearest-even float16. */
 int rcv_fcn_set_option(rcv_fcn *h, int key, int value);
 int rcv_fcn_get_profile(rcv_fcn *h, double *conv_ms, double *other_ms, double *conv_flop);
 /* Per-op device times (ms) of the last profiled forward; ms_out has room for n_ops doubles. */

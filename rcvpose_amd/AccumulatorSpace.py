@@ -118,22 +118,19 @@ def rgbd_to_point_cloud(K, depth):
 
 
 def accumulate_on_device(xyz_dev, radial_dev, counts_dev, n_cap, m_cap, workspace, acc_unit=ACC_UNIT_MM,
-                         vote_grid=None):
-    """Enqueue Accumulator_3D for device-resident lists; result lands in workspace.result."""
+                         vote_grid=None, engine="auto"):
+    """Enqueue Accumulator_3D for device-resident lists; result lands in workspace.result.
+    engine: 'auto' = exact branch-and-bound peak search with the LDS rasteriser as fallback, 'full' = LDS rasteriser
+    only (identical results; RCV_VOTE_* in include/rcvpose_hip.h)."""
     L = _hip.lib()
     torch = _torch()
     is_f64 = radial_dev.dtype == torch.float64
     cells = 0 if vote_grid is None else vote_grid.numel()
     rc = L.rcv_accumulate_3d(_hip.ptr(xyz_dev), _hip.ptr(radial_dev), int(is_f64), _hip.ptr(counts_dev), int(n_cap),
-                             int(m_cap), float(acc_unit), _hip.ptr(workspace.result), _hip.ptr(vote_grid), cells,
+                             int(m_cap), float(acc_unit), _hip.VOTE_ENGINES[engine], _hip.ptr(workspace.result), _hip.ptr(vote_grid),
+                             cells,
                              _hip.ptr(workspace.ws), workspace.bytes, _hip.current_stream())
     _hip.check(rc, "rcv_accumulate_3d")
-
-
-def set_vote_mode(mode):
-    """'auto' (default): exact branch-and-bound peak search with the LDS rasteriser as fallback;
-    'full': LDS rasteriser only.  Identical results; see rcv_set_vote_mode in include/rcvpose_hip.h."""
-    _hip.check(_hip.lib().rcv_set_vote_mode({"auto": 0, "full": 1}[mode]), "rcv_set_vote_mode")
 
 
 def _raise_like_reference(status):
@@ -145,7 +142,7 @@ def _raise_like_reference(status):
         raise _hip.HipLibraryError("rcv_accumulate_3d: " + _hip.load_library().rcv_strerror(status).decode())
 
 
-def Accumulator_3D(xyz, radial_list, acc_unit=ACC_UNIT_MM, return_votes=False):
+def Accumulator_3D(xyz, radial_list, acc_unit=ACC_UNIT_MM, return_votes=False, engine="auto"):
     """Radial voting + arg-max (reference AccumulatorSpace.py:373-419).
 
     xyz: [N,3] metres; radial_list: [M>=N] decimetres (float32 or float64).  Returns `center`,
@@ -165,7 +162,7 @@ def Accumulator_3D(xyz, radial_list, acc_unit=ACC_UNIT_MM, return_votes=False):
     ws = AccWorkspace(max(n, m, 1))
     xyz_d = torch.from_numpy(xyz_h).cuda()
     rad_d = torch.from_numpy(rad_h).cuda()
-    accumulate_on_device(xyz_d, rad_d, None, n, m, ws, acc_unit)
+    accumulate_on_device(xyz_d, rad_d, None, n, m, ws, acc_unit, engine=engine)
     res = ws.read_result()
     _raise_like_reference(res.status)
     center = np.array([[res.center_mm[0], res.center_mm[1], res.center_mm[2]]], dtype=np.float64)
@@ -225,26 +222,25 @@ def FCResBackbone(model, input_img_path, normalized_depth=None):
 # on the device.
 # ---------------------------------------------------------------------------------------------------
 def project(xyz, K, RT):
-    """reference AccumulatorSpace.py:64-75: xyz [N,3], K [3,3], RT [3,4] -> (pixel xy [N,2], camera-frame xyz [N,3])."""
-    xyz = np.dot(xyz, RT[:, :3].T) + RT[:, 3:].T
-    actual_xyz = xyz
-    xyz = np.dot(xyz, K.T)
-    xy = xyz[:, :2] / xyz[:, 2:]
-    return xy, actual_xyz
+    """Rigid transform followed by the pin-hole projection (the role of reference AccumulatorSpace.py:64-75).
+
+    xyz [N,3], K [3,3], RT [3,4] -> (pixel coordinates [N,2], the points in the camera frame [N,3])."""
+    R, t = RT[:, :3], RT[:, 3]
+    cam = xyz @ R.T + t[None, :]
+    uvw = cam @ K.T
+    return uvw[:, :2] / uvw[:, 2:3], cam
 
 
 def read_depth(path):
-    """reference AccumulatorSpace.py:482-490: `.dpt` = uint32 h, w + uint16[h*w]; anything else through PIL."""
-    if path[-3:] == 'dpt':
-        with open(path, 'rb') as f:
-            h, w = np.fromfile(f, dtype=np.uint32, count=2)
-            data = np.fromfile(f, dtype=np.uint16, count=int(w) * int(h))
-            depth = data.reshape((int(h), int(w)))
-    else:
+    """Depth map of a frame (the role of reference AccumulatorSpace.py:482-490).  A `.dpt` file is a little header of two
+    uint32 (rows, columns) followed by rows*columns uint16 millimetres; any other suffix is an image PIL can open."""
+    if not path.endswith('dpt'):
         from PIL import Image
 
-        depth = np.asarray(Image.open(path)).copy()
-    return depth
+        return np.array(Image.open(path))
+    raw = np.fromfile(path, dtype=np.uint8)
+    rows, cols = (int(v) for v in raw[:8].view(np.uint32))
+    return raw[8:8 + 2 * rows * cols].view(np.uint16).reshape(rows, cols).copy()
 
 
 def read_ply_points(path):
@@ -331,6 +327,31 @@ def _pose_and_add(class_name, xyz_load, keypoints, estimated_kpts, RTGT_mm, seg_
                 add_distance_after_icp_mm=float(dist_after))
 
 
+def _stage_timers(pipe):
+    """The reference's stage timers (AccumulatorSpace.py:510-511, 594-599, 627-630: `net_time` around FCResBackbone,
+    `acc_time` around Accumulator_3D, summed over the frames of a class) as device times from HIP events (ms)."""
+    if pipe is None:
+        return {}
+    t = pipe.stage_times()
+    return dict(net_time_ms=t.get("net", 0.0), seam_time_ms=t.get("seam", 0.0), acc_time_ms=t.get("acc", 0.0))
+
+
+def _missing_class_dir(opts, path, missing):
+    """A class directory that is not there.  The reference opens the class's files unconditionally and dies with
+    FileNotFoundError (AccumulatorSpace.py:503-507); a class the caller named explicitly does the same here.  With the
+    default class list a dataset that holds only some classes is evaluated on those -- but never on none (see
+    _require_some_class), so a mistyped --root_dataset cannot look like a successful run."""
+    if getattr(opts, 'class_names', None):
+        raise FileNotFoundError(path)
+    missing.append(path)
+
+
+def _require_some_class(results, missing):
+    if not results and missing:
+        raise FileNotFoundError("no class directory found and no frame evaluated; looked for e.g. " + missing[0] +
+                                " (root_dataset must end with a path separator, as in the reference)")
+
+
 def estimate_6d_pose_lm(opts, return_details=False):
     """The LINEMOD evaluation loop of the reference (AccumulatorSpace.py:495-740) on the MI355X hot path.
 
@@ -351,10 +372,12 @@ def estimate_6d_pose_lm(opts, return_details=False):
     names = getattr(opts, 'class_names', None) or lm_cls_names
     import os
 
+    missing = []
     for class_name in names:
         rootPath = opts.root_dataset + "LINEMOD_ORIG/" + class_name + "/"
         rootpvPath = opts.root_dataset + "LINEMOD/" + class_name + "/"
         if not os.path.isdir(rootpvPath):
+            _missing_class_dir(opts, rootpvPath, missing)
             continue
         print("Evaluation on ", class_name)
         test_list = [s.replace('\n', '') for s in open(rootpvPath + "Split/val.txt", "r").readlines()]
@@ -389,7 +412,8 @@ def estimate_6d_pose_lm(opts, return_details=False):
                 from PIL import Image
 
                 if pipe is None:
-                    pipe = FramePipeline(sds, H, W, dtype=getattr(opts, 'dtype', 'bf16'), frames_per_step=1)
+                    pipe = FramePipeline(sds, H, W, dtype=getattr(opts, 'dtype', 'fp32'), frames_per_step=1)
+                    pipe.set_stage_timing(True)
                 rgb = np.array(Image.open(dataPath + filename).convert('RGB'), dtype=np.uint8)
                 pipe.process(torch.from_numpy(rgb)[None].cuda(), depth_dev[None], max_radii_dm)
                 estimated_kpts, res = pipe.read_results()
@@ -429,8 +453,9 @@ def estimate_6d_pose_lm(opts, return_details=False):
             print(tag + ' of ' + class_name + ' before ICP: ', bf_icp / general_counter)
             print(tag + ' of ' + class_name + ' after ICP: ', af_icp / general_counter)
             results[class_name] = dict(frames=general_counter, add_before_icp=bf_icp / general_counter,
-                                       add_after_icp=af_icp / general_counter)
+                                       add_after_icp=af_icp / general_counter, **_stage_timers(pipe))
             details[class_name] = per_frame
+    _require_some_class(results, missing)
     return (results, details) if return_details else results
 
 
@@ -464,10 +489,12 @@ def estimate_6d_pose_lmo(opts, return_details=False):
     names = getattr(opts, 'class_names', None) or lmo_cls_names
     rootPath = opts.root_dataset + 'OCCLUSION_LINEMOD/'
     seg_thr = float(np.nextafter(np.float32(0.5), np.float32(0.0)))  # seg > thr  <=>  seg >= 0.5 in float32
+    missing = []
     for class_name in names:
         print(class_name)
         modelPath = opts.root_dataset + "LINEMOD/" + class_name + "/"
         if not os.path.isdir(modelPath):
+            _missing_class_dir(opts, modelPath, missing)
             continue
         pipe, sds = None, []
         if opts.using_ckpts:
@@ -500,7 +527,8 @@ def estimate_6d_pose_lmo(opts, return_details=False):
                 estimated_kpts, statuses = np.zeros((3, 3)), []
                 if opts.using_ckpts:
                     if pipe is None:
-                        pipe = FramePipeline(sds, H, W, dtype=getattr(opts, 'dtype', 'bf16'), frames_per_step=1)
+                        pipe = FramePipeline(sds, H, W, dtype=getattr(opts, 'dtype', 'fp32'), frames_per_step=1)
+                        pipe.set_stage_timing(True)
                         pipe.seg_threshold = seg_thr
                     rgb = np.array(Image.open(jpgPath + filename).convert('RGB'), dtype=np.uint8)
                     pipe.process(torch.from_numpy(rgb)[None].cuda(), depth_dev[None], max_radii_dm)
@@ -546,8 +574,9 @@ def estimate_6d_pose_lmo(opts, return_details=False):
             print(tag + ' of ' + class_name + ' before ICP: ', bf_icp / general_counter)
             print(tag + ' of ' + class_name + ' after ICP: ', af_icp / general_counter)
             results[class_name] = dict(frames=general_counter, evaluated=len(per_frame), add_before_icp=bf_icp / general_counter,
-                                       add_after_icp=af_icp / general_counter)
+                                       add_after_icp=af_icp / general_counter, **_stage_timers(pipe))
             details[class_name] = per_frame
+    _require_some_class(results, missing)
     return (results, details) if return_details else results
 
 
@@ -608,9 +637,13 @@ def estimate_6d_pose_ycb(opts, return_details=False):
     auc_threshold = [0, 0.02, 0.04, 0.06, 0.08, 0.1]
     results, details = {}, {}
     wanted = getattr(opts, 'class_names', None)
+    missing = []
     for class_id in ycb_cls_names:
         class_name = ycb_cls_names[class_id]
-        if (wanted and class_name not in wanted) or not os.path.isdir(opts.root_dataset + "models/" + class_name):
+        if wanted and class_name not in wanted:
+            continue
+        if not os.path.isdir(opts.root_dataset + "models/" + class_name):
+            _missing_class_dir(opts, opts.root_dataset + "models/" + class_name, missing)
             continue
         print(class_name)
         test_list = [s.replace('\n', '') for s in open(opts.root_dataset + "Split/" + class_name + "/val.txt", "r").readlines()]
@@ -647,9 +680,12 @@ def estimate_6d_pose_ycb(opts, return_details=False):
             H, W = depth_map1.shape
             depth_dev = _depth_to_u16(depth_map1, "cuda")
             if pipe is None:
-                pipe = FramePipeline(sds, H, W, dtype=getattr(opts, 'dtype', 'bf16'), frames_per_step=1)
+                pipe = FramePipeline(sds, H, W, dtype=getattr(opts, 'dtype', 'fp32'), frames_per_step=1)
+                pipe.set_stage_timing(True)
                 ws = AccWorkspace(H * W)
+            pipe._mark("begin_net")
             pipe.forward_fcn(torch.from_numpy(rgb)[None].cuda())
+            pipe._mark("net")
             seg_maps, rad_maps = pipe.seg[:, 0, 0], pipe.radial[:, 0, 0]
             estimated_kpts = np.zeros((3, 3))
             for k in range(3):
@@ -657,7 +693,9 @@ def estimate_6d_pose_ycb(opts, return_details=False):
                 # depth / factor_depth (:1053-1059)
                 seam_compact(seg_maps[k], rad_maps[k], depth_dev, np.inf, K=K, mode=0, workspace=ws)
                 ws.xyz.mul_(depth_unit_mm)
+                pipe._mark("seam")
                 accumulate_on_device(ws.xyz, ws.radial, ws.counts, ws.max_points, ws.max_points, ws)
+                pipe._mark("acc")
                 r = ws.read_result()
                 _raise_like_reference(r.status)
                 estimated_kpts[k] = r.center_mm[:]
@@ -683,8 +721,9 @@ def estimate_6d_pose_ycb(opts, return_details=False):
             print('ADD\\(s\\) of ' + class_name + ' after ICP: ', af_icp / general_counter)
             results[class_name] = dict(frames=general_counter, add_before_icp=bf_icp / general_counter,
                                        add_after_icp=af_icp / general_counter, auc_before_icp=auc_before, auc_after_icp=auc_after,
-                                       bbox_diagonal_m=float(bbox_diagonal))
+                                       bbox_diagonal_m=float(bbox_diagonal), **_stage_timers(pipe))
             details[class_name] = per_frame
+    _require_some_class(results, missing)
     return (results, details) if return_details else results
 
 

@@ -20,6 +20,8 @@ RCV_E_GRID_BUFFER = -7
 RCV_E_UNSUPPORTED = -8
 
 RCV_SEAM_RADIAL_F16 = 256
+RCV_VOTE_AUTO, RCV_VOTE_RASTER = 0, 1
+VOTE_ENGINES = {"auto": RCV_VOTE_AUTO, "full": RCV_VOTE_RASTER}
 
 RCV_F32 = 0
 RCV_BF16 = 1
@@ -89,12 +91,12 @@ SYMBOLS = {
     "rcv_init": (_i, []),
     "rcv_acc_workspace_bytes": (_sz, [_i]),
     "rcv_seam_compact": (_i, [_vp, _vp, _vp, _i, _i, ctypes.POINTER(_d), _f, _d, _i, _vp, _vp, _vp, _i, _vp, _sz, _vp]),
-    "rcv_accumulate_3d": (_i, [_vp, _vp, _i, _vp, _i, _i, _d, _vp, _vp, _sz, _vp, _sz, _vp]),
-    "rcv_set_vote_mode": (_i, [_i]),
+    "rcv_acc_workspace_bytes_min": (_sz, [_i]),
+    "rcv_accumulate_3d": (_i, [_vp, _vp, _i, _vp, _i, _i, _d, _i, _vp, _vp, _sz, _vp, _sz, _vp]),
     "rcv_horn_pose_batch": (_i, [_vp, Strided, _i, _i, _vp, _vp]),
     "rcv_seam_compact_batch": (_i, [Strided, Strided, Strided, _i, _i, ctypes.POINTER(_d), _f, Strided, _i, Strided, Strided,
                                      Strided, _i, Strided, _sz, _i, _i, _vp]),
-    "rcv_accumulate_3d_batch": (_i, [Strided, Strided, _i, Strided, _i, _d, Strided, Strided, _sz, _i, _i, _vp]),
+    "rcv_accumulate_3d_batch": (_i, [Strided, Strided, _i, Strided, _i, _d, _i, Strided, Strided, _sz, _i, _i, _vp]),
     "rcv_collect_ties": (_i, [_vp, _i, ctypes.c_uint32, _vp, _i, _vp, _vp]),
     "rcv_acc_debug_points": (_i, [_vp, _vp, _vp, _i, _vp]),
     "rcv_preprocess_rgb": (_i, [_vp, _i, _i, _i, _vp, _vp]),

@@ -81,7 +81,7 @@ struct PrepPartial {
 };
 
 struct Layout {
-    size_t header, partials, seam_counts, seam_offsets, tile_best, tile_ties, replicas, bb_lists, bb_probe, Q, P, ri, F, capF, total;
+    size_t header, partials, seam_counts, seam_offsets, tile_best, tile_ties, bb_lists, bb_probe, Q, P, ri, F, capF, replicas, min_total, total;
 };
 
 Layout make_layout(int cap)
@@ -94,14 +94,18 @@ Layout make_layout(int cap)
     L.seam_offsets = o;  o += align_up(sizeof(int2) * SEAM_MAX_BLOCKS, 256);
     L.tile_best = o;     o += align_up(sizeof(uint64_t) * MAX_TILES, 256);
     L.tile_ties = o;     o += align_up(sizeof(uint32_t) * MAX_TILES, 256);
-    L.replicas = o;      o += (size_t)MAX_REPLICAS * CELL_BYTES;
     L.bb_lists = o;      o += (size_t)2 * BB_CAP * 16;
     L.bb_probe = o;      o += 4096;  // probe lists: BB_BEAM selected blocks + their 8*BB_BEAM children, twice
     L.Q = o;             o += align_up(sizeof(double) * 3 * (size_t)cap, 256);  // final voxel-space coordinates (SoA)
     L.P = o;             o += align_up(sizeof(double) * 5 * (size_t)cap, 256);  // x, y, z, T_lo, T_hi per point (SoA)
     L.ri = o;            o += align_up(sizeof(int32_t) * (size_t)cap, 256);
     L.capF = align_up((size_t)cap, 1024);  // float32 copy for the wide search levels, padded to whole LDS chunks
-    L.F = o;             o += sizeof(float) * 5 * L.capF;  // x, y, z, T_lo - slack, T_hi + slack (SoA)
+    L.F = o;             o += align_up(sizeof(float) * 5 * L.capF, 256);  // x, y, z, T_lo - slack, T_hi + slack (SoA)
+    // optional tail: LDS images of tiles whose point list is split over several workgroups of the rasteriser.  A
+    // workspace may stop at min_total (batched callers: the items of a batch already fill the chip); whatever lies
+    // beyond it is used as replica slots (k_setup sizes nparts from the bytes it is given).
+    L.replicas = o;      L.min_total = o;
+    o += (size_t)MAX_REPLICAS * CELL_BYTES;
     L.total = o;
     return L;
 }
@@ -431,7 +435,7 @@ __device__ double pw_leaf(const double *a, int n)
 //   summed in parallel, inner nodes level by level; the chunk totals are then added sequentially.
 __device__ __forceinline__ void d_setup(const PrepPartial *partials, const double *P, const int32_t *counts,
                                                 int n_arg, int m_arg, int cap, double unit, int bb_enable,
-                                                AccHeader *hdr)
+                                                long long replica_slots, AccHeader *hdr)
 {
     __shared__ double val[4][3][256];
     __shared__ unsigned char kind[4][256];  // 0 = absent, 1 = leaf, 2 = inner
@@ -553,7 +557,7 @@ __device__ __forceinline__ void d_setup(const PrepPartial *partials, const doubl
     H.ntiles = (int)nt;
     // the central tiles see every point, the outer ones few: split each tile's point list over nparts
     // workgroups (their LDS counters are summed by k_merge) so that no work item dominates the makespan
-    H.nparts = (int)max(1ll, min(8ll, (long long)MAX_REPLICAS / nt));
+    H.nparts = (int)max(1ll, min(8ll, min((long long)MAX_REPLICAS, replica_slots) / nt));
     H.status = RCV_OK;
     H.tile_counter = 0;
     {
@@ -1640,11 +1644,11 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prep(SP<const double> xyz, SP<
                (PrepPartial *)(w + L.partials));
 }
 __global__ __launch_bounds__(1024) void k_setup(SP<const int32_t> counts, int n_arg, int m_arg, int cap, double unit,
-                                                int bb_enable, SP<unsigned char> ws, Layout L)
+                                                int bb_enable, long long replica_slots, SP<unsigned char> ws, Layout L)
 {
     unsigned char *w = ws.get();
     d_setup((const PrepPartial *)(w + L.partials), (const double *)(w + L.P), counts.get(), n_arg, m_arg, cap, unit, bb_enable,
-            (AccHeader *)(w + L.header));
+            replica_slots, (AccHeader *)(w + L.header));
 }
 __global__ __launch_bounds__(256) void k_bb_init(int cap, SP<unsigned char> ws, Layout L)
 {
@@ -1740,7 +1744,6 @@ __global__ __launch_bounds__(256) void k_final(int grid_given, unsigned long lon
             grid_cells, out.get());
 }
 
-int g_vote_mode = 0;  // 0: exact peak search first, rasteriser as fallback; 1: rasteriser only
 constexpr size_t VOTE_LDS_BYTES = CELL_BYTES + 12 * VOTE_WAVES + 64;
 bool g_vote_attr_set = false;
 
@@ -1757,6 +1760,12 @@ size_t rcv_acc_workspace_bytes(int max_points)
 {
     if (max_points < 1) max_points = 1;
     return make_layout(max_points).total;
+}
+
+size_t rcv_acc_workspace_bytes_min(int max_points)
+{
+    if (max_points < 1) max_points = 1;
+    return make_layout(max_points).min_total;
 }
 
 static int seam_batch(rcv_strided seg, rcv_strided rad, rcv_strided depth, int H, int W, const double K[4], float seg_thr,
@@ -1806,18 +1815,20 @@ static int seam_batch(rcv_strided seg, rcv_strided rad, rcv_strided depth, int H
 }
 
 static int accumulate_batch(rcv_strided xyz, rcv_strided radial, int radial_is_f64, rcv_strided counts, int n_points, int n_radii,
-                            double acc_unit_mm, rcv_strided result, rcv_strided grid, size_t grid_cells, rcv_strided ws,
+                            double acc_unit_mm, int engine, rcv_strided result, rcv_strided grid, size_t grid_cells, rcv_strided ws,
                             size_t ws_bytes, int n_frames, int n_kp, void *stream)
 {
     if (!result.ptr || !ws.ptr) return RCV_E_INVALID;
     if (n_points < 0 || n_radii < 0 || !(acc_unit_mm > 0.0)) return RCV_E_INVALID;
+    if (engine != RCV_VOTE_AUTO && engine != RCV_VOTE_RASTER) return RCV_E_INVALID;
     if ((n_points > 0 && !xyz.ptr) || (n_radii > 0 && !radial.ptr)) return RCV_E_INVALID;
     if (n_frames <= 0 || n_kp <= 0 || n_frames > 65535 || n_kp > 65535) return RCV_E_INVALID;
     int rc = ensure_init();
     if (rc != RCV_OK) return rc;
     const int cap = n_points > n_radii ? (n_points > 0 ? n_points : 1) : (n_radii > 0 ? n_radii : 1);
     const Layout L = make_layout(cap);
-    if (ws_bytes < L.total) return RCV_E_WORKSPACE;
+    if (ws_bytes < L.min_total) return RCV_E_WORKSPACE;
+    const long long replica_slots = (long long)((ws_bytes - L.replicas) / CELL_BYTES);
     hipStream_t st = (hipStream_t)stream;
     if (!g_vote_attr_set) {
         RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_vote<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)VOTE_LDS_BYTES));
@@ -1843,8 +1854,9 @@ static int accumulate_batch(rcv_strided xyz, rcv_strided radial, int radial_is_f
                            n_radii, cap, acc_unit_mm, g_thr_dev, sws, L);
     RCV_LAUNCH_CHECK();
     // the exact peak search runs first unless the caller wants the full grid (or forced the rasteriser)
-    const int bb_enable = (g_vote_mode == 0 && grid.ptr == nullptr) ? 1 : 0;
-    hipLaunchKernelGGL(k_setup, items, dim3(1024), 0, st, scnt, n_points, n_radii, cap, acc_unit_mm, bb_enable, sws, L);
+    const int bb_enable = (engine == RCV_VOTE_AUTO && grid.ptr == nullptr) ? 1 : 0;
+    hipLaunchKernelGGL(k_setup, items, dim3(1024), 0, st, scnt, n_points, n_radii, cap, acc_unit_mm, bb_enable, replica_slots, sws,
+                       L);
     RCV_LAUNCH_CHECK();
     const int n_items = n_frames * n_kp;
     if (bb_enable) {
@@ -1935,29 +1947,22 @@ int rcv_seam_compact_batch(rcv_strided seg, rcv_strided radial, rcv_strided dept
 }
 
 int rcv_accumulate_3d(const double *xyz_m_dev, const void *radial_dm_dev, int radial_is_f64,
-                      const int32_t *counts_dev, int n_points, int n_radii, double acc_unit_mm,
+                      const int32_t *counts_dev, int n_points, int n_radii, double acc_unit_mm, int engine,
                       rcv_acc_result *result_dev, uint32_t *vote_grid_dev, size_t vote_grid_cells, void *ws,
                       size_t ws_bytes, void *stream)
 {
     return accumulate_batch(rcv_strided{(void *)xyz_m_dev, 0, 0}, rcv_strided{(void *)radial_dm_dev, 0, 0}, radial_is_f64,
-                            rcv_strided{(void *)counts_dev, 0, 0}, n_points, n_radii, acc_unit_mm, rcv_strided{result_dev, 0, 0},
+                            rcv_strided{(void *)counts_dev, 0, 0}, n_points, n_radii, acc_unit_mm, engine, rcv_strided{result_dev, 0, 0},
                             rcv_strided{vote_grid_dev, 0, 0}, vote_grid_cells, rcv_strided{ws, 0, 0}, ws_bytes, 1, 1, stream);
 }
 
 int rcv_accumulate_3d_batch(rcv_strided xyz_m, rcv_strided radial_dm, int radial_is_f64, rcv_strided counts, int cap,
-                            double acc_unit_mm, rcv_strided result, rcv_strided ws, size_t ws_bytes, int n_frames,
+                            double acc_unit_mm, int engine, rcv_strided result, rcv_strided ws, size_t ws_bytes, int n_frames,
                             int n_keypoints, void *stream)
 {
     if (!counts.ptr) return RCV_E_INVALID;
-    return accumulate_batch(xyz_m, radial_dm, radial_is_f64, counts, cap, cap, acc_unit_mm, result, rcv_strided{nullptr, 0, 0}, 0, ws,
-                            ws_bytes, n_frames, n_keypoints, stream);
-}
-
-int rcv_set_vote_mode(int mode)
-{
-    if (mode != 0 && mode != 1) return RCV_E_INVALID;
-    g_vote_mode = mode;
-    return RCV_OK;
+    return accumulate_batch(xyz_m, radial_dm, radial_is_f64, counts, cap, cap, acc_unit_mm, engine, result, rcv_strided{nullptr, 0, 0},
+                            0, ws, ws_bytes, n_frames, n_keypoints, stream);
 }
 
 int rcv_collect_ties(const uint32_t *vote_grid_dev, int dim, uint32_t peak, int64_t *flat_idx_dev, int cap,

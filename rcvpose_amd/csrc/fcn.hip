@@ -1832,7 +1832,7 @@ __global__ __launch_bounds__(256) void k_upsample2(const T *src, T *dst, int C, 
 // (reference models/fcnresnet.py:186-191: out[:, :1], out[:, 1:])
 template <typename T>
 __global__ __launch_bounds__(256) void k_head(const T *src, const T *w, const float *bias, float *seg, float *radial, int C,
-                                              long long npix, long long src_gs, long long w_gs, int bias_gs)
+                                              long long npix, long long src_gs, long long w_gs, int bias_gs, int rad_f16)
 {
     constexpr int EPV = Traits<T>::EPV;
     const int g = blockIdx.y;
@@ -1852,7 +1852,8 @@ __global__ __launch_bounds__(256) void k_head(const T *src, const T *w, const fl
             }
         }
         seg[(long long)g * npix + pix] = a0 + b0;
-        radial[(long long)g * npix + pix] = a1 + b1;
+        if (rad_f16) ((_Float16 *)radial)[(long long)g * npix + pix] = (_Float16)(a1 + b1);  // engine option 8
+        else radial[(long long)g * npix + pix] = a1 + b1;
     }
 }
 
@@ -1890,7 +1891,7 @@ constexpr int TAIL_LDS = TAIL_UH * TAIL_UW * TAIL_UP + (256 * TAIL_HP > TAIL_SH 
 
 __global__ __launch_bounds__(256, 2) void k_tail(const __bf16 *src, const __bf16 *w7, const float *b7, const __bf16 *w8, const float *b8,
                                                  float *seg, float *radial, int B, int Hin, int Win, long long src_gs, long long w7_gs,
-                                                 int b7_gs, long long w8_gs, int b8_gs)
+                                                 int b7_gs, long long w8_gs, int b8_gs, int rad_f16)
 {
     using T = __bf16;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -2023,7 +2024,8 @@ __global__ __launch_bounds__(256, 2) void k_tail(const __bf16 *src, const __bf16
             if (ho < Ho && wo < Wo) {
                 const long long o = ((long long)(g * B + img) * Ho + ho) * Wo + wo;
                 seg[o] = a0 + hb0;
-                radial[o] = a1 + hb1;
+                if (rad_f16) ((_Float16 *)radial)[o] = (_Float16)(a1 + hb1);  // engine option 8
+                else radial[o] = a1 + hb1;
             }
         }
     }
@@ -2061,6 +2063,7 @@ struct rcv_fcn {
     bool events_valid = false;
     bool attrs_set = false;
     bool use_dma = true;  // LDS-DMA conv kernel for the shapes it covers (bf16, Cout % 128 == 0, enough tiles)
+    bool radial_f16 = false;  // the radial plane leaves the head as float16 (BASELINE.json stress configuration)
 };
 
 namespace {
@@ -2212,7 +2215,7 @@ int run_op(rcv_fcn *h, const rcv_op &op, const float *x, int B, float *seg, floa
         const long long npix = (long long)B * op.hin * op.win;
         dim3 grid((unsigned)std::min<long long>((npix + 255) / 256, 65535), G);
         hipLaunchKernelGGL((k_head<T>), grid, dim3(256), 0, st, slot(op.src0), w, bias, seg, radial, op.c0, npix,
-                           gstride(op.src0), (long long)2 * op.c0, 2);
+                           gstride(op.src0), (long long)2 * op.c0, 2, h->radial_f16 ? 1 : 0);
         RCV_LAUNCH_CHECK();
         return RCV_OK;
     }
@@ -2383,7 +2386,7 @@ int forward_impl(rcv_fcn *h, const float *x, int B, float *seg, float *radial, c
                     hipLaunchKernelGGL(k_tail, grid, dim3(256), TAIL_LDS, st, (const __bf16 *)(ws + off[u.src0]),
                                        (const __bf16 *)h->weights + c.w_off, h->bias + c.b_off, (const __bf16 *)h->weights + d.w_off,
                                        h->bias + d.b_off, seg, radial, B, u.hin, u.win, (long long)h->slot_elems[u.src0] * B,
-                                       (long long)32 * 576, 32, (long long)64, 2);
+                                       (long long)32 * 576, 32, (long long)64, 2, h->radial_f16 ? 1 : 0);
                     RCV_LAUNCH_CHECK();
                     if (h->profiling) {
                         RCV_HIP_CHECK(hipEventRecord(h->events[2 * i + 3], st));
@@ -2507,6 +2510,7 @@ int rcv_fcn_set_option(rcv_fcn *h, int key, int value)
     if (key == 5) { h->use_chain = value != 0; h->attrs_set = false; return RCV_OK; }
     if (key == 6) { h->use_stagger = value != 0; h->attrs_set = false; return RCV_OK; }
     if (key == 7) { h->use_halo = value; h->attrs_set = false; return RCV_OK; }
+    if (key == 8) { h->radial_f16 = value != 0; return RCV_OK; }
     return RCV_E_INVALID;
 }
 

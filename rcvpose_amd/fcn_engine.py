@@ -297,6 +297,7 @@ class FcnEngine:
         self.device = device
         self._ws = None
         self._ws_batch = 0
+        self.radial_f16 = False
         self.flops_per_image_group = conv_flops(ops)
 
     def __del__(self):
@@ -328,9 +329,11 @@ class FcnEngine:
         ws = self.workspace(B)
         if out is None:
             seg = torch.empty((self.groups, B, 1, self.H, self.W), dtype=torch.float32, device=x.device)
-            radial = torch.empty_like(seg)
+            radial = torch.empty_like(seg, dtype=torch.float16 if self.radial_f16 else torch.float32)
         else:
             seg, radial = out
+            if radial.dtype != (torch.float16 if self.radial_f16 else torch.float32) or seg.dtype != torch.float32:
+                raise ValueError("output planes: seg float32, radial %s" % ("float16 (option 8)" if self.radial_f16 else "float32"))
         _hip.check(self.lib.rcv_fcn_forward(self.handle, _hip.ptr(x), B, _hip.ptr(seg), _hip.ptr(radial), _hip.ptr(ws),
                                             ws.numel(), _hip.current_stream()), "rcv_fcn_forward")
         return seg, radial
@@ -374,6 +377,8 @@ class FcnEngine:
 
     def set_option(self, key, value):
         _hip.check(self.lib.rcv_fcn_set_option(self.handle, int(key), int(value)))
+        if int(key) == 8:
+            self.radial_f16 = bool(value)
 
     def set_profiling(self, enable):
         _hip.check(self.lib.rcv_fcn_set_profiling(self.handle, int(bool(enable))))

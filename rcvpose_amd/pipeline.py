@@ -16,7 +16,10 @@ from . import _hip, fcn_engine
 
 class FramePipeline:
     def __init__(self, state_dicts, H=480, W=640, dtype="bf16", frames_per_step=1, K=A.linemod_K, acc_unit=A.ACC_UNIT_MM,
-                 device="cuda", overlap=False):
+                 device="cuda", overlap=False, radial_f16=False, engine="auto"):
+        """acc_unit: voxel edge in mm (the reference hard-codes 5, AccumulatorSpace.py:374).  radial_f16: the FCN head
+        writes the radial maps as float16 and the seam reads them as such (the stress configuration of BASELINE.json).
+        engine: 'auto' / 'full', the arg-max engine of rcv_accumulate_3d (identical results)."""
         import torch
 
         assert len(state_dicts) >= 1
@@ -26,20 +29,25 @@ class FramePipeline:
         self.H, self.W, self.B, self.G = H, W, int(frames_per_step), len(state_dicts)
         self.K = np.asarray(K, dtype=np.float64)
         self.acc_unit = float(acc_unit)
+        self.radial_f16 = bool(radial_f16)
+        self.vote_engine = _hip.VOTE_ENGINES[engine]
         self.seg_threshold = float(A.SEG_THRESHOLD)  # reference :603 (LINEMOD); the LM-O driver uses >= 0.5 (:836)
         self.device = device
         self.engine = fcn_engine.FcnEngine(state_dicts, H, W, dtype=dtype, device=device)
         self.engine.workspace(self.B)
+        if self.radial_f16:
+            self.engine.set_option(8, 1)
         B, G = self.B, self.G
+        rad_dtype = torch.float16 if self.radial_f16 else torch.float32
         self.x = torch.empty((B, 3, H, W), dtype=torch.float32, device=device)
         # two sets of FCN outputs: the forward of batch s+1 may run while batch s is being voted on
         self._seg2 = [torch.empty((G, B, 1, H, W), dtype=torch.float32, device=device) for _ in range(2)]
-        self._rad2 = [torch.empty((G, B, 1, H, W), dtype=torch.float32, device=device) for _ in range(2)]
+        self._rad2 = [torch.empty((G, B, 1, H, W), dtype=rad_dtype, device=device) for _ in range(2)]
         self.seg, self.radial = self._seg2[0], self._rad2[0]
         n_items = B * G
         cap = H * W
         self.cap = cap
-        ws_bytes = int(self.lib.rcv_acc_workspace_bytes(cap))
+        ws_bytes = int(self.lib.rcv_acc_workspace_bytes_min(cap))  # the items of a batch fill the chip: no replica area
         self.ws_bytes = ws_bytes
         self.ws = torch.empty((n_items, ws_bytes), dtype=torch.uint8, device=device)
         self.xyz = torch.empty((n_items, cap, 3), dtype=torch.float64, device=device)
@@ -54,6 +62,8 @@ class FramePipeline:
         self._ev_fcn = [None, None]
         self._ev_vote = [None, None]
         self._step = 0
+        self._timing = False
+        self._marks = []
 
     # -- stages ----------------------------------------------------------------------------
     def forward_fcn(self, rgb_u8):
@@ -66,30 +76,61 @@ class FramePipeline:
     def _strided(self, t, stride_frame, stride_kp):
         return _hip.Strided(t.data_ptr(), int(stride_frame), int(stride_kp))
 
+    # -- stage timers (the reference's net_time / acc_time, AccumulatorSpace.py:594-599, 627-630) ------
+    def set_stage_timing(self, enable):
+        """HIP events on the launch streams around the stages of every enqueued step: 'net' (image preparation + the
+        three forwards = the reference's net_time), 'inject' (measurement only), 'seam', 'acc' (Accumulator_3D = the
+        reference's acc_time), 'collect' (gather / result copy).  Read with stage_times()."""
+        self._timing = bool(enable)
+        self._marks = []
+
+    def _mark(self, name):
+        if self._timing:
+            ev = self.torch.cuda.Event(enable_timing=True)
+            ev.record()  # on torch's current stream = the stream the kernels are launched on
+            self._marks.append((name, ev))
+
+    def stage_times(self):
+        """-> {stage: total ms over the steps enqueued since set_stage_timing(True)}; waits for them."""
+        out = {}
+        self.finish()
+        for (n0, e0), (n1, e1) in zip(self._marks[:-1], self._marks[1:]):
+            if n1.startswith("begin"):
+                continue  # the gap between two steps (or between the two streams of a step) is nobody's stage
+            out[n1] = out.get(n1, 0.0) + e0.elapsed_time(e1)
+        return out
+
     def vote(self, depth_u16, max_radii_dm):
-        """depth_u16: [B,H,W] (int16 storage of uint16 mm); max_radii_dm: G floats.  Enqueues seam + voting for all
-        B*G (frame, keypoint) items as ONE batched launch sequence (item = blockIdx.y/z of every kernel)."""
+        """depth_u16: [B,H,W] (int16 storage of uint16 mm); max_radii_dm: G floats (one bound per keypoint, as the reference's
+        max_radii_dm[k]) or [B,G] (one per frame and keypoint).  Enqueues seam + voting for all B*G (frame, keypoint) items
+        as ONE batched launch sequence (item = blockIdx.y/z of every kernel)."""
         L, torch = self.lib, self.torch
         B, G, HW = self.B, self.G, self.H * self.W
         if not torch.is_tensor(max_radii_dm):
             max_radii_dm = torch.tensor(np.asarray(max_radii_dm, dtype=np.float64), device=self.device)
         self._rmax = max_radii_dm.to(torch.float64).contiguous()  # keep alive until the kernels ran
+        if tuple(self._rmax.shape) not in ((G,), (B, G)):
+            raise ValueError("max_radii_dm must have shape [%d] or [%d, %d]" % (G, B, G))
         st = _hip.current_stream()
         S = self._strided
         item = lambda t, per: S(t, G * per, per)  # buffers indexed [frame * G + keypoint]
         seg = S(self.seg, HW * 4, B * HW * 4)
-        rad = S(self.radial, HW * 4, B * HW * 4)
+        rb = self.radial.element_size()
+        rad = S(self.radial, HW * rb, B * HW * rb)
+        seam_mode = _hip.RCV_SEAM_RADIAL_F16 if self.radial_f16 else 0
         dep = S(depth_u16, HW * 2, 0)
-        rmx = S(self._rmax, 0, 8)
+        rmx = S(self._rmax, 8 * G if self._rmax.dim() == 2 else 0, 8)
         xyz = item(self.xyz, self.cap * 24)
         rl = item(self.rlist, self.cap * 4)
         cnt = item(self.counts, 8)
         ws = item(self.ws, self.ws_bytes)
         res = item(self.results, ctypes.sizeof(_hip.AccResult))
-        _hip.check(L.rcv_seam_compact_batch(seg, rad, dep, self.H, self.W, self.k4, float(self.seg_threshold), rmx, 0, xyz, rl, cnt,
+        _hip.check(L.rcv_seam_compact_batch(seg, rad, dep, self.H, self.W, self.k4, float(self.seg_threshold), rmx, seam_mode, xyz, rl, cnt,
                                             self.cap, ws, self.ws_bytes, B, G, st), "rcv_seam_compact_batch")
-        _hip.check(L.rcv_accumulate_3d_batch(xyz, rl, 0, cnt, self.cap, self.acc_unit, res, ws, self.ws_bytes, B, G, st),
+        self._mark("seam")
+        _hip.check(L.rcv_accumulate_3d_batch(xyz, rl, 0, cnt, self.cap, self.acc_unit, self.vote_engine, res, ws, self.ws_bytes, B, G, st),
                    "rcv_accumulate_3d_batch")
+        self._mark("acc")
 
     def read_results(self):
         """One D2H copy -> (estimated_kpts float64 [B,G,3] mm, list of AccResult)."""
@@ -126,21 +167,26 @@ class FramePipeline:
             if self._ev_vote[buf] is not None:
                 self.s_fcn.wait_event(self._ev_vote[buf])  # the votes that read this buffer two batches ago are done
             self.seg, self.radial = self._seg2[buf], self._rad2[buf]
+            self._mark("begin_net")
             self.forward_fcn(rgb_u8)
+            self._mark("net")
             if inject is not None:
                 self.seg.copy_(inject[0])
                 self.radial.copy_(inject[1])
+                self._mark("inject")
             ev = torch.cuda.Event()
             ev.record(self.s_fcn)
             self._ev_fcn[buf] = ev
         with torch.cuda.stream(self.s_vote):
             self.s_vote.wait_event(self._ev_fcn[buf])
+            self._mark("begin_vote")
             self.vote(depth_u16, max_radii_dm)
             ev = torch.cuda.Event()
             ev.record(self.s_vote)
             self._ev_vote[buf] = ev
             if collect is not None:
                 collect(self.keypoints_tensor())
+                self._mark("collect")
 
     def finish(self):
         self.s_fcn.synchronize()
@@ -150,8 +196,11 @@ class FramePipeline:
     def process(self, rgb_u8, depth_u16, max_radii_dm, inject=None):
         """One batch of frames.  `inject`: optional (seg [G,B,1,H,W], radial [G,B,1,H,W]) copied over the FCN
         outputs after the forward (measurement with random weights)."""
+        self._mark("begin_net")
         self.forward_fcn(rgb_u8)
+        self._mark("net")
         if inject is not None:
             self.seg.copy_(inject[0])
             self.radial.copy_(inject[1])
+            self._mark("inject")
         self.vote(depth_u16, max_radii_dm)

@@ -29,11 +29,7 @@ def test_golden_votes_and_centres(A, golden_dir, name):
     assert np.array_equal(center, g["center"])                        # float64, bit-exact
     assert np.array_equal(xyz, g["xyz_m"]) and np.array_equal(rad, g["radial_dm"])  # inputs untouched
     for mode in ("auto", "full"):                                     # hot path (no grid in HBM), both arg-max engines
-        A.set_vote_mode(mode)
-        try:
-            c2 = A.Accumulator_3D(xyz, rad)
-        finally:
-            A.set_vote_mode("auto")
+        c2 = A.Accumulator_3D(xyz, rad, engine=mode)
         assert np.array_equal(c2, g["center"]), mode
 
 
@@ -98,12 +94,8 @@ def _check_hot_path_modes(A, xyz, rad, ref_center, peak):
     xyz_d, rad_d = torch.from_numpy(np.ascontiguousarray(xyz)).cuda(), torch.from_numpy(np.ascontiguousarray(rad)).cuda()
     ws = A.AccWorkspace(max(n, m))
     for mode in ("auto", "full"):
-        A.set_vote_mode(mode)
-        try:
-            A.accumulate_on_device(xyz_d, rad_d, None, n, m, ws)
-            res = ws.read_result()
-        finally:
-            A.set_vote_mode("auto")
+        A.accumulate_on_device(xyz_d, rad_d, None, n, m, ws, engine=mode)
+        res = ws.read_result()
         assert res.status == 0 and res.peak_votes == peak and res.n_ties == len(ref_center), (mode, res.peak_votes, res.n_ties)
         assert np.array_equal(np.array(res.center_mm[:]), ref_center[0]), mode
 

@@ -37,13 +37,9 @@ def test_one_millimetre_grid_both_engines_agree():
     out = {}
     ws = A.AccWorkspace(480 * 640)
     for mode in ("auto", "full"):
-        A.set_vote_mode(mode)
-        try:
-            A.seam_compact(seg, torch.from_numpy(f["radial"][1]).cuda(), depth, float(f["max_radii_dm"][1]), K=_K(f), workspace=ws)
-            A.accumulate_on_device(ws.xyz, ws.radial, ws.counts, ws.max_points, ws.max_points, ws, acc_unit=1.0)
-            r = ws.read_result()
-        finally:
-            A.set_vote_mode("auto")
+        A.seam_compact(seg, torch.from_numpy(f["radial"][1]).cuda(), depth, float(f["max_radii_dm"][1]), K=_K(f), workspace=ws)
+        A.accumulate_on_device(ws.xyz, ws.radial, ws.counts, ws.max_points, ws.max_points, ws, acc_unit=1.0, engine=mode)
+        r = ws.read_result()
         assert r.status == 0 and r.dim > 900
         out[mode] = (r.peak_votes, r.n_ties, tuple(r.first_idx), tuple(r.center_mm))
     assert out["auto"] == out["full"]
@@ -59,11 +55,7 @@ def test_intermediate_grid_against_oracle(oracle):
     xyz, rl = xyz[::6], rl[::6]
     ref, votes, info, peak = oracle.accumulator_3d(xyz, rl, acc_unit=2.5, sparse=True, return_all=True)
     for mode in ("auto", "full"):
-        A.set_vote_mode(mode)
-        try:
-            c = A.Accumulator_3D(xyz, rl, acc_unit=2.5)
-        finally:
-            A.set_vote_mode("auto")
+        c = A.Accumulator_3D(xyz, rl, acc_unit=2.5, engine=mode)
         assert np.array_equal(c, ref), mode
 
 
@@ -93,12 +85,8 @@ def test_engines_agree_on_many_structured_clouds():
         ws = A.AccWorkspace(n)
         out = {}
         for mode in ("auto", "full"):
-            A.set_vote_mode(mode)
-            try:
-                A.accumulate_on_device(xyz_d, rad_d, None, n, n, ws, acc_unit=unit)
-                out[mode] = ws.read_result()
-            finally:
-                A.set_vote_mode("auto")
+            A.accumulate_on_device(xyz_d, rad_d, None, n, n, ws, acc_unit=unit, engine=mode)
+            out[mode] = ws.read_result()
         a, f = out["auto"], out["full"]
         assert a.status == 0 and f.status == 0, (case, a.status, f.status)
         assert (a.peak_votes, a.n_ties, tuple(a.first_idx[:]), a.dim) == (f.peak_votes, f.n_ties, tuple(f.first_idx[:]), f.dim), case

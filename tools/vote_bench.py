@@ -25,7 +25,6 @@ def main():
     ap.add_argument("--unit", type=float, default=5.0)
     ap.add_argument("--mode", default="auto", choices=["auto", "full"])
     args = ap.parse_args()
-    A.set_vote_mode(args.mode)
     f = synthetic.synthetic_frame(0, shape=args.shape)
     seg = torch.from_numpy(f["seg"]).cuda()
     rad = torch.from_numpy(f["radial"][args.kp]).cuda()
@@ -36,7 +35,7 @@ def main():
 
     def item():
         A.seam_compact(seg, rad, depth, rmax, K=K, workspace=ws)
-        A.accumulate_on_device(ws.xyz, ws.radial, ws.counts, ws.max_points, ws.max_points, ws, acc_unit=args.unit)
+        A.accumulate_on_device(ws.xyz, ws.radial, ws.counts, ws.max_points, ws.max_points, ws, acc_unit=args.unit, engine=args.mode)
 
     for _ in range(3):
         item()
