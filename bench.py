@@ -44,7 +44,7 @@ def parse(argv=None):
     ap.add_argument("--overlap", action="store_true", help="FCN of batch s+1 and voting of batch s on two HIP streams")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the fp32-mode and batch-1 (configs[1]) side measurements")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU vote samples (all frames together)")
+    ap.add_argument("--cpu-seconds", type=float, default=9.0, help="budget of the CPU vote samples (all frames together)")
     ap.add_argument("--parity-frames", type=int, default=8, help="frames of the last step checked against the oracle")
     ap.add_argument("--selftest-launcher", action="store_true",
                     help="CPU only: exercise the launcher / rendezvous / gather with gloo ranks and no GPU work (tests)")
@@ -138,7 +138,7 @@ def cpu_baseline(frames, budget_s):
         xyz, rl = cpu_oracle.seam(f["seg"], f["radial"][0], f["depth"], f["max_radii_dm"][0])
         pts, rv, info = cpu_oracle.prepare(xyz, rl)
         n = len(pts)
-        probe = 16
+        probe = 64
         t0 = time.perf_counter()
         cpu_oracle.fast_for(pts[:probe], rv[:probe], info.dim)
         per_point = (time.perf_counter() - t0) / probe

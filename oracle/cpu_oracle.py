@@ -161,6 +161,30 @@ def accumulator_3d(xyz_m, radial_dm, acc_unit=5.0, sparse=False, threads=0, retu
     return center
 
 
+def peak_without_grid(xyz_m, radial_dm, acc_unit=5.0, probe_idx=None, threads=0):
+    """Accumulator_3D's peak for grids too large to hold (1 mm voxels): -> dict(center_mm (row 0 of the reference's
+    `center`), peak, n_ties, first_idx (i, j, k), dim, zero_boundary, probe_votes).  Same arithmetic as accumulator_3d
+    (prepare + the sparse candidate walk + the reference predicate), plane by plane; see orc_peak_planes."""
+    pts, rv, info = prepare(xyz_m, radial_dm, acc_unit)
+    D = info.dim
+    peak = ctypes.c_uint32()
+    first = ctypes.c_int64()
+    probe = np.zeros((0,), dtype=np.int64) if probe_idx is None else np.ascontiguousarray(
+        [(i * D + j) * D + k for i, j, k in probe_idx], dtype=np.int64)
+    pv = np.zeros((max(len(probe), 1),), dtype=np.uint32)
+    pts = np.ascontiguousarray(pts, dtype=np.float64)
+    rvn = np.ascontiguousarray(rv[: len(pts)], dtype=np.float64)
+    L = lib()
+    L.orc_peak_planes.restype = ctypes.c_long
+    cnt = L.orc_peak_planes(_p(pts), _p(rvn), ctypes.c_long(len(pts)), int(D), ctypes.byref(peak), ctypes.byref(first), _p(probe),
+                            ctypes.c_long(len(probe)), _p(pv), int(threads))
+    flat = int(first.value)
+    row0 = np.empty(3, dtype=np.float64)
+    L.orc_center_row0(ctypes.c_int64(flat), ctypes.byref(info), ctypes.c_double(acc_unit), _p(row0))
+    return dict(center_mm=row0, peak=int(peak.value), n_ties=int(cnt), first_idx=(flat // (D * D), (flat // D) % D, flat % D),
+                dim=int(D), zero_boundary=int(info.zero_boundary), probe_votes=pv[: len(probe)].copy())
+
+
 def horn(P1, P2):
     """HornPoseFitting.lmshorn, util/horn.py:75-181 -> 4x4 RT with P2 ~ R P1 + T."""
     P1 = np.ascontiguousarray(P1, dtype=np.float64)

@@ -89,6 +89,93 @@ def forward(state_dict, x, return_stages=False):
     return seg, radial
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# bf16-emulating variant (VERDICT r01 #1a): the same graph with every tensor rounded where the bf16 engine rounds it.
+#
+# The engine (rcvpose_amd/csrc/fcn.hip, dtype bf16) stores weights and activations as bfloat16 and accumulates in fp32:
+#   * BatchNorm is folded into the preceding convolution in float64 on the host, the folded weight is rounded to bf16
+#     (round-to-nearest-even), the folded bias stays fp32;
+#   * the network input is rounded to bf16 by the stem; every convolution computes sum(bf16 x bf16) in fp32 (the products
+#     are exact in fp32; only the summation order is the implementation's), adds the fp32 bias, adds the residual
+#     (a stored bf16 tensor) in fp32, applies ReLU and rounds the result to bf16;
+#   * max-pool is exact on bf16; the bilinear x2 upsampling blends four bf16 values in fp32 and rounds to bf16;
+#   * the head (conv8) is an fp32 FMA chain over the bf16 conv7 output and bf16 weights; its output stays fp32.
+# This restatement rounds at exactly those places with torch's own bf16 conversion (also round-to-nearest-even) and runs
+# the convolutions in fp32 on the rounded operands.  What remains between it and the engine is fp32 summation order
+# (~1e-6 relative before a rounding), which occasionally tips a value to the neighbouring bf16 number; the tolerance of
+# tests/test_gpu_fcn.py::test_bf16_engine_against_bf16_emulation covers exactly that and nothing else.
+# ---------------------------------------------------------------------------------------------------------------------
+def _r16(t):
+    """Round an fp32 tensor to the nearest bfloat16 (ties to even), returned as fp32."""
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+def _fold(sd, conv, bn, bias, cout):
+    """(conv [+ bias]) followed by eval-mode BatchNorm as one convolution, folded in float64:
+    w' = w * gamma / sqrt(var + eps),  b' = (b - mean) * gamma / sqrt(var + eps) + beta."""
+    w = sd[conv + ".weight"].to(torch.float64)
+    b = sd[conv + ".bias"].to(torch.float64) if bias else torch.zeros(cout, dtype=torch.float64)
+    if bn is not None:
+        scale = sd[bn + ".weight"].to(torch.float64) / torch.sqrt(sd[bn + ".running_var"].to(torch.float64) + 1e-5)
+        w = w * scale.view(-1, 1, 1, 1)
+        b = (b - sd[bn + ".running_mean"].to(torch.float64)) * scale + sd[bn + ".bias"].to(torch.float64)
+    return _r16(w.to(torch.float32)), b.to(torch.float32)
+
+
+def _conv16(sd, x, conv, bn, bias, stride=1, padding=0, relu=True, res=None):
+    w, b = _fold(sd, conv, bn, bias, sd[conv + ".weight"].shape[0])
+    y = F.conv2d(x, w, None, stride=stride, padding=padding) + b.view(1, -1, 1, 1)
+    if res is not None:
+        y = y + res
+    if relu:
+        y = F.relu(y)
+    return _r16(y)
+
+
+def _bottleneck16(sd, p, x, stride, project):
+    out = _conv16(sd, x, p + ".conv1", p + ".bn1", False)
+    out = _conv16(sd, out, p + ".conv2", p + ".bn2", True, stride=stride, padding=1)
+    res = x
+    if project:
+        res = _conv16(sd, x, p + ".upsample_.0", p + ".upsample_.1", False, stride=stride, relu=False)
+    return _conv16(sd, out, p + ".conv3", p + ".bn3", False, res=res)
+
+
+def forward_bf16(state_dict, x, return_stages=False):
+    """The DenseFCNResNet152 forward as the bf16 engine computes it (see the block comment above).
+    x: float32 [B,3,H,W] -> (seg, radial) float32 [B,1,H,W]; stages are the stored (bf16-valued) tensors as fp32."""
+    sd = {k[7:] if k.startswith("module.") else k: v for k, v in state_dict.items()}
+    st = {}
+    with torch.no_grad():
+        x = _conv16(sd, _r16(x), "conv1", "bn1", False, stride=2, padding=3)
+        st["bn1"] = x
+        h = F.max_pool2d(x, kernel_size=3, stride=2, padding=1)
+        st["maxpool"] = h
+        skips = []
+        for first, rest, count, stride in _STAGES:
+            h = _bottleneck16(sd, first, h, stride, True)
+            for i in range(count):
+                h = _bottleneck16(sd, "%s.%d" % (rest, i), h, 1, False)
+            skips.append(h)
+            st[rest] = h
+        x2s, x4s, x8s, x16s = skips
+        up = _conv16(sd, x16s, "conv6", "bn6", True, padding=1)
+        st["bn6"] = up
+        for name, skip in (("5", x16s), ("4", x8s), ("3", x4s), ("2", x2s), ("1", x)):
+            up = _conv16(sd, torch.cat((up, skip), 1), "conv_up%s.0" % name, "conv_up%s.1" % name, True, padding=1)
+            st["conv_up" + name] = up
+            up = _r16(_up2(up))
+            st["up" + name] = up
+        up = _conv16(sd, up, "conv7.0", "conv7.1", True, padding=1)
+        st["conv7"] = up
+        out = F.conv2d(up, _r16(sd["conv8.weight"]), None) + sd["conv8.bias"].view(1, -1, 1, 1)
+        st["conv8"] = out
+    seg, radial = out[:, :1], out[:, 1:]
+    if return_stages:
+        return seg, radial, st
+    return seg, radial
+
+
 def forward_res(state_dict, x, return_stages=False):
     """`ResFCNResNet152.forward` (reference models/fcnresnet.py:263-318): the same encoder, additive skips
     `conv_upK(up + conv_upK_1(skip))`, a final x2 upsampling before conv7.  Pinned by tests/golden/resfcn1_64x96.npz."""

@@ -231,50 +231,102 @@ void orc_fast_for(const double *points_vox, const double *radius_vox, long n, in
 /* Same votes as orc_fast_for (proved equal on the golden/small cases by tests/test_oracle.py),
  * but only the voxels near each shell are tested -- used to check the GPU at sizes where the
  * brute force would take minutes.  The predicate applied to each candidate is identical. */
-void orc_fast_for_sparse(const double *points_vox, const double *radius_vox, long n, int D, uint32_t *votes, int threads)
+/* votes of all points into the i-th plane of the grid (plane: uint32 [D][D], indexed [j][k]) */
+static void sparse_plane(const double *points_vox, const double *radius_vox, long n, int D, int i, uint32_t *plane)
 {
     const double factor = sqrt(3.0) / 4.0;
-#ifdef _OPENMP
-    if (threads > 0) omp_set_num_threads(threads);
-#endif
-#pragma omp parallel for schedule(dynamic, 1)
-    for (int i = 0; i < D; i++) {
-        for (long p = 0; p < n; p++) {
-            const double x = points_vox[3 * p], y = points_vox[3 * p + 1], z = points_vox[3 * p + 2];
-            const long ri = radius_int(radius_vox[p]);
-            if (ri <= 0) continue;
-            const double radius = (double)ri;
-            const double dx = (double)i - x, dx2 = dx * dx;
-            if (dx2 >= radius * radius + 1.0) continue;
-            int j0 = (int)floor(y - radius - 1.0), j1 = (int)ceil(y + radius + 1.0);
-            if (j0 < 0) j0 = 0;
-            if (j1 > D - 1) j1 = D - 1;
-            for (int j = j0; j <= j1; j++) {
-                const double dy = (double)j - y, sxy = dx2 + dy * dy;
-                const double hi = radius * radius - sxy;
-                if (hi < -1.0) continue;
-                const double inner = radius - factor;
-                const double lo = inner * inner - sxy;
-                const double zb_ = sqrt(hi > 0 ? hi : 0) + 1.0, za_ = lo > 0 ? sqrt(lo) - 1.0 : -1.0;
-                uint32_t *row = votes + ((long)i * D + j) * D;
-                /* candidate k ranges: [z - zb_, z - za_] and [z + za_, z + zb_] (merged when they touch) */
-                int a0 = (int)floor(z - zb_), a1 = (int)ceil(z - za_);
-                int b0 = (int)floor(z + za_), b1 = (int)ceil(z + zb_);
-                if (b0 <= a1) { a1 = b1; b0 = b1 + 1; }
-                for (int pass = 0; pass < 2; pass++) {
-                    int k0 = pass ? b0 : a0, k1 = pass ? b1 : a1;
-                    if (k0 < 0) k0 = 0;
-                    if (k1 > D - 1) k1 = D - 1;
-                    for (int k = k0; k <= k1; k++) {
-                        const double dz = (double)k - z;
-                        const double distance = sqrt(sxy + dz * dz);
-                        const double t = radius - distance;
-                        if (t < factor && t > 0) row[k] += 1;
-                    }
+    for (long p = 0; p < n; p++) {
+        const double x = points_vox[3 * p], y = points_vox[3 * p + 1], z = points_vox[3 * p + 2];
+        const long ri = radius_int(radius_vox[p]);
+        if (ri <= 0) continue;
+        const double radius = (double)ri;
+        const double dx = (double)i - x, dx2 = dx * dx;
+        if (dx2 >= radius * radius + 1.0) continue;
+        int j0 = (int)floor(y - radius - 1.0), j1 = (int)ceil(y + radius + 1.0);
+        if (j0 < 0) j0 = 0;
+        if (j1 > D - 1) j1 = D - 1;
+        for (int j = j0; j <= j1; j++) {
+            const double dy = (double)j - y, sxy = dx2 + dy * dy;
+            const double hi = radius * radius - sxy;
+            if (hi < -1.0) continue;
+            const double inner = radius - factor;
+            const double lo = inner * inner - sxy;
+            const double zb_ = sqrt(hi > 0 ? hi : 0) + 1.0, za_ = lo > 0 ? sqrt(lo) - 1.0 : -1.0;
+            uint32_t *row = plane + (long)j * D;
+            /* candidate k ranges: [z - zb_, z - za_] and [z + za_, z + zb_] (merged when they touch) */
+            int a0 = (int)floor(z - zb_), a1 = (int)ceil(z - za_);
+            int b0 = (int)floor(z + za_), b1 = (int)ceil(z + zb_);
+            if (b0 <= a1) { a1 = b1; b0 = b1 + 1; }
+            for (int pass = 0; pass < 2; pass++) {
+                int k0 = pass ? b0 : a0, k1 = pass ? b1 : a1;
+                if (k0 < 0) k0 = 0;
+                if (k1 > D - 1) k1 = D - 1;
+                for (int k = k0; k <= k1; k++) {
+                    const double dz = (double)k - z;
+                    const double distance = sqrt(sxy + dz * dz);
+                    const double t = radius - distance;
+                    if (t < factor && t > 0) row[k] += 1;
                 }
             }
         }
     }
+}
+
+void orc_fast_for_sparse(const double *points_vox, const double *radius_vox, long n, int D, uint32_t *votes, int threads)
+{
+#ifdef _OPENMP
+    if (threads > 0) omp_set_num_threads(threads);
+#endif
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int i = 0; i < D; i++) sparse_plane(points_vox, radius_vox, n, D, i, votes + (long)i * D * D);
+}
+
+/* VoteMap_3D.max() and argwhere(VoteMap_3D == max) (AccumulatorSpace.py:406) WITHOUT holding the grid: for grids too
+ * large to allocate (1 mm voxels: D ~ 1000, 4 GB as uint32).  Every i-plane is voted (the same candidate walk and the
+ * same predicate as orc_fast_for_sparse) into a thread-private D x D buffer and scanned for its maximum, the number of
+ * voxels attaining it and the first of them; the planes are then combined in i order.  Returns the number of maxima;
+ * *first_flat = flat C-order index of the first one.  Optionally the counts of `n_probe` given voxels (flat indices)
+ * are written to probe_votes.  Checked against orc_fast_for_sparse + orc_argmax_all in tests/test_oracle_golden.py. */
+long orc_peak_planes(const double *points_vox, const double *radius_vox, long n, int D, uint32_t *peak, int64_t *first_flat,
+                     const int64_t *probe_flat, long n_probe, uint32_t *probe_votes, int threads)
+{
+    uint32_t *pmax = (uint32_t *)calloc((size_t)D, sizeof(uint32_t));
+    long *pcnt = (long *)calloc((size_t)D, sizeof(long));
+    long *pfirst = (long *)calloc((size_t)D, sizeof(long));
+#ifdef _OPENMP
+    if (threads > 0) omp_set_num_threads(threads);
+#endif
+#pragma omp parallel
+    {
+        uint32_t *plane = (uint32_t *)malloc((size_t)D * D * sizeof(uint32_t));
+#pragma omp for schedule(dynamic, 1)
+        for (int i = 0; i < D; i++) {
+            memset(plane, 0, (size_t)D * D * sizeof(uint32_t));
+            sparse_plane(points_vox, radius_vox, n, D, i, plane);
+            uint32_t mx = 0;
+            long cnt = 0, first = 0;
+            const long cells = (long)D * D;
+            for (long t = 0; t < cells; t++) if (plane[t] > mx) mx = plane[t];
+            for (long t = 0; t < cells; t++)
+                if (plane[t] == mx) { if (!cnt) first = t; cnt++; }
+            pmax[i] = mx; pcnt[i] = cnt; pfirst[i] = first;
+            for (long q = 0; q < n_probe; q++)
+                if (probe_flat[q] / cells == i) probe_votes[q] = plane[probe_flat[q] % cells];
+        }
+        free(plane);
+    }
+    uint32_t mx = 0;
+    for (int i = 0; i < D; i++) if (pmax[i] > mx) mx = pmax[i];
+    long total = 0;
+    int have_first = 0;
+    for (int i = 0; i < D; i++)
+        if (pmax[i] == mx) {
+            if (!have_first) { *first_flat = (int64_t)i * D * D + pfirst[i]; have_first = 1; }
+            total += pcnt[i];
+        }
+    *peak = mx;
+    free(pmax); free(pcnt); free(pfirst);
+    return total;
 }
 
 /* argwhere(V == V.max()) in C order, AccumulatorSpace.py:406.  Returns the number of maxima;

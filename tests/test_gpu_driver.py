@@ -114,7 +114,13 @@ def test_main_entry_runs_the_driver(tmp_path):
     from rcvpose_amd import AccumulatorSpace as A
 
     assert A.main(["--dataset", "lm", "--root_dataset", root, "--model_dir", root]) == res
-    assert A.main(["--dataset", "ycb", "--root_dataset", root, "--model_dir", root]) == {}   # no YCB classes under this root
+    # a root without a single class directory must not look like a successful evaluation (the reference dies with
+    # FileNotFoundError on the first class's files): no YCB classes under this root, and the reference's default
+    # --root_dataset without the trailing separator
+    with pytest.raises(FileNotFoundError):
+        A.main(["--dataset", "ycb", "--root_dataset", root, "--model_dir", root])
+    with pytest.raises(FileNotFoundError):
+        main(["--mode", "test", "--root_dataset", root.rstrip("/"), "--model_dir", root, "--using_ckpts", "false"])
 
 
 def _write_lmo_dataset(root, n_frames=2):

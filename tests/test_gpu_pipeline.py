@@ -70,3 +70,51 @@ def test_small_frame_fcn_outputs_feed_the_vote(golden_dir, oracle):
     assert res[0].n_points == len(xyz) and res[0].n_radii == len(rl) and len(xyz) > 50
     ref = oracle.accumulator_3d(xyz, rl, sparse=True)
     assert res[0].status == 0 and np.array_equal(kpts[0, 0], ref[0])
+
+
+def test_bf16_keypoints_against_fp32_keypoints(golden_dir, oracle):
+    """What the bf16 engine's error does to the KEYPOINTS (VERDICT r01 #1b): 8 frames x 3 networks at 480x640 through the
+    fp32 and the bf16 engine.  With random weights (no checkpoints offline) the maps carry no object, so the error field
+    of the real bf16 forward, delta = map_bf16 - map_fp32, is transferred onto the ideal maps of the synthetic frames,
+    scaled by range(ideal) / range(fp32 map) (an affine rescale of the network output to the radial range of a trained
+    network): fp32 pipeline votes on `ideal`, bf16 pipeline on `ideal + scale * delta`.  Gate: keypoints within 1 voxel
+    (north_star), and the voting on the perturbed maps equals the oracle on the same maps."""
+    from rcvpose_amd.pipeline import FramePipeline
+
+    B, G, H, W = 8, 3, 480, 640
+    fr = [frames.synthetic_frame(200 + i) for i in range(B)]
+    sds = _state_dicts(golden_dir)
+    pb = FramePipeline(sds, H, W, dtype="bf16", frames_per_step=B)
+    pf = FramePipeline(sds, H, W, dtype="fp32", frames_per_step=B)
+    rgb = torch.from_numpy(np.stack([f["rgb"] for f in fr])).cuda()
+    depth = torch.from_numpy(np.stack([f["depth"] for f in fr]).view(np.int16)).cuda()
+    ideal_seg = torch.from_numpy(np.stack([np.stack([f["seg"] for f in fr])] * G))[:, :, None].contiguous().cuda()
+    ideal_rad = torch.from_numpy(np.stack([np.stack([f["radial"][k] for f in fr]) for k in range(G)]))[:, :, None].contiguous().cuda()
+    pb.forward_fcn(rgb)
+    pf.forward_fcn(rgb)
+    d_rad, d_seg = pb.radial - pf.radial, pb.seg - pf.seg
+    for k in range(G):
+        print("network %d: bf16 - fp32 maps, max |delta| / max |map|: radial %.3e seg %.3e" % (
+            k, float(d_rad[k].abs().max() / pf.radial[k].abs().max()), float(d_seg[k].abs().max() / pf.seg[k].abs().max())))
+    scale_r = (ideal_rad.amax(dim=(1, 2, 3, 4)) / pf.radial.abs().amax(dim=(1, 2, 3, 4))).view(G, 1, 1, 1, 1)
+    scale_s = (1.0 / pf.seg.abs().amax(dim=(1, 2, 3, 4))).view(G, 1, 1, 1, 1)
+    pert_rad, pert_seg = ideal_rad + scale_r * d_rad, ideal_seg + scale_s * d_seg
+    print("radial perturbation: max %.4f dm = %.2f voxels, rms %.4f dm" % (
+        float((scale_r * d_rad).abs().max()), float((scale_r * d_rad).abs().max()) * 20, float((scale_r * d_rad).pow(2).mean().sqrt())))
+    pb.seg.copy_(pert_seg)
+    pb.radial.copy_(pert_rad)
+    pf.seg.copy_(ideal_seg)
+    pf.radial.copy_(ideal_rad)
+    rmax = np.max([f["max_radii_dm"] for f in fr], axis=0) + 0.5   # the perturbation must not push radii over the bound
+    pb.vote(depth, rmax)
+    pf.vote(depth, rmax)
+    kb, rb = pb.read_results()
+    kf, rf = pf.read_results()
+    assert all(r.status == 0 for r in rb + rf)
+    dev = np.abs(kb - kf).max(axis=2) / 5.0          # voxels, [B,G]
+    print("bf16 vs fp32 keypoints: max %.2f voxels, mean %.3f voxels over %d keypoints" % (dev.max(), dev.mean(), dev.size))
+    assert dev.max() <= 1.0
+    ps, pr = pert_seg.cpu().numpy(), pert_rad.cpu().numpy()
+    for b, k in ((0, 0), (3, 1), (7, 2)):             # the device voted exactly like the oracle on the perturbed maps
+        xyz, rl = oracle.seam(ps[k, b, 0], pr[k, b, 0], fr[b]["depth"], rmax[k])
+        assert np.array_equal(kb[b, k], oracle.accumulator_3d(xyz, rl, sparse=True)[0])

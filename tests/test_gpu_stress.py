@@ -27,23 +27,66 @@ def test_fp16_radial_seam_equals_oracle_on_rounded_maps(oracle):
     assert np.array_equal(ws.xyz[:n].cpu().numpy(), xyz) and np.array_equal(ws.radial[:m].cpu().numpy(), rl)
 
 
-def test_one_millimetre_grid_both_engines_agree():
-    """D ~ 1000 (10^9 voxels): the exact peak search and the LDS rasteriser must give the same peak, tie count and
-    keypoint (the dense oracle grid would need > 4 GB; the engines are checked against the oracle at 5 mm)."""
+def test_configs4_eight_frames_fp16_radial_one_millimetre_against_oracle(oracle, golden_dir):
+    """BASELINE.json configs[4] as stated: a batch of 8 YCB-shaped frames (~50k points each) x 3 keypoints in ONE batched
+    call sequence (rcv_seam_compact_batch with RCV_SEAM_RADIAL_F16, rcv_accumulate_3d_batch with acc_unit = 1 mm), the
+    radial maps written as float16 by the FCN engine's head (option 8) resp. injected as float16.  Checked against the
+    oracle AT 1 mm (plane-wise peak: D ~ 900, the dense grid would need 3 GB): peak, tie count, first index, centre."""
+    import json
+    import os
+
+    import fcn_weights
+    from rcvpose_amd.pipeline import FramePipeline
+
+    B, G, H, W = 8, 3, 480, 640
+    fr = [frames.synthetic_frame(300 + i, shape="ycb") for i in range(B)]
+    shapes = json.load(open(os.path.join(golden_dir, "fcn_state_dict_keys.json")))
+    sds = [{k: torch.from_numpy(v) for k, v in fcn_weights.make_state_dict_numpy(shapes, seed=s).items()} for s in range(G)]
+    pipe = FramePipeline(sds, H, W, dtype="bf16", frames_per_step=B, K=_K(fr[0]), acc_unit=1.0, radial_f16=True)
+    assert pipe.radial.dtype == torch.float16
+    rgb = torch.from_numpy(np.stack([f["rgb"] for f in fr])).cuda()
+    depth = torch.from_numpy(np.stack([f["depth"] for f in fr]).view(np.int16)).cuda()
+    rad16 = np.stack([np.stack([f["radial"][k] for f in fr]) for k in range(G)]).astype(np.float16)      # [G,B,H,W]
+    seg = torch.from_numpy(np.stack([np.stack([f["seg"] for f in fr])] * G))[:, :, None].contiguous().cuda()
+    rmax = rad16.astype(np.float32).max(axis=(2, 3)).T.astype(np.float64)                                  # [B,G]
+    pipe.process(rgb, depth, torch.from_numpy(rmax).cuda(), inject=(seg, torch.from_numpy(rad16)[:, :, None].contiguous().cuda()))
+    kpts, res = pipe.read_results()
+    for b in range(B):
+        for k in range(G):
+            r = res[b * G + k]
+            assert r.status == 0 and r.dim > 800 and 47500 <= r.n_points <= 52500, (b, k, r.status, r.dim, r.n_points)
+            assert np.abs(kpts[b, k] - fr[b]["keypoints_m"][k] * 1000).max() <= 5.0      # 1 mm voxels: within 5 voxels of the truth
+    for b, k in ((0, 0), (4, 1), (7, 2)):
+        xyz, rl = oracle.seam(fr[b]["seg"], rad16[k, b].astype(np.float32), fr[b]["depth"], rmax[b, k], K=fr[b]["K"])
+        r = res[b * G + k]
+        assert (r.n_points, r.n_radii) == (len(xyz), len(rl))
+        ref = oracle.peak_without_grid(xyz, rl, acc_unit=1.0)
+        assert (r.dim, r.zero_boundary) == (ref["dim"], ref["zero_boundary"])
+        assert (r.peak_votes, r.n_ties, tuple(r.first_idx[:])) == (ref["peak"], ref["n_ties"], ref["first_idx"]), (b, k)
+        assert np.array_equal(kpts[b, k], ref["center_mm"]), (b, k)
+
+
+def test_one_millimetre_rasteriser_against_oracle(oracle):
+    """The LDS rasteriser (engine 'full') at 1 mm on one YCB-shaped item against the same 1 mm oracle, with the full
+    workspace (replica area: a tile's point list split over several workgroups) and with the minimal one."""
     from rcvpose_amd import AccumulatorSpace as A
+    from rcvpose_amd import _hip
 
     f = frames.synthetic_frame(2, shape="ycb")
     seg, depth = torch.from_numpy(f["seg"]).cuda(), torch.from_numpy(f["depth"].view(np.int16)).cuda()
-    out = {}
+    rmax = float(f["max_radii_dm"][1])
+    xyz, rl = oracle.seam(f["seg"], f["radial"][1], f["depth"], rmax, K=f["K"])
+    ref = oracle.peak_without_grid(xyz, rl, acc_unit=1.0)
     ws = A.AccWorkspace(480 * 640)
-    for mode in ("auto", "full"):
-        A.seam_compact(seg, torch.from_numpy(f["radial"][1]).cuda(), depth, float(f["max_radii_dm"][1]), K=_K(f), workspace=ws)
-        A.accumulate_on_device(ws.xyz, ws.radial, ws.counts, ws.max_points, ws.max_points, ws, acc_unit=1.0, engine=mode)
+    small = int(_hip.lib().rcv_acc_workspace_bytes_min(480 * 640))
+    assert small < ws.bytes // 3
+    for nbytes in (ws.bytes, small):
+        ws.bytes = nbytes
+        A.seam_compact(seg, torch.from_numpy(f["radial"][1]).cuda(), depth, rmax, K=_K(f), workspace=ws)
+        A.accumulate_on_device(ws.xyz, ws.radial, ws.counts, ws.max_points, ws.max_points, ws, acc_unit=1.0, engine="full")
         r = ws.read_result()
-        assert r.status == 0 and r.dim > 900
-        out[mode] = (r.peak_votes, r.n_ties, tuple(r.first_idx), tuple(r.center_mm))
-    assert out["auto"] == out["full"]
-    assert np.abs(np.array(out["auto"][3]) - f["keypoints_m"][1] * 1000).max() <= 5.0  # 1 mm voxels: within 5 voxels
+        assert r.status == 0 and (r.dim, r.peak_votes, r.n_ties, tuple(r.first_idx[:])) == (ref["dim"], ref["peak"], ref["n_ties"], ref["first_idx"])
+        assert np.array_equal(np.array(r.center_mm[:]), ref["center_mm"])
 
 
 def test_intermediate_grid_against_oracle(oracle):

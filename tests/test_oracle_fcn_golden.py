@@ -82,3 +82,29 @@ def test_resfcn_model_has_the_reference_state_dict_keys(golden_dir):
     ref = json.load(open(os.path.join(GOLDEN, "resfcn_state_dict_keys.json")))
     mine = {k: list(v.shape) for k, v in ResFCNResNet152(3, 2).state_dict().items()}
     assert list(mine.keys()) == list(ref.keys()) and mine == ref
+
+
+def test_bf16_emulation_is_the_fp32_graph_with_rounded_storage():
+    """oracle/fcn_torch.forward_bf16 (what the bf16 engine is compared with, tests/test_gpu_fcn.py) against the pinned fp32
+    restatement: same graph, so the outputs agree to bf16-storage accuracy; every stored stage holds bf16 numbers."""
+    import json
+    import os
+
+    import torch
+
+    import fcn_weights
+    from oracle import fcn_torch
+
+    golden = os.path.join(os.path.dirname(__file__), "golden")
+    shapes = json.load(open(os.path.join(golden, "fcn_state_dict_keys.json")))
+    sd = {k: torch.from_numpy(v) for k, v in fcn_weights.make_state_dict_numpy(shapes, seed=0).items()}
+    x = torch.from_numpy(fcn_weights.make_input(3, (1, 3, 64, 96)))
+    s32, r32, st32 = fcn_torch.forward(sd, x, return_stages=True)
+    s16, r16, st16 = fcn_torch.forward_bf16(sd, x, return_stages=True)
+    assert set(st16) == set(st32)
+    for k, v in st16.items():
+        assert v.shape == st32[k].shape
+        if k != "conv8":
+            assert torch.equal(v, v.to(torch.bfloat16).to(torch.float32)), k  # stored activations are bf16 numbers
+        assert float((v - st32[k]).abs().max() / st32[k].abs().max()) < 5e-2, k
+    assert 1e-3 < float((r16 - r32).abs().max() / r32.abs().max()) < 5e-2

@@ -110,3 +110,32 @@ def test_horn_golden(oracle, golden_dir):
     for i in range(len(g["n"])):
         n = int(g["n"][i])
         assert np.array_equal(oracle.horn(g["P1"][i][:n], g["P2"][i][:n]), g["RT"][i]), i
+
+
+@pytest.mark.parametrize("name", ACC)
+def test_plane_wise_peak_equals_grid_arg_max(oracle, golden_dir, name):
+    """orc_peak_planes (the 1 mm oracle: no grid in memory) against the golden grids of the reference: peak, number of
+    maxima, first maximum in C order, row 0 of `center`, and probed single-voxel counts."""
+    g = _load(golden_dir, name)
+    votes = g["votes"].astype(np.uint32)
+    D = votes.shape[0]
+    rng = np.random.default_rng(1)
+    probe = [tuple(int(v) for v in rng.integers(0, D, size=3)) for _ in range(5)] + [tuple(int(v) for v in np.argwhere(votes == votes.max())[0])]
+    r = oracle.peak_without_grid(g["xyz_m"], g["radial_dm"], probe_idx=probe)
+    assert r["dim"] == D and r["peak"] == int(votes.max()) and r["n_ties"] == int((votes == votes.max()).sum())
+    assert r["first_idx"] == tuple(int(v) for v in np.argwhere(votes == votes.max())[0])
+    assert np.array_equal(r["center_mm"], g["center"][0])
+    assert [int(v) for v in r["probe_votes"]] == [int(votes[p]) for p in probe]
+
+
+def test_plane_wise_peak_on_a_fine_grid(oracle):
+    """... and against the grid oracle at 2 mm on a thinned frame cloud (D ~ 500)."""
+    import frames
+
+    f = frames.synthetic_frame(5)
+    xyz, rl = oracle.seam(f["seg"], f["radial"][1], f["depth"], f["max_radii_dm"][1])
+    xyz, rl = xyz[::40], rl[::40]
+    ref, votes, info, peak = oracle.accumulator_3d(xyz, rl, acc_unit=2.0, sparse=True, return_all=True)
+    r = oracle.peak_without_grid(xyz, rl, acc_unit=2.0)
+    assert (r["peak"], r["n_ties"], r["dim"]) == (peak, len(ref), info.dim)
+    assert np.array_equal(r["center_mm"], ref[0])
