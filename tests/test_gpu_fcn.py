@@ -314,47 +314,86 @@ def test_batch_size_may_grow_between_calls(shapes, state_dict):
     assert torch.equal(seg9[:, :1], seg1) and torch.equal(rad9[:, :1], rad1)
 
 
-# Tolerances of the bf16 engine against its emulation (oracle/fcn_torch.forward_bf16: the same graph, rounded to bf16 exactly
-# where the engine rounds, fp32 accumulation).  What is left between the two is the fp32 summation order (MFMA blocks vs
-# torch's loops), ~1e-6 relative, which now and then tips a stored value to the neighbouring bf16 number (2^-8 relative);
-# such a flip then travels on.  So: the overwhelming majority of stored values is IDENTICAL, a mismatch is one or two bf16
-# steps, and the fp32 outputs agree to a few 1e-3 of their range.
-EMU_OUT = 2e-3        # final seg / radial maps: max |diff| / max |ref|
-EMU_STAGE = 8e-3      # a stored stage: max |diff| / max |ref|  (= one bf16 step of a value in the top binade)
-EMU_MISMATCH = 0.05   # a stored stage: fraction of elements that differ at all
+# The bf16 engine against its emulation (oracle/fcn_torch: the same graph, rounded to bf16 exactly where the engine rounds,
+# fp32 accumulation).  What is left between the two is the fp32 summation order (MFMA blocks vs torch's loops), ~1e-6..1e-5
+# relative, which now and then tips a stored value to the neighbouring bf16 number.  Fed with IDENTICAL inputs, one layer
+# therefore agrees except for a small fraction of elements that are one bf16 step apart.  (Through the whole network those
+# flips multiply until the two are independent realisations of the rounding noise -- see oracle/fcn_torch.py -- so the
+# whole-network comparison cannot be tighter than bf16-vs-fp32 itself; the per-layer comparison is the tight one.)
+EMU_STEP = 2.0 ** -7   # one bf16 step of a value in the top binade, relative to the tensor's max |value|
+EMU_MISMATCH = 0.02    # fraction of a layer's outputs that may differ at all (measured <= ~3e-3)
+EMU_HEAD = 2e-5        # the fp32 head output on identical conv7 input: summation order only
 
 
-def test_bf16_engine_against_bf16_emulation(state_dict):
-    """480x640: every named stage and the outputs of the bf16 engine against the bf16-emulating torch oracle (VERDICT r01 #1a).
-    This is the tight link of the timed precision to the oracle; test_bf16_vs_golden keeps the end-to-end figure against the
-    reference's fp32 golden forward."""
+def test_bf16_engine_layer_by_layer_against_bf16_emulation(state_dict):
+    """480x640, every op of the layer program (stem, max-pool, 161 convolutions, 5 upsamplings, head): the bf16 engine's
+    stored output against the bf16-emulating torch oracle applied to the engine's own stored inputs of that op
+    (VERDICT r01 #1a: the tight link of the timed precision to the oracle).  The fused kernels of the default path are
+    bit-identical to the per-op kernels used here (test_fused_* / test_halo_* / test_bf16_full_size_both_conv_kernels)."""
+    from oracle import fcn_torch
+    from rcvpose_amd import _hip, fcn_engine
+    from rcvpose_amd.fcn_engine import FcnEngine
+
+    H, W = 480, 640
+    sd = state_dict
+    x = torch.from_numpy(fcn_weights.make_input(11, (1, 3, H, W)))
+    prog = fcn_engine.build_program(H, W)
+    eng = FcnEngine([sd], H, W, dtype="bf16", reuse_slots=False)   # one slot per logical tensor
+    eng.set_option(3, 0)   # no fused tail: up1 / conv7 are materialised
+    eng.set_option(4, 0)   # no fused bottleneck halves: every intermediate tensor is materialised
+    seg, rad = eng.forward(x.cuda())
+
+    def stored(t):
+        return eng.debug_slot(1, 0, t, prog.shapes[t]).permute(0, 3, 1, 2).contiguous().cpu()   # NCHW fp32 (bf16 values)
+
+    worst_frac, worst_rel, n_conv = 0.0, 0.0, 0
+    for op, spec in zip(prog.ops, prog.wspecs):
+        kind = op["kind"]
+        if kind == _hip.OP_STEM:
+            ref = fcn_torch.conv_bf16(sd, x.to(torch.bfloat16).to(torch.float32), spec["conv"], spec["bn"], False, stride=2, padding=3)
+        elif kind == _hip.OP_MAXPOOL:
+            ref = torch.nn.functional.max_pool2d(stored(op["src0"]), kernel_size=3, stride=2, padding=1)
+        elif kind == _hip.OP_UPSAMPLE2:
+            ref = fcn_torch.upsample2_bf16(stored(op["src0"]))
+        elif kind == _hip.OP_CONV:
+            src = stored(op["src0"])
+            if op["src1"] >= 0:
+                src = torch.cat((src, stored(op["src1"])), 1)
+            ref = fcn_torch.conv_bf16(sd, src, spec["conv"], spec["bn"], spec["bias"], stride=op["stride"], padding=op["pad"],
+                                      relu=bool(op["relu"]), res=stored(op["res"]) if op["res"] >= 0 else None)
+            n_conv += 1
+        else:  # head: fp32 planes
+            ref = fcn_torch.head_bf16(sd, stored(op["src0"]))
+            got = torch.cat((seg[0].cpu(), rad[0].cpu()), 1)
+            assert float((got - ref).abs().max() / ref.abs().max()) <= EMU_HEAD
+            continue
+        got = stored(op["dst"])
+        assert got.shape == ref.shape
+        rel = float((got - ref).abs().max() / ref.abs().max())
+        frac = float((got != ref).float().mean())
+        if kind == _hip.OP_MAXPOOL:
+            assert rel == 0.0   # exact
+        worst_frac, worst_rel = max(worst_frac, frac), max(worst_rel, rel)
+        assert rel <= EMU_STEP and frac <= EMU_MISMATCH, (spec and spec["conv"], kind, rel, frac)
+    assert n_conv == 161
+    print("bf16 engine vs emulation, layer by layer: worst mismatch fraction %.2e, worst max-rel %.2e" % (worst_frac, worst_rel))
+
+
+def test_bf16_engine_whole_network_against_bf16_emulation(state_dict):
+    """The whole forward against the emulation, for the record: both are bf16 realisations of the same graph, so they sit
+    within the bf16 tolerance of each other (and of the fp32 golden), not closer (see the note above)."""
     from oracle import fcn_torch
     from rcvpose_amd.fcn_engine import FcnEngine
 
     x = torch.from_numpy(fcn_weights.make_input(11, (1, 3, 480, 640)))
-    s_ref, r_ref, st = fcn_torch.forward_bf16(state_dict, x, return_stages=True)
-    eng = FcnEngine([state_dict], 480, 640, dtype="bf16", reuse_slots=False)
-    worst = {}
-    for tail_fused in (1, 0):
-        eng.set_option(3, tail_fused)
-        seg, rad = eng.forward(x.cuda())
-        er, es = _rel(rad[0].cpu().numpy(), r_ref.numpy()), _rel(seg[0].cpu().numpy(), s_ref.numpy())
-        print("bf16 engine vs emulation (tail fused %d): radial %.3e seg %.3e" % (tail_fused, er, es))
-        assert er <= EMU_OUT and es <= EMU_OUT, (er, es)
-        for name in eng.stages:
-            if tail_fused and name in ("up1", "conv7"):
-                continue  # never materialised by the fused tail kernel
-            if not tail_fused and name not in ("up1", "conv7"):
-                continue
-            got = eng.debug_stage(1, 0, name).cpu()
-            ref = st[name]
-            assert got.shape == ref.shape, name
-            rel = float((got - ref).abs().max() / ref.abs().max())
-            frac = float((got != ref).float().mean())
-            worst[name] = (rel, frac)
-            print("  stage %-9s max rel %.3e  mismatching elements %.4f" % (name, rel, frac))
-            assert rel <= EMU_STAGE and frac <= EMU_MISMATCH, (name, rel, frac)
-    assert set(worst) == set(eng.stages)
+    s_ref, r_ref = fcn_torch.forward_bf16(state_dict, x)
+    s32, r32 = fcn_torch.forward(state_dict, x)
+    seg, rad = FcnEngine([state_dict], 480, 640, dtype="bf16").forward(x.cuda())
+    e_emu, e_32 = _rel(rad[0].cpu().numpy(), r_ref.numpy()), _rel(rad[0].cpu().numpy(), r32.numpy())
+    o_32 = _rel(r_ref.numpy(), r32.numpy())
+    print("radial: engine vs emulation %.3e, engine vs fp32 %.3e, emulation vs fp32 %.3e" % (e_emu, e_32, o_32))
+    assert e_emu <= REL_BF16 and e_32 <= REL_BF16
+    assert e_32 <= 2.0 * o_32   # the engine is no worse a bf16 implementation than the straightforward one
 
 
 def test_radial_plane_as_float16(shapes, state_dict):
