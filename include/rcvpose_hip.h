@@ -127,6 +127,33 @@ int rcv_accumulate_3d(const double *xyz_m_dev, const void *radial_dm_dev, int ra
                       size_t ws_bytes, void *stream);
 
 /*
+ * The RGB-only variant (defined but not called by the reference's drivers).
+ *
+ * rcv_backproject_no_depth: rgbd_to_point_cloud_no_depth(K, depth), reference AccumulatorSpace.py:100-120.
+ *   depth_m_dev  float64 [H,W], METRES (the reference scales by 1000 only to count the hypotheses); K = {fx, fy, cx, cy}
+ *   pts_dev      float64 [Z,N,3]: every nonzero pixel (row-major) at the depths zmin + i * 0.001, i < Z =
+ *                int(zmax*1000) + 1 - int(zmin*1000); cap_points bounds Z*N.  pts_dev = NULL: size query only.
+ *   zn_out       HOST int32[2] = {Z, N}.  The result's shape depends on the data, so this call synchronises the stream
+ *                (as the reference's return value does).  ws: 256 + 4*H*W bytes of device scratch.
+ *   No nonzero pixel: RCV_E_EMPTY (the reference raises ValueError at :103).
+ *
+ * rcv_accumulate_3d_no_depth: Accumulator_3D_no_depth(xyz, radial_list, pixel_coor) with fast_for_no_depth, reference
+ * AccumulatorSpace.py:421-479, computed exactly as the reference computes it on a [Z,N,3] array:
+ *   xyz_mm = xyz*200; the three "means" are taken over xyz_mm[:,0], [:,1], [:,2] -- all hypotheses and coordinates of
+ *   pixel 0 / 1 / 2 -- and subtracted from those three pixels only (:440-445); radii = radial_list*20, NOT rounded (:427);
+ *   grid edge int(max)+1 without a radius margin (:459); every hypothesis of pixel p votes with radius p; `center` is an
+ *   int64 array, so row 0 = int64(idx + zero_boundary + mean) * 5 and the other rows (idx + zero_boundary) * 5 (:468-477).
+ *   xyz_m_dev float64 [n_hypotheses, n_pixels, 3] metres; radial_dm_dev float32 / float64 [n_radii >= n_pixels].
+ *   result_dev->center_mm holds row 0 (integer-valued), mean_vox the three means, dim the grid edge.
+ *   n_pixels < 3: RCV_E_INVALID (the reference raises IndexError).  Workspace: rcv_acc_workspace_bytes(Z*N).
+ */
+int rcv_backproject_no_depth(const double *depth_m_dev, int H, int W, const double K[4], double *pts_dev, long long cap_points,
+                             int32_t *zn_out, void *ws, size_t ws_bytes, void *stream);
+int rcv_accumulate_3d_no_depth(const double *xyz_m_dev, const void *radial_dm_dev, int radial_is_f64, int n_hypotheses, int n_pixels,
+                               int n_radii, int engine, rcv_acc_result *result_dev, uint32_t *vote_grid_dev, size_t vote_grid_cells,
+                               void *ws, size_t ws_bytes, void *stream);
+
+/*
  * Batched forms: one launch sequence for n_frames x n_keypoints independent (frame, keypoint) items -- the
  * per-frame loop body of estimate_6d_pose_lm (reference AccumulatorSpace.py:566-659) for a whole batch.
  * Every buffer is given as base + frame * stride_frame + keypoint * stride_kp (bytes; stride 0 = shared,

@@ -185,6 +185,52 @@ def peak_without_grid(xyz_m, radial_dm, acc_unit=5.0, probe_idx=None, threads=0)
                 dim=int(D), zero_boundary=int(info.zero_boundary), probe_votes=pv[: len(probe)].copy())
 
 
+def backproject_no_depth(K4, depth_m):
+    """rgbd_to_point_cloud_no_depth, AccumulatorSpace.py:100-120: depth float64 [H,W] metres -> pts [Z,N,3]."""
+    d = np.ascontiguousarray(depth_m, dtype=np.float64)
+    H, W = d.shape
+    n = int(np.count_nonzero(d))
+    if n == 0:
+        raise ValueError("zero-size array to reduction operation")  # zs.min() of an empty array
+    nz = d[d != 0]
+    Z = int(nz.max() * 1000) + 1 - int(nz.min() * 1000)
+    out = np.empty((Z, n, 3), dtype=np.float64)
+    Kd = np.asarray(K4, dtype=np.float64)
+    nn = ctypes.c_long()
+    L = lib()
+    L.orc_backproject_no_depth.restype = ctypes.c_long
+    z = L.orc_backproject_no_depth(_p(d), H, W, _p(Kd), _p(out), ctypes.c_long(Z * n), ctypes.byref(nn))
+    assert z == Z and nn.value == n
+    return out
+
+
+def accumulator_3d_no_depth(xyz_m, radial_dm, return_all=False, threads=0):
+    """Accumulator_3D_no_depth, AccumulatorSpace.py:436-479 -> center int64 [M,3] (all rows x5, row 0 shifted by the means)."""
+    xyz_m = np.ascontiguousarray(xyz_m, dtype=np.float64)
+    if xyz_m.ndim != 3 or xyz_m.shape[2] != 3 or xyz_m.shape[1] < 3:
+        raise IndexError("Accumulator_3D_no_depth needs a [Z, N>=3, 3] hypothesis array")  # xyz_mm[:,2] in the reference
+    radial_dm = np.ascontiguousarray(radial_dm)
+    if radial_dm.dtype not in (np.float32, np.float64):
+        radial_dm = radial_dm.astype(np.float64)
+    Z, N = xyz_m.shape[:2]
+    pts = np.empty((Z, N, 3), dtype=np.float64)
+    rv = np.empty((max(len(radial_dm), 1),), dtype=np.float64)
+    info = GridInfo()
+    rc = lib().orc_nd_prepare(_p(xyz_m), ctypes.c_long(Z), ctypes.c_long(N), _p(radial_dm), int(radial_dm.dtype == np.float64),
+                              ctypes.c_long(len(radial_dm)), _p(pts), _p(rv), ctypes.byref(info))
+    if rc != 0:
+        raise ValueError("oracle: reference would raise here (status %d)" % rc)
+    D = info.dim
+    votes = np.zeros((D, D, D), dtype=np.uint32)
+    lib().orc_fast_for_nd(_p(pts), _p(rv), ctypes.c_long(Z), ctypes.c_long(N), int(D), _p(votes), int(threads))
+    peak, cnt, idx = argmax_all(votes)
+    center = np.empty((len(idx), 3), dtype=np.int64)
+    lib().orc_nd_center(_p(idx), ctypes.c_long(len(idx)), ctypes.byref(info), _p(center))
+    if return_all:
+        return center, votes, info, peak, pts, rv
+    return center
+
+
 def horn(P1, P2):
     """HornPoseFitting.lmshorn, util/horn.py:75-181 -> 4x4 RT with P2 ~ R P1 + T."""
     P1 = np.ascontiguousarray(P1, dtype=np.float64)

@@ -357,6 +357,136 @@ void orc_center_row0(int64_t flat, const orc_grid_info *info, double acc_unit, d
     }
 }
 
+/* ------------------------------------------------------------------------------------------
+ * RGB-only variant (SURVEY f-5): the depth of every masked pixel is unknown, so each pixel is back-projected at
+ * every millimetre of a depth range and all hypotheses vote.
+ * ------------------------------------------------------------------------------------------ */
+
+/* rgbd_to_point_cloud_no_depth, AccumulatorSpace.py:100-120.  depth: float64 [H,W] in METRES (the reference converts
+ * with *1000 for the hypothesis count only).  pts [Z][N][3] with Z = int(zmax*1000)+1-int(zmin*1000), hypothesis i at
+ * depth zmin + i*0.001 for every nonzero pixel (row-major).  Returns Z (0: nothing / buffer too small), *n_out = N. */
+long orc_backproject_no_depth(const double *depth, int H, int W, const double *K, double *pts, long cap_points, long *n_out)
+{
+    long n = 0;
+    double zmin = 0, zmax = 0;
+    for (long p = 0; p < (long)H * W; p++)
+        if (depth[p] != 0.0) {
+            if (!n || depth[p] < zmin) zmin = depth[p];
+            if (!n || depth[p] > zmax) zmax = depth[p];
+            n++;
+        }
+    *n_out = n;
+    if (!n) return 0;
+    const long Z = (long)(zmax * 1000.) + 1 - (long)(zmin * 1000.);
+    if (Z * n > cap_points) return 0;
+    for (long i = 0; i < Z; i++) {
+        const double z = zmin + (double)i * 0.001;
+        long q = 0;
+        for (int v = 0; v < H; v++)
+            for (int u = 0; u < W; u++) {
+                if (depth[(long)v * W + u] == 0.0) continue;
+                double *o = pts + 3 * (i * n + q);
+                o[0] = (((double)u - K[2]) * z) / K[0];
+                o[1] = (((double)v - K[3]) * z) / K[1];
+                o[2] = z;
+                q++;
+            }
+    }
+    return Z;
+}
+
+/* Accumulator_3D_no_depth up to the call of fast_for_no_depth, AccumulatorSpace.py:436-463.  xyz_m [Z][N][3] metres.
+ *   :438      xyz_mm = xyz*200
+ *   :440-445  x_mean_mm = np.mean(xyz_mm[:,0]) -- with a [Z,N,3] array that is the mean over ALL hypotheses and ALL three
+ *             coordinates of POINT 0 (likewise points 1, 2), and the subtraction shifts those three points only.
+ *             (np.mean of the [Z,3] strided view = the chunked pairwise sum of its C-order elements, orc_mean_strided.)
+ *   :447      radial_list_mm = radial_list*20: NOT rounded later (fast_for_no_depth uses it as is); float32 stays float32
+ *   :453-460  zero_boundary / shift as in Accumulator_3D; length = int(max)+1 WITHOUT the radius margin
+ * info->dim = length, info->mean = the three means.  N < 3 -> the reference raises IndexError. */
+int orc_nd_prepare(const double *xyz_m, long Z, long N, const void *radial, int radial_is_f64, long m, double *points_vox,
+                   double *radius_vox, orc_grid_info *info)
+{
+    memset(info, 0, sizeof(*info));
+    if (N < 3 || Z < 1 || m < 1) { info->status = ORC_E_EMPTY; return ORC_E_EMPTY; }
+    const long total = 3 * Z * N;
+    for (long i = 0; i < total; i++) points_vox[i] = xyz_m[i] * 200.;                       /* :438 */
+    double *tmp = (double *)malloc(sizeof(double) * 3 * (size_t)Z);
+    for (int a = 0; a < 3; a++) {                                                            /* :440-442 */
+        for (long z = 0; z < Z; z++)
+            for (int c = 0; c < 3; c++) tmp[3 * z + c] = points_vox[3 * (z * N + a) + c];
+        info->mean[a] = orc_mean_strided(tmp, 3 * Z, 1);
+    }
+    free(tmp);
+    for (int a = 0; a < 3; a++)                                                              /* :443-445 */
+        for (long z = 0; z < Z; z++)
+            for (int c = 0; c < 3; c++) points_vox[3 * (z * N + a) + c] -= info->mean[a];
+    if (radial_is_f64) {
+        const double *r = (const double *)radial;
+        for (long i = 0; i < m; i++) radius_vox[i] = r[i] * 20.;
+    } else {
+        const float *r = (const float *)radial;
+        for (long i = 0; i < m; i++) radius_vox[i] = (double)(r[i] * 20.f);
+    }
+    double rmax = radius_vox[0];
+    for (long i = 1; i < m; i++) if (radius_vox[i] > rmax) rmax = radius_vox[i];
+    double pmin = points_vox[0], pmax;
+    for (long i = 1; i < total; i++) if (points_vox[i] < pmin) pmin = points_vox[i];
+    int32_t zb = (int32_t)(pmin - rmax) + 1;                                                 /* :453 */
+    if (zb < 0)
+        for (long i = 0; i < total; i++) points_vox[i] -= (double)zb;                        /* :456-457 */
+    pmax = points_vox[0];
+    for (long i = 1; i < total; i++) if (points_vox[i] > pmax) pmax = points_vox[i];
+    info->radius_max = rmax;
+    info->zero_boundary = zb;
+    info->length = (int32_t)pmax + 1;                                                        /* :459 */
+    info->dim = info->length;
+    if (info->dim <= 0) { info->status = ORC_E_BADGRID; return ORC_E_BADGRID; }
+    return ORC_OK;
+}
+
+/* fast_for_no_depth, AccumulatorSpace.py:421-434: every hypothesis of every point against every voxel; the radius of
+ * point `count` is radial_list_mm[count], a real number (no rounding), shared by all its hypotheses. */
+void orc_fast_for_nd(const double *points_vox, const double *radius_vox, long Z, long N, int D, uint32_t *votes, int threads)
+{
+    const double factor = sqrt(3.0) / 4.0;
+#ifdef _OPENMP
+    if (threads > 0) omp_set_num_threads(threads);
+#endif
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int i = 0; i < D; i++)
+        for (long z = 0; z < Z; z++)
+            for (long p = 0; p < N; p++) {
+                const double *q = points_vox + 3 * (z * N + p);
+                const double radius = radius_vox[p];
+                const double dx = (double)i - q[0], dx2 = dx * dx;
+                for (int j = 0; j < D; j++) {
+                    const double dy = (double)j - q[1], sxy = dx2 + dy * dy;
+                    uint32_t *row = votes + ((long)i * D + j) * D;
+                    for (int k = 0; k < D; k++) {
+                        const double dz = (double)k - q[2];
+                        const double distance = sqrt(sxy + dz * dz);
+                        const double t = radius - distance;
+                        if (t < factor && t > 0) row[k] += 1;
+                    }
+                }
+            }
+}
+
+/* `center` of Accumulator_3D_no_depth, AccumulatorSpace.py:468-479: int64 rows; row 0 gets the float means added and is
+ * truncated back to int64 by the item assignment; every row is multiplied by 5. */
+void orc_nd_center(const int64_t *flat_idx, long n_rows, const orc_grid_info *info, int64_t *center)
+{
+    const long D = info->dim;
+    for (long r = 0; r < n_rows; r++) {
+        int64_t c[3] = {flat_idx[r] / (D * D), (flat_idx[r] / D) % D, flat_idx[r] % D};
+        for (int a = 0; a < 3; a++) {
+            if (info->zero_boundary < 0) c[a] += info->zero_boundary;
+            if (r == 0) c[a] = (int64_t)((double)c[a] + info->mean[a]);   /* float into an int64 element: C cast, toward zero */
+            center[3 * r + a] = c[a] * 5;
+        }
+    }
+}
+
 int orc_num_threads(void)
 {
 #ifdef _OPENMP

@@ -194,6 +194,81 @@ def Accumulator_3D(xyz, radial_list, acc_unit=ACC_UNIT_MM, return_votes=False, e
     return center
 
 
+def rgbd_to_point_cloud_no_depth(K, depth):
+    """Back-projection of every nonzero pixel at each millimetre of the depth range (reference :100-120).
+    depth: float array [H,W] in metres -> float64 [Z,N,3]."""
+    torch = _torch()
+    L = _hip.lib()
+    d = torch.from_numpy(np.ascontiguousarray(depth, dtype=np.float64)).cuda()
+    H, W = d.shape
+    ws = torch.empty(256 + 4 * H * W, dtype=torch.uint8, device="cuda")
+    zn = (ctypes.c_int32 * 2)()
+    rc = L.rcv_backproject_no_depth(_hip.ptr(d), H, W, _k4(K), None, 0, zn, _hip.ptr(ws), ws.numel(), _hip.current_stream())
+    if rc == _hip.RCV_E_EMPTY:
+        raise ValueError("zero-size array to reduction operation minimum which has no identity")  # zs.min(), reference :103
+    _hip.check(rc, "rcv_backproject_no_depth")
+    Z, N = int(zn[0]), int(zn[1])
+    pts = torch.empty((Z, N, 3), dtype=torch.float64, device="cuda")
+    _hip.check(L.rcv_backproject_no_depth(_hip.ptr(d), H, W, _k4(K), _hip.ptr(pts), Z * N, zn, _hip.ptr(ws), ws.numel(),
+                                          _hip.current_stream()), "rcv_backproject_no_depth")
+    print((Z, N, 3))  # the reference prints pts.shape (:118)
+    return pts.cpu().numpy()
+
+
+def Accumulator_3D_no_depth(xyz, radial_list, pixel_coor=None, engine="auto", return_votes=False):
+    """The RGB-only accumulator (reference AccumulatorSpace.py:436-479, fast_for_no_depth :421-434): xyz [Z,N,3] metres (the
+    hypotheses of rgbd_to_point_cloud_no_depth), radial_list [N] decimetres.  Returns `center`, int64 [ties,3], computed
+    exactly as the reference computes it (see rcv_accumulate_3d_no_depth in include/rcvpose_hip.h).  pixel_coor is
+    accepted and ignored, as in the reference.  Fewer than three pixels raise IndexError like the reference."""
+    torch = _torch()
+    L = _hip.lib()
+    xyz_h = np.ascontiguousarray(np.asarray(xyz, dtype=np.float64))
+    if xyz_h.ndim != 3 or xyz_h.shape[2] != 3 or xyz_h.shape[1] < 3:
+        raise IndexError("index 2 is out of bounds for axis 1 (Accumulator_3D_no_depth needs a [Z, N>=3, 3] array)")
+    rad_h = np.ascontiguousarray(np.asarray(radial_list))
+    if rad_h.dtype not in (np.float32, np.float64):
+        rad_h = rad_h.astype(np.float64)
+    Z, N = xyz_h.shape[:2]
+    if len(rad_h) < N:
+        raise IndexError("radial_list shorter than the pixel list")
+    ws = AccWorkspace(Z * N)
+    xyz_d, rad_d = torch.from_numpy(xyz_h).cuda(), torch.from_numpy(rad_h).cuda()
+
+    def run(grid):
+        cells = 0 if grid is None else grid.numel()
+        _hip.check(L.rcv_accumulate_3d_no_depth(_hip.ptr(xyz_d), _hip.ptr(rad_d), int(rad_h.dtype == np.float64), Z, N, len(rad_h),
+                                                _hip.VOTE_ENGINES[engine], _hip.ptr(ws.result), _hip.ptr(grid), cells, _hip.ptr(ws.ws),
+                                                ws.bytes, _hip.current_stream()), "rcv_accumulate_3d_no_depth")
+        res = ws.read_result()
+        _raise_like_reference(res.status)
+        return res
+
+    res = run(None)
+    center = np.array([[res.center_mm[0], res.center_mm[1], res.center_mm[2]]]).astype(np.int64)
+    votes = None
+    if res.n_ties > 1 or return_votes:
+        D = res.dim
+        grid = torch.empty(D * D * D, dtype=torch.int32, device="cuda")
+        res = run(grid)
+        if res.n_ties > 1:
+            idx = torch.empty(res.n_ties, dtype=torch.int64, device="cuda")
+            cnt = torch.zeros(1, dtype=torch.int32, device="cuda")
+            _hip.check(L.rcv_collect_ties(_hip.ptr(grid), D, res.peak_votes, _hip.ptr(idx), res.n_ties, _hip.ptr(cnt),
+                                          _hip.current_stream()), "rcv_collect_ties")
+            flat = idx.cpu().numpy()
+            rows = np.stack([flat // (D * D), (flat // D) % D, flat % D], axis=1).astype(np.int64)
+            if res.zero_boundary < 0:
+                rows = rows + res.zero_boundary
+            rows = rows * 5
+            rows[0] = center[0]
+            center = rows
+        if return_votes:
+            votes = grid.cpu().numpy().view(np.uint32).reshape(D, D, D)
+    if return_votes:
+        return center, votes, res
+    return center
+
+
 def FCResBackbone(model, input_img_path, normalized_depth=None):
     """Run one RGB image through a DenseFCNResNet152 (reference AccumulatorSpace.py:122-162).
 

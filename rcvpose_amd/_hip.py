@@ -93,6 +93,8 @@ SYMBOLS = {
     "rcv_seam_compact": (_i, [_vp, _vp, _vp, _i, _i, ctypes.POINTER(_d), _f, _d, _i, _vp, _vp, _vp, _i, _vp, _sz, _vp]),
     "rcv_acc_workspace_bytes_min": (_sz, [_i]),
     "rcv_accumulate_3d": (_i, [_vp, _vp, _i, _vp, _i, _i, _d, _i, _vp, _vp, _sz, _vp, _sz, _vp]),
+    "rcv_backproject_no_depth": (_i, [_vp, _i, _i, ctypes.POINTER(_d), _vp, ctypes.c_longlong, ctypes.POINTER(ctypes.c_int32), _vp, _sz, _vp]),
+    "rcv_accumulate_3d_no_depth": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp, _sz, _vp]),
     "rcv_horn_pose_batch": (_i, [_vp, Strided, _i, _i, _vp, _vp]),
     "rcv_seam_compact_batch": (_i, [Strided, Strided, Strided, _i, _i, ctypes.POINTER(_d), _f, Strided, _i, Strided, Strided,
                                      Strided, _i, Strided, _sz, _i, _i, _vp]),

@@ -73,7 +73,13 @@ struct alignas(16) AccHeader {
     uint32_t pb_count[8];    // same for the greedy probe (beam of BB_BEAM blocks per level)
     uint32_t sel_count[8];
     unsigned long long bb_best_key;  // bb_best << 32 | flat index of a voxel attaining it (hill-climb start)
+    // RGB-only variant (rcv_accumulate_3d_no_depth): the points in P are final voxel coordinates (mean = shift = 0 above)
+    // and the result is formed the reference's other way (AccumulatorSpace.py:468-477)
+    int32_t variant;         // 0: Accumulator_3D, 1: Accumulator_3D_no_depth
+    int32_t pad_;
+    double nd_mean[3];       // x/y/z_mean_mm of :440-442
 };
+static_assert(sizeof(AccHeader) <= 512, "AccHeader must fit the 512 bytes reserved in the workspace");
 
 struct PrepPartial {
     double mn[3], mx[3], rmax;
@@ -433,15 +439,12 @@ __device__ double pw_leaf(const double *a, int n)
 //   running total in order.  Here a chunk's recursion tree is laid out as a binary heap (<= 255 nodes):
 //   one thread per heap node finds its (offset, length) by walking down from the root, leaves are
 //   summed in parallel, inner nodes level by level; the chunk totals are then added sequentially.
-__device__ __forceinline__ void d_setup(const PrepPartial *partials, const double *P, const int32_t *counts,
-                                                int n_arg, int m_arg, int cap, double unit, int bb_enable,
-                                                long long replica_slots, AccHeader *hdr)
+// Sum of each of three arrays A + a * stride (a = 0..2, n elements each) exactly as numpy's add.reduce forms it (see above);
+// all 1024 threads of the workgroup call it; the totals land in shared `total[3]`.
+__device__ __forceinline__ void np_sums3(const double *A, size_t stride, int n, double *total)
 {
     __shared__ double val[4][3][256];
     __shared__ unsigned char kind[4][256];  // 0 = absent, 1 = leaf, 2 = inner
-    __shared__ double total[3];
-    int n = n_arg, m = m_arg;
-    if (counts) { n = min(counts[0], cap); m = min(counts[1], cap); }
     const int t = threadIdx.x, grp = t >> 8, h = t & 255;
     if (t < 3) total[t] = 0.0;
     __syncthreads();
@@ -463,7 +466,7 @@ __device__ __forceinline__ void d_setup(const PrepPartial *partials, const doubl
             if (exists) {
                 if (len <= PW_BLOCK) {
                     kd = 1;
-                    for (int a = 0; a < 3; a++) val[grp][a][h] = pw_leaf(P + (size_t)a * cap + off0 + o, len);
+                    for (int a = 0; a < 3; a++) val[grp][a][h] = pw_leaf(A + (size_t)a * stride + off0 + o, len);
                 } else {
                     kd = 2;
                 }
@@ -483,6 +486,60 @@ __device__ __forceinline__ void d_setup(const PrepPartial *partials, const doubl
         }
         __syncthreads();
     }
+}
+
+// grid-dependent part of the header: tile geometry of the LDS rasteriser, root blocks of the peak search
+__device__ __forceinline__ bool finish_header(AccHeader &H, long long dim, int n, bool overflow, int bb_enable, long long replica_slots)
+{
+    if (dim <= 0) { H.status = RCV_E_BADGRID; return false; }
+    if (overflow) { H.status = RCV_E_TOO_LARGE; return false; }
+    if (dim > MAX_DIM) { H.status = RCV_E_TOO_LARGE; H.dim = (int)min(dim, 2000000000ll); return false; }
+    const int D = (int)dim;
+    H.dim = D;
+    H.wide = n >= 65536;
+    const int cell_bytes = H.wide ? 4 : 2;
+    const int cells = CELL_BYTES / cell_bytes;
+    // tile: TJ = 16 (or D if smaller) columns across j; TI rows; full k extent when it fits
+    int TJ = D < 16 ? D : 16, TI, TK = D, TKp = (D + 1) & ~1;
+    if ((long long)TJ * TKp > cells) {  // a single row of columns does not fit: split k
+        TI = 1;
+        TJ = D < 64 ? D : 64;
+        TKp = (cells / TJ) & ~1;
+        TK = TKp;
+    } else {
+        TI = cells / (TJ * TKp);
+        if (TI * TJ > 128) TI = 128 / TJ;  // two 64-column passes per point
+        if (TI > D) TI = D;
+        // prefer at least ~2 workgroups per CU worth of tiles as long as a wave still gets 64 columns
+        while (TI > 4 && (long long)((D + TI - 1) / TI) * ((D + TJ - 1) / TJ) < 512) TI >>= 1;
+    }
+    H.TI = TI; H.TJ = TJ; H.TK = TK; H.TKp = TKp;
+    H.nti = (D + TI - 1) / TI; H.ntj = (D + TJ - 1) / TJ; H.ntk = (D + TK - 1) / TK;
+    const long long nt = (long long)H.nti * H.ntj * H.ntk;
+    if (nt > MAX_TILES) { H.status = RCV_E_TOO_LARGE; return false; }
+    H.ntiles = (int)nt;
+    // the central tiles see every point, the outer ones few: split each tile's point list over nparts
+    // workgroups (their LDS counters are summed by k_merge) so that no work item dominates the makespan
+    H.nparts = (int)max(1ll, min(8ll, min((long long)MAX_REPLICAS, replica_slots) / nt));
+    H.status = RCV_OK;
+    H.tile_counter = 0;
+    {
+        const long long nb = (D + BB_ROOT - 1) / BB_ROOT;
+        H.bb_enabled = bb_enable && nb * nb * nb <= BB_CAP;
+        H.bb_count[0] = (uint32_t)(nb * nb * nb);
+    }
+    return true;
+}
+
+__device__ __forceinline__ void d_setup(const PrepPartial *partials, const double *P, const int32_t *counts,
+                                                int n_arg, int m_arg, int cap, double unit, int bb_enable,
+                                                long long replica_slots, AccHeader *hdr)
+{
+    __shared__ double total[3];
+    int n = n_arg, m = m_arg;
+    if (counts) { n = min(counts[0], cap); m = min(counts[1], cap); }
+    const int t = threadIdx.x;
+    np_sums3(P, (size_t)cap, n, total);
     // extrema of the per-block partials (k_prep), reduced by the first wave
     __shared__ double s_ext[8];
     if (t < 64) {
@@ -528,43 +585,7 @@ __device__ __forceinline__ void d_setup(const PrepPartial *partials, const doubl
     const double pmax = zb < 0 ? qmax - (double)zb : qmax;
     const int length = clamp_to_int(pmax);                  // :399
     const long long dim = (long long)length + (long long)clamp_to_int(rmax);  // :401
-    if (dim <= 0) { H.status = RCV_E_BADGRID; *hdr = H; return; }
-    if (overflow) { H.status = RCV_E_TOO_LARGE; *hdr = H; return; }
-    if (dim > MAX_DIM) { H.status = RCV_E_TOO_LARGE; H.dim = (int)min(dim, 2000000000ll); *hdr = H; return; }
-    const int D = (int)dim;
-    H.dim = D;
-    H.wide = n >= 65536;
-    const int cell_bytes = H.wide ? 4 : 2;
-    const int cells = CELL_BYTES / cell_bytes;
-    // tile: TJ = 16 (or D if smaller) columns across j; TI rows; full k extent when it fits
-    int TJ = D < 16 ? D : 16, TI, TK = D, TKp = (D + 1) & ~1;
-    if ((long long)TJ * TKp > cells) {  // a single row of columns does not fit: split k
-        TI = 1;
-        TJ = D < 64 ? D : 64;
-        TKp = (cells / TJ) & ~1;
-        TK = TKp;
-    } else {
-        TI = cells / (TJ * TKp);
-        if (TI * TJ > 128) TI = 128 / TJ;  // two 64-column passes per point
-        if (TI > D) TI = D;
-        // prefer at least ~2 workgroups per CU worth of tiles as long as a wave still gets 64 columns
-        while (TI > 4 && (long long)((D + TI - 1) / TI) * ((D + TJ - 1) / TJ) < 512) TI >>= 1;
-    }
-    H.TI = TI; H.TJ = TJ; H.TK = TK; H.TKp = TKp;
-    H.nti = (D + TI - 1) / TI; H.ntj = (D + TJ - 1) / TJ; H.ntk = (D + TK - 1) / TK;
-    const long long nt = (long long)H.nti * H.ntj * H.ntk;
-    if (nt > MAX_TILES) { H.status = RCV_E_TOO_LARGE; *hdr = H; return; }
-    H.ntiles = (int)nt;
-    // the central tiles see every point, the outer ones few: split each tile's point list over nparts
-    // workgroups (their LDS counters are summed by k_merge) so that no work item dominates the makespan
-    H.nparts = (int)max(1ll, min(8ll, min((long long)MAX_REPLICAS, replica_slots) / nt));
-    H.status = RCV_OK;
-    H.tile_counter = 0;
-    {
-        const long long nb = (D + BB_ROOT - 1) / BB_ROOT;
-        H.bb_enabled = bb_enable && nb * nb * nb <= BB_CAP;
-        H.bb_count[0] = (uint32_t)(nb * nb * nb);
-    }
+    finish_header(H, dim, n, overflow, bb_enable, replica_slots);
     *hdr = H;
 }
 
@@ -1466,6 +1487,22 @@ __device__ __forceinline__ void d_bb_topk(const AccHeader *hdr, const BBEntry *l
     if (tid == 0) *sel_count = (uint32_t)picked;
 }
 
+// row 0 of the reference's `center` from the voxel index of the first maximum
+__device__ __forceinline__ double center_component(const AccHeader &H, int idx, int a)
+{
+    if (H.variant) {
+        // Accumulator_3D_no_depth (AccumulatorSpace.py:468-477): `center` is an int64 array; center + zero_boundary stays
+        // integer, `center[0,a] += mean` stores a float into an int64 element (C cast, toward zero), then center * 5
+        long long c = idx;
+        if (H.zb < 0) c += H.zb;
+        const double shifted = (double)c + H.nd_mean[a];
+        return (double)((long long)shifted * 5ll);
+    }
+    double c = (double)idx;
+    if (H.zb < 0) c = c + (double)H.zb;                 // center + zero_boundary, :409-410
+    return ((c + H.mean[a]) + 0.5) * H.unit;            // (center + mean + 0.5) * acc_unit, :413-415
+}
+
 __device__ __forceinline__ void d_bb_final(AccHeader *hdr, const BBEntry *voxels, rcv_acc_result *out)
 {
     __shared__ uint32_t s_first[16];
@@ -1499,11 +1536,9 @@ __device__ __forceinline__ void d_bb_final(AccHeader *hdr, const BBEntry *voxels
     R.radius_max = H.rmax;
     const int idx[3] = {(int)(first / (D * D)), (int)((first / D) % D), (int)(first % D)};
     for (int a = 0; a < 3; a++) {
-        R.mean_vox[a] = H.mean[a];
+        R.mean_vox[a] = H.variant ? H.nd_mean[a] : H.mean[a];
         R.first_idx[a] = idx[a];
-        double c = (double)idx[a];
-        if (H.zb < 0) c = c + (double)H.zb;                 // center + zero_boundary, :409-410
-        R.center_mm[a] = ((c + H.mean[a]) + 0.5) * H.unit;  // (center + mean + 0.5) * acc_unit, :413-415
+        R.center_mm[a] = center_component(H, idx[a], a);
     }
     R.peak_votes = peak;
     R.n_ties = ties;
@@ -1522,7 +1557,7 @@ __device__ __forceinline__ void d_final(const AccHeader *hdr, const uint64_t *ti
     memset(&R, 0, sizeof(R));
     R.dim = H.dim; R.zero_boundary = H.zb; R.n_points = H.n; R.n_radii = H.m; R.status = H.status;
     R.radius_max = H.rmax;
-    for (int a = 0; a < 3; a++) R.mean_vox[a] = H.mean[a];
+    for (int a = 0; a < 3; a++) R.mean_vox[a] = H.variant ? H.nd_mean[a] : H.mean[a];
     if (H.status != RCV_OK) {
         if (threadIdx.x == 0) *out = R;
         return;
@@ -1548,9 +1583,7 @@ __device__ __forceinline__ void d_final(const AccHeader *hdr, const uint64_t *ti
     const int idx[3] = {(int)(flat / (D * D)), (int)((flat / D) % D), (int)(flat % D)};
     for (int a = 0; a < 3; a++) {
         R.first_idx[a] = idx[a];
-        double c = (double)idx[a];
-        if (H.zb < 0) c = c + (double)H.zb;                 // center + zero_boundary, :409-410
-        R.center_mm[a] = ((c + H.mean[a]) + 0.5) * H.unit;  // (center + mean + 0.5) * acc_unit, :413-415
+        R.center_mm[a] = center_component(H, idx[a], a);
     }
     R.peak_votes = (int32_t)vmax;
     R.n_ties = ties > 2147483647ull ? 2147483647 : (int32_t)ties;
@@ -1744,6 +1777,199 @@ __global__ __launch_bounds__(256) void k_final(int grid_given, unsigned long lon
             grid_cells, out.get());
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// RGB-only variant (SURVEY f-5): rgbd_to_point_cloud_no_depth (AccumulatorSpace.py:100-120) and
+// Accumulator_3D_no_depth / fast_for_no_depth (:421-479).  Every pixel is back-projected at each millimetre of a depth
+// range; all Z * N hypotheses vote with the (unrounded) radius of their pixel.  The arithmetic the reference actually
+// performs on the [Z,N,3] array is kept, quirks included (see the oracle, oracle/rcv_oracle.c: orc_nd_prepare).
+// The voting itself runs in the engines above: a hypothesis is a point with its own float64 threshold pair.
+// ---------------------------------------------------------------------------------------------
+struct NdRange {
+    double zmin, zmax;
+    int32_t n, pad_;
+};
+
+// nonzero pixels of a float64 depth map in row-major order (np.nonzero) + their depth range.  One workgroup walks the
+// image in order (a data-preparation step off the hot path).
+__global__ __launch_bounds__(1024) void k_nd_pixels(const double *depth, int HW, int32_t *pix_out, int cap, NdRange *range)
+{
+    __shared__ int wc[16];
+    __shared__ int running;
+    __shared__ double smin[16], smax[16];
+    if (threadIdx.x == 0) running = 0;
+    __syncthreads();
+    const double INF = __longlong_as_double(0x7FF0000000000000ll);
+    double mn = INF, mx = -INF;
+    for (int base = 0; base < HW; base += 1024) {
+        const int p = base + threadIdx.x;
+        const bool hit = p < HW && depth[p] != 0.0;
+        if (hit) { mn = fmin(mn, depth[p]); mx = fmax(mx, depth[p]); }
+        const uint64_t b = __ballot(hit);
+        if (lane_id() == 0) wc[wave_id()] = __popcll(b);
+        __syncthreads();
+        int before = running;
+        for (int q = 0; q < wave_id(); q++) before += wc[q];
+        if (hit) {
+            const int dst = before + __popcll(b & ((1ull << lane_id()) - 1ull));
+            if (dst < cap) pix_out[dst] = p;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) { int t = 0; for (int q = 0; q < 16; q++) t += wc[q]; running += t; }
+        __syncthreads();
+    }
+    mn = wave_min(mn); mx = wave_max(mx);
+    if (lane_id() == 0) { smin[wave_id()] = mn; smax[wave_id()] = mx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int q = 1; q < 16; q++) { mn = fmin(mn, smin[q]); mx = fmax(mx, smax[q]); }
+        range->zmin = mn; range->zmax = mx; range->n = running; range->pad_ = 0;
+    }
+}
+
+// pts[i][q] = (((u - cx) * z) / fx, ((v - cy) * z) / fy, z) with z = zmin + i * 0.001  (AccumulatorSpace.py:110-113)
+__global__ __launch_bounds__(256) void k_nd_hypotheses(const int32_t *pix, int n, int Z, int W, double fx, double fy, double cx, double cy,
+                                                       double zmin, double *pts)
+{
+    const long long total = (long long)Z * n;
+    for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long long)gridDim.x * 256) {
+        const int i = (int)(t / n), q = (int)(t - (long long)i * n);
+        const int p = pix[q], v = p / W, u = p - v * W;
+        const double z = zmin + (double)i * 0.001;
+        pts[3 * t + 0] = (((double)u - cx) * z) / fx;
+        pts[3 * t + 1] = (((double)v - cy) * z) / fy;
+        pts[3 * t + 2] = z;
+    }
+}
+
+// the shell of a real radius R as a threshold pair on d2 (float64): vote <=> T_lo <= d2 < T_hi, where
+//   T_hi = min{ d : sqrt(d) >= R }      (`radius - distance > 0`  <=>  d2 < T_hi)
+//   T_lo = min{ d : R - sqrt(d) < f }   (`radius - distance < factor`)
+// found with the device's correctly rounded float64 sqrt and subtraction -- the operations of the reference's predicate
+// (:431-432) -- by bisection on the bit pattern (both predicates are monotone in d).
+__device__ void nd_thresholds(double R, double f, double &tlo, double &thi)
+{
+    tlo = 0.0; thi = 0.0;  // R <= 0 (or NaN): `radius - distance > 0` never holds
+    if (!(R > 0.0)) return;
+    if (!(R < 1.0e150)) { tlo = 0.0; thi = __longlong_as_double(0x7FEFFFFFFFFFFFFFll); return; }
+    // predicate true at hi_u, false at lo_u
+    unsigned long long lo_u = 0ull, hi_u = (unsigned long long)__double_as_longlong(R * R * 1.0000001 + 1e-300);
+    while (hi_u - lo_u > 1) {
+        const unsigned long long mid = lo_u + (hi_u - lo_u) / 2;
+        if (sqrt(__longlong_as_double((long long)mid)) >= R) hi_u = mid; else lo_u = mid;
+    }
+    thi = __longlong_as_double((long long)hi_u);
+    lo_u = 0ull;  // at d = +0: R - 0 < f ?  (tiny radii: every d2 < T_hi votes)
+    if (R - 0.0 < f) { tlo = 0.0; return; }
+    hi_u = (unsigned long long)__double_as_longlong(thi);  // at T_hi: R - sqrt(d) <= 0 < f
+    while (hi_u - lo_u > 1) {
+        const unsigned long long mid = lo_u + (hi_u - lo_u) / 2;
+        if (R - sqrt(__longlong_as_double((long long)mid)) < f) hi_u = mid; else lo_u = mid;
+    }
+    tlo = __longlong_as_double((long long)hi_u);
+}
+
+// step 1: xyz * 200 into the SoA point arrays, the three points the reference recentres gathered for their means,
+// per-pixel radii (* 20, float32 lists stay float32) and their threshold pairs, radius maximum
+template <typename RT>
+__global__ __launch_bounds__(PREP_THREADS) void k_nd_prep(const double *xyz_m, const RT *radial, int Z, int N, int m, int cap, double scale,
+                                                          double *P, double *Q, double *Tq, PrepPartial *partials)
+{
+    __shared__ double red[PREP_THREADS / 64];
+    const long long total = (long long)Z * N;
+    const double INF = __longlong_as_double(0x7FF0000000000000ll);
+    volatile double three = 3.0;
+    const double f = sqrt(three) / 4.0;  // (3**0.5)/4, :423
+    double rmax = -INF;
+    for (long long t = (long long)blockIdx.x * PREP_THREADS + threadIdx.x; t < total || t < m; t += (long long)PREP_BLOCKS * PREP_THREADS) {
+        if (t < total) {
+            const int z = (int)(t / N), p = (int)(t - (long long)z * N);
+            for (int c = 0; c < 3; c++) {
+                const double v = xyz_m[3 * t + c] * scale;  // xyz*200, :438
+                P[(size_t)c * cap + t] = v;
+                if (p < 3) Q[(size_t)p * cap + 3 * z + c] = v;  // xyz_mm[:, p] as numpy flattens it (C order)
+            }
+        }
+        if (t < m) {
+            const RT rv = radial[t] * (RT)20;  // radial_list*20, :447 (weak python scalar: float32 stays float32)
+            const double rd = (double)rv;
+            if (rd > rmax) rmax = rd;
+            if (t < N) {
+                double tlo, thi;
+                nd_thresholds(rd, f, tlo, thi);
+                Tq[2 * t] = tlo;   // per pixel; replicated over the hypotheses by k_nd_finish
+                Tq[2 * t + 1] = thi;
+            }
+        }
+    }
+    rmax = wave_max(rmax);
+    if (lane_id() == 0) red[wave_id()] = rmax;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < PREP_THREADS / 64; w++) rmax = fmax(rmax, red[w]);
+        PrepPartial pp;
+        memset(&pp, 0, sizeof(pp));
+        pp.rmax = rmax;
+        partials[blockIdx.x] = pp;
+    }
+}
+
+// step 2 (one workgroup): the three means, the recentring of points 0..2 of every hypothesis, extrema, grid
+__global__ __launch_bounds__(1024) void k_nd_setup(int Z, int N, int m, int cap, int bb_enable, long long replica_slots, double *P,
+                                                   const double *Q, const PrepPartial *partials, AccHeader *hdr)
+{
+    __shared__ double total[3];
+    __shared__ double s_mn[16], s_mx[16];
+    const int t = threadIdx.x;
+    np_sums3(Q, (size_t)cap, 3 * Z, total);   // np.mean(xyz_mm[:, a]) over the [Z,3] view, a = 0..2  (:440-442)
+    double mean[3];
+    for (int a = 0; a < 3; a++) mean[a] = total[a] / (double)(3 * Z);
+    for (int e = t; e < 9 * Z; e += 1024) {   // xyz_mm[:, a] -= mean_a  (:443-445): points 0..2, all coordinates
+        const int z = e / 9, a = (e / 3) % 3, c = e % 3;
+        P[(size_t)c * cap + (size_t)z * N + a] -= mean[a];
+    }
+    __syncthreads();
+    const double INF = __longlong_as_double(0x7FF0000000000000ll);
+    double mn = INF, mx = -INF;
+    const long long n = (long long)Z * N;
+    for (int c = 0; c < 3; c++)
+        for (long long i = t; i < n; i += 1024) { const double v = P[(size_t)c * cap + i]; mn = fmin(mn, v); mx = fmax(mx, v); }
+    mn = wave_min(mn); mx = wave_max(mx);
+    if (lane_id() == 0) { s_mn[wave_id()] = mn; s_mx[wave_id()] = mx; }
+    __syncthreads();
+    if (t != 0) return;
+    for (int q = 1; q < 16; q++) { mn = fmin(mn, s_mn[q]); mx = fmax(mx, s_mx[q]); }
+    double rmax = -INF;
+    for (int b = 0; b < PREP_BLOCKS; b++) rmax = fmax(rmax, partials[b].rmax);
+    AccHeader H;
+    memset(&H, 0, sizeof(H));
+    H.variant = 1;
+    H.n = (int)n; H.m = m; H.unit = 5.0;
+    for (int a = 0; a < 3; a++) H.nd_mean[a] = mean[a];
+    H.rmax = rmax;
+    const int zb = clamp_to_int(mn - rmax) + 1;            // :453
+    H.zb = zb;
+    const double pmax = zb < 0 ? mx - (double)zb : mx;     // :456-457 (the shift itself is applied by k_nd_finish)
+    const long long dim = (long long)clamp_to_int(pmax) + 1;  // :459 -- no radius margin
+    finish_header(H, dim, (int)n, false, bb_enable, replica_slots);
+    *hdr = H;
+}
+
+// step 3: the zero_boundary shift into the stored coordinates (the engines then see mean = shift = 0) and the pixel's
+// threshold pair for every hypothesis
+__global__ __launch_bounds__(256) void k_nd_finish(int Z, int N, int cap, double *P, const double *Tq, const AccHeader *hdr)
+{
+    const AccHeader H = *hdr;
+    const long long n = (long long)Z * N;
+    for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < n; t += (long long)gridDim.x * 256) {
+        if (H.zb < 0)
+            for (int c = 0; c < 3; c++) P[(size_t)c * cap + t] = P[(size_t)c * cap + t] - (double)H.zb;  // xyz_mm - zero_boundary
+        const int p = (int)(t % N);
+        P[(size_t)3 * cap + t] = Tq[2 * p];
+        P[(size_t)4 * cap + t] = Tq[2 * p + 1];
+    }
+}
+
 constexpr size_t VOTE_LDS_BYTES = CELL_BYTES + 12 * VOTE_WAVES + 64;
 bool g_vote_attr_set = false;
 
@@ -1814,50 +2040,12 @@ static int seam_batch(rcv_strided seg, rcv_strided rad, rcv_strided depth, int H
     return RCV_OK;
 }
 
-static int accumulate_batch(rcv_strided xyz, rcv_strided radial, int radial_is_f64, rcv_strided counts, int n_points, int n_radii,
-                            double acc_unit_mm, int engine, rcv_strided result, rcv_strided grid, size_t grid_cells, rcv_strided ws,
-                            size_t ws_bytes, int n_frames, int n_kp, void *stream)
+// the arg-max engines on a prepared item (header + point arrays in the workspace): exact peak search, LDS rasteriser
+static int run_engines(int cap, int bb_enable, SP<rcv_acc_result> sres, SP<uint32_t> sgrid, size_t grid_cells, bool grid_given,
+                       SP<unsigned char> sws, const Layout &L, int n_frames, int n_kp, hipStream_t st)
 {
-    if (!result.ptr || !ws.ptr) return RCV_E_INVALID;
-    if (n_points < 0 || n_radii < 0 || !(acc_unit_mm > 0.0)) return RCV_E_INVALID;
-    if (engine != RCV_VOTE_AUTO && engine != RCV_VOTE_RASTER) return RCV_E_INVALID;
-    if ((n_points > 0 && !xyz.ptr) || (n_radii > 0 && !radial.ptr)) return RCV_E_INVALID;
-    if (n_frames <= 0 || n_kp <= 0 || n_frames > 65535 || n_kp > 65535) return RCV_E_INVALID;
-    int rc = ensure_init();
-    if (rc != RCV_OK) return rc;
-    const int cap = n_points > n_radii ? (n_points > 0 ? n_points : 1) : (n_radii > 0 ? n_radii : 1);
-    const Layout L = make_layout(cap);
-    if (ws_bytes < L.min_total) return RCV_E_WORKSPACE;
-    const long long replica_slots = (long long)((ws_bytes - L.replicas) / CELL_BYTES);
-    hipStream_t st = (hipStream_t)stream;
-    if (!g_vote_attr_set) {
-        RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_vote<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)VOTE_LDS_BYTES));
-        RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_vote<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)VOTE_LDS_BYTES));
-        RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_merge<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)VOTE_LDS_BYTES));
-        RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_merge<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)VOTE_LDS_BYTES));
-        g_vote_attr_set = true;
-    }
-    const SP<unsigned char> sws{(unsigned char *)ws.ptr, ws.stride_frame, ws.stride_kp};
-    const SP<const double> sxyz{(const double *)xyz.ptr, xyz.stride_frame, xyz.stride_kp};
-    const SP<const int32_t> scnt{(const int32_t *)counts.ptr, counts.stride_frame, counts.stride_kp};
-    const SP<rcv_acc_result> sres{(rcv_acc_result *)result.ptr, result.stride_frame, result.stride_kp};
-    const SP<uint32_t> sgrid{(uint32_t *)grid.ptr, grid.stride_frame, grid.stride_kp};
     const dim3 items(1, n_frames, n_kp);
     auto grid3 = [&](int x) { return dim3(x, n_frames, n_kp); };
-    if (radial_is_f64)
-        hipLaunchKernelGGL(k_prep<double>, grid3(PREP_BLOCKS), dim3(PREP_THREADS), 0, st, sxyz,
-                           SP<const double>{(const double *)radial.ptr, radial.stride_frame, radial.stride_kp}, scnt, n_points,
-                           n_radii, cap, acc_unit_mm, g_thr_dev, sws, L);
-    else
-        hipLaunchKernelGGL(k_prep<float>, grid3(PREP_BLOCKS), dim3(PREP_THREADS), 0, st, sxyz,
-                           SP<const float>{(const float *)radial.ptr, radial.stride_frame, radial.stride_kp}, scnt, n_points,
-                           n_radii, cap, acc_unit_mm, g_thr_dev, sws, L);
-    RCV_LAUNCH_CHECK();
-    // the exact peak search runs first unless the caller wants the full grid (or forced the rasteriser)
-    const int bb_enable = (engine == RCV_VOTE_AUTO && grid.ptr == nullptr) ? 1 : 0;
-    hipLaunchKernelGGL(k_setup, items, dim3(1024), 0, st, scnt, n_points, n_radii, cap, acc_unit_mm, bb_enable, replica_slots, sws,
-                       L);
-    RCV_LAUNCH_CHECK();
     const int n_items = n_frames * n_kp;
     if (bb_enable) {
         hipLaunchKernelGGL(k_bb_init, grid3(256), dim3(256), 0, st, cap, sws, L);
@@ -1910,9 +2098,56 @@ static int accumulate_batch(rcv_strided xyz, rcv_strided radial, int radial_is_f
                            (unsigned long long)grid_cells, sws, L);
         RCV_LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(k_final, items, dim3(256), 0, st, grid.ptr != nullptr ? 1 : 0, (unsigned long long)grid_cells, sres, sws, L);
+    hipLaunchKernelGGL(k_final, items, dim3(256), 0, st, grid_given ? 1 : 0, (unsigned long long)grid_cells, sres, sws, L);
     RCV_LAUNCH_CHECK();
     return RCV_OK;
+}
+
+static int accumulate_batch(rcv_strided xyz, rcv_strided radial, int radial_is_f64, rcv_strided counts, int n_points, int n_radii,
+                            double acc_unit_mm, int engine, rcv_strided result, rcv_strided grid, size_t grid_cells, rcv_strided ws,
+                            size_t ws_bytes, int n_frames, int n_kp, void *stream)
+{
+    if (!result.ptr || !ws.ptr) return RCV_E_INVALID;
+    if (n_points < 0 || n_radii < 0 || !(acc_unit_mm > 0.0)) return RCV_E_INVALID;
+    if (engine != RCV_VOTE_AUTO && engine != RCV_VOTE_RASTER) return RCV_E_INVALID;
+    if ((n_points > 0 && !xyz.ptr) || (n_radii > 0 && !radial.ptr)) return RCV_E_INVALID;
+    if (n_frames <= 0 || n_kp <= 0 || n_frames > 65535 || n_kp > 65535) return RCV_E_INVALID;
+    int rc = ensure_init();
+    if (rc != RCV_OK) return rc;
+    const int cap = n_points > n_radii ? (n_points > 0 ? n_points : 1) : (n_radii > 0 ? n_radii : 1);
+    const Layout L = make_layout(cap);
+    if (ws_bytes < L.min_total) return RCV_E_WORKSPACE;
+    const long long replica_slots = (long long)((ws_bytes - L.replicas) / CELL_BYTES);
+    hipStream_t st = (hipStream_t)stream;
+    if (!g_vote_attr_set) {
+        RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_vote<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)VOTE_LDS_BYTES));
+        RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_vote<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)VOTE_LDS_BYTES));
+        RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_merge<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)VOTE_LDS_BYTES));
+        RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_merge<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)VOTE_LDS_BYTES));
+        g_vote_attr_set = true;
+    }
+    const SP<unsigned char> sws{(unsigned char *)ws.ptr, ws.stride_frame, ws.stride_kp};
+    const SP<const double> sxyz{(const double *)xyz.ptr, xyz.stride_frame, xyz.stride_kp};
+    const SP<const int32_t> scnt{(const int32_t *)counts.ptr, counts.stride_frame, counts.stride_kp};
+    const SP<rcv_acc_result> sres{(rcv_acc_result *)result.ptr, result.stride_frame, result.stride_kp};
+    const SP<uint32_t> sgrid{(uint32_t *)grid.ptr, grid.stride_frame, grid.stride_kp};
+    const dim3 items(1, n_frames, n_kp);
+    auto grid3 = [&](int x) { return dim3(x, n_frames, n_kp); };
+    if (radial_is_f64)
+        hipLaunchKernelGGL(k_prep<double>, grid3(PREP_BLOCKS), dim3(PREP_THREADS), 0, st, sxyz,
+                           SP<const double>{(const double *)radial.ptr, radial.stride_frame, radial.stride_kp}, scnt, n_points,
+                           n_radii, cap, acc_unit_mm, g_thr_dev, sws, L);
+    else
+        hipLaunchKernelGGL(k_prep<float>, grid3(PREP_BLOCKS), dim3(PREP_THREADS), 0, st, sxyz,
+                           SP<const float>{(const float *)radial.ptr, radial.stride_frame, radial.stride_kp}, scnt, n_points,
+                           n_radii, cap, acc_unit_mm, g_thr_dev, sws, L);
+    RCV_LAUNCH_CHECK();
+    // the exact peak search runs first unless the caller wants the full grid (or forced the rasteriser)
+    const int bb_enable = (engine == RCV_VOTE_AUTO && grid.ptr == nullptr) ? 1 : 0;
+    hipLaunchKernelGGL(k_setup, items, dim3(1024), 0, st, scnt, n_points, n_radii, cap, acc_unit_mm, bb_enable, replica_slots, sws,
+                       L);
+    RCV_LAUNCH_CHECK();
+    return run_engines(cap, bb_enable, sres, sgrid, grid_cells, grid.ptr != nullptr, sws, L, n_frames, n_kp, st);
 }
 
 int rcv_union_depth(const float *seg_dev, const float *radial_dev, long long kp_stride, const uint16_t *depth_dev, int H, int W,
@@ -1985,6 +2220,76 @@ int rcv_acc_debug_points(const void *ws, double *points_vox_dev, int32_t *radius
                        points_vox_dev, radius_int_dev);
     RCV_LAUNCH_CHECK();
     return RCV_OK;
+}
+
+int rcv_backproject_no_depth(const double *depth_m_dev, int H, int W, const double K[4], double *pts_dev, long long cap_points,
+                             int32_t *zn_out, void *ws, size_t ws_bytes, void *stream)
+{
+    if (!depth_m_dev || !K || !zn_out || !ws || H <= 0 || W <= 0) return RCV_E_INVALID;
+    const long long HW = (long long)H * W;
+    if (HW > 0x7fffffffLL) return RCV_E_TOO_LARGE;
+    if (ws_bytes < 256 + sizeof(int32_t) * (size_t)HW) return RCV_E_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    NdRange *range = (NdRange *)ws;
+    int32_t *pix = (int32_t *)((char *)ws + 256);
+    hipLaunchKernelGGL(k_nd_pixels, dim3(1), dim3(1024), 0, st, depth_m_dev, (int)HW, pix, (int)HW, range);
+    RCV_LAUNCH_CHECK();
+    // the shape of the result depends on the data (as the reference's return value does): one synchronisation
+    NdRange h;
+    RCV_HIP_CHECK(hipMemcpyAsync(&h, range, sizeof(h), hipMemcpyDeviceToHost, st));
+    RCV_HIP_CHECK(hipStreamSynchronize(st));
+    zn_out[0] = 0; zn_out[1] = h.n;
+    if (h.n <= 0) return RCV_E_EMPTY;  // the reference raises on zs.min() of an empty array (:103)
+    const long long Z = (long long)(h.zmax * 1000.0) + 1 - (long long)(h.zmin * 1000.0);  // :105
+    if (Z <= 0 || Z > 0x7fffffffLL / h.n) return RCV_E_TOO_LARGE;
+    zn_out[0] = (int32_t)Z;
+    if (!pts_dev) return RCV_OK;  // size query
+    if (cap_points < Z * h.n) return RCV_E_WORKSPACE;
+    const long long total = Z * h.n;
+    hipLaunchKernelGGL(k_nd_hypotheses, dim3((unsigned)std::min<long long>((total + 255) / 256, 65535)), dim3(256), 0, st, pix, h.n, (int)Z, W,
+                       K[0], K[1], K[2], K[3], h.zmin, pts_dev);
+    RCV_LAUNCH_CHECK();
+    return RCV_OK;
+}
+
+int rcv_accumulate_3d_no_depth(const double *xyz_m_dev, const void *radial_dm_dev, int radial_is_f64, int n_hypotheses, int n_pixels,
+                               int n_radii, int engine, rcv_acc_result *result_dev, uint32_t *vote_grid_dev, size_t vote_grid_cells,
+                               void *ws, size_t ws_bytes, void *stream)
+{
+    if (!xyz_m_dev || !radial_dm_dev || !result_dev || !ws) return RCV_E_INVALID;
+    if (engine != RCV_VOTE_AUTO && engine != RCV_VOTE_RASTER) return RCV_E_INVALID;
+    if (n_hypotheses < 1 || n_pixels < 3 || n_radii < n_pixels) return RCV_E_INVALID;  // the reference raises IndexError below 3 pixels
+    if ((long long)n_hypotheses * n_pixels > 0x3fffffffLL) return RCV_E_TOO_LARGE;
+    const int cap = n_hypotheses * n_pixels;
+    const Layout L = make_layout(cap);
+    if (ws_bytes < L.min_total) return RCV_E_WORKSPACE;
+    const long long replica_slots = (long long)((ws_bytes - L.replicas) / CELL_BYTES);
+    hipStream_t st = (hipStream_t)stream;
+    if (!g_vote_attr_set) {
+        RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_vote<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)VOTE_LDS_BYTES));
+        RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_vote<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)VOTE_LDS_BYTES));
+        RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_merge<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)VOTE_LDS_BYTES));
+        RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_merge<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)VOTE_LDS_BYTES));
+        g_vote_attr_set = true;
+    }
+    unsigned char *w = (unsigned char *)ws;
+    double *P = (double *)(w + L.P), *Q = (double *)(w + L.Q), *Tq = (double *)(w + L.F);
+    PrepPartial *partials = (PrepPartial *)(w + L.partials);
+    AccHeader *hdr = (AccHeader *)(w + L.header);
+    if (radial_is_f64)
+        hipLaunchKernelGGL(k_nd_prep<double>, dim3(PREP_BLOCKS), dim3(PREP_THREADS), 0, st, xyz_m_dev, (const double *)radial_dm_dev, n_hypotheses,
+                           n_pixels, n_radii, cap, 200.0, P, Q, Tq, partials);
+    else
+        hipLaunchKernelGGL(k_nd_prep<float>, dim3(PREP_BLOCKS), dim3(PREP_THREADS), 0, st, xyz_m_dev, (const float *)radial_dm_dev, n_hypotheses,
+                           n_pixels, n_radii, cap, 200.0, P, Q, Tq, partials);
+    RCV_LAUNCH_CHECK();
+    const int bb_enable = (engine == RCV_VOTE_AUTO && vote_grid_dev == nullptr) ? 1 : 0;
+    hipLaunchKernelGGL(k_nd_setup, dim3(1), dim3(1024), 0, st, n_hypotheses, n_pixels, n_radii, cap, bb_enable, replica_slots, P, Q, partials, hdr);
+    RCV_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_nd_finish, dim3(std::min((cap + 255) / 256, 4096)), dim3(256), 0, st, n_hypotheses, n_pixels, cap, P, Tq, hdr);
+    RCV_LAUNCH_CHECK();
+    return run_engines(cap, bb_enable, SP<rcv_acc_result>{result_dev, 0, 0}, SP<uint32_t>{vote_grid_dev, 0, 0}, vote_grid_cells,
+                       vote_grid_dev != nullptr, SP<unsigned char>{w, 0, 0}, L, 1, 1, st);
 }
 
 }  // extern "C"

@@ -433,8 +433,86 @@ def gen_horn(A):
     print("  horn: %d cases" % len(ns))
 
 
+# --------------------------------------------------------------------------------------
+# ND-*: the RGB-only variant (SURVEY f-5): rgbd_to_point_cloud_no_depth (AccumulatorSpace.py:100-120),
+# Accumulator_3D_no_depth (:436-479) + fast_for_no_depth (:421-434).  Pinned exactly as the reference computes it
+# (it indexes the [Z,N,3] hypothesis array like an [N,3] cloud: only the first three points are recentred, by the
+# mean over all hypotheses and coordinates of point 0 / 1 / 2; the radii are NOT rounded; the grid has no radius
+# margin; `center` is an int64 array, so adding the float mean truncates; every row is multiplied by 5).
+# --------------------------------------------------------------------------------------
+def nd_cases(A):
+    rng = np.random.default_rng(4242)
+    cases = {}
+
+    def hypotheses(n_pix, z0, dz_mm, H=12, W=16):
+        depth = np.zeros((H, W))
+        pix = rng.choice(H * W, size=n_pix, replace=False)
+        depth.reshape(-1)[np.sort(pix)] = z0 + rng.integers(0, dz_mm + 1, size=n_pix) * 0.001
+        depth.reshape(-1)[np.sort(pix)[0]] = z0
+        depth.reshape(-1)[np.sort(pix)[-1]] = z0 + dz_mm * 0.001
+        K = np.array([[57.24114, 0., 8.2], [0., 57.357043, 6.1], [0., 0., 1.]])
+        return K, depth, A.rgbd_to_point_cloud_no_depth(K, depth)
+
+    # ND-1: 9 pixels x 4 depth hypotheses, float32 radii (what the FCN would emit), zero_boundary < 0
+    K, depth, xyz = hypotheses(9, 0.150, 3)
+    cases["nd1_f32"] = (K, depth, xyz, rng.uniform(0.04, 0.30, size=9).astype(np.float32))
+    # ND-2: float64 radii, some of them integers / half-integers in voxel units (no rounding happens: pinned), one zero
+    K, depth, xyz = hypotheses(7, 0.120, 2)
+    rad = rng.uniform(0.05, 0.25, size=7)
+    rad[0], rad[1], rad[2], rad[3] = 0.25, 0.175, 0.0, 0.2
+    cases["nd2_f64"] = (K, depth, xyz, rad.astype(np.float64))
+    # ND-3: the smallest legal input: three pixels, one hypothesis
+    K, depth, xyz = hypotheses(3, 0.100, 0)
+    cases["nd3_three_points"] = (K, depth, xyz, np.array([0.11, 0.13, 0.09], dtype=np.float32))
+    # ND-4: every coordinate beyond the largest radius -> zero_boundary > 0, the un-shifted branch
+    depth = np.zeros((12, 16))
+    for (v, u, z) in ((9, 12, 0.210), (10, 13, 0.211), (10, 14, 0.212), (11, 15, 0.210), (9, 15, 0.212)):
+        depth[v, u] = z
+    K = np.array([[30.0, 0., 2.0], [0., 30.0, 1.5], [0., 0., 1.]])
+    cases["nd4_unshifted"] = (K, depth, A.rgbd_to_point_cloud_no_depth(K, depth), np.array([0.05, 0.06, 0.04, 0.055, 0.045], dtype=np.float32))
+    return cases
+
+
+def gen_nodepth(A):
+    captured = {}
+    orig = A.fast_for_no_depth
+
+    def spy(xyz_mm, radial_list_mm, vote_map):
+        captured["points_vox"] = np.array(xyz_mm, dtype=np.float64, copy=True)
+        captured["radii_vox"] = np.array(radial_list_mm, copy=True)
+        out = orig(xyz_mm, radial_list_mm, vote_map)
+        captured["votes"] = np.array(out, copy=True)
+        return out
+
+    A.fast_for_no_depth = spy
+    index = {}
+    for name, (K, depth, xyz, rad) in nd_cases(A).items():
+        xyz_in, rad_in = np.array(xyz, copy=True), np.array(rad, copy=True)
+        t0 = time.time()
+        center = A.Accumulator_3D_no_depth(xyz_in, rad_in, None)
+        assert np.array_equal(xyz_in, xyz) and np.array_equal(rad_in, rad), "reference mutated its inputs"
+        votes = captured["votes"]
+        assert np.array_equal(votes, np.round(votes)) and votes.max() < 65536
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), K=K, depth_m=depth, xyz_m=xyz, radial_dm=rad, votes=votes.astype(np.uint16),
+                            center=center, points_vox=captured["points_vox"], radii_vox=captured["radii_vox"])
+        index[name] = {"Z": int(xyz.shape[0]), "N": int(xyz.shape[1]), "D": int(votes.shape[0]), "peak": int(votes.max()),
+                       "ties": int(center.shape[0]), "center_dtype": str(center.dtype), "radial_dtype": str(rad.dtype),
+                       "seconds": round(time.time() - t0, 1)}
+        print("  %-20s %s" % (name, index[name]))
+    A.fast_for_no_depth = orig
+    for label, xyz, rad in (("nd_two_points", np.zeros((2, 2, 3)) + 0.1, np.array([0.1, 0.1], dtype=np.float32)),
+                            ("nd_empty", np.zeros((1, 0, 3)), np.zeros((0,), dtype=np.float32))):
+        try:
+            A.Accumulator_3D_no_depth(xyz, rad, None)
+            index[label] = {"raises": None}
+        except Exception as e:
+            index[label] = {"raises": type(e).__name__}
+    with open(os.path.join(HERE, "nd_index.json"), "w") as f:
+        json.dump(index, f, indent=1, sort_keys=True)
+
+
 def main():
-    which = set(sys.argv[1:]) or {"acc", "seam", "fcn", "horn", "resfcn"}
+    which = set(sys.argv[1:]) or {"acc", "seam", "fcn", "horn", "resfcn", "nd"}
     A = _import_reference()
     if "acc" in which:
         print("ACC cases (reference fast_for runs as pure Python, ~1 us per point*voxel test)")
@@ -447,6 +525,9 @@ def main():
         gen_horn(A)
     if "resfcn" in which:
         gen_resfcn(A)
+    if "nd" in which:
+        print("ND cases (RGB-only accumulator; pure-Python fast_for_no_depth)")
+        gen_nodepth(A)
 
 
 if __name__ == "__main__":

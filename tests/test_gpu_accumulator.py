@@ -159,3 +159,46 @@ def test_depth_hole_misalignment_is_reproduced(A, oracle, golden_dir):
     assert len(g["radial_list"]) > len(g["xyz_m"])
     center = A.Accumulator_3D(g["xyz_m"], g["radial_list"])
     assert np.array_equal(center, oracle.accumulator_3d(g["xyz_m"], g["radial_list"], sparse=True))
+
+
+ND = ["nd1_f32", "nd2_f64", "nd3_three_points", "nd4_unshifted"]
+
+
+@pytest.mark.parametrize("name", ND)
+def test_no_depth_accumulator_golden(A, golden_dir, name):
+    """SURVEY f-5: rgbd_to_point_cloud_no_depth + Accumulator_3D_no_depth on the device against the reference's own outputs
+    (full vote grids, every tie row, int64 centres), both arg-max engines."""
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    pts = A.rgbd_to_point_cloud_no_depth(g["K"], g["depth_m"])
+    assert pts.shape == g["xyz_m"].shape and np.array_equal(pts, g["xyz_m"])
+    xyz, rad = g["xyz_m"].copy(), g["radial_dm"].copy()
+    center, votes, res = A.Accumulator_3D_no_depth(xyz, rad, None, return_votes=True)
+    assert res.dim == g["votes"].shape[0]
+    assert np.array_equal(votes, g["votes"].astype(np.uint32))
+    assert center.dtype == np.int64 and center.shape == g["center"].shape and np.array_equal(center, g["center"])
+    assert np.array_equal(xyz, g["xyz_m"]) and np.array_equal(rad, g["radial_dm"])
+    for mode in ("auto", "full"):
+        assert np.array_equal(A.Accumulator_3D_no_depth(xyz, rad, None, engine=mode), g["center"]), mode
+
+
+def test_no_depth_accumulator_vs_oracle_and_errors(A, oracle):
+    """A larger hypothesis sweep (20 depth steps x 400 pixels, float32 radii) against the C oracle, and the error behaviour."""
+    rng = np.random.default_rng(12)
+    depth = np.zeros((48, 64))
+    pix = rng.choice(48 * 64, size=400, replace=False)
+    depth.reshape(-1)[pix] = 0.300 + rng.integers(0, 20, size=400) * 0.001
+    depth.reshape(-1)[pix[0]], depth.reshape(-1)[pix[1]] = 0.300, 0.319
+    K = np.array([[120.0, 0., 31.5], [0., 121.0, 23.5], [0., 0., 1.]])
+    pts = A.rgbd_to_point_cloud_no_depth(K, depth)
+    assert np.array_equal(pts, oracle.backproject_no_depth((120.0, 121.0, 31.5, 23.5), depth)) and pts.shape == (20, 400, 3)
+    rad = rng.uniform(0.1, 0.6, size=400).astype(np.float32)
+    ref, votes, info, peak, _, _ = oracle.accumulator_3d_no_depth(pts, rad, return_all=True)
+    center, gv, res = A.Accumulator_3D_no_depth(pts, rad, None, return_votes=True)
+    assert res.dim == info.dim and res.peak_votes == peak and np.array_equal(gv, votes)
+    assert np.array_equal(center, ref)
+    for mode in ("auto", "full"):
+        assert np.array_equal(A.Accumulator_3D_no_depth(pts, rad, None, engine=mode), ref), mode
+    with pytest.raises(IndexError):
+        A.Accumulator_3D_no_depth(np.zeros((2, 2, 3)) + 0.1, np.array([0.1, 0.1], dtype=np.float32), None)
+    with pytest.raises(ValueError):
+        A.rgbd_to_point_cloud_no_depth(K, np.zeros((4, 4)))

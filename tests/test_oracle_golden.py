@@ -139,3 +139,32 @@ def test_plane_wise_peak_on_a_fine_grid(oracle):
     r = oracle.peak_without_grid(xyz, rl, acc_unit=2.0)
     assert (r["peak"], r["n_ties"], r["dim"]) == (peak, len(ref), info.dim)
     assert np.array_equal(r["center_mm"], ref[0])
+
+
+ND = ["nd1_f32", "nd2_f64", "nd3_three_points", "nd4_unshifted"]
+
+
+@pytest.mark.parametrize("name", ND)
+def test_no_depth_accumulator_matches_reference(oracle, golden_dir, name):
+    """SURVEY f-5: Accumulator_3D_no_depth / fast_for_no_depth / rgbd_to_point_cloud_no_depth restated in C against the
+    reference's own outputs, quirks included (only three points recentred, unrounded radii, no radius margin on the grid,
+    int64 truncation of the shifted row, every row x5)."""
+    g = _load(golden_dir, name)
+    K = g["K"]
+    pts = oracle.backproject_no_depth((K[0, 0], K[1, 1], K[0, 2], K[1, 2]), g["depth_m"])
+    assert np.array_equal(pts, g["xyz_m"])
+    center, votes, info, peak, pv, rv = oracle.accumulator_3d_no_depth(g["xyz_m"], g["radial_dm"], return_all=True)
+    assert np.array_equal(pv, g["points_vox"])
+    assert np.array_equal(rv[: len(g["radii_vox"])].astype(g["radii_vox"].dtype), g["radii_vox"])
+    assert np.array_equal(votes, g["votes"].astype(np.uint32))
+    assert center.dtype == np.int64 and np.array_equal(center, g["center"])
+
+
+def test_no_depth_error_cases(oracle, golden_dir):
+    idx = json.load(open(os.path.join(golden_dir, "nd_index.json")))
+    assert idx["nd_two_points"]["raises"] == "IndexError" and idx["nd_empty"]["raises"] == "IndexError"
+    with pytest.raises(IndexError):
+        oracle.accumulator_3d_no_depth(np.zeros((2, 2, 3)) + 0.1, np.array([0.1, 0.1], dtype=np.float32))
+    with pytest.raises(IndexError):
+        oracle.accumulator_3d_no_depth(np.zeros((1, 0, 3)), np.zeros((0,), dtype=np.float32))
+    assert any(json.load(open(os.path.join(golden_dir, "nd_index.json")))[n]["ties"] > 1 for n in ND)
