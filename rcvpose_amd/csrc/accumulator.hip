@@ -1782,7 +1782,7 @@ __global__ __launch_bounds__(256) void k_final(int grid_given, unsigned long lon
 // RGB-only variant (SURVEY f-5): rgbd_to_point_cloud_no_depth (AccumulatorSpace.py:100-120) and
 // Accumulator_3D_no_depth / fast_for_no_depth (:421-479).  Every pixel is back-projected at each millimetre of a depth
 // range; all Z * N hypotheses vote with the (unrounded) radius of their pixel.  The arithmetic the reference actually
-// performs on the [Z,N,3] array is kept, quirks included (see the oracle, oracle/rcv_oracle.c: orc_nd_prepare).
+// performs on the [Z,N,3] array is kept, quirks included (include/rcvpose_hip.h: rcv_accumulate_3d_no_depth).
 // The voting itself runs in the engines above: a hypothesis is a point with its own float64 threshold pair.
 // ---------------------------------------------------------------------------------------------
 struct NdRange {
