@@ -7,7 +7,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librcvpose_hip.so")
+LIB_PATH = os.environ.get("RCV_LIB_PATH") or os.path.join(_HERE, "librcvpose_hip.so")  # (override: A-B builds of tools/)
 
 RCV_OK = 0
 RCV_E_INVALID = -1

@@ -39,7 +39,16 @@ constexpr int MAX_REPLICAS = 2048;      // workgroups that share a tile park the
 constexpr int BB_CAP = 1 << 19;         // candidate blocks per level of the branch-and-bound peak search
 constexpr int BB_ROOT = 64;            // edge (voxels) of the root blocks; 6 halvings down to single voxels
 constexpr int BB_LEVELS = 6;
-constexpr int BB_BEAM = 8;             // blocks per level followed by the greedy probe that seeds the lower bound
+// Probe width and hill-climb length only steer how close the lower bound gets to the peak before the wide levels run
+// (any exact count is a valid bound).  Measured on the bench workload (72 frames x 3 keypoints, seam + voting, ms):
+// beam/rounds 8/8 26.1, 4/8 27.3, 2/8 83.6, 8/4 32.1, 8/12 25.7, 8/16 26.3, 4/12 24.8, 4/16 25.3, 3/16 25.4, 4/24 26.5.
+#ifndef RCV_BB_BEAM
+#define RCV_BB_BEAM 4
+#endif
+#ifndef RCV_BB_CLIMB_ROUNDS
+#define RCV_BB_CLIMB_ROUNDS 12
+#endif
+constexpr int BB_BEAM = RCV_BB_BEAM;   // blocks per level followed by the greedy probe that seeds the lower bound
 constexpr int PREP_BLOCKS = 128;
 constexpr int PREP_THREADS = 256;
 constexpr int SEAM_PIX_PER_BLOCK = 1024;
@@ -1297,7 +1306,7 @@ __device__ __forceinline__ void d_bb_wide(AccHeader *hdr, const float *F, size_t
 // is a valid lower bound.
 constexpr int BB_CLIMB_R = 2;
 constexpr int BB_CLIMB_W = 2 * BB_CLIMB_R + 1;
-constexpr int BB_CLIMB_ROUNDS = 8;
+constexpr int BB_CLIMB_ROUNDS = RCV_BB_CLIMB_ROUNDS;
 
 // one workgroup per i-offset of the (2R+1)^3 neighbourhood; every thread scores the (2R+1)^2 voxels of that slice for
 // its points (dx^2 shared), then the slice's counts are reduced and folded into the running best

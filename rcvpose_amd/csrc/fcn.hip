@@ -839,7 +839,7 @@ __global__ __launch_bounds__(512) void k_conv_halo(const HaloParams p)
 // k_stem_mfma (bf16): the same 7x7/2 stem as an MFMA GEMM.  A workgroup owns 8 x 32 output pixels of one image and
 // serves every group (keypoint network) from one im2col image:
 //   1. the fp32 input patch (3 x 21 x 69) is staged in LDS,
-//   2. every thread expands its pixel's 147 taps to bf16 into the A tile [256 px][160 k] (k = (r*7+s)*3+c, the
+//   2. every lane expands the 147 taps of its four pixels to bf16 MFMA A fragments in registers (k = (r*7+s)*3+c, the
 //      weight order; k 147..159 zero) -- built once, used by all groups,
 //   3. per group the [64][147] weights are laid into the B tile [64][160] (zero padded), 4 waves x (64 px x 64 ch)
 //      run 80 MFMAs (16x16x32, operands swapped so that a lane holds consecutive channels), and the result leaves
@@ -848,17 +848,19 @@ __global__ __launch_bounds__(512) void k_conv_halo(const HaloParams p)
 // ---------------------------------------------------------------------------------------------
 constexpr int STEM_TH = 8, STEM_TW = 32, STEM_KP = 160, STEM_PITCH = 336;  // bytes per LDS row: 160 bf16 + 16 (bank spread)
 constexpr int STEM_IH = STEM_TH * 2 + 5, STEM_IW = STEM_TW * 2 + 5;
-constexpr int STEM_LDS = 256 * STEM_PITCH + 64 * STEM_PITCH + 3 * STEM_IH * (STEM_IW + 1) * 4 + STEM_KP * 4;
+constexpr int STEM_LDS = 64 * STEM_PITCH + 3 * STEM_IH * (STEM_IW + 1) * 4 + STEM_KP * 4;  // weights of one group, input patch, tap offsets: 40 KB
 
-__global__ __launch_bounds__(256) void k_stem_mfma(const float *x, const __bf16 *w, const float *bias, __bf16 *dst, int H, int W,
-                                                   int Ho, int Wo, int groups, long long w_gs, int bias_gs, long long dst_gs)
+// (r02) The im2col tile no longer exists in LDS: every lane builds the MFMA A fragments of its own pixels straight from the
+// fp32 patch (the same bf16 values in the same k order, so the result is unchanged) and keeps them in registers for all
+// groups.  LDS drops from 125 KB to 40 KB, two workgroups share a CU, and one's loads / stores overlap the other's MFMAs.
+__global__ __launch_bounds__(256, 2) void k_stem_mfma(const float *x, const __bf16 *w, const float *bias, __bf16 *dst, int H, int W,
+                                                      int Ho, int Wo, int groups, long long w_gs, int bias_gs, long long dst_gs)
 {
     using T = __bf16;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char *sA = smem;                                   // [256][STEM_PITCH]
-    unsigned char *sB = smem + 256 * STEM_PITCH;                // [64][STEM_PITCH]
-    float(*s_in)[STEM_IH][STEM_IW + 1] = (float(*)[STEM_IH][STEM_IW + 1])(smem + 320 * STEM_PITCH);
-    int *s_koff = (int *)(smem + 320 * STEM_PITCH + 3 * STEM_IH * (STEM_IW + 1) * 4);  // [STEM_KP]
+    unsigned char *sB = smem;                                   // [64][STEM_PITCH]
+    float(*s_in)[STEM_IH][STEM_IW + 1] = (float(*)[STEM_IH][STEM_IW + 1])(smem + 64 * STEM_PITCH);
+    int *s_koff = (int *)(smem + 64 * STEM_PITCH + 3 * STEM_IH * (STEM_IW + 1) * 4);  // [STEM_KP]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tiles_x = (Wo + STEM_TW - 1) / STEM_TW;
     const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
@@ -873,46 +875,56 @@ __global__ __launch_bounds__(256) void k_stem_mfma(const float *x, const __bf16 
         if ((unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W) v = x[((long long)(img * 3 + c) * H + hi) * W + wi];
         s_in[c][r][q] = v;
     }
-    if (tid < STEM_KP) {  // patch offset of tap k = (r*7 + s)*3 + c; the padding taps point at element 0 and are zeroed
+    if (tid < STEM_KP) {  // patch offset of tap k = (r*7 + s)*3 + c; the padding taps (k >= 147) are zeroed below
         const int k = tid < 147 ? tid : 0;
         const int c = k % 3, rs = k / 3, r = rs / 7, q = rs - r * 7;
         s_koff[tid] = (c * STEM_IH + r) * (STEM_IW + 1) + q;
     }
     __syncthreads();
+    const int r16 = lane & 15, kq = lane >> 4;
+    // A fragments of this lane: pixel group i (pixel wave*64 + i*16 + r16), K chunk ks: k = ks*32 + kq*8 + e
+    bf16x8 afr[4][STEM_KP / 32];
     {
-        // im2col row of pixel tid: 8 bf16 (16 bytes) at a time
-        const int py = tid >> 5, px = tid & 31;
-        unsigned char *row = sA + tid * STEM_PITCH;
-        const float *base = &s_in[0][py * 2][px * 2];
-#pragma unroll 4
-        for (int k0 = 0; k0 < STEM_KP; k0 += 8) {
-            uint4 pack;
-            T *pv = (T *)&pack;
+        int koff[STEM_KP / 32][8];
 #pragma unroll
-            for (int e = 0; e < 8; e++) pv[e] = (T)(k0 + e < 147 ? base[s_koff[k0 + e]] : 0.f);
-            *(uint4 *)(row + k0 * 2) = pack;
+        for (int ks = 0; ks < STEM_KP / 32; ks++)
+#pragma unroll
+            for (int e = 0; e < 8; e++) koff[ks][e] = s_koff[ks * 32 + kq * 8 + e];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int pix = wave * 64 + i * 16 + r16, py = pix >> 5, px = pix & 31;
+            const float *base = &s_in[0][py * 2][px * 2];
+#pragma unroll
+            for (int ks = 0; ks < STEM_KP / 32; ks++)
+#pragma unroll
+                for (int e = 0; e < 8; e++) afr[i][ks][e] = (T)(ks * 32 + kq * 8 + e < 147 ? base[koff[ks][e]] : 0.f);
         }
     }
-    const int r16 = lane & 15, kq = lane >> 4;
     const int e_ch = (kq & 1) * 16 + (kq >> 1) * 8;  // + 32 for the second channel-tile pair
     for (int g = 0; g < groups; g++) {
-        __syncthreads();  // A tile complete (g = 0) / every wave is done with the previous group's B tile
+        __syncthreads();  // every wave is done with the patch (g = 0) / with the previous group's B tile
         const T *wg = w + (long long)g * w_gs;  // [64][147]
         {
-            // 64 x 147 contiguous weights: all of a thread's loads are issued before the first LDS write
-            constexpr int PER = (64 * 147 + 255) / 256;
-            T wv[PER];
+            // 64 x 147 contiguous weights as 16-byte vectors (1176 of them): all of a thread's loads are issued before the
+            // first LDS write; the eight elements of a vector are scattered to their (out channel, k) cells
+            constexpr int NV = 64 * 147 / 8, PER = (NV + 255) / 256;
+            uint4 wv[PER];
 #pragma unroll
             for (int u = 0; u < PER; u++) {
                 const int i = u * 256 + tid;
-                wv[u] = wg[i < 64 * 147 ? i : 0];
+                wv[u] = *(const uint4 *)(wg + (i < NV ? i : 0) * 8);
             }
 #pragma unroll
             for (int u = 0; u < PER; u++) {
                 const int i = u * 256 + tid;
-                if (i < 64 * 147) {
-                    const int co = i / 147, k = i - co * 147;
-                    *(T *)(sB + co * STEM_PITCH + k * 2) = wv[u];
+                if (i < NV) {
+                    int co = (i * 8) / 147, k = i * 8 - co * 147;
+                    const T *pv = (const T *)&wv[u];
+#pragma unroll
+                    for (int e = 0; e < 8; e++) {
+                        *(T *)(sB + co * STEM_PITCH + k * 2) = pv[e];
+                        if (++k == 147) { k = 0; co++; }
+                    }
                 }
             }
             if (g == 0)  // the padding columns stay zero for every group
@@ -931,7 +943,7 @@ __global__ __launch_bounds__(256) void k_stem_mfma(const float *x, const __bf16 
         for (int ks = 0; ks < STEM_KP / 32; ks++) {
             bf16x8 af[4], bfr[4];
 #pragma unroll
-            for (int i = 0; i < 4; i++) af[i] = *(const bf16x8 *)(sA + (wave * 64 + i * 16 + r16) * STEM_PITCH + (ks * 32 + kq * 8) * 2);
+            for (int i = 0; i < 4; i++) af[i] = afr[i][ks];
 #pragma unroll
             for (int j = 0; j < 4; j++) bfr[j] = *(const bf16x8 *)(sB + (j * 16 + r16) * STEM_PITCH + (ks * 32 + kq * 8) * 2);
 #pragma unroll
