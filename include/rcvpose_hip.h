@@ -308,7 +308,9 @@ int rcv_fcn_set_profiling(rcv_fcn *h, int enable);
  * image tiles well (k_conv_halo; 0: k_conv_dma, bit-identical output; 2: also where the pixel rectangles fit the image badly -- tests).
  * key 8 (default 0, both dtypes): 1 = the radial plane is written as float16 [G,B,1,H,W] (radial_dev then points at 2-byte
  * elements; the stress configuration of BASELINE.json; feed it to rcv_seam_compact with RCV_SEAM_RADIAL_F16).  The value is
- * the float32 head output rounded to nearest-even float16. */
+ * the float32 head output rounded to nearest-even float16.
+ * key 9 (default 1, bf16): latency kernel (k_conv_lat: 64 x 64 tiles, eight LDS-DMA stages in flight) for launches with few output
+ * tiles -- one or a few frames; 0: k_conv, bit-identical output. */
 int rcv_fcn_set_option(rcv_fcn *h, int key, int value);
 int rcv_fcn_get_profile(rcv_fcn *h, double *conv_ms, double *other_ms, double *conv_flop);
 /* Per-op device times (ms) of the last profiled forward; ms_out has room for n_ops doubles. */

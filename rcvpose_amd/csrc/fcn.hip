@@ -546,6 +546,194 @@ __global__ __launch_bounds__(512) void k_conv_dma(const ConvParams p)
 }
 
 // ---------------------------------------------------------------------------------------------
+// k_conv_lat (bf16): the latency variant for launches with few output tiles (one or a few frames: BASELINE.json configs[1],
+// batch 1).  There a workgroup walks its whole K range alone -- 36 ... 432 dependent steps -- and the time of a layer is
+// (steps) x (time of one step), which with k_conv's two-deep register staging is one L2 / HBM round trip per two steps.
+// Here: small tiles (64 x 64, 256 threads = 2 x 2 waves of 32 x 32, so that even M = 300 rows give 80+ workgroups), the
+// operands by LDS-DMA into a ring of LAT_STAGES 16 KB stages, LAT_STAGES - 1 steps in flight, ONE barrier per step, a
+// counted vmcnt (steps past the end are issued with out-of-range offsets so the count never changes).  Same K order and
+// the same MFMA sequence per output element as k_conv / k_conv_dma: bit-identical results (tests/test_gpu_fcn.py), which
+// is what keeps a frame's maps independent of the batch it travels in.  No split-K: a different summation order would
+// break exactly that.
+// ---------------------------------------------------------------------------------------------
+constexpr int LAT_BM = 64, LAT_BN = 64, LAT_STAGES = 8;
+constexpr int LAT_STAGE_BYTES = (LAT_BM + LAT_BN) * 128;
+
+// (plain function: the buffer builtins are device-only and a template kernel's body is also instantiated for the host)
+__device__ __forceinline__ void lat_dma16(const void *base, int num_bytes, unsigned char *lds_wave_base, int voffset)
+{
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, num_bytes, 0x00020000);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void *)lds_wave_base, 16, voffset, 0, 0, 0);
+}
+
+__global__ __launch_bounds__(256) void k_conv_lat(const ConvParams p)
+{
+    using T = __bf16;
+    constexpr int KE = 64, EPV = 8, BM = LAT_BM, BN = LAT_BN, NS = LAT_STAGES;
+    constexpr int MT = 2, NT = 2;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    int mt_, nt_;
+    tile_of_block(p.Cout / BN, mt_, nt_);
+    const int g = blockIdx.z, m0 = mt_ * BM, n0 = nt_ * BN;
+    const int Ctot = p.C0 + p.C1;
+    const T *src0 = (const T *)p.src0 + (long long)g * p.src0_gs;
+    const T *src1 = p.src1 ? (const T *)p.src1 + (long long)g * p.src1_gs : nullptr;
+    const T *wg = (const T *)p.w + (long long)g * p.w_gs;
+    const T *res = p.res ? (const T *)p.res + (long long)g * p.res_gs : nullptr;
+    // residual tile: 64 rows x 8 chunks of 16 B = 512 chunks, two per thread, requested up front
+    uint4 rres[2];
+    if (res) {
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            const int c = q * 256 + tid, row = c >> 3, cc = c & 7;
+            const int m = m0 + row;
+            rres[q] = m < p.M ? *(const uint4 *)(res + (long long)m * p.Cout + n0 + cc * 8) : make_uint4(0u, 0u, 0u, 0u);
+        }
+    }
+    // loader role of this lane: A rows wave*16 + c*8 + lane/8 (c = 0, 1), B rows likewise; 16-byte slot lane%8 of the LDS
+    // row receives the source chunk slot ^ ((row>>1)&7) (k_conv_dma's scheme)
+    const int lrow = lane >> 3, lpos = lane & 7;
+    constexpr int OOB = (int)0x80000000;
+    int a_off0[2], a_off1[2], b_off[2];
+    unsigned a_ok[2];
+    const int HWo = p.Hout * p.Wout;
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+        const int row = wave * 16 + c * 8 + lrow;
+        const int chunk = (lpos ^ ((row >> 1) & 7)) * EPV;
+        a_off0[c] = OOB; a_off1[c] = OOB; a_ok[c] = 0u;
+        const int m = m0 + row;
+        if (m < p.M) {
+            const int img = m / HWo, rem = m - img * HWo;
+            const int ho = rem / p.Wout, wo = rem - ho * p.Wout;
+            const int hc = ho * p.stride, wc = wo * p.stride;
+            const int lin = (img * p.Hin + hc) * p.Win + wc;
+            a_off0[c] = (lin * p.C0 + chunk) * 2;
+            a_off1[c] = (lin * p.C1 + chunk) * 2;
+            const int rlo = max(p.pad - hc, 0), rhi = min(p.Hin - 1 - hc + p.pad, p.KS - 1);
+            const int qlo = max(p.pad - wc, 0), qhi = min(p.Win - 1 - wc + p.pad, p.KS - 1);
+            const unsigned colmask = qhi >= qlo ? ((2u << qhi) - 1u) & ~((1u << qlo) - 1u) : 0u;
+            for (int r = rlo; r <= rhi; r++) a_ok[c] |= colmask << (r * p.KS);
+        }
+        b_off[c] = (row * p.K + chunk) * 2;
+    }
+    const char *b_base = (const char *)(wg + (long long)n0 * p.K);
+    const int n_img = __builtin_amdgcn_readfirstlane(p.M / HWo);
+    const int a_bytes0 = (int)((long long)p.C0 * p.Hin * p.Win * n_img * 2), a_bytes1 = (int)((long long)p.C1 * p.Hin * p.Win * n_img * 2);
+    const int b_bytes = BN * p.K * 2;
+    const int nk = p.K / KE;
+    int tap_r = 0, tap_s = 0, cg = 0, issued = 0;
+
+// the four pieces of the next K step into stage `st_`; past the end of K: out-of-range offsets (zeros into a free stage)
+#define RCV_LAT_ISSUE(st_)                                                                                     \
+    {                                                                                                          \
+        unsigned char *As_ = smem + (st_) * LAT_STAGE_BYTES;                                                   \
+        unsigned char *Bs_ = As_ + BM * 128;                                                                   \
+        const bool live_ = issued < nk;                                                                        \
+        const bool first_ = cg < p.C0;                                                                         \
+        const int Cs_ = first_ ? p.C0 : p.C1, c_ = first_ ? cg : cg - p.C0;                                    \
+        const int tap_ = tap_r * p.KS + tap_s;                                                                 \
+        const long long disp_ = ((long long)((tap_r - p.pad) * p.Win + (tap_s - p.pad)) * Cs_ + c_) * 2;      \
+        const char *abase_ = (const char *)((first_ || !src1) ? src0 : src1) + (live_ ? disp_ : 0);            \
+        _Pragma("unroll") for (int c = 0; c < 2; c++) {                                                        \
+            const int off_ = (live_ && ((a_ok[c] >> tap_) & 1u)) ? (first_ ? a_off0[c] : a_off1[c]) : OOB;     \
+            lat_dma16(abase_, first_ ? a_bytes0 : a_bytes1, As_ + (wave * 16 + c * 8) * 128, off_);            \
+        }                                                                                                      \
+        const char *bbase_ = b_base + (live_ ? (long long)(tap_ * Ctot + cg) * 2 : 0);                         \
+        _Pragma("unroll") for (int c = 0; c < 2; c++)                                                          \
+            lat_dma16(bbase_, b_bytes, Bs_ + (wave * 16 + c * 8) * 128, live_ ? b_off[c] : OOB);               \
+        issued++;                                                                                              \
+        tap_s += 1;                                                                                            \
+        const bool wrap_ = tap_s == p.KS;                                                                      \
+        tap_s = wrap_ ? 0 : tap_s;                                                                             \
+        tap_r += wrap_ ? 1 : 0;                                                                                \
+        const bool wrap2_ = tap_r == p.KS;                                                                     \
+        tap_r = wrap2_ ? 0 : tap_r;                                                                            \
+        cg += wrap2_ ? KE : 0;                                                                                 \
+    }
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; i++)
+#pragma unroll
+        for (int j = 0; j < NT; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int r16 = lane & 15, kq = lane >> 4;
+    const int ch0 = ((0 * 4 + kq) ^ ((r16 >> 1) & 7)) << 4, ch1 = ((1 * 4 + kq) ^ ((r16 >> 1) & 7)) << 4;
+#pragma unroll
+    for (int s_ = 0; s_ < NS - 1; s_++) RCV_LAT_ISSUE(s_);
+    int stage = 0;
+    for (int kt = 0; kt < nk; kt++) {
+        // pieces younger than step kt's: (NS - 2) steps x 4
+        asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+        static_assert((NS - 2) * 4 == 24, "the counted wait above is written for 8 stages of 4 pieces per wave");
+        __builtin_amdgcn_s_barrier();  // step kt has landed for every wave; every wave is done reading step kt - 1
+        const int free_ = stage == 0 ? NS - 1 : stage - 1;  // the stage step kt - 1 was read from
+        RCV_LAT_ISSUE(free_);
+        const unsigned char *Ab = smem + stage * LAT_STAGE_BYTES + (wm * 32 + r16) * 128;
+        const unsigned char *Bb = smem + stage * LAT_STAGE_BYTES + BM * 128 + (wn * 32 + r16) * 128;
+        bf16x8 af[2][MT], bfr[2][NT];
+#pragma unroll
+        for (int i = 0; i < MT; i++) { af[0][i] = *(const bf16x8 *)(Ab + i * 16 * 128 + ch0); af[1][i] = *(const bf16x8 *)(Ab + i * 16 * 128 + ch1); }
+#pragma unroll
+        for (int j = 0; j < NT; j++) { bfr[0][j] = *(const bf16x8 *)(Bb + j * 16 * 128 + ch0); bfr[1][j] = *(const bf16x8 *)(Bb + j * 16 * 128 + ch1); }
+#pragma unroll
+        for (int kk = 0; kk < 2; kk++)
+#pragma unroll
+            for (int i = 0; i < MT; i++)
+#pragma unroll
+                for (int j = 0; j < NT; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[kk][i], bfr[kk][j], acc[i][j], 0, 0, 0);
+        stage = stage + 1 == NS ? 0 : stage + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the zero-filling pieces issued past the end
+#undef RCV_LAT_ISSUE
+    // epilogue: fp32 tile through LDS, 16-byte vectors of contiguous channels (bias + residual + ReLU fused)
+    T *dst = (T *)p.dst + (long long)g * p.dst_gs;
+    const float *bias = p.bias + (long long)g * p.bias_gs;
+    constexpr int SROW = BN + 4;
+    float *stg = (float *)smem;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < NT; j++) {
+        const int nl = wn * 32 + j * 16 + r16;
+        const float bv = bias[n0 + nl];
+#pragma unroll
+        for (int i = 0; i < MT; i++)
+#pragma unroll
+            for (int e = 0; e < 4; e++) stg[(wm * 32 + i * 16 + kq * 4 + e) * SROW + nl] = acc[i][j][e] + bv;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+        const int c = q * 256 + tid, row = c >> 3, cc = c & 7;
+        const int m = m0 + row;
+        if (m >= p.M) continue;
+        float v[EPV];
+        const float4 *sp4 = (const float4 *)(stg + row * SROW + cc * EPV);
+#pragma unroll
+        for (int qq = 0; qq < 2; qq++) {
+            const float4 t = sp4[qq];
+            v[qq * 4 + 0] = t.x; v[qq * 4 + 1] = t.y; v[qq * 4 + 2] = t.z; v[qq * 4 + 3] = t.w;
+        }
+        if (res) {
+            const T *rp = (const T *)&rres[q];
+#pragma unroll
+            for (int qq = 0; qq < EPV; qq++) v[qq] += to_f32(rp[qq]);
+        }
+        if (p.relu) {
+#pragma unroll
+            for (int qq = 0; qq < EPV; qq++) v[qq] = fmaxf(v[qq], 0.f);
+        }
+        uint4 outv;
+        T *op = (T *)&outv;
+#pragma unroll
+        for (int qq = 0; qq < EPV; qq++) op[qq] = from_f32<T>(v[qq]);
+        *(uint4 *)(dst + (long long)m * p.Cout + n0 + cc * EPV) = outv;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // k_conv_halo (bf16): 3x3 / stride 1 / pad 1 convolutions with the A operand read from a halo'd pixel patch.
 // k_conv_dma brings the [256 px][64 ch] A tile of a channel slice in nine times, once per tap (32 KB per K step through
 // the CU's 64 B/clk vector-memory path, next to 16 KB of weights).  Here a workgroup owns a th x tw pixel rectangle of one
@@ -2076,6 +2264,7 @@ struct rcv_fcn {
     bool attrs_set = false;
     bool use_dma = true;  // LDS-DMA conv kernel for the shapes it covers (bf16, Cout % 128 == 0, enough tiles)
     bool radial_f16 = false;  // the radial plane leaves the head as float16 (BASELINE.json stress configuration)
+    bool use_lat = true;      // latency kernel (k_conv_lat) for launches with few tiles (small batches)
 };
 
 namespace {
@@ -2153,11 +2342,23 @@ int launch_conv_halo(const ConvParams &p, int B, int groups, int mode, hipStream
     return RCV_OK;
 }
 
+int launch_conv_lat(const ConvParams &p, int groups, hipStream_t st)
+{
+    dim3 grid(p.Cout / LAT_BN, (p.M + LAT_BM - 1) / LAT_BM, groups);
+    hipLaunchKernelGGL(k_conv_lat, grid, dim3(256), LAT_STAGES * LAT_STAGE_BYTES, st, p);
+    RCV_LAUNCH_CHECK();
+    return RCV_OK;
+}
+
 template <typename T>
-int launch_conv(const ConvParams &p, int groups, hipStream_t st, bool set_attr, bool allow_dma)
+int launch_conv(const ConvParams &p, int groups, hipStream_t st, bool set_attr, bool allow_dma, bool allow_lat = false)
 {
     constexpr int KE = Traits<T>::KE;
     if (p.C0 % KE || p.C1 % KE || p.Cout % 32 || p.K % KE) return RCV_E_UNSUPPORTED;
+    // few output tiles (a frame or two in flight): the layer's time is its chain of K steps -> latency kernel
+    if (sizeof(T) == 2 && allow_lat && allow_dma && p.Cout % LAT_BN == 0 &&
+        (long long)((p.M + LAT_BM - 1) / LAT_BM) * (p.Cout / LAT_BN) * groups <= 1024)
+        return launch_conv_lat(p, groups, st);
     if (sizeof(T) == 2 && allow_dma && p.Cout % DMA_BN == 0 &&
         (long long)((p.M + DMA_BM - 1) / DMA_BM) * (p.Cout / DMA_BN) * groups >= 192)
         return launch_conv_dma(p, groups, st, set_attr);
@@ -2254,7 +2455,7 @@ int run_op(rcv_fcn *h, const rcv_op &op, const float *x, int B, float *seg, floa
                 (long long)B * ((op.hout + th - 1) / th) * ((op.wout + tw - 1) / tw) * (p.Cout / (p.Cout % 128 == 0 ? 128 : 64)) * G >= 192)
                 return launch_conv_halo(p, B, G, h->use_halo, st);
         }
-        return launch_conv<T>(p, G, st, !h->attrs_set, dma_ok);
+        return launch_conv<T>(p, G, st, !h->attrs_set, dma_ok, h->use_lat);
     }
     default: return RCV_E_UNSUPPORTED;
     }
@@ -2287,6 +2488,7 @@ int register_kernel_attributes()
     if ((rc = register_conv_variants<float>()) != RCV_OK) return rc;
     if ((rc = register_conv_variants<__bf16>()) != RCV_OK) return rc;
     RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_conv_dma, hipFuncAttributeMaxDynamicSharedMemorySize, DMA_STAGES * DMA_STAGE_BYTES));
+    RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_conv_lat, hipFuncAttributeMaxDynamicSharedMemorySize, LAT_STAGES * LAT_STAGE_BYTES));
     RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_conv_halo<128, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, halo_lds(128)));
     RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_conv_halo<128, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, halo_lds(128)));
     RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_conv_halo<64, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, halo_lds(64)));
@@ -2523,6 +2725,7 @@ int rcv_fcn_set_option(rcv_fcn *h, int key, int value)
     if (key == 6) { h->use_stagger = value != 0; h->attrs_set = false; return RCV_OK; }
     if (key == 7) { h->use_halo = value; h->attrs_set = false; return RCV_OK; }
     if (key == 8) { h->radial_f16 = value != 0; return RCV_OK; }
+    if (key == 9) { h->use_lat = value != 0; return RCV_OK; }
     return RCV_E_INVALID;
 }
 

@@ -413,3 +413,22 @@ def test_radial_plane_as_float16(shapes, state_dict):
             assert torch.equal(rad16, rad32.to(torch.float16)), (dtype, tail)
             with pytest.raises(ValueError):
                 eng.forward(x, out=(seg32, rad32))  # float32 radial buffer under option 8
+
+
+def test_latency_kernel_identical_to_register_staged_kernel(shapes, state_dict):
+    """k_conv_lat (engine option 9: small tiles, eight LDS-DMA stages in flight, used when a launch has few output tiles)
+    against k_conv on every layer it takes over: bit-identical seg / radial maps and stages, at batch 1 / one network
+    (BASELINE.json configs[1]), batch 2 / three networks, and a small image whose tiles are partial."""
+    from rcvpose_amd.fcn_engine import FcnEngine
+
+    for (H, W, B, G) in ((480, 640, 1, 1), (480, 640, 2, 3), (64, 96, 3, 2), (96, 160, 1, 3)):
+        sds = [state_dict, _sd(shapes, 1), _sd(shapes, 2)][:G]
+        eng = FcnEngine(sds, H, W, dtype="bf16", reuse_slots=False)
+        x = torch.from_numpy(fcn_weights.make_input(23, (B, 3, H, W))).cuda()
+        seg_a, rad_a = [t.clone() for t in eng.forward(x)]
+        stages_a = {n: eng.debug_stage(B, G - 1, n).clone() for n in ("block1", "block3", "block4", "bn6", "conv_up5", "conv_up3")}
+        eng.set_option(9, 0)
+        seg_b, rad_b = eng.forward(x)
+        assert torch.equal(seg_a, seg_b) and torch.equal(rad_a, rad_b), (H, W, B, G)
+        for n, t in stages_a.items():
+            assert torch.equal(t, eng.debug_stage(B, G - 1, n)), (n, H, W, B, G)
