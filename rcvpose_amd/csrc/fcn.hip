@@ -549,9 +549,9 @@ __global__ __launch_bounds__(512) void k_conv_dma(const ConvParams p)
 // k_conv_lat (bf16): the latency variant for launches with few output tiles (one or a few frames: BASELINE.json configs[1],
 // batch 1).  There a workgroup walks its whole K range alone -- 36 ... 432 dependent steps -- and the time of a layer is
 // (steps) x (time of one step), which with k_conv's two-deep register staging is one L2 / HBM round trip per two steps.
-// Here: small tiles (64 x 64, 256 threads = 2 x 2 waves of 32 x 32, so that even M = 300 rows give 80+ workgroups), the
-// operands by LDS-DMA into a ring of LAT_STAGES 16 KB stages, LAT_STAGES - 1 steps in flight, ONE barrier per step, a
-// counted vmcnt (steps past the end are issued with out-of-range offsets so the count never changes).  Same K order and
+// Here: small tiles (64 x 64, so that even M = 300 rows give 80+ workgroups; four of the eight waves multiply, 2 x 2 of
+// 32 x 32), the operands by LDS-DMA into a ring of LAT_STAGES 16 KB stages, LAT_STAGES - 1 steps in flight, all eight
+// waves issuing (one A and one B piece each per step), ONE barrier per step, counted vmcnt.  Same K order and
 // the same MFMA sequence per output element as k_conv / k_conv_dma: bit-identical results (tests/test_gpu_fcn.py), which
 // is what keeps a frame's maps independent of the batch it travels in.  No split-K: a different summation order would
 // break exactly that.
@@ -566,14 +566,18 @@ __device__ __forceinline__ void lat_dma16(const void *base, int num_bytes, unsig
     __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void *)lds_wave_base, 16, voffset, 0, 0, 0);
 }
 
-__global__ __launch_bounds__(256) void k_conv_lat(const ConvParams p)
+__global__ __launch_bounds__(512) void k_conv_lat(const ConvParams p)
 {
     using T = __bf16;
     constexpr int KE = 64, EPV = 8, BM = LAT_BM, BN = LAT_BN, NS = LAT_STAGES;
     constexpr int MT = 2, NT = 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    // eight waves bring the operands in (one A and one B piece of 8 rows x 128 B each per K step: a DMA piece costs its
+    // wave ~100 cycles of issue, so the pieces of a step are spread over the waves); waves 0..3 multiply (2 x 2 of
+    // 32 x 32).  (Sixteen waves with twelve pure loaders measured slower: 3.70 vs 2.42 ms per forward at batch 1.)
+    const bool mma = wave < 4;
+    const int wm = (wave >> 1) & 1, wn = wave & 1;
     int mt_, nt_;
     tile_of_block(p.Cout / BN, mt_, nt_);
     const int g = blockIdx.z, m0 = mt_ * BM, n0 = nt_ * BN;
@@ -582,42 +586,37 @@ __global__ __launch_bounds__(256) void k_conv_lat(const ConvParams p)
     const T *src1 = p.src1 ? (const T *)p.src1 + (long long)g * p.src1_gs : nullptr;
     const T *wg = (const T *)p.w + (long long)g * p.w_gs;
     const T *res = p.res ? (const T *)p.res + (long long)g * p.res_gs : nullptr;
-    // residual tile: 64 rows x 8 chunks of 16 B = 512 chunks, two per thread, requested up front
-    uint4 rres[2];
+    // residual tile: 64 rows x 8 chunks of 16 B = 512 chunks, one per thread, requested up front
+    uint4 rres = make_uint4(0u, 0u, 0u, 0u);
     if (res) {
-#pragma unroll
-        for (int q = 0; q < 2; q++) {
-            const int c = q * 256 + tid, row = c >> 3, cc = c & 7;
-            const int m = m0 + row;
-            rres[q] = m < p.M ? *(const uint4 *)(res + (long long)m * p.Cout + n0 + cc * 8) : make_uint4(0u, 0u, 0u, 0u);
-        }
+        const int row = tid >> 3, cc = tid & 7;
+        const int m = m0 + row;
+        if (m < p.M) rres = *(const uint4 *)(res + (long long)m * p.Cout + n0 + cc * 8);
     }
-    // loader role of this lane: A rows wave*16 + c*8 + lane/8 (c = 0, 1), B rows likewise; 16-byte slot lane%8 of the LDS
-    // row receives the source chunk slot ^ ((row>>1)&7) (k_conv_dma's scheme)
+    // loader role of this lane: A row wave*8 + lane/8, B row likewise; 16-byte slot lane%8 of the LDS row receives the
+    // source chunk slot ^ ((row>>1)&7) (k_conv_dma's scheme)
     const int lrow = lane >> 3, lpos = lane & 7;
     constexpr int OOB = (int)0x80000000;
-    int a_off0[2], a_off1[2], b_off[2];
-    unsigned a_ok[2];
+    int a_off0 = OOB, a_off1 = OOB, b_off;
+    unsigned a_ok = 0u;
     const int HWo = p.Hout * p.Wout;
-#pragma unroll
-    for (int c = 0; c < 2; c++) {
-        const int row = wave * 16 + c * 8 + lrow;
+    {
+        const int row = wave * 8 + lrow;
         const int chunk = (lpos ^ ((row >> 1) & 7)) * EPV;
-        a_off0[c] = OOB; a_off1[c] = OOB; a_ok[c] = 0u;
         const int m = m0 + row;
         if (m < p.M) {
             const int img = m / HWo, rem = m - img * HWo;
             const int ho = rem / p.Wout, wo = rem - ho * p.Wout;
             const int hc = ho * p.stride, wc = wo * p.stride;
             const int lin = (img * p.Hin + hc) * p.Win + wc;
-            a_off0[c] = (lin * p.C0 + chunk) * 2;
-            a_off1[c] = (lin * p.C1 + chunk) * 2;
+            a_off0 = (lin * p.C0 + chunk) * 2;
+            a_off1 = (lin * p.C1 + chunk) * 2;
             const int rlo = max(p.pad - hc, 0), rhi = min(p.Hin - 1 - hc + p.pad, p.KS - 1);
             const int qlo = max(p.pad - wc, 0), qhi = min(p.Win - 1 - wc + p.pad, p.KS - 1);
             const unsigned colmask = qhi >= qlo ? ((2u << qhi) - 1u) & ~((1u << qlo) - 1u) : 0u;
-            for (int r = rlo; r <= rhi; r++) a_ok[c] |= colmask << (r * p.KS);
+            for (int r = rlo; r <= rhi; r++) a_ok |= colmask << (r * p.KS);
         }
-        b_off[c] = (row * p.K + chunk) * 2;
+        b_off = (row * p.K + chunk) * 2;
     }
     const char *b_base = (const char *)(wg + (long long)n0 * p.K);
     const int n_img = __builtin_amdgcn_readfirstlane(p.M / HWo);
@@ -626,24 +625,18 @@ __global__ __launch_bounds__(256) void k_conv_lat(const ConvParams p)
     const int nk = p.K / KE;
     int tap_r = 0, tap_s = 0, cg = 0, issued = 0;
 
-// the four pieces of the next K step into stage `st_`; past the end of K: out-of-range offsets (zeros into a free stage)
+// the two pieces of the next K step (if there is one) into stage `st_`
 #define RCV_LAT_ISSUE(st_)                                                                                     \
-    {                                                                                                          \
+    if (issued < nk) {                                                                                         \
         unsigned char *As_ = smem + (st_) * LAT_STAGE_BYTES;                                                   \
         unsigned char *Bs_ = As_ + BM * 128;                                                                   \
-        const bool live_ = issued < nk;                                                                        \
         const bool first_ = cg < p.C0;                                                                         \
         const int Cs_ = first_ ? p.C0 : p.C1, c_ = first_ ? cg : cg - p.C0;                                    \
         const int tap_ = tap_r * p.KS + tap_s;                                                                 \
         const long long disp_ = ((long long)((tap_r - p.pad) * p.Win + (tap_s - p.pad)) * Cs_ + c_) * 2;      \
-        const char *abase_ = (const char *)((first_ || !src1) ? src0 : src1) + (live_ ? disp_ : 0);            \
-        _Pragma("unroll") for (int c = 0; c < 2; c++) {                                                        \
-            const int off_ = (live_ && ((a_ok[c] >> tap_) & 1u)) ? (first_ ? a_off0[c] : a_off1[c]) : OOB;     \
-            lat_dma16(abase_, first_ ? a_bytes0 : a_bytes1, As_ + (wave * 16 + c * 8) * 128, off_);            \
-        }                                                                                                      \
-        const char *bbase_ = b_base + (live_ ? (long long)(tap_ * Ctot + cg) * 2 : 0);                         \
-        _Pragma("unroll") for (int c = 0; c < 2; c++)                                                          \
-            lat_dma16(bbase_, b_bytes, Bs_ + (wave * 16 + c * 8) * 128, live_ ? b_off[c] : OOB);               \
+        lat_dma16((const char *)(first_ ? src0 : src1) + disp_, first_ ? a_bytes0 : a_bytes1, As_ + wave * 8 * 128,  \
+                  ((a_ok >> tap_) & 1u) ? (first_ ? a_off0 : a_off1) : OOB);                                  \
+        lat_dma16(b_base + (long long)(tap_ * Ctot + cg) * 2, b_bytes, Bs_ + wave * 8 * 128, b_off);           \
         issued++;                                                                                              \
         tap_s += 1;                                                                                            \
         const bool wrap_ = tap_s == p.KS;                                                                      \
@@ -665,28 +658,36 @@ __global__ __launch_bounds__(256) void k_conv_lat(const ConvParams p)
     for (int s_ = 0; s_ < NS - 1; s_++) RCV_LAT_ISSUE(s_);
     int stage = 0;
     for (int kt = 0; kt < nk; kt++) {
-        // pieces younger than step kt's: (NS - 2) steps x 4
-        asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
-        static_assert((NS - 2) * 4 == 24, "the counted wait above is written for 8 stages of 4 pieces per wave");
+        // steps issued after step kt: min(NS - 2, nk - 1 - kt), two pieces each (wave-uniform)
+        const int younger = min(NS - 2, nk - 1 - kt);
+        if (younger >= 6) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        else if (younger == 5) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+        else if (younger == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (younger == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else if (younger == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else if (younger == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        static_assert(NS == 8, "the counted waits above are written for 8 stages");
         __builtin_amdgcn_s_barrier();  // step kt has landed for every wave; every wave is done reading step kt - 1
         const int free_ = stage == 0 ? NS - 1 : stage - 1;  // the stage step kt - 1 was read from
         RCV_LAT_ISSUE(free_);
-        const unsigned char *Ab = smem + stage * LAT_STAGE_BYTES + (wm * 32 + r16) * 128;
-        const unsigned char *Bb = smem + stage * LAT_STAGE_BYTES + BM * 128 + (wn * 32 + r16) * 128;
-        bf16x8 af[2][MT], bfr[2][NT];
+        if (mma) {
+            const unsigned char *Ab = smem + stage * LAT_STAGE_BYTES + (wm * 32 + r16) * 128;
+            const unsigned char *Bb = smem + stage * LAT_STAGE_BYTES + BM * 128 + (wn * 32 + r16) * 128;
+            bf16x8 af[2][MT], bfr[2][NT];
 #pragma unroll
-        for (int i = 0; i < MT; i++) { af[0][i] = *(const bf16x8 *)(Ab + i * 16 * 128 + ch0); af[1][i] = *(const bf16x8 *)(Ab + i * 16 * 128 + ch1); }
+            for (int i = 0; i < MT; i++) { af[0][i] = *(const bf16x8 *)(Ab + i * 16 * 128 + ch0); af[1][i] = *(const bf16x8 *)(Ab + i * 16 * 128 + ch1); }
 #pragma unroll
-        for (int j = 0; j < NT; j++) { bfr[0][j] = *(const bf16x8 *)(Bb + j * 16 * 128 + ch0); bfr[1][j] = *(const bf16x8 *)(Bb + j * 16 * 128 + ch1); }
+            for (int j = 0; j < NT; j++) { bfr[0][j] = *(const bf16x8 *)(Bb + j * 16 * 128 + ch0); bfr[1][j] = *(const bf16x8 *)(Bb + j * 16 * 128 + ch1); }
 #pragma unroll
-        for (int kk = 0; kk < 2; kk++)
+            for (int kk = 0; kk < 2; kk++)
 #pragma unroll
-            for (int i = 0; i < MT; i++)
+                for (int i = 0; i < MT; i++)
 #pragma unroll
-                for (int j = 0; j < NT; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[kk][i], bfr[kk][j], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < NT; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[kk][i], bfr[kk][j], acc[i][j], 0, 0, 0);
+        }
         stage = stage + 1 == NS ? 0 : stage + 1;
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the zero-filling pieces issued past the end
 #undef RCV_LAT_ISSUE
     // epilogue: fp32 tile through LDS, 16-byte vectors of contiguous channels (bias + residual + ReLU fused)
     T *dst = (T *)p.dst + (long long)g * p.dst_gs;
@@ -694,42 +695,44 @@ __global__ __launch_bounds__(256) void k_conv_lat(const ConvParams p)
     constexpr int SROW = BN + 4;
     float *stg = (float *)smem;
     __syncthreads();
+    if (mma) {
 #pragma unroll
-    for (int j = 0; j < NT; j++) {
-        const int nl = wn * 32 + j * 16 + r16;
-        const float bv = bias[n0 + nl];
+        for (int j = 0; j < NT; j++) {
+            const int nl = wn * 32 + j * 16 + r16;
+            const float bv = bias[n0 + nl];
 #pragma unroll
-        for (int i = 0; i < MT; i++)
+            for (int i = 0; i < MT; i++)
 #pragma unroll
-            for (int e = 0; e < 4; e++) stg[(wm * 32 + i * 16 + kq * 4 + e) * SROW + nl] = acc[i][j][e] + bv;
+                for (int e = 0; e < 4; e++) stg[(wm * 32 + i * 16 + kq * 4 + e) * SROW + nl] = acc[i][j][e] + bv;
+        }
     }
     __syncthreads();
-#pragma unroll
-    for (int q = 0; q < 2; q++) {
-        const int c = q * 256 + tid, row = c >> 3, cc = c & 7;
+    {
+        const int row = tid >> 3, cc = tid & 7;
         const int m = m0 + row;
-        if (m >= p.M) continue;
-        float v[EPV];
-        const float4 *sp4 = (const float4 *)(stg + row * SROW + cc * EPV);
+        if (m < p.M) {
+            float v[EPV];
+            const float4 *sp4 = (const float4 *)(stg + row * SROW + cc * EPV);
 #pragma unroll
-        for (int qq = 0; qq < 2; qq++) {
-            const float4 t = sp4[qq];
-            v[qq * 4 + 0] = t.x; v[qq * 4 + 1] = t.y; v[qq * 4 + 2] = t.z; v[qq * 4 + 3] = t.w;
+            for (int qq = 0; qq < 2; qq++) {
+                const float4 t = sp4[qq];
+                v[qq * 4 + 0] = t.x; v[qq * 4 + 1] = t.y; v[qq * 4 + 2] = t.z; v[qq * 4 + 3] = t.w;
+            }
+            if (res) {
+                const T *rp = (const T *)&rres;
+#pragma unroll
+                for (int qq = 0; qq < EPV; qq++) v[qq] += to_f32(rp[qq]);
+            }
+            if (p.relu) {
+#pragma unroll
+                for (int qq = 0; qq < EPV; qq++) v[qq] = fmaxf(v[qq], 0.f);
+            }
+            uint4 outv;
+            T *op = (T *)&outv;
+#pragma unroll
+            for (int qq = 0; qq < EPV; qq++) op[qq] = from_f32<T>(v[qq]);
+            *(uint4 *)(dst + (long long)m * p.Cout + n0 + cc * EPV) = outv;
         }
-        if (res) {
-            const T *rp = (const T *)&rres[q];
-#pragma unroll
-            for (int qq = 0; qq < EPV; qq++) v[qq] += to_f32(rp[qq]);
-        }
-        if (p.relu) {
-#pragma unroll
-            for (int qq = 0; qq < EPV; qq++) v[qq] = fmaxf(v[qq], 0.f);
-        }
-        uint4 outv;
-        T *op = (T *)&outv;
-#pragma unroll
-        for (int qq = 0; qq < EPV; qq++) op[qq] = from_f32<T>(v[qq]);
-        *(uint4 *)(dst + (long long)m * p.Cout + n0 + cc * EPV) = outv;
     }
 }
 
@@ -2345,7 +2348,7 @@ int launch_conv_halo(const ConvParams &p, int B, int groups, int mode, hipStream
 int launch_conv_lat(const ConvParams &p, int groups, hipStream_t st)
 {
     dim3 grid(p.Cout / LAT_BN, (p.M + LAT_BM - 1) / LAT_BM, groups);
-    hipLaunchKernelGGL(k_conv_lat, grid, dim3(256), LAT_STAGES * LAT_STAGE_BYTES, st, p);
+    hipLaunchKernelGGL(k_conv_lat, grid, dim3(512), LAT_STAGES * LAT_STAGE_BYTES, st, p);
     RCV_LAUNCH_CHECK();
     return RCV_OK;
 }
@@ -2355,9 +2358,10 @@ int launch_conv(const ConvParams &p, int groups, hipStream_t st, bool set_attr, 
 {
     constexpr int KE = Traits<T>::KE;
     if (p.C0 % KE || p.C1 % KE || p.Cout % 32 || p.K % KE) return RCV_E_UNSUPPORTED;
-    // few output tiles (a frame or two in flight): the layer's time is its chain of K steps -> latency kernel
-    if (sizeof(T) == 2 && allow_lat && allow_dma && p.Cout % LAT_BN == 0 &&
-        (long long)((p.M + LAT_BM - 1) / LAT_BM) * (p.Cout / LAT_BN) * groups <= 1024)
+    // few output tiles (a frame or two in flight) and a long K: the layer's time is its chain of K steps -> latency kernel
+    // (measured at batch 1: it pays from K = 1024 on; short-K layers keep k_conv, whose tiles are cheaper to set up)
+    if (sizeof(T) == 2 && allow_lat && allow_dma && p.Cout % LAT_BN == 0 && p.K >= 1024 &&
+        (long long)((p.M + 127) / 128) * ((p.Cout + 127) / 128) * groups <= 128)
         return launch_conv_lat(p, groups, st);
     if (sizeof(T) == 2 && allow_dma && p.Cout % DMA_BN == 0 &&
         (long long)((p.M + DMA_BM - 1) / DMA_BM) * (p.Cout / DMA_BN) * groups >= 192)
