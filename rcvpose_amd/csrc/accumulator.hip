@@ -1156,6 +1156,7 @@ __device__ __forceinline__ void bbw_dma16(const float *gptr, float *lds_wave_bas
                                      (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
 }
 
+template <bool VOX>
 __device__ __forceinline__ void d_bb_wide(AccHeader *hdr, const float *F, size_t capF,
                                                          const BBEntry *in_list, const uint32_t *in_count, int in_cap,
                                                          BBEntry *out_list, uint32_t *out_count, int out_cap, int level)
@@ -1229,6 +1230,29 @@ __device__ __forceinline__ void d_bb_wide(AccHeader *hdr, const float *F, size_t
                 const f32x2 thi2 = {thi, thi}, tlo2 = {tlo, tlo};
 #pragma unroll
                 for (int u = 0; u < BBW_NP; u++) {
+                    if constexpr (VOX) {
+                        // last level: the children are single voxels (lo == hi), the box distances collapse to the distance
+                        // to the voxel centre: d2 per child, 36 instead of 54 instructions per (parent, point)
+                        f32x2 sq[3];
+#pragma unroll
+                        for (int a = 0; a < 3; a++) {
+                            const f32x2 t = lo2[u][a] - f32x2{q[a], q[a]};
+                            sq[a] = t * t;
+                        }
+                        const f32x2 xy[2] = {f32x2{sq[0].x, sq[0].x} + sq[1], f32x2{sq[0].y, sq[0].y} + sq[1]};
+#pragma unroll
+                        for (int c = 0; c < 4; c++) {
+                            const float v = (c & 1) ? xy[c >> 1].y : xy[c >> 1].x;
+                            const f32x2 d2 = f32x2{v, v} + sq[2];
+                            const f32x2 below = d2 - thi2;  // negative <=> d2 < thi
+                            const f32x2 reach = tlo2 - d2;  // negative <=> d2 > tlo
+                            hist[u][2 * c] = __builtin_amdgcn_alignbit(
+                                hist[u][2 * c], (unsigned)(__float_as_int(below.x) & __float_as_int(reach.x)), 31);
+                            hist[u][2 * c + 1] = __builtin_amdgcn_alignbit(
+                                hist[u][2 * c + 1], (unsigned)(__float_as_int(below.y) & __float_as_int(reach.y)), 31);
+                        }
+                        continue;
+                    }
                     // both halves of an axis as one float2 (v_pk_add_f32 / v_pk_mul_f32)
                     f32x2 mn2[3], mx2[3];
 #pragma unroll
@@ -1725,12 +1749,13 @@ __global__ __launch_bounds__(NT) void k_bb_level(int cap, int level, BBIo io, SP
     d_bb_level<LAST, WITH_LB, NT>((AccHeader *)(w + L.header), (const double *)(w + L.Q), (const double *)(w + L.P), cap, in,
                                   in_count, in_cap, out, out_count, out_cap, level);
 }
+template <bool VOX>
 __global__ __launch_bounds__(BBW_THREADS) void k_bb_wide(int cap, int level, SP<unsigned char> ws, Layout L)
 {
     unsigned char *w = ws.get();
     const BBEntry *in; const uint32_t *in_count; int in_cap; BBEntry *out; uint32_t *out_count; int out_cap;
     bb_resolve(w, L, level, BBIo{0, 0}, in, in_count, in_cap, out, out_count, out_cap);
-    d_bb_wide((AccHeader *)(w + L.header), (const float *)(w + L.F), L.capF, in, in_count, in_cap, out, out_count, out_cap, level);
+    d_bb_wide<VOX>((AccHeader *)(w + L.header), (const float *)(w + L.F), L.capF, in, in_count, in_cap, out, out_count, out_cap, level);
 }
 __global__ __launch_bounds__(256) void k_bb_climb(int cap, SP<unsigned char> ws, Layout L)
 {
@@ -2082,7 +2107,8 @@ static int run_engines(int cap, int bb_enable, SP<rcv_acc_result> sres, SP<uint3
         const int wide_grid = n_items >= 8 ? 256 : 2048 / n_items;
         // (the last of them, on 2^3 parents, bounds single voxels)
         for (int level = 1; level < BB_LEVELS; level++) {
-            hipLaunchKernelGGL(k_bb_wide, grid3(wide_grid), dim3(BBW_THREADS), 0, st, cap, level, sws, L);
+            if (level == BB_LEVELS - 1) hipLaunchKernelGGL(k_bb_wide<true>, grid3(wide_grid), dim3(BBW_THREADS), 0, st, cap, level, sws, L);
+            else hipLaunchKernelGGL(k_bb_wide<false>, grid3(wide_grid), dim3(BBW_THREADS), 0, st, cap, level, sws, L);
             RCV_LAUNCH_CHECK();
         }
         // exact counts of the surviving voxels (float32 bound >= best exact count): typically a few dozen
