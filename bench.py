@@ -398,8 +398,16 @@ def main(argv=None):
             "votes_per_s": votes / vote_s,
         }
         vp = os.path.join(ROOT, "profiles", "r02_vote_pmc.json")
-        if os.path.exists(vp):
-            roof_vote["pmc"] = json.load(open(vp))
+        if os.path.exists(vp):  # separate rocprofv3 --pmc passes of the voting stage at 72 frames (tools/collect_profiles.sh)
+            pj = json.load(open(vp))
+            roof_vote["pmc"] = {"source": "profiles/r02_vote_pmc.json: " + pj["source"], "definitions": pj["definitions"],
+                                "kernels": {k: {q: v[q] for q in ("ms_per_batch", "valu_issue_frac", "hbm_bytes_per_batch") if q in v}
+                                            for k, v in pj["kernels"].items() if v["ms_per_batch"] >= 0.1}}
+            if B == 72:
+                roof_vote["traffic"] = pj["hbm_bytes_per_batch_sum"]
+                roof_vote["traffic_note"] = ("HBM-side bytes per step of all voting kernels (FETCH_SIZE / WRITE_SIZE passes, Infinity-Cache hits "
+                                             "included): the point lists are re-streamed by every pass of every search level out of L2 / "
+                                             "Infinity Cache; the stage is VALU-bound (valu_issue_frac of k_bb_wide), not traffic-bound")
         line = {
             "metric": "end-to-end frames/sec (FCN+3-kpt voting), 640x480 RGB-D",
             "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
