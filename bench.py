@@ -28,7 +28,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}  # dense peaks, /opt/skills/guides/MI355X_MICROARCH.md
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0, "fp32": 157.3}  # dense peaks, /opt/skills/guides/MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0
 GATE_VOXELS = 1.0          # north_star: keypoints within 1 voxel of the reference's
 TRUTH_GATE_VOXELS = 4.0    # sanity only: recovered keypoint vs the synthetic frame's true keypoint (0.02 dm radial noise)
@@ -40,7 +40,7 @@ def parse(argv=None):
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--frames-per-step", type=int, default=72, help="frames per GPU per step")
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32"])
     ap.add_argument("--overlap", action="store_true", help="FCN of batch s+1 and voting of batch s on two HIP streams")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the fp32-mode and batch-1 (configs[1]) side measurements")
@@ -370,7 +370,7 @@ def main(argv=None):
         traffic, traffic_src = None, None
         for name in ("r02_conv_hbm_traffic.json", "r01n_conv_hbm_traffic.json"):
             tpath = os.path.join(ROOT, "profiles", name)
-            if os.path.exists(tpath) and args.dtype == "bf16":
+            if os.path.exists(tpath) and args.dtype in ("bf16", "fp16"):
                 tj = json.load(open(tpath))["conv_family"]
                 traffic = tj["hbm_bytes_per_network_forward"] * B * G  # bytes per step on this GPU
                 traffic_src = "profiles/%s (PMC passes at %s frames/step; per-forward bytes x %d forwards)" % (

@@ -243,7 +243,11 @@ int rcv_acc_debug_points(const void *ws, double *points_vox_dev, int32_t *radius
  * uint8 HWC -> float64 /255, -mean, /std -> float32 CHW.  rgb_dev uint8 [B,H,W,3] -> x_dev float32 [B,3,H,W]. */
 int rcv_preprocess_rgb(const uint8_t *rgb_dev, int B, int H, int W, float *x_dev, void *stream);
 
-typedef enum rcv_dtype { RCV_F32 = 0, RCV_BF16 = 1 } rcv_dtype;
+/* Storage type of weights and activations (accumulation is always fp32):
+ *   RCV_F32   the parity mode: radial maps within 1e-4 of the reference's fp32 forward
+ *   RCV_BF16  the throughput mode BASELINE.json names (8 significand bits: map error 1.5-5.5e-2 of range)
+ *   RCV_F16   IEEE half at the same speed (11 significand bits: map error ~3e-3; magnitudes beyond 65504 saturate) */
+typedef enum rcv_dtype { RCV_F32 = 0, RCV_BF16 = 1, RCV_F16 = 2 } rcv_dtype;
 
 typedef enum rcv_op_kind {
     RCV_OP_STEM = 1,     /* conv1 7x7 s2 p3 (no bias) + BN + ReLU, NCHW fp32 in -> NHWC out; fcnresnet.py:54-57,123-125 */

@@ -111,9 +111,12 @@ def forward(state_dict, x, return_stages=False):
 # step: two correct bf16 implementations with different summation orders are two independent realisations of the
 # rounding noise, and differ from each other by as much as each differs from fp32 (measured: tools/bf16_emu_probe.py).
 # ---------------------------------------------------------------------------------------------------------------------
+_STORAGE = torch.bfloat16  # the 16-bit storage type being emulated (forward_fp16 switches it to torch.float16)
+
+
 def _r16(t):
-    """Round an fp32 tensor to the nearest bfloat16 (ties to even), returned as fp32."""
-    return t.to(torch.bfloat16).to(torch.float32)
+    """Round an fp32 tensor to the nearest value of the emulated 16-bit storage type (ties to even), returned as fp32."""
+    return t.to(_STORAGE).to(torch.float32)
 
 
 def _fold(sd, conv, bn, bias, cout):
@@ -194,6 +197,16 @@ def forward_bf16(state_dict, x, return_stages=False):
     if return_stages:
         return seg, radial, st
     return seg, radial
+
+
+def forward_fp16(state_dict, x, return_stages=False):
+    """forward_bf16 with IEEE half as the storage type (the engine's "fp16" mode)."""
+    global _STORAGE
+    _STORAGE = torch.float16
+    try:
+        return forward_bf16(state_dict, x, return_stages=return_stages)
+    finally:
+        _STORAGE = torch.bfloat16
 
 
 def forward_res(state_dict, x, return_stages=False):

@@ -20,6 +20,7 @@ SOURCES = {
     "core.hip": [],
     "accumulator.hip": ["-ffp-contract=off"],
     "fcn.hip": [],
+    "fcn_f16.hip": [],   # fcn.hip again with IEEE half as the 16-bit storage type
     "pose.hip": ["-ffp-contract=off"],
     "icp.hip": ["-ffp-contract=off"],
 }
@@ -54,7 +55,7 @@ def build_library(force=False, verbose=False):
             continue
         obj = os.path.join(obj_dir, src.replace(".hip", ".o"))
         objs.append(obj)
-        if force or _stale(obj, [sp] + headers):
+        if force or _stale(obj, [sp] + headers + ([os.path.join(CSRC, "fcn.hip")] if src == "fcn_f16.hip" else [])):
             cmd = [_hipcc()] + COMMON + extra + ["-c", sp, "-o", obj]
             if verbose:
                 print(" ".join(cmd))

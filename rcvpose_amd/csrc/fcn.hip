@@ -12,7 +12,7 @@
 //                    zero-filled at the borders, staged through XOR-swizzled LDS tiles (16-byte chunk ^= (row>>1)&7:
 //                    the 16 lanes of a ds_read_b128 group land on 16 distinct slots of the 256-byte bank row) with register
 //                    double-buffering (global loads of tile t+1 are in flight while tile t is multiplied).
-//                    T = __bf16 : v_mfma_f32_16x16x32_bf16, fp32 accumulate      (performance mode)
+//                    T = H16 : v_mfma_f32_16x16x32_bf16, fp32 accumulate      (performance mode)
 //                    T = float  : v_mfma_f32_16x16x4_f32, exact fp32 fma chain   (parity mode, 1e-4 gate)
 //                    BatchNorm is folded into w / bias on the host; ReLU and the residual add are fused
 //                    into the epilogue.  blockIdx.z walks the `groups` networks (one per keypoint) that
@@ -37,7 +37,18 @@
 namespace rcv {
 namespace {
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+// The 16-bit storage type of the engine.  This file is compiled twice: as is (bfloat16: RCV_BF16) and through fcn_f16.hip
+// with RCV_FCN_FP16 defined (IEEE half: RCV_F16 -- 11 instead of 8 significand bits, the same MFMA rate; values beyond
+// 65504 saturate to infinity, which BN-folded ResNet activations stay far away from).  Everything below is written against
+// H16 / h16x8 / RCV_MFMA16; the kernels live in an anonymous namespace, so the two translation units do not collide.
+#ifdef RCV_FCN_FP16
+typedef _Float16 H16;
+#define RCV_MFMA16 __builtin_amdgcn_mfma_f32_16x16x32_f16
+#else
+typedef __bf16 H16;
+#define RCV_MFMA16 __builtin_amdgcn_mfma_f32_16x16x32_bf16
+#endif
+typedef __attribute__((ext_vector_type(8))) H16 bf16x8;  // (name kept: eight 16-bit elements = one MFMA operand)
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 
@@ -46,16 +57,16 @@ template <> struct Traits<float> {
     static constexpr int KE = 32;  // elements in one 128-byte K row of an LDS tile
     static constexpr int EPV = 4;  // elements per 16-byte vector
 };
-template <> struct Traits<__bf16> {
+template <> struct Traits<H16> {
     static constexpr int KE = 64;
     static constexpr int EPV = 8;
 };
 
 __device__ __forceinline__ float to_f32(float v) { return v; }
-__device__ __forceinline__ float to_f32(__bf16 v) { return (float)v; }
+__device__ __forceinline__ float to_f32(H16 v) { return (float)v; }
 template <typename T> __device__ __forceinline__ T from_f32(float v);
 template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
-template <> __device__ __forceinline__ __bf16 from_f32<__bf16>(float v) { return (__bf16)v; }
+template <> __device__ __forceinline__ H16 from_f32<H16>(float v) { return (H16)v; }
 
 struct ConvParams {
     const void *src0, *src1, *res, *w;
@@ -182,7 +193,7 @@ __global__ __launch_bounds__(256) void k_conv(const ConvParams p)
                 _Pragma("unroll") for (int j = 0; j < NT; j++) bfr[j] = *(const bf16x8 *)(Bb + j * 16 * 128 + ch); \
                 _Pragma("unroll") for (int i = 0; i < MT; i++)                                               \
                     _Pragma("unroll") for (int j = 0; j < NT; j++)                                           \
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0); \
+                        acc[i][j] = RCV_MFMA16(af[i], bfr[j], acc[i][j], 0, 0, 0); \
             }                                                                                                \
         } else {                                                                                             \
             _Pragma("unroll") for (int ks = 0; ks < 8; ks++) {                                               \
@@ -311,7 +322,7 @@ constexpr int DMA_STAGE_BYTES = (DMA_BM + DMA_BN) * 128;
 
 __global__ __launch_bounds__(512) void k_conv_dma(const ConvParams p)
 {
-    using T = __bf16;
+    using T = H16;
     constexpr int KE = 64, EPV = 8, BM = DMA_BM, BN = DMA_BN;
     constexpr int MT = 4, NT = 4;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -455,7 +466,7 @@ __global__ __launch_bounds__(512) void k_conv_dma(const ConvParams p)
         __builtin_amdgcn_s_setprio(1);                                                                         \
         _Pragma("unroll") for (int i = 0; i < MT; i++)                                                         \
             _Pragma("unroll") for (int j = 0; j < NT; j++)                                                     \
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);        \
+                acc[i][j] = RCV_MFMA16(af[i], bfr[j], acc[i][j], 0, 0, 0);        \
         __builtin_amdgcn_s_setprio(0);                                                                         \
         __builtin_amdgcn_s_barrier();                                                                          \
         _Pragma("unroll") for (int i = 0; i < MT; i++) af[i] = *(const bf16x8 *)(Ab + i * 16 * 128 + ch1);     \
@@ -470,7 +481,7 @@ __global__ __launch_bounds__(512) void k_conv_dma(const ConvParams p)
         __builtin_amdgcn_s_setprio(1);                                                                         \
         _Pragma("unroll") for (int i = 0; i < MT; i++)                                                         \
             _Pragma("unroll") for (int j = 0; j < NT; j++)                                                     \
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);        \
+                acc[i][j] = RCV_MFMA16(af[i], bfr[j], acc[i][j], 0, 0, 0);        \
         __builtin_amdgcn_s_setprio(0);                                                                         \
         __builtin_amdgcn_s_barrier();                                                                          \
         stage = stage + 1 == DMA_STAGES ? 0 : stage + 1;                                                       \
@@ -568,7 +579,7 @@ __device__ __forceinline__ void lat_dma16(const void *base, int num_bytes, unsig
 
 __global__ __launch_bounds__(512) void k_conv_lat(const ConvParams p)
 {
-    using T = __bf16;
+    using T = H16;
     constexpr int KE = 64, EPV = 8, BM = LAT_BM, BN = LAT_BN, NS = LAT_STAGES;
     constexpr int MT = 2, NT = 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -684,7 +695,7 @@ __global__ __launch_bounds__(512) void k_conv_lat(const ConvParams p)
 #pragma unroll
                 for (int i = 0; i < MT; i++)
 #pragma unroll
-                    for (int j = 0; j < NT; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[kk][i], bfr[kk][j], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < NT; j++) acc[i][j] = RCV_MFMA16(af[kk][i], bfr[kk][j], acc[i][j], 0, 0, 0);
         }
         stage = stage + 1 == NS ? 0 : stage + 1;
     }
@@ -771,7 +782,7 @@ __device__ __forceinline__ void halo_dma16(const void *base, int num_bytes, unsi
 template <int BN, int MT>
 __global__ __launch_bounds__(512) void k_conv_halo(const HaloParams p)
 {
-    using T = __bf16;
+    using T = H16;
     constexpr int EPV = 8, NT = BN / 32, RW = 16 * MT;   // 8 waves = 4 x 2 of RW pixels x BN / 2 channels (tile: 4 * RW rows)
     constexpr int BPW = BN / 64;                             // weight pieces per wave and K step
     constexpr int OOB = (int)0x80000000;
@@ -881,7 +892,7 @@ __global__ __launch_bounds__(512) void k_conv_halo(const HaloParams p)
         __builtin_amdgcn_s_setprio(1);                                                                         \
         _Pragma("unroll") for (int i = 0; i < MT; i++)                                                         \
             _Pragma("unroll") for (int j = 0; j < NT; j++)                                                     \
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);        \
+                acc[i][j] = RCV_MFMA16(af[i], bfr[j], acc[i][j], 0, 0, 0);        \
         __builtin_amdgcn_s_setprio(0);                                                                         \
         __builtin_amdgcn_s_barrier();                                                                          \
         _Pragma("unroll") for (int i = 0; i < MT; i++) af[i] = *(const bf16x8 *)(Pb + (ao_[i] ^ 64));          \
@@ -899,7 +910,7 @@ __global__ __launch_bounds__(512) void k_conv_halo(const HaloParams p)
         __builtin_amdgcn_s_setprio(1);                                                                         \
         _Pragma("unroll") for (int i = 0; i < MT; i++)                                                         \
             _Pragma("unroll") for (int j = 0; j < NT; j++)                                                     \
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);        \
+                acc[i][j] = RCV_MFMA16(af[i], bfr[j], acc[i][j], 0, 0, 0);        \
         __builtin_amdgcn_s_setprio(0);                                                                         \
         __builtin_amdgcn_s_barrier();                                                                          \
         stage = stage + 1 == 3 ? 0 : stage + 1;                                                                \
@@ -938,7 +949,7 @@ __global__ __launch_bounds__(512) void k_conv_halo(const HaloParams p)
         _Pragma("unroll") for (int kk = 0; kk < 2; kk++)                                                       \
             _Pragma("unroll") for (int i = 0; i < MT; i++)                                                     \
                 _Pragma("unroll") for (int j = 0; j < NT; j++)                                                 \
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[kk][i], bfr[kk][j], acc[i][j], 0, 0, 0); \
+                    acc[i][j] = RCV_MFMA16(af[kk][i], bfr[kk][j], acc[i][j], 0, 0, 0); \
         __builtin_amdgcn_s_setprio(0);                                                                         \
         __builtin_amdgcn_s_barrier();                                                                          \
         stage = stage + 1 == 3 ? 0 : stage + 1;                                                                \
@@ -1044,10 +1055,10 @@ constexpr int STEM_LDS = 64 * STEM_PITCH + 3 * STEM_IH * (STEM_IW + 1) * 4 + STE
 // (r02) The im2col tile no longer exists in LDS: every lane builds the MFMA A fragments of its own pixels straight from the
 // fp32 patch (the same bf16 values in the same k order, so the result is unchanged) and keeps them in registers for all
 // groups.  LDS drops from 125 KB to 40 KB, two workgroups share a CU, and one's loads / stores overlap the other's MFMAs.
-__global__ __launch_bounds__(256, 2) void k_stem_mfma(const float *x, const __bf16 *w, const float *bias, __bf16 *dst, int H, int W,
+__global__ __launch_bounds__(256, 2) void k_stem_mfma(const float *x, const H16 *w, const float *bias, H16 *dst, int H, int W,
                                                       int Ho, int Wo, int groups, long long w_gs, int bias_gs, long long dst_gs)
 {
-    using T = __bf16;
+    using T = H16;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char *sB = smem;                                   // [64][STEM_PITCH]
     float(*s_in)[STEM_IH][STEM_IW + 1] = (float(*)[STEM_IH][STEM_IW + 1])(smem + 64 * STEM_PITCH);
@@ -1140,7 +1151,7 @@ __global__ __launch_bounds__(256, 2) void k_stem_mfma(const float *x, const __bf
 #pragma unroll
             for (int i = 0; i < 4; i++)
 #pragma unroll
-                for (int j = 0; j < 4; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < 4; j++) acc[i][j] = RCV_MFMA16(bfr[j], af[i], acc[i][j], 0, 0, 0);
         }
         // acc[i][j][e] = channel j*16 + kq*4 + e of pixel wave*64 + i*16 + r16 (operands swapped); see k_conv_dma's
         // notes on the permlane16 swap: afterwards the lane owns 8 consecutive channels
@@ -1256,7 +1267,7 @@ template <int CMID, bool CHAIN, bool STAG = false>
 __global__ __launch_bounds__(512) void k_conv_block(const BlockParams p)
 {
     static_assert(!STAG || (CHAIN && CMID == 256), "the staggered schedule is written for the chained 256-wide block");
-    using T = __bf16;
+    using T = H16;
     constexpr int KE = 64, EPV = 8, BM = BLK_BM, KS = 3, PAD = 1;
     constexpr int COUT = 4 * CMID;
     constexpr int OOB = (int)0x80000000;
@@ -1402,7 +1413,7 @@ __global__ __launch_bounds__(512) void k_conv_block(const BlockParams p)
         __builtin_amdgcn_s_setprio(1);                                                                         \
         _Pragma("unroll") for (int i = 0; i < MT1; i++)                                                        \
             _Pragma("unroll") for (int j = 0; j < NT1; j++)                                                    \
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);        \
+                acc[i][j] = RCV_MFMA16(bfr[j], af[i], acc[i][j], 0, 0, 0);        \
         __builtin_amdgcn_s_setprio(0);                                                                         \
         __builtin_amdgcn_s_barrier();                                                                          \
         _Pragma("unroll") for (int i = 0; i < MT1; i++) af[i] = *(const bf16x8 *)(Ab + i * 16 * 128 + ch1);    \
@@ -1418,7 +1429,7 @@ __global__ __launch_bounds__(512) void k_conv_block(const BlockParams p)
         __builtin_amdgcn_s_setprio(1);                                                                         \
         _Pragma("unroll") for (int i = 0; i < MT1; i++)                                                        \
             _Pragma("unroll") for (int j = 0; j < NT1; j++)                                                    \
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);        \
+                acc[i][j] = RCV_MFMA16(bfr[j], af[i], acc[i][j], 0, 0, 0);        \
         __builtin_amdgcn_s_setprio(0);                                                                         \
         __builtin_amdgcn_s_barrier();                                                                          \
         stage = stage + 1 == 3 ? 0 : stage + 1;                                                                \
@@ -1633,7 +1644,7 @@ __global__ __launch_bounds__(512) void k_conv_block(const BlockParams p)
                     for (int i = 0; i < 2; i++)
 #pragma unroll
                         for (int j = 0; j < 4; j++)
-                            a2[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[kk][j], a2f[i][ks * 2 + kk], a2[i][j], 0, 0, 0);
+                            a2[i][j] = RCV_MFMA16(bfr[kk][j], a2f[i][ks * 2 + kk], a2[i][j], 0, 0, 0);
                 __builtin_amdgcn_s_setprio(0);
                 RCV_STAMP(4 * ks + 3);
                 __builtin_amdgcn_s_barrier();
@@ -1715,7 +1726,7 @@ __global__ __launch_bounds__(512) void k_conv_block(const BlockParams p)
 #pragma unroll
                 for (int i = 0; i < 2; i++)
 #pragma unroll
-                    for (int j = 0; j < NT3; j++) acc3[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf3[j], yf[i], acc3[i][j], 0, 0, 0);
+                    for (int j = 0; j < NT3; j++) acc3[i][j] = RCV_MFMA16(bf3[j], yf[i], acc3[i][j], 0, 0, 0);
                 __builtin_amdgcn_s_setprio(0);
                 RCV_STAMP(18 + 4 * t + 3);
                 __builtin_amdgcn_s_barrier();
@@ -1771,7 +1782,7 @@ __global__ __launch_bounds__(512) void k_conv_block(const BlockParams p)
 #pragma unroll
                 for (int i = 0; i < 2; i++)
 #pragma unroll
-                    for (int j = 0; j < 4; j++) a2[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], a2[i][j], 0, 0, 0);
+                    for (int j = 0; j < 4; j++) a2[i][j] = RCV_MFMA16(bfr[j], af[i], a2[i][j], 0, 0, 0);
             }
         }
         // epilogue of the chunk.  R(nc) (and the reduce weights) were issued at the chunk's first step; with four K steps per
@@ -1843,7 +1854,7 @@ __global__ __launch_bounds__(512) void k_conv_block(const BlockParams p)
                         for (int i = 0; i < 2; i++)
 #pragma unroll
                             for (int j = 0; j < JG; j++)
-                                acc3[i][jh * JG + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], yf[i], acc3[i][jh * JG + j], 0, 0, 0);
+                                acc3[i][jh * JG + j] = RCV_MFMA16(bfr[j], yf[i], acc3[i][jh * JG + j], 0, 0, 0);
                     }
                 }
         }
@@ -2092,11 +2103,11 @@ constexpr int TAIL_HP = 80;  // bytes per pixel of the conv7 staging rows (64 + 
 constexpr int TAIL_UP = 160;  // bytes per pixel of the upsampled patch: 128 + 32 -- conflict-free for ds_read_b128's lane groups (16 consecutive pixels, two 16-byte columns per group; 144 is 2-way)
 constexpr int TAIL_LDS = TAIL_UH * TAIL_UW * TAIL_UP + (256 * TAIL_HP > TAIL_SH * TAIL_SW * 128 ? 256 * TAIL_HP : TAIL_SH * TAIL_SW * 128);
 
-__global__ __launch_bounds__(256, 2) void k_tail(const __bf16 *src, const __bf16 *w7, const float *b7, const __bf16 *w8, const float *b8,
+__global__ __launch_bounds__(256, 2) void k_tail(const H16 *src, const H16 *w7, const float *b7, const H16 *w8, const float *b8,
                                                  float *seg, float *radial, int B, int Hin, int Win, long long src_gs, long long w7_gs,
                                                  int b7_gs, long long w8_gs, int b8_gs, int rad_f16)
 {
-    using T = __bf16;
+    using T = H16;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char *sU = smem;                                        // [340][TAIL_UP] upsampled patch
     unsigned char *sS = smem + TAIL_UH * TAIL_UW * TAIL_UP;          // [6][18][128 B] source patch ...
@@ -2194,7 +2205,7 @@ __global__ __launch_bounds__(256, 2) void k_tail(const __bf16 *src, const __bf16
                 for (int i = 0; i < 8; i++)  // constant offset from the lane's pixel: folds into the ds_read immediate
                     af[i] = *(const bf16x8 *)(sU + ubase[i] * TAIL_UP + kq * 16 + (toff * TAIL_UP + kk * 64));
 #pragma unroll
-                for (int i = 0; i < 8; i++) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bw[t][kk], af[i], acc[i], 0, 0, 0);
+                for (int i = 0; i < 8; i++) acc[i] = RCV_MFMA16(bw[t][kk], af[i], acc[i], 0, 0, 0);
                 asm volatile("" ::: "memory");  // keep the fragment reads of later K steps from being hoisted (registers)
             }
         }
@@ -2399,7 +2410,7 @@ int run_op(rcv_fcn *h, const rcv_op &op, const float *x, int B, float *seg, floa
                 if (!h->attrs_set)
                     RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_stem_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, STEM_LDS));
                 dim3 grid(((op.hout + STEM_TH - 1) / STEM_TH) * ((op.wout + STEM_TW - 1) / STEM_TW), B);
-                hipLaunchKernelGGL(k_stem_mfma, grid, dim3(256), STEM_LDS, st, x, (const __bf16 *)w, bias, (__bf16 *)slot(op.dst), op.hin,
+                hipLaunchKernelGGL(k_stem_mfma, grid, dim3(256), STEM_LDS, st, x, (const H16 *)w, bias, (H16 *)slot(op.dst), op.hin,
                                    op.win, op.hout, op.wout, G, (long long)64 * 147, 64, gstride(op.dst));
                 RCV_LAUNCH_CHECK();
                 return RCV_OK;
@@ -2490,7 +2501,7 @@ int register_kernel_attributes()
     if (done) return RCV_OK;
     int rc;
     if ((rc = register_conv_variants<float>()) != RCV_OK) return rc;
-    if ((rc = register_conv_variants<__bf16>()) != RCV_OK) return rc;
+    if ((rc = register_conv_variants<H16>()) != RCV_OK) return rc;
     RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_conv_dma, hipFuncAttributeMaxDynamicSharedMemorySize, DMA_STAGES * DMA_STAGE_BYTES));
     RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_conv_lat, hipFuncAttributeMaxDynamicSharedMemorySize, LAT_STAGES * LAT_STAGE_BYTES));
     RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_conv_halo<128, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, halo_lds(128)));
@@ -2546,7 +2557,7 @@ int forward_impl(rcv_fcn *h, const float *x, int B, float *seg, float *radial, c
                     BlockParams q;
                     memset(&q, 0, sizeof(q));
                     q.src = ws + off[a.src0]; q.res = ws + off[b.res]; q.dst = ws + off[b.dst];
-                    q.w1 = (const __bf16 *)h->weights + a.w_off; q.w2 = (const __bf16 *)h->weights + b.w_off;
+                    q.w1 = (const H16 *)h->weights + a.w_off; q.w2 = (const H16 *)h->weights + b.w_off;
                     q.b1 = h->bias + a.b_off; q.b2 = h->bias + b.b_off;
                     q.src_gs = gs(a.src0); q.res_gs = gs(b.res); q.dst_gs = gs(b.dst);
                     q.w1_gs = (long long)a.cout * 9 * a.c0; q.w2_gs = (long long)b.cout * b.c0;
@@ -2561,7 +2572,7 @@ int forward_impl(rcv_fcn *h, const float *x, int B, float *seg, float *radial, c
                                 c.src1 < 0 && c.res < 0 && c.relu && c.hout == b.hout && c.wout == b.wout && c.dst != a.src0 &&
                                 c.dst != b.res && c.dst != b.dst;
                         if (chain) {
-                            q.w3 = (const __bf16 *)h->weights + c.w_off; q.b3 = h->bias + c.b_off; q.dst3 = ws + off[c.dst];
+                            q.w3 = (const H16 *)h->weights + c.w_off; q.b3 = h->bias + c.b_off; q.dst3 = ws + off[c.dst];
                             q.w3_gs = (long long)c.cout * c.c0; q.b3_gs = c.cout; q.dst3_gs = gs(c.dst);
                         }
                     }
@@ -2601,8 +2612,8 @@ int forward_impl(rcv_fcn *h, const float *x, int B, float *seg, float *radial, c
                         RCV_HIP_CHECK(hipEventRecord(h->events[2 * i + 2], st));
                     }
                     dim3 grid((u.hout + TAIL_TH - 1) / TAIL_TH, B, h->groups);
-                    hipLaunchKernelGGL(k_tail, grid, dim3(256), TAIL_LDS, st, (const __bf16 *)(ws + off[u.src0]),
-                                       (const __bf16 *)h->weights + c.w_off, h->bias + c.b_off, (const __bf16 *)h->weights + d.w_off,
+                    hipLaunchKernelGGL(k_tail, grid, dim3(256), TAIL_LDS, st, (const H16 *)(ws + off[u.src0]),
+                                       (const H16 *)h->weights + c.w_off, h->bias + c.b_off, (const H16 *)h->weights + d.w_off,
                                        h->bias + d.b_off, seg, radial, B, u.hin, u.win, (long long)h->slot_elems[u.src0] * B,
                                        (long long)32 * 576, 32, (long long)64, 2, h->radial_f16 ? 1 : 0);
                     RCV_LAUNCH_CHECK();
@@ -2628,6 +2639,30 @@ int forward_impl(rcv_fcn *h, const float *x, int B, float *seg, float *radial, c
 
 }  // namespace
 
+// Per-translation-unit entry points of the 16-bit engine: this file's own (bfloat16) and, compiled through fcn_f16.hip, the
+// half-precision twin's.  The C ABI below exists once, in the bfloat16 unit, and dispatches on rcv_fcn::dtype.
+namespace rcv {
+#ifdef RCV_FCN_FP16
+int fcn_forward_f16(rcv_fcn *h, const float *x, int B, float *seg, float *radial, char *ws, hipStream_t st)
+{
+    return forward_impl<H16>(h, x, B, seg, radial, ws, st);
+}
+int fcn_register_f16() { return register_kernel_attributes(); }
+int fcn_debug_slot_f16(const void *src, float *out_dev, long long n, hipStream_t st)
+{
+    const unsigned blocks = (unsigned)std::min<long long>((n + 255) / 256, 65535);
+    hipLaunchKernelGGL((k_slot_to_f32<H16>), dim3(blocks), dim3(256), 0, st, (const H16 *)src, out_dev, n);
+    RCV_LAUNCH_CHECK();
+    return RCV_OK;
+}
+#else
+int fcn_forward_f16(rcv_fcn *h, const float *x, int B, float *seg, float *radial, char *ws, hipStream_t st);
+int fcn_register_f16();
+int fcn_debug_slot_f16(const void *src, float *out_dev, long long n, hipStream_t st);
+#endif
+}  // namespace rcv
+
+#ifndef RCV_FCN_FP16
 extern "C" {
 
 int rcv_preprocess_rgb(const uint8_t *rgb_dev, int B, int H, int W, float *x_dev, void *stream)
@@ -2645,7 +2680,7 @@ int rcv_fcn_create(const rcv_op *ops, int n_ops, int n_slots, const int64_t *slo
 {
     if (!ops || n_ops <= 0 || n_slots <= 0 || !slot_elems || groups <= 0 || !weights_dev || !bias_dev || !out)
         return RCV_E_INVALID;
-    if (dtype != RCV_F32 && dtype != RCV_BF16) return RCV_E_UNSUPPORTED;
+    if (dtype != RCV_F32 && dtype != RCV_BF16 && dtype != RCV_F16) return RCV_E_UNSUPPORTED;
     for (int i = 0; i < n_ops; i++) {
         const rcv_op &o = ops[i];
         const int slots[4] = {o.src0, o.src1, o.res, o.dst};
@@ -2653,7 +2688,8 @@ int rcv_fcn_create(const rcv_op *ops, int n_ops, int n_slots, const int64_t *slo
             if (s >= n_slots || s < -3) return RCV_E_INVALID;
     }
     {
-        const int rc = register_kernel_attributes();
+        int rc = register_kernel_attributes();
+        if (rc == RCV_OK && dtype == RCV_F16) rc = rcv::fcn_register_f16();
         if (rc != RCV_OK) return rc;
     }
     rcv_fcn *h = new rcv_fcn();
@@ -2689,7 +2725,8 @@ int rcv_fcn_forward(rcv_fcn *h, const float *x_dev, int B, float *seg_dev, float
     if (!h || !x_dev || !seg_dev || !radial_dev || !ws || B <= 0) return RCV_E_INVALID;
     if (ws_bytes < rcv_fcn_workspace_bytes(h, B)) return RCV_E_WORKSPACE;
     if (h->dtype == RCV_F32) return forward_impl<float>(h, x_dev, B, seg_dev, radial_dev, (char *)ws, (hipStream_t)stream);
-    return forward_impl<__bf16>(h, x_dev, B, seg_dev, radial_dev, (char *)ws, (hipStream_t)stream);
+    if (h->dtype == RCV_F16) return rcv::fcn_forward_f16(h, x_dev, B, seg_dev, radial_dev, (char *)ws, (hipStream_t)stream);
+    return forward_impl<H16>(h, x_dev, B, seg_dev, radial_dev, (char *)ws, (hipStream_t)stream);
 }
 
 int rcv_fcn_debug_slot(rcv_fcn *h, const void *ws, int B, int g, int slot, float *out_dev, void *stream)
@@ -2700,12 +2737,14 @@ int rcv_fcn_debug_slot(rcv_fcn *h, const void *ws, int B, int g, int slot, float
     slot_offsets(h, B, off, total);
     const long long n = (long long)h->slot_elems[slot] * B;
     const unsigned blocks = (unsigned)std::min<long long>((n + 255) / 256, 65535);
+    if (h->dtype == RCV_F16)
+        return rcv::fcn_debug_slot_f16((const H16 *)((const char *)ws + off[slot]) + (long long)g * n, out_dev, n, (hipStream_t)stream);
     if (h->dtype == RCV_F32)
         hipLaunchKernelGGL((k_slot_to_f32<float>), dim3(blocks), dim3(256), 0, (hipStream_t)stream,
                            (const float *)((const char *)ws + off[slot]) + (long long)g * n, out_dev, n);
     else
-        hipLaunchKernelGGL((k_slot_to_f32<__bf16>), dim3(blocks), dim3(256), 0, (hipStream_t)stream,
-                           (const __bf16 *)((const char *)ws + off[slot]) + (long long)g * n, out_dev, n);
+        hipLaunchKernelGGL((k_slot_to_f32<H16>), dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+                           (const H16 *)((const char *)ws + off[slot]) + (long long)g * n, out_dev, n);
     RCV_LAUNCH_CHECK();
     return RCV_OK;
 }
@@ -2775,3 +2814,4 @@ int rcv_fcn_get_profile(rcv_fcn *h, double *conv_ms, double *other_ms, double *c
 }
 
 }  // extern "C"
+#endif  // !RCV_FCN_FP16

@@ -223,7 +223,7 @@ def pack_weights(state_dicts, builder, ops, dtype):
     import torch
 
     sds = [{(k[7:] if k.startswith("module.") else k): v for k, v in sd.items()} for sd in state_dicts]
-    tdt = torch.float32 if dtype == _hip.RCV_F32 else torch.bfloat16
+    tdt = {_hip.RCV_F32: torch.float32, _hip.RCV_BF16: torch.bfloat16, _hip.RCV_F16: torch.float16}[dtype]
     wparts, bparts, woff, boff = [], [], 0, 0
     for op, spec in zip(ops, builder.wspecs):
         if spec is None:
@@ -263,6 +263,9 @@ class FcnEngine:
     """`groups` DenseFCNResNet152 networks (one state dict each) sharing one input image.
 
     forward(x): x float32 [B,3,H,W] on the GPU -> (seg, radial), each float32 [G,B,1,H,W].
+    dtype: storage type of weights and activations (fp32 accumulation throughout): "fp32" (parity mode), "bf16" (the
+    throughput mode BASELINE.json names) or "fp16" (IEEE half: the same kernels and speed as bf16 with 11 instead of 8
+    significand bits).
     """
 
     def __init__(self, state_dicts, H, W, dtype="bf16", device="cuda", reuse_slots=True, arch="dense"):
@@ -271,8 +274,8 @@ class FcnEngine:
         self.lib = _hip.lib()
         self.H, self.W = int(H), int(W)
         self.groups = len(state_dicts)
-        self.dtype = {"bf16": _hip.RCV_BF16, "fp32": _hip.RCV_F32, "f32": _hip.RCV_F32}[dtype]
-        self.dtype_name = "bf16" if self.dtype == _hip.RCV_BF16 else "fp32"
+        self.dtype = {"bf16": _hip.RCV_BF16, "fp32": _hip.RCV_F32, "f32": _hip.RCV_F32, "fp16": _hip.RCV_F16, "f16": _hip.RCV_F16}[dtype]
+        self.dtype_name = {_hip.RCV_BF16: "bf16", _hip.RCV_F32: "fp32", _hip.RCV_F16: "fp16"}[self.dtype]
         if arch not in ("dense", "res"):
             raise ValueError("arch must be 'dense' (DenseFCNResNet152) or 'res' (ResFCNResNet152)")
         self.arch = arch

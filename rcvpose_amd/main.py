@@ -24,8 +24,8 @@ def build_parser():
     p.add_argument('--demo_mode', type=str2bool, default=False)
     p.add_argument('--test_occ', type=str2bool, default=False)
     p.add_argument('--using_ckpts', type=str2bool, default=True)
-    p.add_argument('--dtype', type=str, default='fp32', choices=['bf16', 'fp32'],
-                   help="engine storage type: fp32 reproduces the reference's forward to 1e-4 (default); bf16 is the fast mode")
+    p.add_argument('--dtype', type=str, default='fp32', choices=['bf16', 'fp16', 'fp32'],
+                   help="engine storage type: fp32 reproduces the reference's forward to 1e-4 (default); bf16 / fp16 are the fast modes (fp16: 8x finer storage)")
     return p
 
 

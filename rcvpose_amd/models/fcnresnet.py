@@ -78,14 +78,14 @@ class DenseFCNResNet152(nn.Module):
         self.conv7 = _decoder_stage(64, 32)
         self.conv8 = nn.Conv2d(32, output_channels, kernel_size=1, stride=1)
         # "fp32": exact-fp32 MFMA kernels (matches the reference's fp32 forward to ~1e-5 relative)
-        # "bf16": bf16 storage / fp32 accumulate (performance mode)
+        # "bf16" / "fp16": 16-bit storage / fp32 accumulate (performance modes; fp16 carries 11 significand bits)
         self.compute_dtype = "fp32"
         self._engine = None
         self._engine_key = None
 
     def set_compute_dtype(self, name):
-        if name not in ("fp32", "bf16"):
-            raise ValueError("compute dtype must be 'fp32' or 'bf16'")
+        if name not in ("fp32", "bf16", "fp16"):
+            raise ValueError("compute dtype must be 'fp32', 'bf16' or 'fp16'")
         self.compute_dtype = name
         return self
 
