@@ -1088,7 +1088,7 @@ __device__ __forceinline__ void d_bb_level(AccHeader *hdr, const double *Q, cons
                         ub[c] += (smin - slack < thi) && (smax + slack >= tlo);
                     }
                 }
-                if (WITH_LB) {
+                if (WITH_LB && LAST) {
                     double c2[3][2];
 #pragma unroll
                     for (int a = 0; a < 3; a++)
@@ -1102,6 +1102,25 @@ __device__ __forceinline__ void d_bb_level(AccHeader *hdr, const double *Q, cons
                         const int hx = (c >> 2) & 1, hy = (c >> 1) & 1, hz = c & 1;
                         const double d2 = (c2[0][hx] + c2[1][hy]) + c2[2][hz];  // exact reference d2 of the centre voxel
                         lb[c] += d2 >= tlo_d && d2 < thi_d;
+                    }
+                }
+                if (WITH_LB && !LAST) {
+                    // above the voxel level the centre count only ranks blocks for the probe (it breaks the ties among the many
+                    // blocks every shell crosses); it is not used as a bound, so float32 is enough
+                    const float thi = (float)thi_d, tlo = (float)tlo_d;
+                    float c2[3][2];
+#pragma unroll
+                    for (int a = 0; a < 3; a++)
+#pragma unroll
+                        for (int h = 0; h < 2; h++) {
+                            const float dc = (float)(ce[a][h] - forg[a]) - (float)(q[a] - forg[a]);
+                            c2[a][h] = dc * dc;
+                        }
+#pragma unroll
+                    for (int c = 0; c < 8; c++) {
+                        const int hx = (c >> 2) & 1, hy = (c >> 1) & 1, hz = c & 1;
+                        const float d2 = (c2[0][hx] + c2[1][hy]) + c2[2][hz];
+                        lb[c] += d2 >= tlo && d2 < thi;
                     }
                 }
             }
@@ -1118,7 +1137,7 @@ __device__ __forceinline__ void d_bb_level(AccHeader *hdr, const double *Q, cons
             for (int w = 0; w < NT / 64; w++) { u += red[w][c]; l += red[w][8 + c]; }
             if (ok[0][hx] && ok[1][hy] && ok[2][hz]) {
                 int best = __hip_atomic_load(&hdr->bb_best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (WITH_LB) {
+                if (WITH_LB && LAST) {  // exact counts only: a lower bound of the peak and a start for the hill-climb
                     best = max(atomicMax(&hdr->bb_best, l), l);
                     const unsigned long long flat = ((unsigned long long)ce[0][hx] * D + (unsigned long long)ce[1][hy]) * D +
                                                     (unsigned long long)ce[2][hz];
