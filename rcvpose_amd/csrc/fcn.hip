@@ -2101,7 +2101,8 @@ constexpr int TAIL_TH = 8, TAIL_TW = 32, TAIL_UW = TAIL_TW + 2, TAIL_UH = TAIL_T
 constexpr int TAIL_SH = TAIL_TH / 2 + 2, TAIL_SW = TAIL_TW / 2 + 2;
 constexpr int TAIL_HP = 80;  // bytes per pixel of the conv7 staging rows (64 + bank spread)
 constexpr int TAIL_UP = 160;  // bytes per pixel of the upsampled patch: 128 + 32 -- conflict-free for ds_read_b128's lane groups (16 consecutive pixels, two 16-byte columns per group; 144 is 2-way)
-constexpr int TAIL_LDS = TAIL_UH * TAIL_UW * TAIL_UP + (256 * TAIL_HP > TAIL_SH * TAIL_SW * 128 ? 256 * TAIL_HP : TAIL_SH * TAIL_SW * 128);
+constexpr int TAIL_LDS_MAIN = TAIL_UH * TAIL_UW * TAIL_UP + (256 * TAIL_HP > TAIL_SH * TAIL_SW * 128 ? 256 * TAIL_HP : TAIL_SH * TAIL_SW * 128);
+constexpr int TAIL_LDS = TAIL_LDS_MAIN + 64 * 4;  // + the head weights as fp32 (read back as broadcasts)
 
 __global__ __launch_bounds__(256, 2) void k_tail(const H16 *src, const H16 *w7, const float *b7, const H16 *w8, const float *b8,
                                                  float *seg, float *radial, int B, int Hin, int Win, long long src_gs, long long w7_gs,
@@ -2118,29 +2119,33 @@ __global__ __launch_bounds__(256, 2) void k_tail(const H16 *src, const H16 *w7, 
     const int ty = blockIdx.x, img = blockIdx.y, g = blockIdx.z;
     const int ho0 = ty * TAIL_TH;
     const T *sg = src + (long long)g * src_gs + (long long)img * Hin * Win * 64;
-    // wave = (pixel half ph, channel tile j): 128 pixels x 16 output channels.  Its conv7 weights stay in registers
-    // as MFMA fragments for the whole strip: lane (co = j*16 + r16, k = tap*64 + kk*32 + kq*8)
-    const int ph = wave >> 1, j = wave & 1;
-    bf16x8 bw[9][2];
+    // wave = pixel quarter: 64 pixels x all 32 output channels (two 16-channel tiles).  Its conv7 weights stay in registers
+    // as MFMA fragments for the whole strip: lane (co = j*16 + r16, k = tap*64 + kk*32 + kq*8).  (r02: was 128 pixels x 16
+    // channels per wave -- every A fragment of the patch was then read from LDS by two waves; the kernel is LDS-read-bound.)
+    const int pq = wave;
+    bf16x8 bw[2][9][2];
     {
         const T *wg = w7 + (long long)g * w7_gs;
 #pragma unroll
-        for (int t = 0; t < 9; t++)
+        for (int j = 0; j < 2; j++)
 #pragma unroll
-            for (int kk = 0; kk < 2; kk++) bw[t][kk] = *(const bf16x8 *)(wg + (j * 16 + r16) * 576 + t * 64 + kk * 32 + kq * 8);
+            for (int t = 0; t < 9; t++)
+#pragma unroll
+                for (int kk = 0; kk < 2; kk++) bw[j][t][kk] = *(const bf16x8 *)(wg + (j * 16 + r16) * 576 + t * 64 + kk * 32 + kq * 8);
     }
-    float bias7[4];
+    float bias7[2][4];
 #pragma unroll
-    for (int e = 0; e < 4; e++) bias7[e] = b7[(long long)g * b7_gs + j * 16 + kq * 4 + e];
-    float hw[64];  // head weights [2][32]
+    for (int j = 0; j < 2; j++)
 #pragma unroll
-    for (int q = 0; q < 64; q++) hw[q] = (float)w8[(long long)g * w8_gs + q];
+        for (int e = 0; e < 4; e++) bias7[j][e] = b7[(long long)g * b7_gs + j * 16 + kq * 4 + e];
+    float *hw = (float *)(smem + TAIL_LDS_MAIN);  // head weights [2][32] (in LDS: 64 fewer registers per lane)
+    if (tid < 64) hw[tid] = (float)w8[(long long)g * w8_gs + tid];
     const float hb0 = b8[(long long)g * b8_gs], hb1 = b8[(long long)g * b8_gs + 1];
-    // pixel of this lane in each of the wave's eight 16-pixel groups, as index into U (tap (0,0))
-    int ubase[8];
+    // pixel of this lane in each of the wave's four 16-pixel groups, as index into U (tap (0,0))
+    int ubase[4];
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
-        const int m = ph * 128 + i * 16 + r16;
+    for (int i = 0; i < 4; i++) {
+        const int m = pq * 64 + i * 16 + r16;
         ubase[i] = (m >> 5) * TAIL_UW + (m & 31);
     }
     const int sy0 = ho0 / 2 - 1;
@@ -2192,33 +2197,39 @@ __global__ __launch_bounds__(256, 2) void k_tail(const H16 *src, const H16 *w7, 
         }
         __syncthreads();
         // ---- conv7: K = 9 taps x 64 channels, in k_conv's order (tap-major, 32 channels per MFMA)
-        f32x4 acc[8];
+        f32x4 acc[4][2];
 #pragma unroll
-        for (int i = 0; i < 8; i++) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int j = 0; j < 2; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int t = 0; t < 9; t++) {
             const int toff = (t / 3) * TAIL_UW + (t % 3);
 #pragma unroll
             for (int kk = 0; kk < 2; kk++) {
-                bf16x8 af[8];
+                bf16x8 af[4];
 #pragma unroll
-                for (int i = 0; i < 8; i++)  // constant offset from the lane's pixel: folds into the ds_read immediate
+                for (int i = 0; i < 4; i++)  // constant offset from the lane's pixel: folds into the ds_read immediate
                     af[i] = *(const bf16x8 *)(sU + ubase[i] * TAIL_UP + kq * 16 + (toff * TAIL_UP + kk * 64));
 #pragma unroll
-                for (int i = 0; i < 8; i++) acc[i] = RCV_MFMA16(bw[t][kk], af[i], acc[i], 0, 0, 0);
+                for (int i = 0; i < 4; i++)
+#pragma unroll
+                    for (int j = 0; j < 2; j++) acc[i][j] = RCV_MFMA16(bw[j][t][kk], af[i], acc[i][j], 0, 0, 0);
                 asm volatile("" ::: "memory");  // keep the fragment reads of later K steps from being hoisted (registers)
             }
         }
         // ---- bias + ReLU, rounded to bf16 as the stored conv7 activation would be; operands were swapped, so
-        // acc[i][e] is channel j*16 + kq*4 + e of pixel ph*128 + i*16 + r16
+        // acc[i][j][e] is channel j*16 + kq*4 + e of pixel pq*64 + i*16 + r16
 #pragma unroll
-        for (int i = 0; i < 8; i++) {
-            uint2 pk;
-            T *pv = (T *)&pk;
+        for (int i = 0; i < 4; i++)
 #pragma unroll
-            for (int e = 0; e < 4; e++) pv[e] = (T)fmaxf(acc[i][e] + bias7[e], 0.f);
-            *(uint2 *)(sH + (ph * 128 + i * 16 + r16) * TAIL_HP + (j * 16 + kq * 4) * 2) = pk;
-        }
+            for (int j = 0; j < 2; j++) {
+                uint2 pk;
+                T *pv = (T *)&pk;
+#pragma unroll
+                for (int e = 0; e < 4; e++) pv[e] = (T)fmaxf(acc[i][j][e] + bias7[j][e], 0.f);
+                *(uint2 *)(sH + (pq * 64 + i * 16 + r16) * TAIL_HP + (j * 16 + kq * 4) * 2) = pk;
+            }
         __syncthreads();
         // ---- head: thread = pixel, the sequential FMA chain of k_head
         {
