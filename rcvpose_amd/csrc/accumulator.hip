@@ -1502,6 +1502,50 @@ __device__ __forceinline__ void d_bb_exact(AccHeader *hdr, const double *Q, cons
     }
 }
 
+// Ranking counts for the probe: the (float32, approximate) number of votes at the centre voxel of every block of a list.
+// Many blocks of a coarse level are crossed by every shell (equal upper bounds); the centre counts break those ties so
+// that the probe descends into the block that holds the peak.  Never used as a bound.  A workgroup takes 8 blocks per
+// pass over the float32 point list (read straight from L2: 20 bytes per point).
+__device__ __forceinline__ void d_bb_centres(const AccHeader *hdr, const float *F, size_t capF, BBEntry *list, const uint32_t *count,
+                                             int list_cap, int level)
+{
+    __shared__ int red[4][8];
+    const AccHeader H = *hdr;
+    if (H.status != RCV_OK || !H.bb_enabled) return;
+    const int D = H.dim, s = (BB_ROOT >> level) >> 1;  // edge of the blocks in the list (children of `level`)
+    const unsigned nin = min(*count, (uint32_t)list_cap);
+    const int npad = (H.n + 1023) & ~1023;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    for (unsigned pp = blockIdx.x; pp * 8 < nin; pp += gridDim.x) {
+        float cx[8], cy[8], cz[8];
+#pragma unroll
+        for (int v = 0; v < 8; v++) {
+            const BBEntry e = list[min(pp * 8 + v, nin - 1)];
+            cx[v] = (float)min((int)e.i + s / 2, D - 1); cy[v] = (float)min((int)e.j + s / 2, D - 1); cz[v] = (float)min((int)e.k + s / 2, D - 1);
+        }
+        int cnt[8];
+#pragma unroll
+        for (int v = 0; v < 8; v++) cnt[v] = 0;
+        for (int p = tid; p < npad; p += 256) {
+            const float x = F[p], y = F[capF + p], z = F[2 * capF + p], tlo = F[3 * capF + p], thi = F[4 * capF + p];
+#pragma unroll
+            for (int v = 0; v < 8; v++) {
+                const float dx = cx[v] - x, dy = cy[v] - y, dz = cz[v] - z;
+                const float d2 = (dx * dx + dy * dy) + dz * dz;
+                cnt[v] += (d2 >= tlo) & (d2 < thi);
+            }
+        }
+        __syncthreads();  // red[] of the previous pass has been read
+#pragma unroll
+        for (int v = 0; v < 8; v++) {
+            const int c = wave_sum_i32(cnt[v]);
+            if (lane == 0) red[wv][v] = c;
+        }
+        __syncthreads();
+        if (tid < 8 && pp * 8 + tid < nin) list[pp * 8 + tid].lb = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+    }
+}
+
 // the BB_BEAM entries with the largest upper bound (ties: larger lower bound), for the greedy probe
 __device__ __forceinline__ void d_bb_topk(const AccHeader *hdr, const BBEntry *list, const uint32_t *count, int cap,
                                                   BBEntry *sel, uint32_t *sel_count)
@@ -1769,11 +1813,11 @@ __global__ __launch_bounds__(NT) void k_bb_level(int cap, int level, BBIo io, SP
                                   in_count, in_cap, out, out_count, out_cap, level);
 }
 template <bool VOX>
-__global__ __launch_bounds__(BBW_THREADS) void k_bb_wide(int cap, int level, SP<unsigned char> ws, Layout L)
+__global__ __launch_bounds__(BBW_THREADS) void k_bb_wide(int cap, int level, BBIo io, SP<unsigned char> ws, Layout L)
 {
     unsigned char *w = ws.get();
     const BBEntry *in; const uint32_t *in_count; int in_cap; BBEntry *out; uint32_t *out_count; int out_cap;
-    bb_resolve(w, L, level, BBIo{0, 0}, in, in_count, in_cap, out, out_count, out_cap);
+    bb_resolve(w, L, level, io, in, in_count, in_cap, out, out_count, out_cap);
     d_bb_wide<VOX>((AccHeader *)(w + L.header), (const float *)(w + L.F), L.capF, in, in_count, in_cap, out, out_count, out_cap, level);
 }
 __global__ __launch_bounds__(256) void k_bb_climb(int cap, SP<unsigned char> ws, Layout L)
@@ -1787,6 +1831,17 @@ __global__ __launch_bounds__(BBL_THREADS) void k_bb_exact(int cap, SP<unsigned c
     AccHeader *hdr = (AccHeader *)(w + L.header);
     BBEntry *la = (BBEntry *)(w + L.bb_lists), *lb = la + BB_CAP;
     d_bb_exact(hdr, (const double *)(w + L.Q), (const double *)(w + L.P), cap, (BB_LEVELS & 1) ? lb : la, &hdr->bb_count[BB_LEVELS], BB_CAP);
+}
+__global__ __launch_bounds__(256) void k_bb_centres(int level, int probe, SP<unsigned char> ws, Layout L)
+{
+    unsigned char *w = ws.get();
+    AccHeader *hdr = (AccHeader *)(w + L.header);
+    BBEntry *la = (BBEntry *)(w + L.bb_lists), *lb = la + BB_CAP;
+    BBEntry *psel = (BBEntry *)(w + L.bb_probe);
+    BBEntry *pkids[2] = {psel + 16, psel + 16 + 8 * BB_BEAM};
+    // the list that level `level` wrote: the probe's children or the breadth-first list
+    if (probe) d_bb_centres(hdr, (const float *)(w + L.F), L.capF, pkids[level & 1], &hdr->pb_count[level], 8 * BB_BEAM, level);
+    else d_bb_centres(hdr, (const float *)(w + L.F), L.capF, ((level + 1) & 1) ? lb : la, &hdr->bb_count[level + 1], BB_CAP, level);
 }
 // probe selection before level `level`: from the breadth-first list (level 1) or the previous probe children
 __global__ __launch_bounds__(1024) void k_bb_topk(int level, SP<unsigned char> ws, Layout L)
@@ -2103,20 +2158,28 @@ static int run_engines(int cap, int bb_enable, SP<rcv_acc_result> sres, SP<uint3
     if (bb_enable) {
         hipLaunchKernelGGL(k_bb_init, grid3(256), dim3(256), 0, st, cap, sws, L);
         RCV_LAUNCH_CHECK();
-        // level 0 of the breadth-first search scores the 32-voxel blocks (children of the 64-voxel roots)
-        hipLaunchKernelGGL((k_bb_level<false, true, 1024>), grid3(512 / (n_items > 8 ? 8 : n_items) + 1), dim3(1024), 0, st, cap, 0,
-                           BBIo{0, 0}, sws, L);
+        // level 0 of the breadth-first search scores the 32-voxel blocks (children of the 64-voxel roots): upper bounds with
+        // the wide kernel, then the centre counts that rank them for the probe (r02: was one k_bb_level launch with an exact
+        // centre count per child, 2.0 ms per 216 items)
+        const int wide_grid0 = n_items >= 8 ? 64 : 2048 / n_items;
+        hipLaunchKernelGGL(k_bb_wide<false>, grid3(wide_grid0), dim3(BBW_THREADS), 0, st, cap, 0, BBIo{0, 0}, sws, L);
+        RCV_LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_bb_centres, grid3(64), dim3(256), 0, st, 0, 0, sws, L);
         RCV_LAUNCH_CHECK();
         // greedy probe: follow the BB_BEAM most promising blocks of each level down to voxels; the exact
         // counts found there give the search a lower bound close to the peak before it widens
         for (int level = 1; level < BB_LEVELS; level++) {
             hipLaunchKernelGGL(k_bb_topk, items, dim3(1024), 0, st, level, sws, L);
             RCV_LAUNCH_CHECK();
-            if (level == BB_LEVELS - 1)
+            if (level == BB_LEVELS - 1) {  // voxel level: exact counts (the lower bound of the search)
                 hipLaunchKernelGGL((k_bb_level<true, true, 1024>), grid3(BB_BEAM), dim3(1024), 0, st, cap, level, BBIo{1, 1}, sws, L);
-            else
-                hipLaunchKernelGGL((k_bb_level<false, true, 1024>), grid3(BB_BEAM), dim3(1024), 0, st, cap, level, BBIo{1, 1}, sws, L);
-            RCV_LAUNCH_CHECK();
+                RCV_LAUNCH_CHECK();
+            } else {  // upper bounds of the selected blocks' children + the centre counts that rank them
+                hipLaunchKernelGGL(k_bb_wide<false>, grid3((BB_BEAM + BBW_NP - 1) / BBW_NP), dim3(BBW_THREADS), 0, st, cap, level, BBIo{1, 1}, sws, L);
+                RCV_LAUNCH_CHECK();
+                hipLaunchKernelGGL(k_bb_centres, grid3(BB_BEAM), dim3(256), 0, st, level, 1, sws, L);
+                RCV_LAUNCH_CHECK();
+            }
         }
         for (int round = 0; round < BB_CLIMB_ROUNDS; round++) {  // exact hill-climb from the probe's best voxel
             hipLaunchKernelGGL(k_bb_climb, grid3(BB_CLIMB_W), dim3(256), 0, st, cap, sws, L);
@@ -2126,8 +2189,8 @@ static int run_engines(int cap, int bb_enable, SP<rcv_acc_result> sres, SP<uint3
         const int wide_grid = n_items >= 8 ? 256 : 2048 / n_items;
         // (the last of them, on 2^3 parents, bounds single voxels)
         for (int level = 1; level < BB_LEVELS; level++) {
-            if (level == BB_LEVELS - 1) hipLaunchKernelGGL(k_bb_wide<true>, grid3(wide_grid), dim3(BBW_THREADS), 0, st, cap, level, sws, L);
-            else hipLaunchKernelGGL(k_bb_wide<false>, grid3(wide_grid), dim3(BBW_THREADS), 0, st, cap, level, sws, L);
+            if (level == BB_LEVELS - 1) hipLaunchKernelGGL(k_bb_wide<true>, grid3(wide_grid), dim3(BBW_THREADS), 0, st, cap, level, BBIo{0, 0}, sws, L);
+            else hipLaunchKernelGGL(k_bb_wide<false>, grid3(wide_grid), dim3(BBW_THREADS), 0, st, cap, level, BBIo{0, 0}, sws, L);
             RCV_LAUNCH_CHECK();
         }
         // exact counts of the surviving voxels (float32 bound >= best exact count): typically a few dozen
