@@ -87,6 +87,7 @@ struct alignas(16) AccHeader {
     int32_t variant;         // 0: Accumulator_3D, 1: Accumulator_3D_no_depth
     int32_t pad_;
     double nd_mean[3];       // x/y/z_mean_mm of :440-442
+    unsigned long long climb_center[2];  // 1 + flat index of the voxel the hill-climb round (parity) was centred on; 0: none
 };
 static_assert(sizeof(AccHeader) <= 512, "AccHeader must fit the 512 bytes reserved in the workspace");
 
@@ -1353,7 +1354,7 @@ constexpr int BB_CLIMB_ROUNDS = RCV_BB_CLIMB_ROUNDS;
 
 // one workgroup per i-offset of the (2R+1)^3 neighbourhood; every thread scores the (2R+1)^2 voxels of that slice for
 // its points (dx^2 shared), then the slice's counts are reduced and folded into the running best
-__device__ __forceinline__ void d_bb_climb(AccHeader *hdr, const double *Q, const double *P, int cap)
+__device__ __forceinline__ void d_bb_climb(AccHeader *hdr, const double *Q, const double *P, int cap, int round)
 {
     constexpr int W = BB_CLIMB_W, NV = W * W;
     __shared__ int red[4][NV];
@@ -1361,6 +1362,13 @@ __device__ __forceinline__ void d_bb_climb(AccHeader *hdr, const double *Q, cons
     if (H.status != RCV_OK || !H.bb_enabled || H.bb_best_key == 0) return;
     const int D = H.dim, n = H.n;
     const unsigned long long flat = H.bb_best_key & 0xFFFFFFFFull;
+    // converged: the best voxel is the one the previous round was centred on -- its whole neighbourhood has been counted
+    // and nothing in it was better.  (Every workgroup of the round reads the same header; the first one records the centre.)
+    if (round > 0 && H.climb_center[(round - 1) & 1] == flat + 1) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) hdr->climb_center[round & 1] = flat + 1;
+        return;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) hdr->climb_center[round & 1] = flat + 1;
     const int ci = (int)(flat / ((unsigned long long)D * D)) + (int)blockIdx.x - BB_CLIMB_R;
     const int cj0 = (int)((flat / D) % D) - BB_CLIMB_R, ck0 = (int)(flat % D) - BB_CLIMB_R;
     if (ci < 0 || ci >= D) return;
@@ -1820,10 +1828,10 @@ __global__ __launch_bounds__(BBW_THREADS) void k_bb_wide(int cap, int level, BBI
     bb_resolve(w, L, level, io, in, in_count, in_cap, out, out_count, out_cap);
     d_bb_wide<VOX>((AccHeader *)(w + L.header), (const float *)(w + L.F), L.capF, in, in_count, in_cap, out, out_count, out_cap, level);
 }
-__global__ __launch_bounds__(256) void k_bb_climb(int cap, SP<unsigned char> ws, Layout L)
+__global__ __launch_bounds__(256) void k_bb_climb(int cap, int round, SP<unsigned char> ws, Layout L)
 {
     unsigned char *w = ws.get();
-    d_bb_climb((AccHeader *)(w + L.header), (const double *)(w + L.Q), (const double *)(w + L.P), cap);
+    d_bb_climb((AccHeader *)(w + L.header), (const double *)(w + L.Q), (const double *)(w + L.P), cap, round);
 }
 __global__ __launch_bounds__(BBL_THREADS) void k_bb_exact(int cap, SP<unsigned char> ws, Layout L)
 {
@@ -2182,7 +2190,7 @@ static int run_engines(int cap, int bb_enable, SP<rcv_acc_result> sres, SP<uint3
             }
         }
         for (int round = 0; round < BB_CLIMB_ROUNDS; round++) {  // exact hill-climb from the probe's best voxel
-            hipLaunchKernelGGL(k_bb_climb, grid3(BB_CLIMB_W), dim3(256), 0, st, cap, sws, L);
+            hipLaunchKernelGGL(k_bb_climb, grid3(BB_CLIMB_W), dim3(256), 0, st, cap, round, sws, L);
             RCV_LAUNCH_CHECK();
         }
         // the lower bound now sits at (or next to) the peak: the wide levels only need upper bounds
