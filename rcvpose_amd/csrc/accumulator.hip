@@ -37,6 +37,7 @@ constexpr int TABLE_N = 8192;          // largest integer radius (voxels) with a
 constexpr int MAX_TILES = 1 << 17;
 constexpr int MAX_REPLICAS = 2048;      // workgroups that share a tile park their counters here (CELL_BYTES each)
 constexpr int BB_CAP = 1 << 19;         // candidate blocks per level of the branch-and-bound peak search
+constexpr int BB_HALF = BB_CAP / 2;     // a level's list is two regions: [0, BB_HALF) x-sibling pairs, [BB_HALF, BB_CAP) single blocks
 constexpr int BB_ROOT = 64;            // edge (voxels) of the root blocks; 6 halvings down to single voxels
 constexpr int BB_LEVELS = 6;
 // Probe width and hill-climb length only steer how close the lower bound gets to the peak before the wide levels run
@@ -78,7 +79,8 @@ struct alignas(16) AccHeader {
     int32_t bb_done;         // set by k_bb_final when the search produced the result (rasteriser is skipped)
     int32_t bb_best;         // best exact vote count seen so far (lower bound of the peak)
     int32_t bb_overflow;     // a candidate list ran out of room -> fall back
-    uint32_t bb_count[8];    // entries of the candidate list consumed by level l (count[0] = root blocks)
+    uint32_t bb_count[8];    // entries of the PAIR region of the candidate list consumed by level l (two per pair)
+    uint32_t bs_count[8];    // entries of its SINGLES region (bs_count[0] = root blocks)
     uint32_t pb_count[8];    // same for the greedy probe (beam of BB_BEAM blocks per level)
     uint32_t sel_count[8];
     unsigned long long bb_best_key;  // bb_best << 32 | flat index of a voxel attaining it (hill-climb start)
@@ -535,8 +537,8 @@ __device__ __forceinline__ bool finish_header(AccHeader &H, long long dim, int n
     H.tile_counter = 0;
     {
         const long long nb = (D + BB_ROOT - 1) / BB_ROOT;
-        H.bb_enabled = bb_enable && nb * nb * nb <= BB_CAP;
-        H.bb_count[0] = (uint32_t)(nb * nb * nb);
+        H.bb_enabled = bb_enable && nb * nb * nb <= BB_HALF;
+        H.bs_count[0] = (uint32_t)(nb * nb * nb);
     }
     return true;
 }
@@ -1176,14 +1178,28 @@ __device__ __forceinline__ void bbw_dma16(const float *gptr, float *lds_wave_bas
                                      (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
 }
 
-template <bool VOX>
+// One child pair of the inner loop: the two z halves of child (hx, hy) of parent u as packed sign tests
+#define RCV_BBW_TAIL(u, c, below, reach)                                                                                   \
+    hist[u][2 * (c)] = __builtin_amdgcn_alignbit(hist[u][2 * (c)], (unsigned)(__float_as_int((below).x) & __float_as_int((reach).x)), 31); \
+    hist[u][2 * (c) + 1] = __builtin_amdgcn_alignbit(hist[u][2 * (c) + 1], (unsigned)(__float_as_int((below).y) & __float_as_int((reach).y)), 31);
+
+// VOX: the children are single voxels (last level).
+// PAIRED_IN: the input list holds x-adjacent pairs of sibling blocks (entries 2q, 2q+1: same j, k, i one block apart); a pair
+//   shares the y and z terms of every point: 43 instead of 54 instructions per parent-point.  60-80 % of the survivors of a
+//   level have their x-sibling surviving too, so every level list is kept as two regions -- pairs and single blocks -- and each
+//   region gets its own (compile-time specialised) launch.
+// PAIR_OUT: the surviving children are sorted into the two regions of the next level's list; otherwise all go to one list.
+template <bool VOX, bool PAIRED_IN, bool PAIR_OUT>
 __device__ __forceinline__ void d_bb_wide(AccHeader *hdr, const float *F, size_t capF,
                                                          const BBEntry *in_list, const uint32_t *in_count, int in_cap,
-                                                         BBEntry *out_list, uint32_t *out_count, int out_cap, int level)
+                                                         BBEntry *out_list, uint32_t *out_pair_count, uint32_t *out_single_count,
+                                                         int out_single_off, int out_cap, int level)
 {
+    static_assert(!(VOX && PAIRED_IN), "the voxel level takes single blocks");
     __shared__ __attribute__((aligned(16))) float sbuf[2][5][BBW_CHUNK];  // [stage][x, y, z, T_lo, T_hi][point]
     __shared__ int red[BBW_THREADS / 64][8 * BBW_NP];
     __shared__ int s_valid[BBW_NP], s_org[BBW_NP][3];
+    static_assert(BBW_NP == 4, "two pairs per pass");
     const AccHeader H = *hdr;
     if (H.status != RCV_OK || !H.bb_enabled) return;
     const int D = H.dim, n = H.n;
@@ -1220,12 +1236,14 @@ __device__ __forceinline__ void d_bb_wide(AccHeader *hdr, const float *F, size_t
 #pragma unroll
         for (int u = 0; u < BBW_NP; u++) { valid[u] = s_valid[u] != 0; any = any || valid[u]; }
         if (!any) continue;  // (workgroup-uniform) chunk 0 stays in stage g & 1 for the next pass
+        // block ranges: x per parent; y, z per parent -- or, for pairs, per pair (held in the first parent's slot)
         f32x2 lo2[BBW_NP][3], hi2[BBW_NP][3];
 #pragma unroll
         for (int u = 0; u < BBW_NP; u++) {
             const int org[3] = {e[u].i, e[u].j, e[u].k};
 #pragma unroll
             for (int a = 0; a < 3; a++) {
+                if (PAIRED_IN && a > 0 && (u & 1)) continue;
                 const int l0 = org[a], l1 = org[a] + s;
                 lo2[u][a] = f32x2{(float)l0, (float)l1};
                 hi2[u][a] = f32x2{(float)min(l0 + s - 1, D - 1), (float)min(l1 + s - 1, D - 1)};
@@ -1248,11 +1266,22 @@ __device__ __forceinline__ void d_bb_wide(AccHeader *hdr, const float *F, size_t
                 const float q[3] = {sb[0][li], sb[1][li], sb[2][li]};
                 const float tlo = sb[3][li], thi = sb[4][li];
                 const f32x2 thi2 = {thi, thi}, tlo2 = {tlo, tlo};
+                // dmin^2 / dmax^2 of both halves of one axis of parent u as float2 (v_pk_add_f32 / v_pk_mul_f32);
+                // max(e1^2, e2^2) = max(|e1|, |e2|)^2 exactly (the |.| are free source modifiers): one multiply less
+#define RCV_BBW_AXIS(u, a, mn, mx)                                                                                          \
+    {                                                                                                                       \
+        const f32x2 qq = {q[a], q[a]};                                                                                      \
+        const f32x2 e1 = lo2[u][a] - qq, e2 = qq - hi2[u][a];                                                               \
+        const f32x2 dmin = {fmaxf(fmaxf(e1.x, e2.x), 0.f), fmaxf(fmaxf(e1.y, e2.y), 0.f)};                                  \
+        const f32x2 dmax = {fmaxf(fabsf(e1.x), fabsf(e2.x)), fmaxf(fabsf(e1.y), fabsf(e2.y))};                              \
+        mn = dmin * dmin;                                                                                                   \
+        mx = dmax * dmax;                                                                                                   \
+    }
+                if constexpr (VOX) {
+                    // last level: the children are single voxels (lo == hi), the box distances collapse to the distance
+                    // to the voxel centre: d2 per child, 36 instead of 54 instructions per (parent, point)
 #pragma unroll
-                for (int u = 0; u < BBW_NP; u++) {
-                    if constexpr (VOX) {
-                        // last level: the children are single voxels (lo == hi), the box distances collapse to the distance
-                        // to the voxel centre: d2 per child, 36 instead of 54 instructions per (parent, point)
+                    for (int u = 0; u < BBW_NP; u++) {
                         f32x2 sq[3];
 #pragma unroll
                         for (int a = 0; a < 3; a++) {
@@ -1266,43 +1295,56 @@ __device__ __forceinline__ void d_bb_wide(AccHeader *hdr, const float *F, size_t
                             const f32x2 d2 = f32x2{v, v} + sq[2];
                             const f32x2 below = d2 - thi2;  // negative <=> d2 < thi
                             const f32x2 reach = tlo2 - d2;  // negative <=> d2 > tlo
-                            hist[u][2 * c] = __builtin_amdgcn_alignbit(
-                                hist[u][2 * c], (unsigned)(__float_as_int(below.x) & __float_as_int(reach.x)), 31);
-                            hist[u][2 * c + 1] = __builtin_amdgcn_alignbit(
-                                hist[u][2 * c + 1], (unsigned)(__float_as_int(below.y) & __float_as_int(reach.y)), 31);
+                            RCV_BBW_TAIL(u, c, below, reach);
                         }
-                        continue;
                     }
-                    // both halves of an axis as one float2 (v_pk_add_f32 / v_pk_mul_f32)
-                    f32x2 mn2[3], mx2[3];
+                } else if constexpr (PAIRED_IN) {
+                    // (smin < thi) && (smax > tlo) as sign bits, the thresholds folded into the z terms, the yz sums shared by
+                    // the two parents of a pair and by both x halves
 #pragma unroll
-                    for (int a = 0; a < 3; a++) {
-                        const f32x2 qq = {q[a], q[a]};
-                        const f32x2 e1 = lo2[u][a] - qq, e2 = qq - hi2[u][a];
-                        const f32x2 dmin = {fmaxf(fmaxf(e1.x, e2.x), 0.f), fmaxf(fmaxf(e1.y, e2.y), 0.f)};
-                        // max(e1^2, e2^2) = max(|e1|, |e2|)^2 exactly (the |.| are free source modifiers): one multiply less
-                        const f32x2 dmax = {fmaxf(fabsf(e1.x), fabsf(e2.x)), fmaxf(fabsf(e1.y), fabsf(e2.y))};
-                        mn2[a] = dmin * dmin;
-                        mx2[a] = dmax * dmax;
+                    for (int pr = 0; pr < BBW_NP / 2; pr++) {
+                        const int uA = 2 * pr;
+                        f32x2 mny, mxy, mnz, mxz;
+                        RCV_BBW_AXIS(uA, 1, mny, mxy);
+                        RCV_BBW_AXIS(uA, 2, mnz, mxz);
+                        const f32x2 zb = mnz - thi2, zr = tlo2 - mxz;
+                        const f32x2 byz[2] = {f32x2{mny.x, mny.x} + zb, f32x2{mny.y, mny.y} + zb};
+                        const f32x2 ryz[2] = {zr - f32x2{mxy.x, mxy.x}, zr - f32x2{mxy.y, mxy.y}};
+#pragma unroll
+                        for (int u = uA; u <= uA + 1; u++) {
+                            f32x2 mnx, mxx;
+                            RCV_BBW_AXIS(u, 0, mnx, mxx);
+#pragma unroll
+                            for (int c = 0; c < 4; c++) {  // c = hx * 2 + hy
+                                const float mn = (c >> 1) ? mnx.y : mnx.x, mx = (c >> 1) ? mxx.y : mxx.x;
+                                const f32x2 below = f32x2{mn, mn} + byz[c & 1];
+                                const f32x2 reach = ryz[c & 1] - f32x2{mx, mx};
+                                RCV_BBW_TAIL(u, c, below, reach);
+                            }
+                        }
                     }
-                    // (smin < thi) && (smax > tlo) as sign bits; the xy partial sums are shared by the two z halves
-                    // and the thresholds are folded into the z terms
-                    const f32x2 mnxy[2] = {f32x2{mn2[0].x, mn2[0].x} + mn2[1], f32x2{mn2[0].y, mn2[0].y} + mn2[1]};
-                    const f32x2 mxxy[2] = {f32x2{mx2[0].x, mx2[0].x} + mx2[1], f32x2{mx2[0].y, mx2[0].y} + mx2[1]};
-                    const f32x2 zb = mn2[2] - thi2;
-                    const f32x2 zr = tlo2 - mx2[2];
+                } else {
 #pragma unroll
-                    for (int c = 0; c < 4; c++) {
-                        const float mn = (c & 1) ? mnxy[c >> 1].y : mnxy[c >> 1].x;
-                        const float mx = (c & 1) ? mxxy[c >> 1].y : mxxy[c >> 1].x;
-                        const f32x2 below = f32x2{mn, mn} + zb;  // negative <=> smin < thi
-                        const f32x2 reach = zr - f32x2{mx, mx};  // negative <=> smax > tlo
-                        hist[u][2 * c] = __builtin_amdgcn_alignbit(
-                            hist[u][2 * c], (unsigned)(__float_as_int(below.x) & __float_as_int(reach.x)), 31);
-                        hist[u][2 * c + 1] = __builtin_amdgcn_alignbit(
-                            hist[u][2 * c + 1], (unsigned)(__float_as_int(below.y) & __float_as_int(reach.y)), 31);
+                    for (int u = 0; u < BBW_NP; u++) {
+                        f32x2 mn2[3], mx2[3];
+#pragma unroll
+                        for (int a = 0; a < 3; a++) RCV_BBW_AXIS(u, a, mn2[a], mx2[a]);
+                        // the xy partial sums are shared by the two z halves, the thresholds are folded into the z terms
+                        const f32x2 mnxy[2] = {f32x2{mn2[0].x, mn2[0].x} + mn2[1], f32x2{mn2[0].y, mn2[0].y} + mn2[1]};
+                        const f32x2 mxxy[2] = {f32x2{mx2[0].x, mx2[0].x} + mx2[1], f32x2{mx2[0].y, mx2[0].y} + mx2[1]};
+                        const f32x2 zb = mn2[2] - thi2;
+                        const f32x2 zr = tlo2 - mx2[2];
+#pragma unroll
+                        for (int c = 0; c < 4; c++) {
+                            const float mn = (c & 1) ? mnxy[c >> 1].y : mnxy[c >> 1].x;
+                            const float mx = (c & 1) ? mxxy[c >> 1].y : mxxy[c >> 1].x;
+                            const f32x2 below = f32x2{mn, mn} + zb;  // negative <=> smin < thi
+                            const f32x2 reach = zr - f32x2{mx, mx};  // negative <=> smax > tlo
+                            RCV_BBW_TAIL(u, c, below, reach);
+                        }
                     }
                 }
+#undef RCV_BBW_AXIS
             }
             if ((ch & (32 / PT - 1)) == 32 / PT - 1) {
 #pragma unroll
@@ -1319,30 +1361,49 @@ __device__ __forceinline__ void d_bb_wide(AccHeader *hdr, const float *F, size_t
                 if (lane == 0) red[wv][u * 8 + c] = v;
             }
         __syncthreads();
-        if (tid < 8 * BBW_NP) {
+        if (tid < 8 * BBW_NP) {  // lanes 0..31 of wave 0: parent u = tid / 8, child c = hx * 4 + hy * 2 + hz
             const int u = tid >> 3, c = tid & 7, hx = (c >> 2) & 1, hy = (c >> 1) & 1, hz = c & 1;
             int cnt = 0;
             for (int w = 0; w < BBW_THREADS / 64; w++) cnt += red[w][tid];
             const int oi = s_org[u][0] + hx * s, oj = s_org[u][1] + hy * s, ok_ = s_org[u][2] + hz * s;
-            if (s_valid[u] && oi <= D - 1 && oj <= D - 1 && ok_ <= D - 1) {
-                const int best = __hip_atomic_load(&hdr->bb_best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (cnt > 0 && cnt >= best) {
-                    const unsigned slot = atomicAdd(out_count, 1u);
-                    if (slot < (unsigned)out_cap) {
-                        BBEntry o;
-                        o.i = (uint16_t)oi; o.j = (uint16_t)oj; o.k = (uint16_t)ok_;
-                        o.pad_ = 0; o.ub = cnt; o.lb = 0;
-                        out_list[slot] = o;
+            const int best = __hip_atomic_load(&hdr->bb_best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const bool alive = s_valid[u] && oi <= D - 1 && oj <= D - 1 && ok_ <= D - 1 && cnt > 0 && cnt >= best;
+            BBEntry o;
+            o.i = (uint16_t)oi; o.j = (uint16_t)oj; o.k = (uint16_t)ok_;
+            o.pad_ = 0; o.ub = cnt; o.lb = 0;
+            if constexpr (PAIR_OUT) {
+                const unsigned m8 = (unsigned)((__ballot(alive) >> (u * 8)) & 0xFFull);  // this parent's survivors, bit = c
+                const unsigned pairs = m8 & (m8 >> 4) & 0xFu;                             // (hy, hz) groups with both x halves alive
+                const unsigned singles = m8 & ~(pairs | (pairs << 4));
+                const int npairs = __popc(pairs), nsingles = __popc(singles);
+                unsigned bp = 0, bs = 0;
+                if (c == 0 && npairs > 0) bp = atomicAdd(out_pair_count, (unsigned)(2 * npairs));
+                if (c == 0 && nsingles > 0) bs = atomicAdd(out_single_count, (unsigned)nsingles);
+                bp = (unsigned)__shfl((int)bp, u * 8);
+                bs = (unsigned)__shfl((int)bs, u * 8);
+                if (alive) {
+                    const int grp = c & 3;
+                    if ((pairs >> grp) & 1u) {
+                        const unsigned slot = bp + 2 * __popc(pairs & ((1u << grp) - 1u)) + hx;
+                        if (bp + 2 * npairs <= (unsigned)out_cap) out_list[slot] = o;
+                        else atomicExch(&hdr->bb_overflow, 1);
                     } else {
-                        atomicExch(&hdr->bb_overflow, 1);
+                        const unsigned slot = bs + __popc(singles & ((1u << c) - 1u));
+                        if (bs + nsingles <= (unsigned)out_cap) out_list[out_single_off + slot] = o;
+                        else atomicExch(&hdr->bb_overflow, 1);
                     }
                 }
+            } else if (alive) {
+                const unsigned slot = atomicAdd(out_single_count, 1u);
+                if (slot < (unsigned)out_cap) out_list[out_single_off + slot] = o;
+                else atomicExch(&hdr->bb_overflow, 1);
             }
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the look-ahead chunk of the last pass
 #undef RCV_BBW_ISSUE
 }
+#undef RCV_BBW_TAIL
 
 // Hill-climb on exact voxel counts around the best voxel found so far (5 x 5 x 5 neighbourhood, one workgroup
 // per voxel).  The greedy probe lands near the peak; a few rounds of this bring the lower bound to the peak
@@ -1555,23 +1616,25 @@ __device__ __forceinline__ void d_bb_centres(const AccHeader *hdr, const float *
 }
 
 // the BB_BEAM entries with the largest upper bound (ties: larger lower bound), for the greedy probe
-__device__ __forceinline__ void d_bb_topk(const AccHeader *hdr, const BBEntry *list, const uint32_t *count, int cap,
-                                                  BBEntry *sel, uint32_t *sel_count)
+// (the list may be two regions: entries [0, count_a) and [off_b, off_b + count_b); count_b may be null)
+__device__ __forceinline__ void d_bb_topk(const AccHeader *hdr, const BBEntry *list, const uint32_t *count_a, const uint32_t *count_b,
+                                                  int off_b, int cap, BBEntry *sel, uint32_t *sel_count)
 {
     __shared__ unsigned long long s_key[16];
     __shared__ unsigned long long s_taken[BB_BEAM];
     const AccHeader H = *hdr;
     if (H.status != RCV_OK || !H.bb_enabled) return;
-    const uint32_t n = min(*count, (uint32_t)cap);
+    const uint32_t na = min(*count_a, (uint32_t)cap), nb = count_b ? min(*count_b, (uint32_t)cap) : 0u, n = na + nb;
     const int tid = threadIdx.x;
     int picked = 0;
     for (int round = 0; round < BB_BEAM && round < (int)n; round++) {
         unsigned long long best = 0;
         for (uint32_t t = tid; t < n; t += 1024) {
-            const BBEntry e = list[t];
+            const uint32_t idx = t < na ? t : (uint32_t)off_b + (t - na);
+            const BBEntry e = list[idx];
             // key: ub (31 bits) | lb (clamped to 12 bits) | index (20 bits) + 1 so that 0 means "none"
             unsigned long long key = ((unsigned long long)(uint32_t)min(e.ub, 0x7FFFFFFF) << 32) |
-                                     ((unsigned long long)min(e.lb, 4095) << 20) | (unsigned long long)(t & 0xFFFFF);
+                                     ((unsigned long long)min(e.lb, 4095) << 20) | (unsigned long long)(idx & 0xFFFFF);
             bool taken = false;
             for (int q = 0; q < round; q++) taken |= s_taken[q] == key;
             if (!taken && key + 1 > best) best = key + 1;
@@ -1613,8 +1676,8 @@ __device__ __forceinline__ void d_bb_final(AccHeader *hdr, const BBEntry *voxels
     __shared__ int s_ties[16];
     const AccHeader H = *hdr;
     if (H.status != RCV_OK || !H.bb_enabled || H.bb_overflow || H.bb_best <= 0) return;  // the rasteriser decides
-    const uint32_t nv = H.bb_count[BB_LEVELS];
-    if (nv == 0 || nv > (uint32_t)BB_CAP) return;
+    const uint32_t nv = H.bs_count[BB_LEVELS];
+    if (nv == 0 || nv > (uint32_t)BB_HALF) return;
     const int peak = H.bb_best;
     const uint32_t D = (uint32_t)H.dim;
     uint32_t first = 0xFFFFFFFFu;
@@ -1790,8 +1853,8 @@ __global__ __launch_bounds__(1024) void k_setup(SP<const int32_t> counts, int n_
 __global__ __launch_bounds__(256) void k_bb_init(int cap, SP<unsigned char> ws, Layout L)
 {
     unsigned char *w = ws.get();
-    d_bb_init((const AccHeader *)(w + L.header), (const double *)(w + L.P), cap, (double *)(w + L.Q), (BBEntry *)(w + L.bb_lists),
-              (float *)(w + L.F), L.capF);
+    d_bb_init((const AccHeader *)(w + L.header), (const double *)(w + L.P), cap, (double *)(w + L.Q),
+              (BBEntry *)(w + L.bb_lists) + BB_HALF /* the roots are single blocks */, (float *)(w + L.F), L.capF);
 }
 // which candidate lists a level kernel reads / writes (all live in the item's workspace)
 struct BBIo {
@@ -1820,13 +1883,25 @@ __global__ __launch_bounds__(NT) void k_bb_level(int cap, int level, BBIo io, SP
     d_bb_level<LAST, WITH_LB, NT>((AccHeader *)(w + L.header), (const double *)(w + L.Q), (const double *)(w + L.P), cap, in,
                                   in_count, in_cap, out, out_count, out_cap, level);
 }
-template <bool VOX>
-__global__ __launch_bounds__(BBW_THREADS) void k_bb_wide(int cap, int level, BBIo io, SP<unsigned char> ws, Layout L)
+// PROBE: from the probe's selection to the probe's children list (plain lists); otherwise level list -> next level list
+template <bool VOX, bool PAIRED_IN, bool PAIR_OUT, bool PROBE = false>
+__global__ __launch_bounds__(BBW_THREADS) void k_bb_wide(int cap, int level, SP<unsigned char> ws, Layout L)
 {
+    static_assert(!PROBE || (!PAIRED_IN && !PAIR_OUT), "the probe's lists are plain");
     unsigned char *w = ws.get();
-    const BBEntry *in; const uint32_t *in_count; int in_cap; BBEntry *out; uint32_t *out_count; int out_cap;
-    bb_resolve(w, L, level, io, in, in_count, in_cap, out, out_count, out_cap);
-    d_bb_wide<VOX>((AccHeader *)(w + L.header), (const float *)(w + L.F), L.capF, in, in_count, in_cap, out, out_count, out_cap, level);
+    AccHeader *hdr = (AccHeader *)(w + L.header);
+    BBEntry *la = (BBEntry *)(w + L.bb_lists), *lb = la + BB_CAP;
+    BBEntry *psel = (BBEntry *)(w + L.bb_probe);
+    BBEntry *pkids[2] = {psel + 16, psel + 16 + 8 * BB_BEAM};
+    if constexpr (PROBE) {
+        d_bb_wide<VOX, false, false>(hdr, (const float *)(w + L.F), L.capF, psel, &hdr->sel_count[level], BB_BEAM, pkids[level & 1], nullptr,
+                                     &hdr->pb_count[level], 0, 8 * BB_BEAM, level);
+    } else {
+        const BBEntry *in = ((level & 1) ? lb : la) + (PAIRED_IN ? 0 : BB_HALF);
+        const uint32_t *in_count = PAIRED_IN ? &hdr->bb_count[level] : &hdr->bs_count[level];
+        d_bb_wide<VOX, PAIRED_IN, PAIR_OUT>(hdr, (const float *)(w + L.F), L.capF, in, in_count, BB_HALF, (level & 1) ? la : lb,
+                                            &hdr->bb_count[level + 1], &hdr->bs_count[level + 1], BB_HALF, BB_HALF, level);
+    }
 }
 __global__ __launch_bounds__(256) void k_bb_climb(int cap, int round, SP<unsigned char> ws, Layout L)
 {
@@ -1838,7 +1913,8 @@ __global__ __launch_bounds__(BBL_THREADS) void k_bb_exact(int cap, SP<unsigned c
     unsigned char *w = ws.get();
     AccHeader *hdr = (AccHeader *)(w + L.header);
     BBEntry *la = (BBEntry *)(w + L.bb_lists), *lb = la + BB_CAP;
-    d_bb_exact(hdr, (const double *)(w + L.Q), (const double *)(w + L.P), cap, (BB_LEVELS & 1) ? lb : la, &hdr->bb_count[BB_LEVELS], BB_CAP);
+    d_bb_exact(hdr, (const double *)(w + L.Q), (const double *)(w + L.P), cap, ((BB_LEVELS & 1) ? lb : la) + BB_HALF,
+               &hdr->bs_count[BB_LEVELS], BB_HALF);
 }
 __global__ __launch_bounds__(256) void k_bb_centres(int level, int probe, SP<unsigned char> ws, Layout L)
 {
@@ -1849,7 +1925,11 @@ __global__ __launch_bounds__(256) void k_bb_centres(int level, int probe, SP<uns
     BBEntry *pkids[2] = {psel + 16, psel + 16 + 8 * BB_BEAM};
     // the list that level `level` wrote: the probe's children or the breadth-first list
     if (probe) d_bb_centres(hdr, (const float *)(w + L.F), L.capF, pkids[level & 1], &hdr->pb_count[level], 8 * BB_BEAM, level);
-    else d_bb_centres(hdr, (const float *)(w + L.F), L.capF, ((level + 1) & 1) ? lb : la, &hdr->bb_count[level + 1], BB_CAP, level);
+    else {
+        BBEntry *lst = ((level + 1) & 1) ? lb : la;
+        d_bb_centres(hdr, (const float *)(w + L.F), L.capF, lst, &hdr->bb_count[level + 1], BB_HALF, level);
+        d_bb_centres(hdr, (const float *)(w + L.F), L.capF, lst + BB_HALF, &hdr->bs_count[level + 1], BB_HALF, level);
+    }
 }
 // probe selection before level `level`: from the breadth-first list (level 1) or the previous probe children
 __global__ __launch_bounds__(1024) void k_bb_topk(int level, SP<unsigned char> ws, Layout L)
@@ -1859,15 +1939,14 @@ __global__ __launch_bounds__(1024) void k_bb_topk(int level, SP<unsigned char> w
     BBEntry *la = (BBEntry *)(w + L.bb_lists), *lb = la + BB_CAP;
     BBEntry *psel = (BBEntry *)(w + L.bb_probe);
     BBEntry *pkids[2] = {psel + 16, psel + 16 + 8 * BB_BEAM};
-    const BBEntry *src = level == 1 ? lb : pkids[(level - 1) & 1];
-    const uint32_t *src_count = level == 1 ? &hdr->bb_count[1] : &hdr->pb_count[level - 1];
-    d_bb_topk(hdr, src, src_count, level == 1 ? BB_CAP : 8 * BB_BEAM, psel, &hdr->sel_count[level]);
+    if (level == 1) d_bb_topk(hdr, lb, &hdr->bb_count[1], &hdr->bs_count[1], BB_HALF, BB_HALF, psel, &hdr->sel_count[level]);
+    else d_bb_topk(hdr, pkids[(level - 1) & 1], &hdr->pb_count[level - 1], nullptr, 0, 8 * BB_BEAM, psel, &hdr->sel_count[level]);
 }
 __global__ __launch_bounds__(1024) void k_bb_final(SP<rcv_acc_result> out, SP<unsigned char> ws, Layout L)
 {
     unsigned char *w = ws.get();
     BBEntry *la = (BBEntry *)(w + L.bb_lists), *lb = la + BB_CAP;
-    d_bb_final((AccHeader *)(w + L.header), (BB_LEVELS & 1) ? lb : la, out.get());
+    d_bb_final((AccHeader *)(w + L.header), ((BB_LEVELS & 1) ? lb : la) + BB_HALF, out.get());
 }
 template <bool WIDE>
 __global__ __launch_bounds__(VOTE_THREADS) void k_vote(int cap, SP<uint32_t> grid, unsigned long long grid_cells,
@@ -2170,7 +2249,7 @@ static int run_engines(int cap, int bb_enable, SP<rcv_acc_result> sres, SP<uint3
         // the wide kernel, then the centre counts that rank them for the probe (r02: was one k_bb_level launch with an exact
         // centre count per child, 2.0 ms per 216 items)
         const int wide_grid0 = n_items >= 8 ? 64 : 2048 / n_items;
-        hipLaunchKernelGGL(k_bb_wide<false>, grid3(wide_grid0), dim3(BBW_THREADS), 0, st, cap, 0, BBIo{0, 0}, sws, L);
+        hipLaunchKernelGGL((k_bb_wide<false, false, true>), grid3(wide_grid0), dim3(BBW_THREADS), 0, st, cap, 0, sws, L);
         RCV_LAUNCH_CHECK();
         hipLaunchKernelGGL(k_bb_centres, grid3(64), dim3(256), 0, st, 0, 0, sws, L);
         RCV_LAUNCH_CHECK();
@@ -2183,7 +2262,8 @@ static int run_engines(int cap, int bb_enable, SP<rcv_acc_result> sres, SP<uint3
                 hipLaunchKernelGGL((k_bb_level<true, true, 1024>), grid3(BB_BEAM), dim3(1024), 0, st, cap, level, BBIo{1, 1}, sws, L);
                 RCV_LAUNCH_CHECK();
             } else {  // upper bounds of the selected blocks' children + the centre counts that rank them
-                hipLaunchKernelGGL(k_bb_wide<false>, grid3((BB_BEAM + BBW_NP - 1) / BBW_NP), dim3(BBW_THREADS), 0, st, cap, level, BBIo{1, 1}, sws, L);
+                hipLaunchKernelGGL((k_bb_wide<false, false, false, true>), grid3((BB_BEAM + BBW_NP - 1) / BBW_NP), dim3(BBW_THREADS), 0, st,
+                                   cap, level, sws, L);
                 RCV_LAUNCH_CHECK();
                 hipLaunchKernelGGL(k_bb_centres, grid3(BB_BEAM), dim3(256), 0, st, level, 1, sws, L);
                 RCV_LAUNCH_CHECK();
@@ -2197,8 +2277,19 @@ static int run_engines(int cap, int bb_enable, SP<rcv_acc_result> sres, SP<uint3
         const int wide_grid = n_items >= 8 ? 256 : 2048 / n_items;
         // (the last of them, on 2^3 parents, bounds single voxels)
         for (int level = 1; level < BB_LEVELS; level++) {
-            if (level == BB_LEVELS - 1) hipLaunchKernelGGL(k_bb_wide<true>, grid3(wide_grid), dim3(BBW_THREADS), 0, st, cap, level, BBIo{0, 0}, sws, L);
-            else hipLaunchKernelGGL(k_bb_wide<false>, grid3(wide_grid), dim3(BBW_THREADS), 0, st, cap, level, BBIo{0, 0}, sws, L);
+            // every level list is two regions, x-sibling pairs and single blocks, each with its own launch; the level before
+            // the voxel level and the voxel level itself write single entries only
+            if (level == BB_LEVELS - 1) {
+                hipLaunchKernelGGL((k_bb_wide<true, false, false>), grid3(wide_grid), dim3(BBW_THREADS), 0, st, cap, level, sws, L);
+            } else if (level == BB_LEVELS - 2) {
+                hipLaunchKernelGGL((k_bb_wide<false, true, false>), grid3(wide_grid), dim3(BBW_THREADS), 0, st, cap, level, sws, L);
+                RCV_LAUNCH_CHECK();
+                hipLaunchKernelGGL((k_bb_wide<false, false, false>), grid3(wide_grid), dim3(BBW_THREADS), 0, st, cap, level, sws, L);
+            } else {
+                hipLaunchKernelGGL((k_bb_wide<false, true, true>), grid3(wide_grid), dim3(BBW_THREADS), 0, st, cap, level, sws, L);
+                RCV_LAUNCH_CHECK();
+                hipLaunchKernelGGL((k_bb_wide<false, false, true>), grid3(wide_grid), dim3(BBW_THREADS), 0, st, cap, level, sws, L);
+            }
             RCV_LAUNCH_CHECK();
         }
         // exact counts of the surviving voxels (float32 bound >= best exact count): typically a few dozen

@@ -20,6 +20,9 @@ pipe.vote(depth, rmax)
 torch.cuda.synchronize()
 kp, res = pipe.read_results()
 for i in range(B * 3):
-    ints = pipe.ws[i, 48:224].cpu().numpy().view(np.int32)
-    print("item %2d (frame %d kp %d) n %d dim %d peak %d | bb done %d best %d | lists %s | probe %s" %
-          (i, i // 3, i % 3, ints[0], ints[3], res[i].peak_votes, ints[17], ints[18], list(ints[20:27]), list(ints[28:34])))
+    ints = pipe.ws[i, 48:288].cpu().numpy().view(np.int32)
+    # AccHeader after the six doubles: n, m, zb, dim, tile geometry (8), wide, nparts, status, tile_counter, bb_enabled, bb_done,
+    # bb_best, bb_overflow, bb_count[8] (pair regions), bs_count[8] (single regions), pb_count[8], sel_count[8]
+    print("item %2d (frame %d kp %d) n %d dim %d peak %d | bb done %d best %d | pair entries %s | single entries %s | probe %s" %
+          (i, i // 3, i % 3, ints[0], ints[3], res[i].peak_votes, ints[17], ints[18], [int(v) for v in ints[20:27]],
+           [int(v) for v in ints[28:35]], [int(v) for v in ints[36:42]]))
