@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--no-dma", action="store_true", help="disable the LDS-DMA conv kernel")
     ap.add_argument("--off", type=int, action="append", default=[], help="engine option key to switch off (repeatable)")
+    ap.add_argument("--opt", action="append", default=[], help="engine option as key=value (repeatable)")
     ap.add_argument("--graph", action="store_true", help="also time the forward replayed as one HIP graph")
     ap.add_argument("--all", action="store_true", help="print every op, not the per-shape summary")
     args = ap.parse_args()
@@ -40,6 +41,8 @@ def main():
         eng.set_option(1, 0)
     for key in args.off:
         eng.set_option(key, 0)
+    for kv in args.opt:
+        eng.set_option(int(kv.split("=")[0]), int(kv.split("=")[1]))
     x = torch.randn(args.batch, 3, 480, 640, device="cuda")
     for _ in range(2):
         eng.forward(x)
