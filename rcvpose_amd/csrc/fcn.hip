@@ -2101,8 +2101,17 @@ constexpr int TAIL_TH = 8, TAIL_TW = 32, TAIL_UW = TAIL_TW + 2, TAIL_UH = TAIL_T
 constexpr int TAIL_SH = TAIL_TH / 2 + 2, TAIL_SW = TAIL_TW / 2 + 2;
 constexpr int TAIL_HP = 80;  // bytes per pixel of the conv7 staging rows (64 + bank spread)
 constexpr int TAIL_UP = 160;  // bytes per pixel of the upsampled patch: 128 + 32 -- conflict-free for ds_read_b128's lane groups (16 consecutive pixels, two 16-byte columns per group; 144 is 2-way)
-constexpr int TAIL_LDS_MAIN = TAIL_UH * TAIL_UW * TAIL_UP + (256 * TAIL_HP > TAIL_SH * TAIL_SW * 128 ? 256 * TAIL_HP : TAIL_SH * TAIL_SW * 128);
+constexpr int TAIL_SPIECES = (TAIL_SH * TAIL_SW + 7) / 8;  // DMA pieces (8 pixels x 128 B) of the source patch
+constexpr int TAIL_LDS_MAIN = TAIL_UH * TAIL_UW * TAIL_UP + TAIL_SPIECES * 1024;  // U (later the conv7 rows) + source patch
 constexpr int TAIL_LDS = TAIL_LDS_MAIN + 64 * 4;  // + the head weights as fp32 (read back as broadcasts)
+static_assert(256 * TAIL_HP <= TAIL_UH * TAIL_UW * TAIL_UP, "the conv7 rows reuse the upsampled patch's LDS");
+
+// (plain function: the buffer builtins are device-only and a template kernel's body is also instantiated for the host)
+__device__ __forceinline__ void tail_dma16(const void *base, int num_bytes, unsigned char *lds_wave_base, int voffset)
+{
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, num_bytes, 0x00020000);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void *)lds_wave_base, 16, voffset, 0, 0, 0);
+}
 
 __global__ __launch_bounds__(256, 2) void k_tail(const H16 *src, const H16 *w7, const float *b7, const H16 *w8, const float *b8,
                                                  float *seg, float *radial, int B, int Hin, int Win, long long src_gs, long long w7_gs,
@@ -2110,9 +2119,9 @@ __global__ __launch_bounds__(256, 2) void k_tail(const H16 *src, const H16 *w7, 
 {
     using T = H16;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char *sU = smem;                                        // [340][TAIL_UP] upsampled patch
-    unsigned char *sS = smem + TAIL_UH * TAIL_UW * TAIL_UP;          // [6][18][128 B] source patch ...
-    unsigned char *sH = sS;                                          // ... later [256][TAIL_HP] conv7 output (bf16)
+    unsigned char *sU = smem;                                        // [340][TAIL_UP] upsampled patch ...
+    unsigned char *sH = sU;                                          // ... later [256][TAIL_HP] conv7 output (bf16)
+    unsigned char *sS = smem + TAIL_UH * TAIL_UW * TAIL_UP;          // [6][18][128 B] source patch of the NEXT tile by LDS-DMA
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r16 = lane & 15, kq = lane >> 4;
     const int Ho = Hin * 2, Wo = Win * 2;
@@ -2149,17 +2158,29 @@ __global__ __launch_bounds__(256, 2) void k_tail(const H16 *src, const H16 *w7, 
         ubase[i] = (m >> 5) * TAIL_UW + (m & 31);
     }
     const int sy0 = ho0 / 2 - 1;
+    // source patch of a tile (6 x 18 pixels x 128 B, rows / columns clamped into the image: only clamped positions are ever
+    // referenced) as TAIL_SPIECES DMA pieces of 8 pixels, piece q by wave q % 4.  It is requested while the previous tile is
+    // in its MFMA phase, so that the tile loop never waits for HBM (r02; before, every tile began with a synchronous load).
+    const int src_bytes = Hin * Win * 128;
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    int s_row[(TAIL_SPIECES + 3) / 4], s_col[(TAIL_SPIECES + 3) / 4];  // byte offset of the patch row; patch column, or -1
+#pragma unroll
+    for (int k = 0; k < (TAIL_SPIECES + 3) / 4; k++) {
+        const int pp = (k * 4 + wv) * 8 + (lane >> 3);
+        const int a = pp / TAIL_SW, b = pp - a * TAIL_SW;
+        s_row[k] = min(max(sy0 + a, 0), Hin - 1) * Win * 128 + (lane & 7) * 16;
+        s_col[k] = (k * 4 + wv < TAIL_SPIECES && pp < TAIL_SH * TAIL_SW) ? b : -1;
+    }
+#define RCV_TAIL_SOURCE(sx0_)                                                                                  \
+    _Pragma("unroll") for (int k = 0; k < (TAIL_SPIECES + 3) / 4; k++)                                         \
+        if (k * 4 + wv < TAIL_SPIECES)                                                                       \
+            tail_dma16(sg, src_bytes, sS + (k * 4 + wv) * 1024,                                              \
+                       s_col[k] >= 0 ? s_row[k] + min(max((sx0_) + s_col[k], 0), Win - 1) * 128 : (int)0x80000000);
+    RCV_TAIL_SOURCE(-1);
     for (int tx = 0; tx * TAIL_TW < Wo; tx++) {
-        const int wo0 = tx * TAIL_TW, sx0 = wo0 / 2 - 1;
-        __syncthreads();  // previous tile: every thread is done with sS / sU / sH
-        // ---- source patch, rows/columns clamped into the image (only clamped positions are ever referenced)
-#pragma unroll 1
-        for (int v = tid; v < TAIL_SH * TAIL_SW * 8; v += 256) {
-            const int c = v & 7, pp = v >> 3, a = pp / TAIL_SW, b = pp - a * TAIL_SW;
-            const int ys = min(max(sy0 + a, 0), Hin - 1), xs = min(max(sx0 + b, 0), Win - 1);
-            *(uint4 *)(sS + pp * 128 + c * 16) = *(const uint4 *)(sg + ((long long)ys * Win + xs) * 64 + c * 8);
-        }
-        __syncthreads();
+        const int wo0 = tx * TAIL_TW;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of the source patch (and its stores of the previous tile)
+        __syncthreads();  // the whole patch is in sS; every thread is done with the previous tile's conv7 rows in sU
         // ---- upsampled patch: one task = one source cell (rows ai, ai+1; columns bi, bi+1 of the source patch) and one
         // channel chunk -> the 2 x 2 patch pixels (2ai.., 2bi..) that interpolate inside that cell (k_upsample2's scheme;
         // the patch rows / columns pair up with the cells because ho0 and wo0 are even)
@@ -2195,7 +2216,8 @@ __global__ __launch_bounds__(256, 2) void k_tail(const H16 *src, const H16 *w7, 
                 }
             }
         }
-        __syncthreads();
+        __syncthreads();  // U is complete, sS is free
+        if ((tx + 1) * TAIL_TW < Wo) RCV_TAIL_SOURCE((wo0 + TAIL_TW) / 2 - 1);
         // ---- conv7: K = 9 taps x 64 channels, in k_conv's order (tap-major, 32 channels per MFMA)
         f32x4 acc[4][2];
 #pragma unroll
@@ -2218,6 +2240,7 @@ __global__ __launch_bounds__(256, 2) void k_tail(const H16 *src, const H16 *w7, 
                 asm volatile("" ::: "memory");  // keep the fragment reads of later K steps from being hoisted (registers)
             }
         }
+        __syncthreads();  // every wave is done reading U: its LDS takes the conv7 rows
         // ---- bias + ReLU, rounded to bf16 as the stored conv7 activation would be; operands were swapped, so
         // acc[i][j][e] is channel j*16 + kq*4 + e of pixel pq*64 + i*16 + r16
 #pragma unroll
@@ -2254,6 +2277,7 @@ __global__ __launch_bounds__(256, 2) void k_tail(const H16 *src, const H16 *w7, 
             }
         }
     }
+#undef RCV_TAIL_SOURCE
 }
 
 template <typename T>
