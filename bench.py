@@ -46,6 +46,9 @@ def parse(argv=None):
     ap.add_argument("--no-extras", action="store_true", help="skip the fp32-mode and batch-1 (configs[1]) side measurements")
     ap.add_argument("--cpu-seconds", type=float, default=9.0, help="budget of the CPU vote samples (all frames together)")
     ap.add_argument("--parity-frames", type=int, default=8, help="frames of the last step checked against the oracle")
+    ap.add_argument("--rccl-one-rank", action="store_true",
+                    help="with --gpus 1: build the RCCL communicator anyway and run the per-step all_gather, barrier and "
+                         "all_reduce of the N-rank path in a one-rank group (exercises that path on a one-GPU box)")
     ap.add_argument("--selftest-launcher", action="store_true",
                     help="CPU only: exercise the launcher / rendezvous / gather with gloo ranks and no GPU work (tests)")
     return ap.parse_args(argv)
@@ -261,8 +264,13 @@ def main(argv=None):
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
     torch.cuda.set_device(local)
-    if world > 1:
+    use_dist = world > 1 or args.rccl_one_rank
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:
+            os.environ.setdefault("MASTER_PORT", str(_free_port()))
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
 
     from rcvpose_amd import sharding, synthetic, synthetic_weights
@@ -317,7 +325,7 @@ def main(argv=None):
         rgb, depth, rmax, inject = batches[tuple(ids)]
 
         def collect(k):
-            out = sharding.gather_keypoints(k, B * world)
+            out = sharding.gather_keypoints(k, B * world, always_collective=use_dist)
             host_out[step].copy_(out, non_blocking=True)
 
         pipe.enqueue_step(rgb, depth, rmax, inject=inject, collect=collect)
@@ -325,7 +333,7 @@ def main(argv=None):
 
     def fence():
         pipe.finish()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -346,7 +354,7 @@ def main(argv=None):
     pipe.engine.set_profiling(False)
     pipe.set_stage_timing(False)
     tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
-    if world > 1:
+    if use_dist:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
     frames_total = args.steps * B * world
@@ -433,7 +441,7 @@ def main(argv=None):
             "metric": "end-to-end frames/sec (FCN+3-kpt voting), 640x480 RGB-D",
             "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": args.dtype, "data": "synthetic", "rccl_ranks": dist.get_world_size() if world > 1 else 1,
+            "dtype": args.dtype, "data": "synthetic", "rccl_ranks": dist.get_world_size() if use_dist else 1,
             "config": {"workload": "1-GPU full pipeline: 3x DenseFCNResNet152 forward + seam + LDS radial voting + arg-max, "
                                    "3 keypoints, ~15.5k back-projected pts, 5 mm voxel grid (D~228), 640x480",
                        "frames_per_step_per_gpu": B, "weights": "random (seeded He), ideal maps injected after the forward",
@@ -481,7 +489,7 @@ def main(argv=None):
             line["extras"] = extras(sds, fr, H, W)
         line["ok"] = bool(ok)
         print(json.dumps(line))
-    if world > 1:
+    if use_dist:
         flag = torch.tensor([1 if ok else 0], device="cuda")
         dist.broadcast(flag, src=0)
         ok = bool(flag.item())

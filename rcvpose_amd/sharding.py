@@ -19,13 +19,14 @@ def padded_count(n_frames, world):
     return (n_frames + world - 1) // world
 
 
-def gather_keypoints(local_kpts, n_frames, group=None):
+def gather_keypoints(local_kpts, n_frames, group=None, always_collective=False):
     """local_kpts: [ceil(n_frames/world), G, 3] tensor of this rank's frames (rows past the rank's last
-    frame are padding).  Returns the [n_frames, G, 3] tensor in global frame order on every rank."""
+    frame are padding).  Returns the [n_frames, G, 3] tensor in global frame order on every rank.
+    always_collective: issue the all_gather even in a one-rank group (tests: the RCCL path on a one-GPU box)."""
     import torch
     import torch.distributed as dist
 
-    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if not dist.is_available() or not dist.is_initialized() or (dist.get_world_size(group) == 1 and not always_collective):
         return local_kpts[:n_frames]
     world = dist.get_world_size(group)
     per = padded_count(n_frames, world)
