@@ -432,3 +432,22 @@ def test_latency_kernel_identical_to_register_staged_kernel(shapes, state_dict):
         assert torch.equal(seg_a, seg_b) and torch.equal(rad_a, rad_b), (H, W, B, G)
         for n, t in stages_a.items():
             assert torch.equal(t, eng.debug_stage(B, G - 1, n)), (n, H, W, B, G)
+
+
+def test_fast_kernels_against_the_plain_kernel_over_sizes_and_batches(shapes, state_dict):
+    """The LDS-DMA, halo-patch, fused-block, fused-tail and latency kernels (all on by default) against the register-staged
+    k_conv alone (options 1, 3, 4, 7, 9 off) on image sizes whose tiles are ragged in every layer, batches from one frame
+    to dozens and one to three networks: bit-identical seg / radial maps."""
+    from rcvpose_amd.fcn_engine import FcnEngine
+
+    sds = [state_dict, _sd(shapes, 1), _sd(shapes, 2)]
+    for (H, W, B, G) in ((32, 32, 1, 1), (32, 64, 7, 2), (96, 32, 3, 3), (64, 96, 33, 1), (160, 96, 5, 2), (224, 288, 2, 3),
+                         (480, 640, 1, 3), (480, 640, 2, 1), (256, 640, 11, 2)):
+        x = torch.from_numpy(fcn_weights.make_input(31 + B, (B, 3, H, W))).cuda()
+        eng = FcnEngine(sds[:G], H, W, dtype="bf16")
+        seg_a, rad_a = [t.clone() for t in eng.forward(x)]
+        for key in (1, 3, 4, 7, 9):
+            eng.set_option(key, 0)
+        seg_b, rad_b = eng.forward(x)
+        assert torch.equal(seg_a, seg_b) and torch.equal(rad_a, rad_b), (H, W, B, G)
+        assert bool(torch.isfinite(seg_a).all()) and bool(torch.isfinite(rad_a).all())
