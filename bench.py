@@ -252,6 +252,11 @@ def main(argv=None):
         sys.exit(self_launch(args, argv))  # nothing in this process has touched a GPU yet
     if args.selftest_launcher:
         sys.exit(selftest(args))
+    # stdout carries the JSON line and nothing else: libraries that print to file descriptor 1 (RCCL announces its path there
+    # when the communicator is torn down) are sent to stderr; the line itself goes out through a copy of the real stdout
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -488,7 +493,7 @@ def main(argv=None):
             torch.cuda.empty_cache()
             line["extras"] = extras(sds, fr, H, W)
         line["ok"] = bool(ok)
-        print(json.dumps(line))
+        print(json.dumps(line), file=json_out, flush=True)
     if use_dist:
         flag = torch.tensor([1 if ok else 0], device="cuda")
         dist.broadcast(flag, src=0)

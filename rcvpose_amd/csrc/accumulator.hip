@@ -90,6 +90,9 @@ struct alignas(16) AccHeader {
     int32_t pad_;
     double nd_mean[3];       // x/y/z_mean_mm of :440-442
     unsigned long long climb_center[2];  // 1 + flat index of the voxel the hill-climb round (parity) was centred on; 0: none
+    unsigned long long seed;             // 1 + flat index of the least-squares estimate of the keypoint's voxel (k_bb_seed); 0: none
+    int32_t probe_skip;                  // the round of exact counts around the seed already found a strong peak: no greedy probe
+    int32_t pad2_;
 };
 static_assert(sizeof(AccHeader) <= 512, "AccHeader must fit the 512 bytes reserved in the workspace");
 
@@ -1405,6 +1408,85 @@ __device__ __forceinline__ void d_bb_wide(AccHeader *hdr, const float *F, size_t
 }
 #undef RCV_BBW_TAIL
 
+// Where to start climbing.  Every point says "the keypoint lies r_p voxels from me": |c - q_p|^2 = r_p^2, and the difference
+// to the mean equation is linear in c -- the 4 x 4 normal equations of (c, |c|^2) over the item's points give the
+// multilateration estimate in one pass (coordinates taken relative to the grid centre for conditioning).  With the radii
+// the network is trained to produce it lands within two voxels of the vote peak (bench frames: 0.4 ... 2.0), which one
+// 5 x 5 x 5 round of exact counts turns into the peak itself; the greedy probe alone needed ten rounds of two voxels
+// each.  Only a starting point for exact counts: a poor estimate (outliers, the RGB-only variant) costs nothing but its
+// round.  One workgroup per item, sums in a fixed order (the start voxel is the same from run to run).
+__device__ __forceinline__ void d_bb_seed(AccHeader *hdr, const double *Q, const double *P, const int32_t *ri, int cap)
+{
+    constexpr int NS = 14;  // upper triangle of A^T A (10) + A^T b (4), rows a_p = (-2x, -2y, -2z, 1), b_p = r^2 - |q|^2
+    __shared__ double part[NS][256];
+    __shared__ double tot[NS];
+    const AccHeader H = *hdr;
+    if (H.status != RCV_OK || !H.bb_enabled) return;
+    if (threadIdx.x == 0) hdr->seed = 0;
+    if (H.variant != 0) return;
+    const int n = H.n;
+    const double t0 = 0.5 * (double)H.dim;
+    const double *Phi = P + 4 * (size_t)cap;
+    double sm[NS];
+#pragma unroll
+    for (int k = 0; k < NS; k++) sm[k] = 0.0;
+    for (int p = threadIdx.x; p < n; p += 256) {
+        if (!(Phi[p] > 0.0)) continue;  // never votes
+        const double x = Q[p] - t0, y = Q[(size_t)cap + p] - t0, z = Q[2 * (size_t)cap + p] - t0, r = (double)ri[p];
+        const double a[4] = {-2.0 * x, -2.0 * y, -2.0 * z, 1.0};
+        const double b = r * r - ((x * x + y * y) + z * z);
+        int k = 0;
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+#pragma unroll
+            for (int v = u; v < 4; v++) sm[k++] += a[u] * a[v];
+#pragma unroll
+        for (int u = 0; u < 4; u++) sm[10 + u] += a[u] * b;
+    }
+#pragma unroll
+    for (int k = 0; k < NS; k++) part[k][threadIdx.x] = sm[k];
+    __syncthreads();
+    if (threadIdx.x < NS) {
+        double acc = 0.0;
+        for (int t = 0; t < 256; t++) acc += part[threadIdx.x][t];
+        tot[threadIdx.x] = acc;
+    }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    double M[4][5];
+    {
+        int k = 0;
+        for (int u = 0; u < 4; u++)
+            for (int v = u; v < 4; v++) { M[u][v] = tot[k]; M[v][u] = tot[k]; k++; }
+        for (int u = 0; u < 4; u++) M[u][4] = tot[10 + u];
+    }
+    for (int c = 0; c < 4; c++) {  // Gaussian elimination, partial pivoting
+        int piv = c;
+        for (int r = c + 1; r < 4; r++)
+            if (fabs(M[r][c]) > fabs(M[piv][c])) piv = r;
+        if (!(fabs(M[piv][c]) > 0.0)) return;
+        for (int v = 0; v < 5; v++) { const double tmp = M[c][v]; M[c][v] = M[piv][v]; M[piv][v] = tmp; }
+        for (int r = c + 1; r < 4; r++) {
+            const double f = M[r][c] / M[c][c];
+            for (int v = c; v < 5; v++) M[r][v] -= f * M[c][v];
+        }
+    }
+    double sol[4];
+    for (int c = 3; c >= 0; c--) {
+        double v = M[c][4];
+        for (int u = c + 1; u < 4; u++) v -= M[c][u] * sol[u];
+        sol[c] = v / M[c][c];
+    }
+    long long vox[3];
+    for (int a = 0; a < 3; a++) {
+        const double c = sol[a] + t0;
+        if (!(c > -1.0e6 && c < 1.0e6)) return;  // NaN / far outside: no seed
+        vox[a] = llrint(c);
+        vox[a] = vox[a] < 0 ? 0 : (vox[a] >= H.dim ? H.dim - 1 : vox[a]);
+    }
+    hdr->seed = 1ull + (unsigned long long)((vox[0] * H.dim + vox[1]) * H.dim + vox[2]);
+}
+
 // Hill-climb on exact voxel counts around the best voxel found so far (5 x 5 x 5 neighbourhood, one workgroup
 // per voxel).  The greedy probe lands near the peak; a few rounds of this bring the lower bound to the peak
 // itself (or next to it), which is what lets the wide levels prune.  Purely an accelerator: any exact count
@@ -1420,9 +1502,11 @@ __device__ __forceinline__ void d_bb_climb(AccHeader *hdr, const double *Q, cons
     constexpr int W = BB_CLIMB_W, NV = W * W;
     __shared__ int red[4][NV];
     const AccHeader H = *hdr;
-    if (H.status != RCV_OK || !H.bb_enabled || H.bb_best_key == 0) return;
+    if (H.status != RCV_OK || !H.bb_enabled) return;
+    const bool from_seed = round == 0 && H.seed != 0;  // the first round looks around the least-squares estimate
+    if (!from_seed && H.bb_best_key == 0) return;
     const int D = H.dim, n = H.n;
-    const unsigned long long flat = H.bb_best_key & 0xFFFFFFFFull;
+    const unsigned long long flat = from_seed ? H.seed - 1 : (H.bb_best_key & 0xFFFFFFFFull);
     // converged: the best voxel is the one the previous round was centred on -- its whole neighbourhood has been counted
     // and nothing in it was better.  (Every workgroup of the round reads the same header; the first one records the centre.)
     if (round > 0 && H.climb_center[(round - 1) & 1] == flat + 1) {
@@ -1880,6 +1964,7 @@ __global__ __launch_bounds__(NT) void k_bb_level(int cap, int level, BBIo io, SP
     unsigned char *w = ws.get();
     const BBEntry *in; const uint32_t *in_count; int in_cap; BBEntry *out; uint32_t *out_count; int out_cap;
     bb_resolve(w, L, level, io, in, in_count, in_cap, out, out_count, out_cap);
+    if (io.in_sel && ((const AccHeader *)(w + L.header))->probe_skip) return;  // a probe launch, and the probe is off
     d_bb_level<LAST, WITH_LB, NT>((AccHeader *)(w + L.header), (const double *)(w + L.Q), (const double *)(w + L.P), cap, in,
                                   in_count, in_cap, out, out_count, out_cap, level);
 }
@@ -1894,6 +1979,7 @@ __global__ __launch_bounds__(BBW_THREADS) void k_bb_wide(int cap, int level, SP<
     BBEntry *psel = (BBEntry *)(w + L.bb_probe);
     BBEntry *pkids[2] = {psel + 16, psel + 16 + 8 * BB_BEAM};
     if constexpr (PROBE) {
+        if (hdr->probe_skip) return;
         d_bb_wide<VOX, false, false>(hdr, (const float *)(w + L.F), L.capF, psel, &hdr->sel_count[level], BB_BEAM, pkids[level & 1], nullptr,
                                      &hdr->pb_count[level], 0, 8 * BB_BEAM, level);
     } else {
@@ -1902,6 +1988,19 @@ __global__ __launch_bounds__(BBW_THREADS) void k_bb_wide(int cap, int level, SP<
         d_bb_wide<VOX, PAIRED_IN, PAIR_OUT>(hdr, (const float *)(w + L.F), L.capF, in, in_count, BB_HALF, (level & 1) ? la : lb,
                                             &hdr->bb_count[level + 1], &hdr->bs_count[level + 1], BB_HALF, BB_HALF, level);
     }
+}
+__global__ __launch_bounds__(256) void k_bb_seed(int cap, SP<unsigned char> ws, Layout L)
+{
+    unsigned char *w = ws.get();
+    d_bb_seed((AccHeader *)(w + L.header), (const double *)(w + L.Q), (const double *)(w + L.P), (const int32_t *)(w + L.ri), cap);
+}
+// After the round around the seed: a voxel that an eighth of all points vote for is the peak's neighbourhood for every purpose
+// of the search (its count is the lower bound the wide levels prune with) -- the greedy probe, which exists to find such a
+// voxel, is skipped.  Otherwise (no seed, outliers, several weak maxima) the probe runs as before.
+__global__ void k_bb_gate(SP<unsigned char> ws, Layout L)
+{
+    AccHeader *hdr = (AccHeader *)(ws.get() + L.header);
+    if (threadIdx.x == 0) hdr->probe_skip = (hdr->seed != 0 && (long long)hdr->bb_best * 8 >= (long long)hdr->n) ? 1 : 0;
 }
 __global__ __launch_bounds__(256) void k_bb_climb(int cap, int round, SP<unsigned char> ws, Layout L)
 {
@@ -1923,6 +2022,7 @@ __global__ __launch_bounds__(256) void k_bb_centres(int level, int probe, SP<uns
     BBEntry *la = (BBEntry *)(w + L.bb_lists), *lb = la + BB_CAP;
     BBEntry *psel = (BBEntry *)(w + L.bb_probe);
     BBEntry *pkids[2] = {psel + 16, psel + 16 + 8 * BB_BEAM};
+    if (hdr->probe_skip) return;  // the centre counts only rank blocks for the probe
     // the list that level `level` wrote: the probe's children or the breadth-first list
     if (probe) d_bb_centres(hdr, (const float *)(w + L.F), L.capF, pkids[level & 1], &hdr->pb_count[level], 8 * BB_BEAM, level);
     else {
@@ -1939,6 +2039,7 @@ __global__ __launch_bounds__(1024) void k_bb_topk(int level, SP<unsigned char> w
     BBEntry *la = (BBEntry *)(w + L.bb_lists), *lb = la + BB_CAP;
     BBEntry *psel = (BBEntry *)(w + L.bb_probe);
     BBEntry *pkids[2] = {psel + 16, psel + 16 + 8 * BB_BEAM};
+    if (hdr->probe_skip) return;
     if (level == 1) d_bb_topk(hdr, lb, &hdr->bb_count[1], &hdr->bs_count[1], BB_HALF, BB_HALF, psel, &hdr->sel_count[level]);
     else d_bb_topk(hdr, pkids[(level - 1) & 1], &hdr->pb_count[level - 1], nullptr, 0, 8 * BB_BEAM, psel, &hdr->sel_count[level]);
 }
@@ -2245,6 +2346,14 @@ static int run_engines(int cap, int bb_enable, SP<rcv_acc_result> sres, SP<uint3
     if (bb_enable) {
         hipLaunchKernelGGL(k_bb_init, grid3(256), dim3(256), 0, st, cap, sws, L);
         RCV_LAUNCH_CHECK();
+        // a least-squares estimate of the keypoint's voxel, one round of exact counts around it, and the decision whether the
+        // greedy probe is still needed (r02; see d_bb_seed / k_bb_gate)
+        hipLaunchKernelGGL(k_bb_seed, grid3(1), dim3(256), 0, st, cap, sws, L);
+        RCV_LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_bb_climb, grid3(BB_CLIMB_W), dim3(256), 0, st, cap, 0, sws, L);
+        RCV_LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_bb_gate, items, dim3(64), 0, st, sws, L);
+        RCV_LAUNCH_CHECK();
         // level 0 of the breadth-first search scores the 32-voxel blocks (children of the 64-voxel roots): upper bounds with
         // the wide kernel, then the centre counts that rank them for the probe (r02: was one k_bb_level launch with an exact
         // centre count per child, 2.0 ms per 216 items)
@@ -2269,7 +2378,7 @@ static int run_engines(int cap, int bb_enable, SP<rcv_acc_result> sres, SP<uint3
                 RCV_LAUNCH_CHECK();
             }
         }
-        for (int round = 0; round < BB_CLIMB_ROUNDS; round++) {  // exact hill-climb from the probe's best voxel
+        for (int round = 1; round < BB_CLIMB_ROUNDS; round++) {  // exact hill-climb from the best voxel so far
             hipLaunchKernelGGL(k_bb_climb, grid3(BB_CLIMB_W), dim3(256), 0, st, cap, round, sws, L);
             RCV_LAUNCH_CHECK();
         }
