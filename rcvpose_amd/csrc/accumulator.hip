@@ -1571,6 +1571,7 @@ __device__ __forceinline__ void d_bb_climb(AccHeader *hdr, const double *Q, cons
 constexpr int BBL_THREADS = 256;
 constexpr int BBL_CHUNK = 1024;
 constexpr int BBL_NV = 8;
+constexpr int BBL_PARTS = 8;
 
 __device__ __forceinline__ void d_bb_exact(AccHeader *hdr, const double *Q, const double *P, int cap, BBEntry *list,
                                            const uint32_t *count, int list_cap)
@@ -1579,13 +1580,17 @@ __device__ __forceinline__ void d_bb_exact(AccHeader *hdr, const double *Q, cons
     __shared__ int red[BBL_THREADS / 64][BBL_NV];
     const AccHeader H = *hdr;
     if (H.status != RCV_OK || !H.bb_enabled || H.bb_overflow) return;
-    const int D = H.dim, n = H.n;
+    const int n = H.n;
     const unsigned nin = min(*count, (uint32_t)list_cap);
     const double *Qx = Q, *Qy = Q + (size_t)cap, *Qz = Q + 2 * (size_t)cap;
     const double *Plo = P + 3 * (size_t)cap, *Phi = P + 4 * (size_t)cap;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     constexpr int PT = BBL_CHUNK / BBL_THREADS;
-    for (unsigned pp = blockIdx.x; pp * BBL_NV < nin; pp += gridDim.x) {
+    // workgroup = (group of BBL_NV candidates, every BBL_PARTS-th chunk of the point list): the partial counts are added to the
+    // entries' lb fields (zero on entry) and k_bb_final takes the maximum.  (r02: one workgroup per candidate group walked the
+    // whole list -- with 1 ... 13 candidates per item that was one or two busy workgroups per item, 0.47 ms per 216 items.)
+    const int part = (int)(blockIdx.x % BBL_PARTS);
+    for (unsigned pp = blockIdx.x / BBL_PARTS; pp * BBL_NV < nin; pp += gridDim.x / BBL_PARTS) {
         double ci[BBL_NV], cj[BBL_NV], ck[BBL_NV];
 #pragma unroll
         for (int v = 0; v < BBL_NV; v++) {
@@ -1597,7 +1602,7 @@ __device__ __forceinline__ void d_bb_exact(AccHeader *hdr, const double *Q, cons
 #pragma unroll
         for (int v = 0; v < BBL_NV; v++) { cnt[v] = 0; hist[v] = 0u; }
         int chunk_no = 0;
-        for (int base = 0; base < n; base += BBL_CHUNK, chunk_no++) {
+        for (int base = part * BBL_CHUNK; base < n; base += BBL_PARTS * BBL_CHUNK, chunk_no++) {
             __syncthreads();
             {
                 double rx[PT], ry[PT], rz[PT], rl[PT], rh[PT];
@@ -1644,12 +1649,7 @@ __device__ __forceinline__ void d_bb_exact(AccHeader *hdr, const double *Q, cons
         if (tid < BBL_NV && pp * BBL_NV + tid < nin) {
             int u = 0;
             for (int w = 0; w < BBL_THREADS / 64; w++) u += red[w][tid];
-            BBEntry e = list[pp * BBL_NV + tid];
-            e.ub = u; e.lb = u;
-            list[pp * BBL_NV + tid] = e;
-            atomicMax(&hdr->bb_best, u);
-            const unsigned long long flat = ((unsigned long long)e.i * D + (unsigned long long)e.j) * D + (unsigned long long)e.k;
-            atomicMax(&hdr->bb_best_key, ((unsigned long long)u << 32) | flat);
+            if (u) atomicAdd(&list[pp * BBL_NV + tid].lb, u);
         }
         __syncthreads();  // red[] is rewritten by the next pass
     }
@@ -1762,7 +1762,16 @@ __device__ __forceinline__ void d_bb_final(AccHeader *hdr, const BBEntry *voxels
     if (H.status != RCV_OK || !H.bb_enabled || H.bb_overflow || H.bb_best <= 0) return;  // the rasteriser decides
     const uint32_t nv = H.bs_count[BB_LEVELS];
     if (nv == 0 || nv > (uint32_t)BB_HALF) return;
-    const int peak = H.bb_best;
+    // the peak: the largest exact count among the surviving voxels (k_bb_exact left it in lb).  The voxel that gave the search
+    // its lower bound is one of them, so anything below that bound means a broken list: the rasteriser decides then.
+    __shared__ int s_peak[16];
+    int peak = 0;
+    for (uint32_t t = threadIdx.x; t < nv; t += 1024) peak = max(peak, voxels[t].lb);
+    for (int m = 32; m; m >>= 1) peak = max(peak, __shfl_xor(peak, m));
+    if (lane_id() == 0) s_peak[wave_id()] = peak;
+    __syncthreads();
+    for (int w = 0; w < 16; w++) peak = max(peak, s_peak[w]);
+    if (peak < H.bb_best) return;
     const uint32_t D = (uint32_t)H.dim;
     uint32_t first = 0xFFFFFFFFu;
     int ties = 0;
@@ -2402,7 +2411,7 @@ static int run_engines(int cap, int bb_enable, SP<rcv_acc_result> sres, SP<uint3
             RCV_LAUNCH_CHECK();
         }
         // exact counts of the surviving voxels (float32 bound >= best exact count): typically a few dozen
-        hipLaunchKernelGGL(k_bb_exact, grid3(n_items >= 8 ? 32 : 256 / n_items), dim3(BBL_THREADS), 0, st, cap, sws, L);
+        hipLaunchKernelGGL(k_bb_exact, grid3((n_items >= 8 ? 4 : 32) * BBL_PARTS), dim3(BBL_THREADS), 0, st, cap, sws, L);
         RCV_LAUNCH_CHECK();
         hipLaunchKernelGGL(k_bb_final, items, dim3(1024), 0, st, sres, sws, L);
         RCV_LAUNCH_CHECK();
