@@ -1050,138 +1050,170 @@ __global__ __launch_bounds__(512) void k_conv_halo(const HaloParams p)
 // ---------------------------------------------------------------------------------------------
 constexpr int STEM_TH = 8, STEM_TW = 32, STEM_KP = 160, STEM_PITCH = 336;  // bytes per LDS row: 160 bf16 + 16 (bank spread)
 constexpr int STEM_IH = STEM_TH * 2 + 5, STEM_IW = STEM_TW * 2 + 5;
-constexpr int STEM_LDS = 64 * STEM_PITCH + 3 * STEM_IH * (STEM_IW + 1) * 4 + STEM_KP * 4;  // weights of one group, input patch, tap offsets: 40 KB
+constexpr int STEM_MAXG = 3;   // networks whose weights stay in LDS side by side (more: the kernel is launched per slice of groups)
+constexpr int STEM_RUN = 5;    // consecutive tiles of a tile row per workgroup
+constexpr int STEM_LDS = STEM_MAXG * 64 * STEM_PITCH + 3 * STEM_IH * (STEM_IW + 1) * 2 + STEM_KP * 4;  // weights, input patch (16-bit), tap offsets: 74 KB
 
 // (r02) The im2col tile no longer exists in LDS: every lane builds the MFMA A fragments of its own pixels straight from the
-// fp32 patch (the same bf16 values in the same k order, so the result is unchanged) and keeps them in registers for all
-// groups.  LDS drops from 125 KB to 40 KB, two workgroups share a CU, and one's loads / stores overlap the other's MFMAs.
+// input patch (the same bf16 values in the same k order, so the result is unchanged) and keeps them in registers for all
+// groups.  The weights of all groups are laid into LDS ONCE per workgroup, which then walks STEM_RUN tiles of its tile row
+// (before: 21 KB of weights scattered into LDS per group and tile); the patch is stored as 16-bit values -- the rounding the
+// fragments need anyway -- so that two workgroups still share a CU and one's loads / stores overlap the other's MFMAs.
 __global__ __launch_bounds__(256, 2) void k_stem_mfma(const float *x, const H16 *w, const float *bias, H16 *dst, int H, int W,
                                                       int Ho, int Wo, int groups, long long w_gs, int bias_gs, long long dst_gs)
 {
     using T = H16;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char *sB = smem;                                   // [64][STEM_PITCH]
-    float(*s_in)[STEM_IH][STEM_IW + 1] = (float(*)[STEM_IH][STEM_IW + 1])(smem + 64 * STEM_PITCH);
-    int *s_koff = (int *)(smem + 64 * STEM_PITCH + 3 * STEM_IH * (STEM_IW + 1) * 4);  // [STEM_KP]
+    unsigned char *sBall = smem;                                // [groups][64][STEM_PITCH]
+    T(*s_in)[STEM_IH][STEM_IW + 1] = (T(*)[STEM_IH][STEM_IW + 1])(smem + STEM_MAXG * 64 * STEM_PITCH);
+    int *s_koff = (int *)(smem + STEM_MAXG * 64 * STEM_PITCH + 3 * STEM_IH * (STEM_IW + 1) * 2);  // [STEM_KP]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int tiles_x = (Wo + STEM_TW - 1) / STEM_TW;
-    const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+    const int tiles_x = (Wo + STEM_TW - 1) / STEM_TW, runs_x = (tiles_x + STEM_RUN - 1) / STEM_RUN;
+    const int ty = blockIdx.x / runs_x, run = blockIdx.x - ty * runs_x;
     const int img = blockIdx.y;
-    const int ho0 = ty * STEM_TH, wo0 = tx * STEM_TW;
-    const int hi0 = ho0 * 2 - 3, wi0 = wo0 * 2 - 3;
-    for (int i = tid; i < 3 * STEM_IH * STEM_IW; i += 256) {
-        const int c = i / (STEM_IH * STEM_IW), rem = i - c * (STEM_IH * STEM_IW);
-        const int r = rem / STEM_IW, q = rem - r * STEM_IW;
-        const int hi = hi0 + r, wi = wi0 + q;
-        float v = 0.f;
-        if ((unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W) v = x[((long long)(img * 3 + c) * H + hi) * W + wi];
-        s_in[c][r][q] = v;
+    const int ho0 = ty * STEM_TH, hi0 = ho0 * 2 - 3;
+    // ---- once per workgroup: every group's [64][147] weights into its B tile [64][160] (zero padded)
+    for (int g = 0; g < groups; g++) {
+        const T *wg = w + (long long)g * w_gs;
+        unsigned char *sB = sBall + g * 64 * STEM_PITCH;
+        // 64 x 147 contiguous weights as 16-byte vectors (1176 of them): all of a thread's loads are issued before the
+        // first LDS write; the eight elements of a vector are scattered to their (out channel, k) cells
+        constexpr int NV = 64 * 147 / 8, PER = (NV + 255) / 256;
+        uint4 wv[PER];
+#pragma unroll
+        for (int u = 0; u < PER; u++) {
+            const int i = u * 256 + tid;
+            wv[u] = *(const uint4 *)(wg + (i < NV ? i : 0) * 8);
+        }
+#pragma unroll
+        for (int u = 0; u < PER; u++) {
+            const int i = u * 256 + tid;
+            if (i < NV) {
+                int co = (i * 8) / 147, k = i * 8 - co * 147;
+                const T *pv = (const T *)&wv[u];
+#pragma unroll
+                for (int e = 0; e < 8; e++) {
+                    *(T *)(sB + co * STEM_PITCH + k * 2) = pv[e];
+                    if (++k == 147) { k = 0; co++; }
+                }
+            }
+        }
+        for (int i = tid; i < 64 * (STEM_KP - 147); i += 256) {
+            const int co = i / (STEM_KP - 147), k = 147 + i - co * (STEM_KP - 147);
+            *(T *)(sB + co * STEM_PITCH + k * 2) = (T)0.f;
+        }
     }
     if (tid < STEM_KP) {  // patch offset of tap k = (r*7 + s)*3 + c; the padding taps (k >= 147) are zeroed below
         const int k = tid < 147 ? tid : 0;
         const int c = k % 3, rs = k / 3, r = rs / 7, q = rs - r * 7;
         s_koff[tid] = (c * STEM_IH + r) * (STEM_IW + 1) + q;
     }
-    __syncthreads();
     const int r16 = lane & 15, kq = lane >> 4;
-    // A fragments of this lane: pixel group i (pixel wave*64 + i*16 + r16), K chunk ks: k = ks*32 + kq*8 + e
-    bf16x8 afr[4][STEM_KP / 32];
-    {
-        int koff[STEM_KP / 32][8];
+    const int e_ch = (kq & 1) * 16 + (kq >> 1) * 8;  // + 32 for the second channel-tile pair
+    // the input patch of a tile: all of a thread's loads are in flight together (a rolled loop at the top of every tile waited
+    // for HBM 17 times per tile).  Issuing the NEXT tile's loads before the MFMA phase costs 17 more live registers: spills.
+    constexpr int NE = 3 * STEM_IH * STEM_IW, PERT = (NE + 255) / 256;
+#define RCV_STEM_PATCH(tx_)                                                                                    \
+    {                                                                                                          \
+        const int wi0_ = (tx_) * STEM_TW * 2 - 3;                                                              \
+        _Pragma("unroll") for (int u = 0; u < PERT; u++) {                                                     \
+            const int i = u * 256 + tl;                                                                       \
+            const int c = i / (STEM_IH * STEM_IW), rem = i - c * (STEM_IH * STEM_IW);                          \
+            const int r = rem / STEM_IW, q = rem - r * STEM_IW;                                                \
+            const int hi = hi0 + r, wi = wi0_ + q;                                                             \
+            const bool in = i < NE && (unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W;                \
+            pv[u] = x[in ? ((long long)(img * 3 + c) * H + hi) * W + wi : 0];                                  \
+            pv[u] = in ? pv[u] : 0.f;                                                                          \
+        }                                                                                                      \
+    }
+    const int tx_end = min((run + 1) * STEM_RUN, tiles_x);
+    for (int tx = run * STEM_RUN; tx < tx_end; tx++) {
+        const int wo0 = tx * STEM_TW;
+        {
+            float pv[PERT];
+            int tl = tid;
+            asm volatile("" : "+v"(tl));  // keeps the 17 address computations inside the loop (hoisted, they spill)
+            RCV_STEM_PATCH(tx);
+            __syncthreads();  // the previous tile's fragments are built: the patch may be overwritten (first tile: weights / offsets done)
 #pragma unroll
-        for (int ks = 0; ks < STEM_KP / 32; ks++)
-#pragma unroll
-            for (int e = 0; e < 8; e++) koff[ks][e] = s_koff[ks * 32 + kq * 8 + e];
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const int pix = wave * 64 + i * 16 + r16, py = pix >> 5, px = pix & 31;
-            const float *base = &s_in[0][py * 2][px * 2];
+            for (int u = 0; u < PERT; u++) {
+                const int i = u * 256 + tl;
+                if (i < NE) {
+                    const int c = i / (STEM_IH * STEM_IW), rem = i - c * (STEM_IH * STEM_IW);
+                    const int r = rem / STEM_IW, q = rem - r * STEM_IW;
+                    s_in[c][r][q] = (T)pv[u];
+                }
+            }
+        }
+        __syncthreads();
+        // A fragments of this lane: pixel group i (pixel wave*64 + i*16 + r16), K chunk ks: k = ks*32 + kq*8 + e
+        bf16x8 afr[4][STEM_KP / 32];
+        {
+            int koff[STEM_KP / 32][8];
 #pragma unroll
             for (int ks = 0; ks < STEM_KP / 32; ks++)
 #pragma unroll
-                for (int e = 0; e < 8; e++) afr[i][ks][e] = (T)(ks * 32 + kq * 8 + e < 147 ? base[koff[ks][e]] : 0.f);
-        }
-    }
-    const int e_ch = (kq & 1) * 16 + (kq >> 1) * 8;  // + 32 for the second channel-tile pair
-    for (int g = 0; g < groups; g++) {
-        __syncthreads();  // every wave is done with the patch (g = 0) / with the previous group's B tile
-        const T *wg = w + (long long)g * w_gs;  // [64][147]
-        {
-            // 64 x 147 contiguous weights as 16-byte vectors (1176 of them): all of a thread's loads are issued before the
-            // first LDS write; the eight elements of a vector are scattered to their (out channel, k) cells
-            constexpr int NV = 64 * 147 / 8, PER = (NV + 255) / 256;
-            uint4 wv[PER];
+                for (int e = 0; e < 8; e++) koff[ks][e] = s_koff[ks * 32 + kq * 8 + e];
 #pragma unroll
-            for (int u = 0; u < PER; u++) {
-                const int i = u * 256 + tid;
-                wv[u] = *(const uint4 *)(wg + (i < NV ? i : 0) * 8);
+            for (int i = 0; i < 4; i++) {
+                const int pix = wave * 64 + i * 16 + r16, py = pix >> 5, px = pix & 31;
+                const T *base = &s_in[0][py * 2][px * 2];
+#pragma unroll
+                for (int ks = 0; ks < STEM_KP / 32; ks++)
+#pragma unroll
+                    for (int e = 0; e < 8; e++) afr[i][ks][e] = ks * 32 + kq * 8 + e < 147 ? base[koff[ks][e]] : (T)0.f;
             }
-#pragma unroll
-            for (int u = 0; u < PER; u++) {
-                const int i = u * 256 + tid;
-                if (i < NV) {
-                    int co = (i * 8) / 147, k = i * 8 - co * 147;
-                    const T *pv = (const T *)&wv[u];
-#pragma unroll
-                    for (int e = 0; e < 8; e++) {
-                        *(T *)(sB + co * STEM_PITCH + k * 2) = pv[e];
-                        if (++k == 147) { k = 0; co++; }
-                    }
-                }
-            }
-            if (g == 0)  // the padding columns stay zero for every group
-                for (int i = tid; i < 64 * (STEM_KP - 147); i += 256) {
-                    const int co = i / (STEM_KP - 147), k = 147 + i - co * (STEM_KP - 147);
-                    *(T *)(sB + co * STEM_PITCH + k * 2) = (T)0.f;
-                }
         }
-        __syncthreads();
-        f32x4 acc[4][4];
-#pragma unroll
-        for (int i = 0; i < 4; i++)
-#pragma unroll
-            for (int j = 0; j < 4; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int ks = 0; ks < STEM_KP / 32; ks++) {
-            bf16x8 af[4], bfr[4];
-#pragma unroll
-            for (int i = 0; i < 4; i++) af[i] = afr[i][ks];
-#pragma unroll
-            for (int j = 0; j < 4; j++) bfr[j] = *(const bf16x8 *)(sB + (j * 16 + r16) * STEM_PITCH + (ks * 32 + kq * 8) * 2);
+        for (int g = 0; g < groups; g++) {
+            const unsigned char *sB = sBall + g * 64 * STEM_PITCH;
+            f32x4 acc[4][4];
 #pragma unroll
             for (int i = 0; i < 4; i++)
 #pragma unroll
-                for (int j = 0; j < 4; j++) acc[i][j] = RCV_MFMA16(bfr[j], af[i], acc[i][j], 0, 0, 0);
-        }
-        // acc[i][j][e] = channel j*16 + kq*4 + e of pixel wave*64 + i*16 + r16 (operands swapped); see k_conv_dma's
-        // notes on the permlane16 swap: afterwards the lane owns 8 consecutive channels
-        const float *bg = bias + (long long)g * bias_gs;
-        T *out = dst + (long long)g * dst_gs;
+                for (int j = 0; j < 4; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const int pix = wave * 64 + i * 16 + r16;
-            const int ho = ho0 + (pix >> 5), wo = wo0 + (pix & 31);
+            for (int ks = 0; ks < STEM_KP / 32; ks++) {
+                bf16x8 af[4], bfr[4];
 #pragma unroll
-            for (int pr = 0; pr < 2; pr++) {
-                float v[8];
+                for (int i = 0; i < 4; i++) af[i] = afr[i][ks];
 #pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[i][2 * pr][e]), __float_as_uint(acc[i][2 * pr + 1][e]), false, false);
-                    v[e] = __uint_as_float(sw[0]);
-                    v[4 + e] = __uint_as_float(sw[1]);
+                for (int j = 0; j < 4; j++) bfr[j] = *(const bf16x8 *)(sB + (j * 16 + r16) * STEM_PITCH + (ks * 32 + kq * 8) * 2);
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+#pragma unroll
+                    for (int j = 0; j < 4; j++) acc[i][j] = RCV_MFMA16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+            }
+            // acc[i][j][e] = channel j*16 + kq*4 + e of pixel wave*64 + i*16 + r16 (operands swapped); see k_conv_dma's
+            // notes on the permlane16 swap: afterwards the lane owns 8 consecutive channels
+            const float *bg = bias + (long long)g * bias_gs;
+            T *out = dst + (long long)g * dst_gs;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int pix = wave * 64 + i * 16 + r16;
+                const int ho = ho0 + (pix >> 5), wo = wo0 + (pix & 31);
+#pragma unroll
+                for (int pr = 0; pr < 2; pr++) {
+                    float v[8];
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[i][2 * pr][e]), __float_as_uint(acc[i][2 * pr + 1][e]), false, false);
+                        v[e] = __uint_as_float(sw[0]);
+                        v[4 + e] = __uint_as_float(sw[1]);
+                    }
+                    const int ch = e_ch + pr * 32;
+                    const float4 b0 = *(const float4 *)(bg + ch), b1 = *(const float4 *)(bg + ch + 4);
+                    v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w;
+                    v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+                    uint4 outv;
+                    T *op = (T *)&outv;
+#pragma unroll
+                    for (int qq = 0; qq < 8; qq++) op[qq] = (T)fmaxf(v[qq], 0.f);
+                    if (ho < Ho && wo < Wo) *(uint4 *)(out + ((long long)(img * Ho + ho) * Wo + wo) * 64 + ch) = outv;
                 }
-                const int ch = e_ch + pr * 32;
-                const float4 b0 = *(const float4 *)(bg + ch), b1 = *(const float4 *)(bg + ch + 4);
-                v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w;
-                v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
-                uint4 outv;
-                T *op = (T *)&outv;
-#pragma unroll
-                for (int qq = 0; qq < 8; qq++) op[qq] = (T)fmaxf(v[qq], 0.f);
-                if (ho < Ho && wo < Wo) *(uint4 *)(out + ((long long)(img * Ho + ho) * Wo + wo) * 64 + ch) = outv;
             }
         }
     }
+#undef RCV_STEM_PATCH
 }
 
 // bilinear blend shared by k_upsample2 and the fused tail kernel: hy * (hx * p00 + lx * p01) + ly * (hx * p10 + lx * p11)
@@ -2444,10 +2476,15 @@ int run_op(rcv_fcn *h, const rcv_op &op, const float *x, int B, float *seg, floa
             if (h->use_mfma_stem) {  // MFMA stem (bf16); option 2 = 0 selects the direct fp32-input kernel
                 if (!h->attrs_set)
                     RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_stem_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, STEM_LDS));
-                dim3 grid(((op.hout + STEM_TH - 1) / STEM_TH) * ((op.wout + STEM_TW - 1) / STEM_TW), B);
-                hipLaunchKernelGGL(k_stem_mfma, grid, dim3(256), STEM_LDS, st, x, (const H16 *)w, bias, (H16 *)slot(op.dst), op.hin,
-                                   op.win, op.hout, op.wout, G, (long long)64 * 147, 64, gstride(op.dst));
-                RCV_LAUNCH_CHECK();
+                const int tiles_x = (op.wout + STEM_TW - 1) / STEM_TW, runs_x = (tiles_x + STEM_RUN - 1) / STEM_RUN;
+                dim3 grid(((op.hout + STEM_TH - 1) / STEM_TH) * runs_x, B);
+                for (int g0 = 0; g0 < G; g0 += STEM_MAXG) {  // the weights of up to STEM_MAXG networks share the LDS
+                    const int gn = std::min(STEM_MAXG, G - g0);
+                    hipLaunchKernelGGL(k_stem_mfma, grid, dim3(256), STEM_LDS, st, x, (const H16 *)w + (long long)g0 * 64 * 147, bias + g0 * 64,
+                                       (H16 *)slot(op.dst) + (long long)g0 * gstride(op.dst), op.hin, op.win, op.hout, op.wout, gn,
+                                       (long long)64 * 147, 64, gstride(op.dst));
+                    RCV_LAUNCH_CHECK();
+                }
                 return RCV_OK;
             }
         }
