@@ -43,6 +43,8 @@ constexpr int BB_LEVELS = 6;
 // Probe width and hill-climb length only steer how close the lower bound gets to the peak before the wide levels run
 // (any exact count is a valid bound).  Measured on the bench workload (72 frames x 3 keypoints, seam + voting, ms):
 // beam/rounds 8/8 26.1, 4/8 27.3, 2/8 83.6, 8/4 32.1, 8/12 25.7, 8/16 26.3, 4/12 24.8, 4/16 25.3, 3/16 25.4, 4/24 26.5.
+// (Since the least-squares seed -- k_bb_seed -- two rounds are active on such frames and the probe is gated off; beam and
+// rounds are what an item without a usable seed falls back on.)
 #ifndef RCV_BB_BEAM
 #define RCV_BB_BEAM 4
 #endif
@@ -1430,6 +1432,7 @@ __device__ __forceinline__ void d_bb_seed(AccHeader *hdr, const double *Q, const
     double sm[NS];
 #pragma unroll
     for (int k = 0; k < NS; k++) sm[k] = 0.0;
+#pragma unroll 4
     for (int p = threadIdx.x; p < n; p += 256) {
         if (!(Phi[p] > 0.0)) continue;  // never votes
         const double x = Q[p] - t0, y = Q[(size_t)cap + p] - t0, z = Q[2 * (size_t)cap + p] - t0, r = (double)ri[p];
