@@ -1285,8 +1285,21 @@ constexpr int BLK_RING = 3, BLK_SLOT = 128 * 128;  // expand-weight ring: 16 KB 
 constexpr int blk_lds(int cmid)
 {
     const int p1 = 3 * (BLK_BM + cmid) * 128;
-    const int p2 = BLK_RING * BLK_SLOT + BLK_BM * 256 + (2 * cmid * 128 > BLK_BM * cmid * 2 ? 2 * cmid * 128 : BLK_BM * cmid * 2);
+    const int p2 = BLK_RING * BLK_SLOT + (cmid <= 128 ? 2 : 1) * BLK_BM * 256 + (2 * cmid * 128 > BLK_BM * cmid * 2 ? 2 * cmid * 128 : BLK_BM * cmid * 2);
     return (p1 > p2 ? p1 : p2) + 5 * cmid * 4;
+}
+
+// s_waitcnt vmcnt(n) for an n that is a compile-time constant after unrolling
+__device__ __forceinline__ void blk_vmwait(int n)
+{
+    switch (n) {
+#define RCV_VMW(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
+        RCV_VMW(0) RCV_VMW(1) RCV_VMW(2) RCV_VMW(3) RCV_VMW(4) RCV_VMW(5) RCV_VMW(6) RCV_VMW(7) RCV_VMW(8) RCV_VMW(9) RCV_VMW(10)
+        RCV_VMW(11) RCV_VMW(12) RCV_VMW(13) RCV_VMW(14) RCV_VMW(15) RCV_VMW(16) RCV_VMW(17) RCV_VMW(18) RCV_VMW(19) RCV_VMW(20)
+        RCV_VMW(21) RCV_VMW(22) RCV_VMW(23) RCV_VMW(24) RCV_VMW(25) RCV_VMW(26) RCV_VMW(27) RCV_VMW(28) RCV_VMW(29) RCV_VMW(30)
+#undef RCV_VMW
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
 }
 
 __device__ __forceinline__ void blk_dma16(const void *base, int num_bytes, unsigned char *lds_wave_base, int voffset)
@@ -1491,8 +1504,15 @@ __global__ __launch_bounds__(512) void k_conv_block(const BlockParams p)
     // slots of CMID x 128 B for the reduce layer's weights behind it.
     unsigned char *sA2 = smem;
     unsigned char *sW = CHAIN ? smem : smem + A2_BYTES;
+    // EXACT (one or two K steps per chunk, CMID <= 128): the residual tile is double buffered -- R(nc + 1) is requested when chunk
+    // nc opens -- and every wait counts exactly the operations issued after the one it needs (the chunk's four output stores
+    // included: they are buffer stores, issued by every wave whatever its rows).  Before (r02), R(nc) was requested when its own
+    // chunk opened and waited for one or two short K steps later, and the small counts of the step waits also drained the
+    // previous chunk's stores: both latencies sat in the open in every chunk of the HBM-bound layer-1 / layer-2 blocks.
+    constexpr bool EXACT = !STAG && KS2 <= 2;
+    static_assert(!EXACT || CMID <= 128, "blk_lds reserves the second residual buffer for CMID <= 128");
     unsigned char *sR = sW + BLK_RING * BLK_SLOT;
-    unsigned char *sW3 = sR + BM * 256;  // CHAIN only
+    unsigned char *sW3 = sR + (CMID <= 128 ? 2 : 1) * BM * 256;  // CHAIN only
 #pragma unroll
     for (int i = 0; i < MT1; i++) {
         const int row = wm * (BM / WM1) + i * 16 + r16;
@@ -1557,7 +1577,8 @@ __global__ __launch_bounds__(512) void k_conv_block(const BlockParams p)
 #define RCV_BLK_R(nc_)                                                                                         \
     {                                                                                                          \
         const char *rb_ = (const char *)res + (long long)(nc_) * 128 * 2;                                      \
-        _Pragma("unroll") for (int c = 0; c < 4; c++) blk_dma16(rb_, res_bytes, sR + (wave * 16 + c * 4) * 256, r_off[c]); \
+        unsigned char *rbuf_ = sR + (EXACT ? ((nc_) & 1) * (BM * 256) : 0);                                    \
+        _Pragma("unroll") for (int c = 0; c < 4; c++) blk_dma16(rb_, res_bytes, rbuf_ + (wave * 16 + c * 4) * 256, r_off[c]); \
     }
 #define RCV_BLK_W3(nc_)                                                                                        \
     {                                                                                                          \
@@ -1771,8 +1792,16 @@ __global__ __launch_bounds__(512) void k_conv_block(const BlockParams p)
             for (int k = 0; k < 80; k++) g_blk_stamps[wave >> 2][k] = stamps[k];
 #endif
     } else {
+    // operations a wave issues, in order (EXACT): W(0) W(1) R(0) | per step, after its barrier: [chunk opens: W3(nc), R(nc + 1)]
+    // W(s + 2) | after a chunk's last step: its ST output stores.  Every count below is "issued after X, before this wait".
+    constexpr int P3 = CHAIN ? 2 * W3P : 0, ST = 4;
+    auto open_n = [&](int c) { return EXACT ? P3 + (c + 1 < NCH ? 4 : 0) : 4 + P3; };
+    auto step_n = [&](int st) { return (st % KS2 == 0 ? open_n(st / KS2) : 0) + (st + 2 < S2 ? 2 : 0); };
+    auto closes = [&](int st) { return st % KS2 == KS2 - 1; };
+    const __amdgpu_buffer_rsrc_t dst_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)dst, 0, res_bytes, 0x00020000);
     RCV_BLK_W(0);
     if (S2 > 1) RCV_BLK_W(1);
+    if (EXACT) RCV_BLK_R(0);
 #pragma unroll
     for (int nc = 0; nc < NCH; nc++) {
         f32x4 a2[2][4];
@@ -1783,22 +1812,27 @@ __global__ __launch_bounds__(512) void k_conv_block(const BlockParams p)
 #pragma unroll
         for (int ks = 0; ks < KS2; ks++) {
             const int s_ = nc * KS2 + ks;
-            // younger pieces: W(s_ + 1) and the chunk-opening pieces of step s_ - 1; the last step simply drains
-            if (s_ + 1 >= S2) {
+            if (EXACT) {  // W(s_) has landed
+                if (s_ == 0) blk_vmwait((S2 > 1 ? 2 : 0) + 4);
+                else if (s_ == 1) blk_vmwait(4 + step_n(0) + (closes(0) ? ST : 0));
+                else blk_vmwait((closes(s_ - 2) ? ST : 0) + step_n(s_ - 1) + (closes(s_ - 1) ? ST : 0));
+            } else if (s_ + 1 >= S2) {  // younger pieces: W(s_ + 1) and the chunk-opening pieces of step s_ - 1; the last step simply drains
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             } else if (s_ >= 1 && (s_ - 1) % KS2 == 0) {
-                if constexpr (OPEN_PIECES + 2 == 14) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
-                else if constexpr (OPEN_PIECES + 2 == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-                else if constexpr (OPEN_PIECES + 2 == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                blk_vmwait(OPEN_PIECES + 2);
             } else {
                 asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();  // step s_ has landed for everybody; slot (s_ + 2) % 3 and (ks == 0) sR / sW3 are free
+            __builtin_amdgcn_s_barrier();  // step s_ has landed for everybody; slot (s_ + 2) % 3 and (ks == 0) the sR buffer / sW3 are free
             if (ks == 0) {
-                RCV_BLK_R(nc);
-                if (CHAIN) RCV_BLK_W3(nc);
+                if (EXACT) {  // the reduce weights first: the chunk's epilogue waits for them and leaves R(nc + 1) in flight
+                    if (CHAIN) RCV_BLK_W3(nc);
+                    if (nc + 1 < NCH) RCV_BLK_R(nc + 1);
+                } else {
+                    RCV_BLK_R(nc);
+                    if (CHAIN) RCV_BLK_W3(nc);
+                }
             }
             if (s_ + 2 < S2) RCV_BLK_W(s_ + 2);
             const unsigned char *Ab = sA2 + ks * (BM * 128) + (wm2 * 32 + r16) * 128;
@@ -1817,14 +1851,17 @@ __global__ __launch_bounds__(512) void k_conv_block(const BlockParams p)
                     for (int j = 0; j < 4; j++) a2[i][j] = RCV_MFMA16(bfr[j], af[i], a2[i][j], 0, 0, 0);
             }
         }
-        // epilogue of the chunk.  R(nc) (and the reduce weights) were issued at the chunk's first step; with four K steps per
-        // chunk the later waits (vmcnt 2) already cover them, with one or two steps they are waited for here.
+        // epilogue of the chunk.  With four K steps per chunk the step waits (vmcnt 2) already cover R(nc) and the reduce
+        // weights; with one or two steps they are waited for here: everything issued before the chunk opened (R(nc) among it)
+        // and W3(nc), the first piece of the opening, have landed when only the later pieces of this chunk are outstanding.
         if (KS2 <= 2) {
-            // (after them only W(s + 2) of the opening step and W(s + 3) of the next were issued: four pieces, none at the end)
-            if (KS2 == 1 || nc == NCH - 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            int later = nc + 1 < NCH ? 4 : 0;
+#pragma unroll
+            for (int k = 0; k < KS2; k++) later += nc * KS2 + k + 2 < S2 ? 2 : 0;
+            blk_vmwait(later);
             __builtin_amdgcn_s_barrier();
         }
+        unsigned char *sRc = sR + (EXACT ? (nc & 1) * (BM * 256) : 0);
         // Chained: the rounded outputs go back into the residual's LDS slot, where they are the A operand (K = this chunk's
         // 128 channels) of the reduce layer.
 #pragma unroll
@@ -1843,7 +1880,7 @@ __global__ __launch_bounds__(512) void k_conv_block(const BlockParams p)
                 // (LDS traffic through inline asm: compiler-visible LDS accesses here make hipcc drain vmcnt(0), i.e. wait for
                 // the next chunk's weight pieces that are already in flight)
                 const unsigned baddr = (unsigned)(size_t)(sB2 + nc * 128 + e_ch);
-                const unsigned raddr = (unsigned)(size_t)(sR + row * 256 + (((e_ch >> 3) ^ (row & 15)) << 4));
+                const unsigned raddr = (unsigned)(size_t)(sRc + row * 256 + (((e_ch >> 3) ^ (row & 15)) << 4));
                 f32x4 bA, bB;
                 u32x4 rq;
                 asm volatile("ds_read_b128 %0, %3\n\tds_read_b128 %1, %3 offset:16\n\tds_read_b128 %2, %4\n\ts_waitcnt lgkmcnt(0)"
@@ -1856,7 +1893,9 @@ __global__ __launch_bounds__(512) void k_conv_block(const BlockParams p)
                 T *op = (T *)&outv;
 #pragma unroll
                 for (int e = 0; e < 8; e++) op[e] = (T)v[e];
-                if (m < p.M) *(u32x4 *)(dst + (long long)m * COUT + nc * 128 + e_ch) = outv;
+                // a buffer store: issued by every wave (rows beyond M get an out-of-range offset and are dropped), so that the
+                // counted waits above can rely on four stores per wave and chunk
+                __builtin_amdgcn_raw_buffer_store_b128(outv, dst_rsrc, m < p.M ? (int)(((long long)m * COUT + nc * 128 + e_ch) * 2) : OOB, 0, 0);
                 if (CHAIN) asm volatile("ds_write_b128 %0, %1" ::"v"(raddr), "v"(outv) : "memory");
             }
         }
@@ -1873,7 +1912,7 @@ __global__ __launch_bounds__(512) void k_conv_block(const BlockParams p)
 #pragma unroll
                     for (int i = 0; i < 2; i++) {
                         const int row = wm2 * 32 + i * 16 + r16;
-                        yf[i] = *(const bf16x8 *)(sR + row * 256 + (((h * 8 + kk * 4 + kq) ^ (row & 15)) << 4));
+                        yf[i] = *(const bf16x8 *)(sRc + row * 256 + (((h * 8 + kk * 4 + kq) ^ (row & 15)) << 4));
                     }
                     const unsigned char *Bb = sW3 + h * (CMID * 128) + (wn2 * (CMID / 2) + r16) * 128 + (kk ? ch1 : ch0);
                     constexpr int JG = NT3 < 4 ? NT3 : 4;
