@@ -1282,12 +1282,16 @@ constexpr int BLK_BM = 128;
 constexpr int BLK_RING = 3, BLK_SLOT = 128 * 128;  // expand-weight ring: 16 KB slots (128 out channels x 64 K)
 // LDS bytes of k_conv_block<CMID, .>: the larger of phase 1 (three operand stages) and phase 2 (weight ring, residual /
 // output chunk, and either the `mid` tile or the two reduce-weight slices), plus the fp32 biases of the 1x1 layers
+// CMID = 64 is planned for TWO workgroups per CU (80 KB each, the whole LDS): its expand layer has two stream steps, so two
+// ring slots, one residual buffer, and the 1x1 biases come from global memory instead of LDS.
 constexpr int blk_lds(int cmid)
 {
     const int p1 = 3 * (BLK_BM + cmid) * 128;
-    const int p2 = BLK_RING * BLK_SLOT + (cmid <= 128 ? 2 : 1) * BLK_BM * 256 + (2 * cmid * 128 > BLK_BM * cmid * 2 ? 2 * cmid * 128 : BLK_BM * cmid * 2);
-    return (p1 > p2 ? p1 : p2) + 5 * cmid * 4;
+    const int ring = cmid == 64 ? 2 : BLK_RING, rbuf = cmid == 128 ? 2 : 1;
+    const int p2 = ring * BLK_SLOT + rbuf * BLK_BM * 256 + (2 * cmid * 128 > BLK_BM * cmid * 2 ? 2 * cmid * 128 : BLK_BM * cmid * 2);
+    return (p1 > p2 ? p1 : p2) + (cmid == 64 ? 0 : 5 * cmid * 4);
 }
+static_assert(blk_lds(64) * 2 <= 160 * 1024, "two k_conv_block<64> workgroups share a CU");
 
 // s_waitcnt vmcnt(n) for an n that is a compile-time constant after unrolling
 __device__ __forceinline__ void blk_vmwait(int n)
@@ -1309,7 +1313,7 @@ __device__ __forceinline__ void blk_dma16(const void *base, int num_bytes, unsig
 }
 
 template <int CMID, bool CHAIN, bool STAG = false>
-__global__ __launch_bounds__(512) void k_conv_block(const BlockParams p)
+__global__ __launch_bounds__(512, (CMID == 64 ? 4 : 2)) void k_conv_block(const BlockParams p)
 {
     static_assert(!STAG || (CHAIN && CMID == 256), "the staggered schedule is written for the chained 256-wide block");
     using T = H16;
@@ -1354,9 +1358,13 @@ __global__ __launch_bounds__(512) void k_conv_block(const BlockParams p)
     for (int j = 0; j < NT1; j++)
 #pragma unroll
         for (int e = 0; e < 4; e++) bias1[j][e] = p.b1[(long long)g * p.b1_gs + wn * (CMID / WN1) + j * 16 + kq * 4 + e];
+    constexpr bool GBIAS = CMID == 64;  // no LDS left for the 1x1 biases: read from global memory where they are used
     float *sB2 = (float *)(smem + blk_lds(CMID) - 5 * CMID * 4);  // [COUT] expand bias, [CMID] reduce bias
-    for (int q = tid; q < COUT; q += 512) sB2[q] = p.b2[(long long)g * p.b2_gs + q];
-    if (CHAIN && tid < CMID) sB2[COUT + tid] = p.b3[(long long)g * p.b3_gs + tid];
+    if (!GBIAS) {
+        for (int q = tid; q < COUT; q += 512) sB2[q] = p.b2[(long long)g * p.b2_gs + q];
+        if (CHAIN && tid < CMID) sB2[COUT + tid] = p.b3[(long long)g * p.b3_gs + tid];
+    }
+    const float *b2g = p.b2 + (long long)g * p.b2_gs;
 #pragma unroll
     for (int j = 0; j < NT1; j++)
 #pragma unroll
@@ -1509,10 +1517,12 @@ __global__ __launch_bounds__(512) void k_conv_block(const BlockParams p)
     // included: they are buffer stores, issued by every wave whatever its rows).  Before (r02), R(nc) was requested when its own
     // chunk opened and waited for one or two short K steps later, and the small counts of the step waits also drained the
     // previous chunk's stores: both latencies sat in the open in every chunk of the HBM-bound layer-1 / layer-2 blocks.
-    constexpr bool EXACT = !STAG && KS2 <= 2;
-    static_assert(!EXACT || CMID <= 128, "blk_lds reserves the second residual buffer for CMID <= 128");
-    unsigned char *sR = sW + BLK_RING * BLK_SLOT;
-    unsigned char *sW3 = sR + (CMID <= 128 ? 2 : 1) * BM * 256;  // CHAIN only
+    constexpr bool EXACT = !STAG && CMID == 128;
+    static_assert(!EXACT || KS2 <= 2, "the exact counts below are written for one or two K steps per chunk");
+    constexpr int RING = CMID == 64 ? 2 : BLK_RING;  // (two stream steps in all for CMID = 64)
+    static_assert(RING == BLK_RING || S2 <= 2, "a ring of two slots serves two stream steps");
+    unsigned char *sR = sW + RING * BLK_SLOT;
+    unsigned char *sW3 = sR + (EXACT ? 2 : 1) * BM * 256;  // CHAIN only
 #pragma unroll
     for (int i = 0; i < MT1; i++) {
         const int row = wm * (BM / WM1) + i * 16 + r16;
@@ -1571,7 +1581,7 @@ __global__ __launch_bounds__(512) void k_conv_block(const BlockParams p)
     {                                                                                                          \
         const int nc_ = (s_) / KS2, ks_ = (s_) % KS2;                                                          \
         const char *wb_ = (const char *)w2 + ((long long)nc_ * 128 * CMID + ks_ * KE) * 2;                     \
-        unsigned char *slot_ = sW + ((s_) % BLK_RING) * BLK_SLOT;                                              \
+        unsigned char *slot_ = sW + ((s_) % RING) * BLK_SLOT;                                                  \
         _Pragma("unroll") for (int c = 0; c < 2; c++) blk_dma16(wb_, w_bytes, slot_ + (wave * 16 + c * 8) * 128, w_off[c]); \
     }
 #define RCV_BLK_R(nc_)                                                                                         \
@@ -1809,6 +1819,17 @@ __global__ __launch_bounds__(512) void k_conv_block(const BlockParams p)
         for (int i = 0; i < 2; i++)
 #pragma unroll
             for (int j = 0; j < 4; j++) a2[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // GBIAS: this lane's 2 x 8 expand biases of the chunk, requested before the chunk's pieces (older than everything the
+        // epilogue waits for)
+        float4 gb[2][2];
+        if (GBIAS) {
+#pragma unroll
+            for (int pr = 0; pr < 2; pr++) {
+                const int e_ch = wn2 * 64 + (2 * pr + (kq & 1)) * 16 + (kq >> 1) * 8;
+                gb[pr][0] = *(const float4 *)(b2g + nc * 128 + e_ch);
+                gb[pr][1] = *(const float4 *)(b2g + nc * 128 + e_ch + 4);
+            }
+        }
 #pragma unroll
         for (int ks = 0; ks < KS2; ks++) {
             const int s_ = nc * KS2 + ks;
@@ -1836,7 +1857,7 @@ __global__ __launch_bounds__(512) void k_conv_block(const BlockParams p)
             }
             if (s_ + 2 < S2) RCV_BLK_W(s_ + 2);
             const unsigned char *Ab = sA2 + ks * (BM * 128) + (wm2 * 32 + r16) * 128;
-            const unsigned char *Bb = sW + (s_ % BLK_RING) * BLK_SLOT + (wn2 * 64 + r16) * 128;
+            const unsigned char *Bb = sW + (s_ % RING) * BLK_SLOT + (wn2 * 64 + r16) * 128;
 #pragma unroll
             for (int kk = 0; kk < 2; kk++) {
                 bf16x8 af[2], bfr[4];
@@ -1855,7 +1876,7 @@ __global__ __launch_bounds__(512) void k_conv_block(const BlockParams p)
         // weights; with one or two steps they are waited for here: everything issued before the chunk opened (R(nc) among it)
         // and W3(nc), the first piece of the opening, have landed when only the later pieces of this chunk are outstanding.
         if (KS2 <= 2) {
-            int later = nc + 1 < NCH ? 4 : 0;
+            int later = EXACT && nc + 1 < NCH ? 4 : 0;
 #pragma unroll
             for (int k = 0; k < KS2; k++) later += nc * KS2 + k + 2 < S2 ? 2 : 0;
             blk_vmwait(later);
@@ -1883,8 +1904,14 @@ __global__ __launch_bounds__(512) void k_conv_block(const BlockParams p)
                 const unsigned raddr = (unsigned)(size_t)(sRc + row * 256 + (((e_ch >> 3) ^ (row & 15)) << 4));
                 f32x4 bA, bB;
                 u32x4 rq;
-                asm volatile("ds_read_b128 %0, %3\n\tds_read_b128 %1, %3 offset:16\n\tds_read_b128 %2, %4\n\ts_waitcnt lgkmcnt(0)"
-                             : "=&v"(bA), "=&v"(bB), "=&v"(rq) : "v"(baddr), "v"(raddr) : "memory");
+                if (GBIAS) {
+                    asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(rq) : "v"(raddr) : "memory");
+                    bA = f32x4{gb[pr][0].x, gb[pr][0].y, gb[pr][0].z, gb[pr][0].w};
+                    bB = f32x4{gb[pr][1].x, gb[pr][1].y, gb[pr][1].z, gb[pr][1].w};
+                } else {
+                    asm volatile("ds_read_b128 %0, %3\n\tds_read_b128 %1, %3 offset:16\n\tds_read_b128 %2, %4\n\ts_waitcnt lgkmcnt(0)"
+                                 : "=&v"(bA), "=&v"(bB), "=&v"(rq) : "v"(baddr), "v"(raddr) : "memory");
+                }
                 const float bb[8] = {bA[0], bA[1], bA[2], bA[3], bB[0], bB[1], bB[2], bB[3]};
                 const T *rp = (const T *)&rq;
 #pragma unroll
@@ -1947,7 +1974,8 @@ __global__ __launch_bounds__(512) void k_conv_block(const BlockParams p)
                     v[e] = __uint_as_float(sw[0]);
                     v[4 + e] = __uint_as_float(sw[1]);
                 }
-                const float4 bA = *(const float4 *)(sB2 + COUT + e_ch), bB = *(const float4 *)(sB2 + COUT + e_ch + 4);
+                const float *b3p = GBIAS ? p.b3 + (long long)g * p.b3_gs + e_ch : sB2 + COUT + e_ch;
+                const float4 bA = *(const float4 *)b3p, bB = *(const float4 *)(b3p + 4);
                 const float bb[8] = {bA.x, bA.y, bA.z, bA.w, bB.x, bB.y, bB.z, bB.w};
                 uint4 outv;
                 T *op = (T *)&outv;
