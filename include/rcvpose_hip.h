@@ -246,8 +246,15 @@ int rcv_preprocess_rgb(const uint8_t *rgb_dev, int B, int H, int W, float *x_dev
 /* Storage type of weights and activations (accumulation is always fp32):
  *   RCV_F32   the parity mode: radial maps within 1e-4 of the reference's fp32 forward
  *   RCV_BF16  the throughput mode BASELINE.json names (8 significand bits: map error 1.5-5.5e-2 of range)
- *   RCV_F16   IEEE half at the same speed (11 significand bits: map error ~3e-3; magnitudes beyond 65504 saturate) */
-typedef enum rcv_dtype { RCV_F32 = 0, RCV_BF16 = 1, RCV_F16 = 2 } rcv_dtype;
+ *   RCV_F16   IEEE half at the same speed (11 significand bits: map error ~3e-3; magnitudes beyond 65504 saturate)
+ *   RCV_F16X3 the fast parity mode: every value is a pair of IEEE halves hi + lo (22 significand bits), a product is
+ *             three half-precision MFMAs (hi*hi + hi*lo + lo*hi) accumulated in fp32: maps within 1e-4 of the reference's
+ *             fp32 forward (measured ~5e-6, like RCV_F32) at a third of the fp16 matrix rate instead of a sixteenth.
+ *             Storage: 4 bytes per element, NHWC with channels in groups of 32 as [32 hi | 32 lo]; weights per op
+ *             [G][cout][kh][kw][cin/32][hi 32 | lo 32], each output channel scaled by a power of two 2^k (so that the lo
+ *             halves are normal numbers) and biases per op [G][cout bias | cout scale 2^-k]; magnitudes beyond 131008
+ *             saturate.  Packing: rcvpose_amd/fcn_engine.py::pack_weights. */
+typedef enum rcv_dtype { RCV_F32 = 0, RCV_BF16 = 1, RCV_F16 = 2, RCV_F16X3 = 3 } rcv_dtype;
 
 typedef enum rcv_op_kind {
     RCV_OP_STEM = 1,     /* conv1 7x7 s2 p3 (no bias) + BN + ReLU, NCHW fp32 in -> NHWC out; fcnresnet.py:54-57,123-125 */

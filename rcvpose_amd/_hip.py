@@ -26,6 +26,7 @@ VOTE_ENGINES = {"auto": RCV_VOTE_AUTO, "full": RCV_VOTE_RASTER}
 RCV_F32 = 0
 RCV_BF16 = 1
 RCV_F16 = 2
+RCV_F16X3 = 3
 
 OP_STEM, OP_MAXPOOL, OP_CONV, OP_UPSAMPLE2, OP_HEAD = 1, 2, 3, 4, 5
 SLOT_NONE, SLOT_INPUT, SLOT_OUTPUT = -1, -2, -3

@@ -21,6 +21,7 @@ SOURCES = {
     "accumulator.hip": ["-ffp-contract=off"],
     "fcn.hip": [],
     "fcn_f16.hip": [],   # fcn.hip again with IEEE half as the 16-bit storage type
+    "fcn_x3.hip": [],    # ... and as the split-precision engine (half hi / lo pairs, three MFMAs per product)
     "pose.hip": ["-ffp-contract=off"],
     "icp.hip": ["-ffp-contract=off"],
 }
@@ -55,7 +56,7 @@ def build_library(force=False, verbose=False):
             continue
         obj = os.path.join(obj_dir, src.replace(".hip", ".o"))
         objs.append(obj)
-        if force or _stale(obj, [sp] + headers + ([os.path.join(CSRC, "fcn.hip")] if src == "fcn_f16.hip" else [])):
+        if force or _stale(obj, [sp] + headers + ([os.path.join(CSRC, "fcn.hip")] if src in ("fcn_f16.hip", "fcn_x3.hip") else [])):
             cmd = [_hipcc()] + COMMON + extra + ["-c", sp, "-o", obj]
             if verbose:
                 print(" ".join(cmd))

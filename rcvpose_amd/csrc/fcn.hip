@@ -41,12 +41,24 @@ namespace {
 // with RCV_FCN_FP16 defined (IEEE half: RCV_F16 -- 11 instead of 8 significand bits, the same MFMA rate; values beyond
 // 65504 saturate to infinity, which BN-folded ResNet activations stay far away from).  Everything below is written against
 // H16 / h16x8 / RCV_MFMA16; the kernels live in an anonymous namespace, so the two translation units do not collide.
-#ifdef RCV_FCN_FP16
+#if defined(RCV_FCN_X3)
+// Third compilation (fcn_x3.hip): the split-precision engine RCV_F16X3.  Every activation and weight is a PAIR of IEEE halves
+// hi = half(v), lo = half(v - hi) (22 significand bits together), a product is three MFMAs hi*hi + hi*lo + lo*hi accumulated in
+// fp32 (the lo*lo term is below 2^-22), i.e. fp32-grade results at a third of the fp16 matrix rate instead of a sixteenth
+// (v_mfma_f32_16x16x4_f32).  Storage: NHWC with the channels in groups of 32, [32 hi | 32 lo] = one 128-byte K row of the
+// GEMM tiles, so a tensor looks like a 16-bit tensor with twice the channels to every loader; weights likewise, scaled per
+// output channel by a power of two (undone exactly in the epilogue) so that their lo halves stay normal numbers.
 typedef _Float16 H16;
 #define RCV_MFMA16 __builtin_amdgcn_mfma_f32_16x16x32_f16
+constexpr bool kX3 = true;
+#elif defined(RCV_FCN_FP16)
+typedef _Float16 H16;
+#define RCV_MFMA16 __builtin_amdgcn_mfma_f32_16x16x32_f16
+constexpr bool kX3 = false;
 #else
 typedef __bf16 H16;
 #define RCV_MFMA16 __builtin_amdgcn_mfma_f32_16x16x32_bf16
+constexpr bool kX3 = false;
 #endif
 typedef __attribute__((ext_vector_type(8))) H16 bf16x8;  // (name kept: eight 16-bit elements = one MFMA operand)
 typedef __attribute__((ext_vector_type(4))) float f32x4;
@@ -67,6 +79,37 @@ __device__ __forceinline__ float to_f32(H16 v) { return (float)v; }
 template <typename T> __device__ __forceinline__ T from_f32(float v);
 template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
 template <> __device__ __forceinline__ H16 from_f32<H16>(float v) { return (H16)v; }
+
+// ---- split-precision storage (kX3): element (pixel, channel c) of a C-channel tensor lives at halves
+// pixel * 2C + x3_off(c) (hi) and + 32 (lo)
+template <typename T> constexpr bool is_x3() { return kX3 && sizeof(T) == 2; }
+__device__ __forceinline__ int x3_off(int c) { return ((c >> 5) << 6) + (c & 31); }
+// offset (in elements of T) of channel n of row m in an [M][C] NHWC tensor
+template <typename T> __device__ __forceinline__ long long nhwc_off(long long m, int C, int n)
+{
+    if constexpr (is_x3<T>()) return m * (2LL * C) + x3_off(n);
+    else return m * C + n;
+}
+// v -> (hi, lo); magnitudes beyond the half range saturate (65504 + 65504) instead of turning into inf - inf
+__device__ __forceinline__ void x3_split(float v, H16 &hi, H16 &lo)
+{
+    const float h = __builtin_amdgcn_fmed3f(v, -65504.f, 65504.f);
+    hi = (H16)h;
+    lo = (H16)__builtin_amdgcn_fmed3f(v - (float)hi, -65504.f, 65504.f);
+}
+// eight consecutive channels as two 16-byte vectors
+__device__ __forceinline__ void x3_split8(const float *v, uint4 &hi, uint4 &lo)
+{
+    H16 *ph = (H16 *)&hi, *pl = (H16 *)&lo;
+#pragma unroll
+    for (int e = 0; e < 8; e++) x3_split(v[e], ph[e], pl[e]);
+}
+__device__ __forceinline__ void x3_join8(const uint4 &hi, const uint4 &lo, float *v)
+{
+    const H16 *ph = (const H16 *)&hi, *pl = (const H16 *)&lo;
+#pragma unroll
+    for (int e = 0; e < 8; e++) v[e] = (float)ph[e] + (float)pl[e];
+}
 
 struct ConvParams {
     const void *src0, *src1, *res, *w;
@@ -185,7 +228,18 @@ __global__ __launch_bounds__(256) void k_conv(const ConvParams p)
     {                                                                                                        \
         const unsigned char *Ab = As + (buf) * BM * 128 + (wm * (BM / 2) + r16) * 128;                       \
         const unsigned char *Bb = Bs + (buf) * BN * 128 + (wn * (BN / 2) + r16) * 128;                       \
-        if constexpr (sizeof(T) == 2) {                                                                      \
+        if constexpr (is_x3<T>()) {  /* [32 hi | 32 lo] K row: hi*hi, hi*lo, lo*hi */                    \
+            bf16x8 ah[MT], al[MT], bh[NT], bl[NT];                                                           \
+            const int chh = (kq ^ ((r16 >> 1) & 7)) << 4, chl = ((4 + kq) ^ ((r16 >> 1) & 7)) << 4;         \
+            _Pragma("unroll") for (int i = 0; i < MT; i++) { ah[i] = *(const bf16x8 *)(Ab + i * 16 * 128 + chh); al[i] = *(const bf16x8 *)(Ab + i * 16 * 128 + chl); } \
+            _Pragma("unroll") for (int j = 0; j < NT; j++) { bh[j] = *(const bf16x8 *)(Bb + j * 16 * 128 + chh); bl[j] = *(const bf16x8 *)(Bb + j * 16 * 128 + chl); } \
+            _Pragma("unroll") for (int i = 0; i < MT; i++)                                                   \
+                _Pragma("unroll") for (int j = 0; j < NT; j++) acc[i][j] = RCV_MFMA16(ah[i], bh[j], acc[i][j], 0, 0, 0); \
+            _Pragma("unroll") for (int i = 0; i < MT; i++)                                                   \
+                _Pragma("unroll") for (int j = 0; j < NT; j++) acc[i][j] = RCV_MFMA16(ah[i], bl[j], acc[i][j], 0, 0, 0); \
+            _Pragma("unroll") for (int i = 0; i < MT; i++)                                                   \
+                _Pragma("unroll") for (int j = 0; j < NT; j++) acc[i][j] = RCV_MFMA16(al[i], bh[j], acc[i][j], 0, 0, 0); \
+        } else if constexpr (sizeof(T) == 2) {                                                               \
             _Pragma("unroll") for (int kk = 0; kk < 2; kk++) {                                               \
                 bf16x8 af[MT], bfr[NT];                                                                      \
                 const int ch = ((kk * 4 + kq) ^ ((r16 >> 1) & 7)) << 4;                                             \
@@ -249,7 +303,8 @@ __global__ __launch_bounds__(256) void k_conv(const ConvParams p)
     constexpr int PER = (CHUNKS + 255) / 256;    // chunks per thread per round
     float *stage = (float *)smem;
     // the residual tile is fetched for both rounds up front: its latency hides behind the LDS staging
-    uint4 rres[2][PER];
+    constexpr int RV = is_x3<T>() ? 2 : 1;       // 16-byte vectors per chunk (split storage: hi and lo)
+    uint4 rres[2][PER][RV];
     if (res) {
 #pragma unroll
         for (int round = 0; round < 2; round++)
@@ -257,8 +312,10 @@ __global__ __launch_bounds__(256) void k_conv(const ConvParams p)
             for (int q = 0; q < PER; q++) {
                 const int c = q * 256 + tid, row = c / CPR, cc = c - row * CPR;
                 const int m = m0 + round * (BM / 2) + row;
-                rres[round][q] = (c < CHUNKS && m < p.M) ? *(const uint4 *)(res + (long long)m * p.Cout + n0 + cc * EPV)
-                                                         : make_uint4(0u, 0u, 0u, 0u);
+                const bool live = c < CHUNKS && m < p.M;
+                const T *rp = res + nhwc_off<T>(m, p.Cout, n0 + cc * EPV);
+#pragma unroll
+                for (int h = 0; h < RV; h++) rres[round][q][h] = live ? *(const uint4 *)(rp + 32 * h) : make_uint4(0u, 0u, 0u, 0u);
             }
     }
 #pragma unroll
@@ -269,10 +326,12 @@ __global__ __launch_bounds__(256) void k_conv(const ConvParams p)
             for (int j = 0; j < NT; j++) {
                 const int nl = wn * (BN / 2) + j * 16 + r16;
                 const float bv = bias[n0 + nl];
+                const float sc = is_x3<T>() ? bias[p.Cout + n0 + nl] : 1.f;  // (split mode: the weights' power-of-two scale, undone here)
 #pragma unroll
                 for (int i = 0; i < MT; i++)
 #pragma unroll
-                    for (int e = 0; e < 4; e++) stage[(i * 16 + kq * 4 + e) * SROW + nl] = acc[i][j][e] + bv;
+                    for (int e = 0; e < 4; e++)
+                        stage[(i * 16 + kq * 4 + e) * SROW + nl] = is_x3<T>() ? __fmaf_rn(acc[i][j][e], sc, bv) : acc[i][j][e] + bv;
             }
         }
         __syncthreads();
@@ -281,7 +340,7 @@ __global__ __launch_bounds__(256) void k_conv(const ConvParams p)
             const int c = q * 256 + tid, row = c / CPR, cc = c - row * CPR;
             const int m = m0 + round * (BM / 2) + row;
             if (c >= CHUNKS || m >= p.M) continue;
-            const long long o = (long long)m * p.Cout + n0 + cc * EPV;
+            const long long o = nhwc_off<T>(m, p.Cout, n0 + cc * EPV);
             float v[EPV];
             const float4 *sp4 = (const float4 *)(stage + row * SROW + cc * EPV);
 #pragma unroll
@@ -290,19 +349,33 @@ __global__ __launch_bounds__(256) void k_conv(const ConvParams p)
                 v[qq * 4 + 0] = t.x; v[qq * 4 + 1] = t.y; v[qq * 4 + 2] = t.z; v[qq * 4 + 3] = t.w;
             }
             if (res) {
-                const T *rp = (const T *)&rres[round][q];
+                if constexpr (is_x3<T>()) {
+                    float rv[8];
+                    x3_join8(rres[round][q][0], rres[round][q][RV - 1], rv);
 #pragma unroll
-                for (int qq = 0; qq < EPV; qq++) v[qq] += to_f32(rp[qq]);
+                    for (int qq = 0; qq < EPV; qq++) v[qq] += rv[qq];
+                } else {
+                    const T *rp = (const T *)&rres[round][q][0];
+#pragma unroll
+                    for (int qq = 0; qq < EPV; qq++) v[qq] += to_f32(rp[qq]);
+                }
             }
             if (p.relu) {
 #pragma unroll
                 for (int qq = 0; qq < EPV; qq++) v[qq] = fmaxf(v[qq], 0.f);
             }
-            uint4 outv;
-            T *op = (T *)&outv;
+            if constexpr (is_x3<T>()) {
+                uint4 oh, ol;
+                x3_split8(v, oh, ol);
+                *(uint4 *)(dst + o) = oh;
+                *(uint4 *)(dst + o + 32) = ol;
+            } else {
+                uint4 outv;
+                T *op = (T *)&outv;
 #pragma unroll
-            for (int qq = 0; qq < EPV; qq++) op[qq] = from_f32<T>(v[qq]);
-            *(uint4 *)(dst + o) = outv;
+                for (int qq = 0; qq < EPV; qq++) op[qq] = from_f32<T>(v[qq]);
+                *(uint4 *)(dst + o) = outv;
+            }
         }
     }
 }
@@ -2019,13 +2092,14 @@ __global__ __launch_bounds__(256) void k_stem(const float *x, const T *w, const 
     const T *wg = w + (long long)g * w_gs;  // [64][7][7][3]
     for (int i = tid; i < 147 * 64; i += 256) {
         const int co = i / 147, t = i - co * 147;
-        s_w[t][co] = to_f32(wg[i]);
+        if constexpr (is_x3<T>()) s_w[t][co] = to_f32(wg[i]) + to_f32(wg[147 * 64 + i]);  // [all hi][all lo], scaled (see the epilogue)
+        else s_w[t][co] = to_f32(wg[i]);
     }
     __syncthreads();
     const int py = tid >> 4, px = tid & 15;
     const int ho = ho0 + py, wo = wo0 + px;
     const float *bg = bias + (long long)g * bias_gs;
-    T *out = dst + (long long)g * dst_gs + ((long long)(img * Ho + ho) * Wo + wo) * 64;
+    T *out = dst + (long long)g * dst_gs + ((long long)(img * Ho + ho) * Wo + wo) * (is_x3<T>() ? 128 : 64);
     for (int cb = 0; cb < 64; cb += 16) {
         float acc[16];
 #pragma unroll
@@ -2046,8 +2120,16 @@ __global__ __launch_bounds__(256) void k_stem(const float *x, const T *w, const 
                     }
                 }
         if (ho < Ho && wo < Wo) {
+            if constexpr (is_x3<T>()) {
 #pragma unroll
-            for (int q = 0; q < 16; q++) out[cb + q] = from_f32<T>(fmaxf(acc[q] + bg[cb + q], 0.f));
+                for (int q = 0; q < 16; q++) {
+                    const float v = fmaxf(__fmaf_rn(acc[q], bg[64 + cb + q], bg[cb + q]), 0.f);
+                    x3_split(v, out[x3_off(cb + q)], out[x3_off(cb + q) + 32]);
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < 16; q++) out[cb + q] = from_f32<T>(fmaxf(acc[q] + bg[cb + q], 0.f));
+            }
         }
     }
 }
@@ -2073,17 +2155,33 @@ __global__ __launch_bounds__(256) void k_maxpool(const T *src, T *dst, int C, in
             for (int s = 0; s < 3; s++) {
                 const int wi = wo * 2 - 1 + s;
                 if ((unsigned)wi >= (unsigned)Win) continue;
-                const uint4 raw = *(const uint4 *)(src + (long long)g * src_gs + (((long long)img * Hin + hi) * Win + wi) * C + c * EPV);
-                const T *pv = (const T *)&raw;
+                const T *sp = src + (long long)g * src_gs + nhwc_off<T>(((long long)img * Hin + hi) * Win + wi, C, c * EPV);
+                const uint4 raw = *(const uint4 *)sp;
+                if constexpr (is_x3<T>()) {
+                    float f[8];
+                    x3_join8(raw, *(const uint4 *)(sp + 32), f);
 #pragma unroll
-                for (int e = 0; e < EPV; e++) best[e] = fmaxf(best[e], to_f32(pv[e]));
+                    for (int e = 0; e < EPV; e++) best[e] = fmaxf(best[e], f[e]);
+                } else {
+                    const T *pv = (const T *)&raw;
+#pragma unroll
+                    for (int e = 0; e < EPV; e++) best[e] = fmaxf(best[e], to_f32(pv[e]));
+                }
             }
         }
-        uint4 o;
-        T *po = (T *)&o;
+        T *dp = dst + (long long)g * dst_gs + nhwc_off<T>(pix, C, c * EPV);
+        if constexpr (is_x3<T>()) {
+            uint4 oh, ol;
+            x3_split8(best, oh, ol);
+            *(uint4 *)dp = oh;
+            *(uint4 *)(dp + 32) = ol;
+        } else {
+            uint4 o;
+            T *po = (T *)&o;
 #pragma unroll
-        for (int e = 0; e < EPV; e++) po[e] = from_f32<T>(best[e]);
-        *(uint4 *)(dst + (long long)g * dst_gs + pix * C + c * EPV) = o;
+            for (int e = 0; e < EPV; e++) po[e] = from_f32<T>(best[e]);
+            *(uint4 *)dp = o;
+        }
     }
 }
 
@@ -2107,16 +2205,23 @@ __global__ __launch_bounds__(256) void k_upsample2(const T *src, T *dst, int C, 
         const int b = (int)(cell % cells_w) - 1, a = (int)((cell / cells_w) % cells_h) - 1;
         const int img = (int)(cell / ((long long)cells_w * cells_h));
         const int r0 = max(a, 0), r1 = min(a + 1, Hin - 1), c0 = max(b, 0), c1 = min(b + 1, Win - 1);
-        const T *base = src + (long long)g * src_gs + (long long)img * Hin * Win * C + c * EPV;
-        const uint4 q00 = *(const uint4 *)(base + ((long long)r0 * Win + c0) * C);
-        const uint4 q01 = *(const uint4 *)(base + ((long long)r0 * Win + c1) * C);
-        const uint4 q10 = *(const uint4 *)(base + ((long long)r1 * Win + c0) * C);
-        const uint4 q11 = *(const uint4 *)(base + ((long long)r1 * Win + c1) * C);
-        const T *p00 = (const T *)&q00, *p01 = (const T *)&q01, *p10 = (const T *)&q10, *p11 = (const T *)&q11;
+        constexpr int PS = is_x3<T>() ? 2 : 1;  // elements of T per channel and pixel
+        const T *base = src + (long long)g * src_gs + (long long)img * Hin * Win * C * PS + nhwc_off<T>(0, C, c * EPV);
+        const T *a00 = base + ((long long)r0 * Win + c0) * C * PS, *a01 = base + ((long long)r0 * Win + c1) * C * PS;
+        const T *a10 = base + ((long long)r1 * Win + c0) * C * PS, *a11 = base + ((long long)r1 * Win + c1) * C * PS;
+        const uint4 q00 = *(const uint4 *)a00, q01 = *(const uint4 *)a01, q10 = *(const uint4 *)a10, q11 = *(const uint4 *)a11;
         float f00[EPV], f01[EPV], f10[EPV], f11[EPV];
+        if constexpr (is_x3<T>()) {
+            x3_join8(q00, *(const uint4 *)(a00 + 32), f00);
+            x3_join8(q01, *(const uint4 *)(a01 + 32), f01);
+            x3_join8(q10, *(const uint4 *)(a10 + 32), f10);
+            x3_join8(q11, *(const uint4 *)(a11 + 32), f11);
+        } else {
+            const T *p00 = (const T *)&q00, *p01 = (const T *)&q01, *p10 = (const T *)&q10, *p11 = (const T *)&q11;
 #pragma unroll
-        for (int e = 0; e < EPV; e++) { f00[e] = to_f32(p00[e]); f01[e] = to_f32(p01[e]); f10[e] = to_f32(p10[e]); f11[e] = to_f32(p11[e]); }
-        T *out = dst + (long long)g * dst_gs + (long long)img * Hout * Wout * C + c * EPV;
+            for (int e = 0; e < EPV; e++) { f00[e] = to_f32(p00[e]); f01[e] = to_f32(p01[e]); f10[e] = to_f32(p10[e]); f11[e] = to_f32(p11[e]); }
+        }
+        T *out = dst + (long long)g * dst_gs + (long long)img * Hout * Wout * C * PS + nhwc_off<T>(0, C, c * EPV);
 #pragma unroll
         for (int dy = 1; dy <= 2; dy++) {
             const int y = 2 * a + dy;
@@ -2131,11 +2236,22 @@ __global__ __launch_bounds__(256) void k_upsample2(const T *src, T *dst, int C, 
                 int x0, x1;
                 float lx, hx;
                 up2_src(x, Win, x0, x1, lx, hx);
-                uint4 o;
-                T *po = (T *)&o;
+                T *op = out + ((long long)y * Wout + x) * C * PS;
+                if constexpr (is_x3<T>()) {
+                    float bl[8];
 #pragma unroll
-                for (int e = 0; e < EPV; e++) po[e] = from_f32<T>(bilerp(hy, hx, ly, lx, f00[e], f01[e], f10[e], f11[e]));
-                *(uint4 *)(out + ((long long)y * Wout + x) * C) = o;
+                    for (int e = 0; e < EPV; e++) bl[e] = bilerp(hy, hx, ly, lx, f00[e], f01[e], f10[e], f11[e]);
+                    uint4 oh, ol;
+                    x3_split8(bl, oh, ol);
+                    *(uint4 *)op = oh;
+                    *(uint4 *)(op + 32) = ol;
+                } else {
+                    uint4 o;
+                    T *po = (T *)&o;
+#pragma unroll
+                    for (int e = 0; e < EPV; e++) po[e] = from_f32<T>(bilerp(hy, hx, ly, lx, f00[e], f01[e], f10[e], f11[e]));
+                    *(uint4 *)op = o;
+                }
             }
         }
     }
@@ -2151,22 +2267,36 @@ __global__ __launch_bounds__(256) void k_head(const T *src, const T *w, const fl
     const int g = blockIdx.y;
     const T *wg = w + (long long)g * w_gs;
     const float b0 = bias[(long long)g * bias_gs], b1 = bias[(long long)g * bias_gs + 1];
+    // split mode: weights as [2C hi][2C lo] scaled by the powers of two behind the biases
+    const float s0 = is_x3<T>() ? bias[(long long)g * bias_gs + 2] : 1.f, s1 = is_x3<T>() ? bias[(long long)g * bias_gs + 3] : 1.f;
     for (long long pix = (long long)blockIdx.x * 256 + threadIdx.x; pix < npix; pix += (long long)gridDim.x * 256) {
         float a0 = 0.f, a1 = 0.f;
-        const T *ps = src + (long long)g * src_gs + pix * C;
+        const T *ps = src + (long long)g * src_gs + nhwc_off<T>(pix, C, 0);
         for (int c = 0; c < C; c += EPV) {
-            const uint4 raw = *(const uint4 *)(ps + c);
-            const T *pv = (const T *)&raw;
+            if constexpr (is_x3<T>()) {
+                const T *pp = ps + x3_off(c);
+                float f[8];
+                x3_join8(*(const uint4 *)pp, *(const uint4 *)(pp + 32), f);
 #pragma unroll
-            for (int e = 0; e < EPV; e++) {
-                const float v = to_f32(pv[e]);
-                a0 = fmaf(v, to_f32(wg[c + e]), a0);
-                a1 = fmaf(v, to_f32(wg[C + c + e]), a1);
+                for (int e = 0; e < EPV; e++) {
+                    a0 = fmaf(f[e], to_f32(wg[c + e]) + to_f32(wg[2 * C + c + e]), a0);
+                    a1 = fmaf(f[e], to_f32(wg[C + c + e]) + to_f32(wg[3 * C + c + e]), a1);
+                }
+            } else {
+                const uint4 raw = *(const uint4 *)(ps + c);
+                const T *pv = (const T *)&raw;
+#pragma unroll
+                for (int e = 0; e < EPV; e++) {
+                    const float v = to_f32(pv[e]);
+                    a0 = fmaf(v, to_f32(wg[c + e]), a0);
+                    a1 = fmaf(v, to_f32(wg[C + c + e]), a1);
+                }
             }
         }
-        seg[(long long)g * npix + pix] = a0 + b0;
-        if (rad_f16) ((_Float16 *)radial)[(long long)g * npix + pix] = (_Float16)(a1 + b1);  // engine option 8
-        else radial[(long long)g * npix + pix] = a1 + b1;
+        const float o0 = is_x3<T>() ? __fmaf_rn(a0, s0, b0) : a0 + b0, o1 = is_x3<T>() ? __fmaf_rn(a1, s1, b1) : a1 + b1;
+        seg[(long long)g * npix + pix] = o0;
+        if (rad_f16) ((_Float16 *)radial)[(long long)g * npix + pix] = (_Float16)o1;  // engine option 8
+        else radial[(long long)g * npix + pix] = o1;
     }
 }
 
@@ -2382,7 +2512,12 @@ __global__ __launch_bounds__(256, 2) void k_tail(const H16 *src, const H16 *w7, 
 template <typename T>
 __global__ void k_slot_to_f32(const T *src, float *dst, long long n)
 {
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) dst[i] = to_f32(src[i]);
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        if constexpr (is_x3<T>()) {  // every tensor has a multiple of 32 channels: logical element i -> its group of 32
+            const long long o = ((i >> 5) << 6) + (i & 31);
+            dst[i] = to_f32(src[o]) + to_f32(src[o + 32]);
+        } else dst[i] = to_f32(src[i]);
+    }
 }
 
 }  // namespace
@@ -2418,7 +2553,7 @@ struct rcv_fcn {
 namespace {
 
 
-size_t esize(int dtype) { return dtype == RCV_F32 ? 4 : 2; }
+size_t esize(int dtype) { return dtype == RCV_F32 || dtype == RCV_F16X3 ? 4 : 2; }  // (split storage: two halves per element)
 
 void slot_offsets(const rcv_fcn *h, int B, std::vector<size_t> &off, size_t &total)
 {
@@ -2505,10 +2640,10 @@ int launch_conv(const ConvParams &p, int groups, hipStream_t st, bool set_attr, 
     if (p.C0 % KE || p.C1 % KE || p.Cout % 32 || p.K % KE) return RCV_E_UNSUPPORTED;
     // few output tiles (a frame or two in flight) and a long K: the layer's time is its chain of K steps -> latency kernel
     // (measured at batch 1: it pays from K = 1024 on; short-K layers keep k_conv, whose tiles are cheaper to set up)
-    if (sizeof(T) == 2 && allow_lat && allow_dma && p.Cout % LAT_BN == 0 && p.K >= 1024 &&
+    if (sizeof(T) == 2 && !kX3 && allow_lat && allow_dma && p.Cout % LAT_BN == 0 && p.K >= 1024 &&
         (long long)((p.M + 127) / 128) * ((p.Cout + 127) / 128) * groups <= 128)
         return launch_conv_lat(p, groups, st);
-    if (sizeof(T) == 2 && allow_dma && p.Cout % DMA_BN == 0 &&
+    if (sizeof(T) == 2 && !kX3 && allow_dma && p.Cout % DMA_BN == 0 &&
         (long long)((p.M + DMA_BM - 1) / DMA_BM) * (p.Cout / DMA_BN) * groups >= 192)
         return launch_conv_dma(p, groups, st, set_attr);
     const int BN = p.Cout % 128 == 0 ? 128 : (p.Cout % 64 == 0 ? 64 : 32);
@@ -2532,14 +2667,15 @@ int run_op(rcv_fcn *h, const rcv_op &op, const float *x, int B, float *seg, floa
            const std::vector<size_t> &off, hipStream_t st)
 {
     const int G = h->groups;
+    constexpr int ES = is_x3<T>() ? 2 : 1;  // elements of T per logical element (split storage: hi and lo halves)
     auto slot = [&](int s) -> T * { return s >= 0 ? (T *)(ws + off[s]) : nullptr; };
-    auto gstride = [&](int s) -> long long { return s >= 0 ? (long long)h->slot_elems[s] * B : 0; };
+    auto gstride = [&](int s) -> long long { return s >= 0 ? (long long)h->slot_elems[s] * B * ES : 0; };
     const T *w = (const T *)h->weights + op.w_off;
     const float *bias = h->bias + op.b_off;
     switch (op.kind) {
     case RCV_OP_STEM: {
         if (op.cout != 64 || op.ksize != 7 || op.stride != 2 || op.pad != 3) return RCV_E_UNSUPPORTED;
-        if constexpr (sizeof(T) == 2) {
+        if constexpr (sizeof(T) == 2 && !kX3) {
             if (h->use_mfma_stem) {  // MFMA stem (bf16); option 2 = 0 selects the direct fp32-input kernel
                 if (!h->attrs_set)
                     RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_stem_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, STEM_LDS));
@@ -2557,7 +2693,7 @@ int run_op(rcv_fcn *h, const rcv_op &op, const float *x, int B, float *seg, floa
         }
         dim3 grid(((op.hout + 15) / 16) * ((op.wout + 15) / 16), B, G);
         hipLaunchKernelGGL((k_stem<T>), grid, dim3(256), 0, st, x, w, bias, slot(op.dst), B, op.hin, op.win, op.hout,
-                           op.wout, (long long)64 * 147, 64, gstride(op.dst));
+                           op.wout, (long long)64 * 147 * ES, 64 * ES, gstride(op.dst));
         RCV_LAUNCH_CHECK();
         return RCV_OK;
     }
@@ -2582,7 +2718,7 @@ int run_op(rcv_fcn *h, const rcv_op &op, const float *x, int B, float *seg, floa
         const long long npix = (long long)B * op.hin * op.win;
         dim3 grid((unsigned)std::min<long long>((npix + 255) / 256, 65535), G);
         hipLaunchKernelGGL((k_head<T>), grid, dim3(256), 0, st, slot(op.src0), w, bias, seg, radial, op.c0, npix,
-                           gstride(op.src0), (long long)2 * op.c0, 2, h->radial_f16 ? 1 : 0);
+                           gstride(op.src0), (long long)2 * op.c0 * ES, 2 * ES, h->radial_f16 ? 1 : 0);
         RCV_LAUNCH_CHECK();
         return RCV_OK;
     }
@@ -2592,17 +2728,19 @@ int run_op(rcv_fcn *h, const rcv_op &op, const float *x, int B, float *seg, floa
         p.src0 = slot(op.src0); p.src1 = slot(op.src1); p.res = slot(op.res); p.dst = slot(op.dst);
         p.w = w; p.bias = bias;
         p.src0_gs = gstride(op.src0); p.src1_gs = gstride(op.src1); p.res_gs = gstride(op.res); p.dst_gs = gstride(op.dst);
-        p.C0 = op.c0; p.C1 = op.src1 >= 0 ? op.c1 : 0; p.Cout = op.cout;
+        // split storage: the loaders see 16-bit tensors with twice the channels ([32 hi | 32 lo] per group of 32); Cout stays
+        // the real channel count (tile indexing, bias) and the epilogues place hi / lo themselves
+        p.C0 = op.c0 * ES; p.C1 = op.src1 >= 0 ? op.c1 * ES : 0; p.Cout = op.cout;
         p.Hin = op.hin; p.Win = op.win; p.Hout = op.hout; p.Wout = op.wout;
         p.KS = op.ksize; p.stride = op.stride; p.pad = op.pad; p.relu = op.relu;
         p.M = B * op.hout * op.wout;
         p.K = op.ksize * op.ksize * (p.C0 + p.C1);
         p.w_gs = (long long)op.cout * p.K;
-        p.bias_gs = op.cout;
+        p.bias_gs = op.cout * ES;  // (split: [bias | scale] per group)
         // the LDS-DMA kernels address a tensor through a buffer descriptor with 32-bit byte offsets: only below 2 GiB per group
-        auto fits32 = [&](int s) { return s < 0 || (long long)h->slot_elems[s] * B * (long long)sizeof(T) < 0x7fffffffLL; };
+        auto fits32 = [&](int s) { return s < 0 || (long long)h->slot_elems[s] * B * (long long)sizeof(T) * ES < 0x7fffffffLL; };
         const bool dma_ok = h->use_dma && fits32(op.src0) && fits32(op.src1) && fits32(op.res) && fits32(op.dst);
-        if constexpr (sizeof(T) == 2) {
+        if constexpr (sizeof(T) == 2 && !kX3) {
             int th, tw;
             if (h->use_halo && dma_ok && op.ksize == 3 && op.stride == 1 && op.pad == 1 && op.res < 0 && p.Cout % 64 == 0 &&
                 p.C0 % 64 == 0 && p.C1 % 64 == 0 && op.hin == op.hout && op.win == op.wout && halo_tile(op.hout, op.wout, h->use_halo, th, tw) && (th * tw <= 256 || p.Cout % 128 == 0) &&
@@ -2671,7 +2809,7 @@ int forward_impl(rcv_fcn *h, const float *x, int B, float *seg, float *radial, c
         for (auto &e : h->events) RCV_HIP_CHECK(hipEventCreate(&e));
     }
     for (size_t i = 0; i < h->ops.size(); i++) {
-        if constexpr (sizeof(T) == 2) {
+        if constexpr (sizeof(T) == 2 && !kX3) {
             // 3x3 (-> 256 channels, ReLU) followed by the 1x1 expand to 1024 channels with residual and ReLU: the second
             // half of a layer-3 bottleneck block as one kernel (option 4)
             if (h->use_block && i + 1 < h->ops.size() && h->ops[i].kind == RCV_OP_CONV && h->ops[i + 1].kind == RCV_OP_CONV &&
@@ -2781,13 +2919,18 @@ int forward_impl(rcv_fcn *h, const float *x, int B, float *seg, float *radial, c
 // Per-translation-unit entry points of the 16-bit engine: this file's own (bfloat16) and, compiled through fcn_f16.hip, the
 // half-precision twin's.  The C ABI below exists once, in the bfloat16 unit, and dispatches on rcv_fcn::dtype.
 namespace rcv {
-#ifdef RCV_FCN_FP16
-int fcn_forward_f16(rcv_fcn *h, const float *x, int B, float *seg, float *radial, char *ws, hipStream_t st)
+#if defined(RCV_FCN_X3)
+#define RCV_TU_SUFFIX(name) name##_x3
+#elif defined(RCV_FCN_FP16)
+#define RCV_TU_SUFFIX(name) name##_f16
+#endif
+#ifdef RCV_TU_SUFFIX
+int RCV_TU_SUFFIX(fcn_forward)(rcv_fcn *h, const float *x, int B, float *seg, float *radial, char *ws, hipStream_t st)
 {
     return forward_impl<H16>(h, x, B, seg, radial, ws, st);
 }
-int fcn_register_f16() { return register_kernel_attributes(); }
-int fcn_debug_slot_f16(const void *src, float *out_dev, long long n, hipStream_t st)
+int RCV_TU_SUFFIX(fcn_register)() { return register_kernel_attributes(); }
+int RCV_TU_SUFFIX(fcn_debug_slot)(const void *src, float *out_dev, long long n, hipStream_t st)
 {
     const unsigned blocks = (unsigned)std::min<long long>((n + 255) / 256, 65535);
     hipLaunchKernelGGL((k_slot_to_f32<H16>), dim3(blocks), dim3(256), 0, st, (const H16 *)src, out_dev, n);
@@ -2798,10 +2941,13 @@ int fcn_debug_slot_f16(const void *src, float *out_dev, long long n, hipStream_t
 int fcn_forward_f16(rcv_fcn *h, const float *x, int B, float *seg, float *radial, char *ws, hipStream_t st);
 int fcn_register_f16();
 int fcn_debug_slot_f16(const void *src, float *out_dev, long long n, hipStream_t st);
+int fcn_forward_x3(rcv_fcn *h, const float *x, int B, float *seg, float *radial, char *ws, hipStream_t st);
+int fcn_register_x3();
+int fcn_debug_slot_x3(const void *src, float *out_dev, long long n, hipStream_t st);
 #endif
 }  // namespace rcv
 
-#ifndef RCV_FCN_FP16
+#ifndef RCV_TU_SUFFIX
 extern "C" {
 
 int rcv_preprocess_rgb(const uint8_t *rgb_dev, int B, int H, int W, float *x_dev, void *stream)
@@ -2819,7 +2965,7 @@ int rcv_fcn_create(const rcv_op *ops, int n_ops, int n_slots, const int64_t *slo
 {
     if (!ops || n_ops <= 0 || n_slots <= 0 || !slot_elems || groups <= 0 || !weights_dev || !bias_dev || !out)
         return RCV_E_INVALID;
-    if (dtype != RCV_F32 && dtype != RCV_BF16 && dtype != RCV_F16) return RCV_E_UNSUPPORTED;
+    if (dtype != RCV_F32 && dtype != RCV_BF16 && dtype != RCV_F16 && dtype != RCV_F16X3) return RCV_E_UNSUPPORTED;
     for (int i = 0; i < n_ops; i++) {
         const rcv_op &o = ops[i];
         const int slots[4] = {o.src0, o.src1, o.res, o.dst};
@@ -2829,6 +2975,7 @@ int rcv_fcn_create(const rcv_op *ops, int n_ops, int n_slots, const int64_t *slo
     {
         int rc = register_kernel_attributes();
         if (rc == RCV_OK && dtype == RCV_F16) rc = rcv::fcn_register_f16();
+        if (rc == RCV_OK && dtype == RCV_F16X3) rc = rcv::fcn_register_x3();
         if (rc != RCV_OK) return rc;
     }
     rcv_fcn *h = new rcv_fcn();
@@ -2865,6 +3012,7 @@ int rcv_fcn_forward(rcv_fcn *h, const float *x_dev, int B, float *seg_dev, float
     if (ws_bytes < rcv_fcn_workspace_bytes(h, B)) return RCV_E_WORKSPACE;
     if (h->dtype == RCV_F32) return forward_impl<float>(h, x_dev, B, seg_dev, radial_dev, (char *)ws, (hipStream_t)stream);
     if (h->dtype == RCV_F16) return rcv::fcn_forward_f16(h, x_dev, B, seg_dev, radial_dev, (char *)ws, (hipStream_t)stream);
+    if (h->dtype == RCV_F16X3) return rcv::fcn_forward_x3(h, x_dev, B, seg_dev, radial_dev, (char *)ws, (hipStream_t)stream);
     return forward_impl<H16>(h, x_dev, B, seg_dev, radial_dev, (char *)ws, (hipStream_t)stream);
 }
 
@@ -2878,6 +3026,8 @@ int rcv_fcn_debug_slot(rcv_fcn *h, const void *ws, int B, int g, int slot, float
     const unsigned blocks = (unsigned)std::min<long long>((n + 255) / 256, 65535);
     if (h->dtype == RCV_F16)
         return rcv::fcn_debug_slot_f16((const H16 *)((const char *)ws + off[slot]) + (long long)g * n, out_dev, n, (hipStream_t)stream);
+    if (h->dtype == RCV_F16X3)  // (two halves per element)
+        return rcv::fcn_debug_slot_x3((const H16 *)((const char *)ws + off[slot]) + 2 * (long long)g * n, out_dev, n, (hipStream_t)stream);
     if (h->dtype == RCV_F32)
         hipLaunchKernelGGL((k_slot_to_f32<float>), dim3(blocks), dim3(256), 0, (hipStream_t)stream,
                            (const float *)((const char *)ws + off[slot]) + (long long)g * n, out_dev, n);
@@ -2953,4 +3103,4 @@ int rcv_fcn_get_profile(rcv_fcn *h, double *conv_ms, double *other_ms, double *c
 }
 
 }  // extern "C"
-#endif  // !RCV_FCN_FP16
+#endif  // !RCV_TU_SUFFIX (the C ABI exists once, in the bfloat16 unit)

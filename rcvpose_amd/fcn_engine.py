@@ -218,12 +218,50 @@ def fold_conv_bn(sd, spec, cout):
     return w.permute(0, 2, 3, 1).contiguous(), b
 
 
+def split_halves(w):
+    """float64 tensor -> (hi, lo) float16 with hi = half(w), lo = half(w - hi): hi + lo carries 22 significand bits."""
+    import torch
+
+    hi = w.to(torch.float16)
+    lo = (w - hi.to(torch.float64)).to(torch.float16)
+    return hi, lo
+
+
+def pack_split(w, kind):
+    """One network's BN-folded float64 weights [cout, kh, kw, cin] in the RCV_F16X3 layout (include/rcvpose_hip.h):
+    every output channel is scaled by a power of two 2^k that puts its largest magnitude into [2^13, 2^14) -- the lo halves of
+    all weights that matter are then normal half-precision numbers, measured to be worth 20x in accuracy on small weights
+    (tools/probe/split_probe.hip) -- and the epilogue multiplies by 2^-k, exactly.
+    -> (flat float16 weights, float32 scales [cout])."""
+    import torch
+
+    cout = w.shape[0]
+    mx = w.reshape(cout, -1).abs().amax(dim=1)
+    _, e = torch.frexp(mx)  # mx = m * 2^e with m in [0.5, 1)
+    k = torch.where(mx > 0, 14 - e, torch.zeros_like(e)).to(torch.float64)
+    ws = w * torch.exp2(k).view(-1, 1, 1, 1)
+    hi, lo = split_halves(ws)
+    if not (torch.isfinite(hi).all() and torch.isfinite(lo).all()):
+        raise ValueError("non-finite weights after BatchNorm folding")
+    if kind == _hip.OP_CONV:
+        cin = w.shape[3]
+        if cin % 32:
+            raise ValueError("RCV_F16X3 convolutions need a multiple of 32 input channels")
+        # [cout][kh][kw][cin/32][hi 32 | lo 32]
+        flat = torch.stack([hi.reshape(cout, w.shape[1], w.shape[2], cin // 32, 32),
+                            lo.reshape(cout, w.shape[1], w.shape[2], cin // 32, 32)], dim=4).reshape(-1)
+    else:  # stem / head: all hi halves, then all lo halves
+        flat = torch.cat([hi.reshape(-1), lo.reshape(-1)])
+    return flat, torch.exp2(-k).to(torch.float32)
+
+
 def pack_weights(state_dicts, builder, ops, dtype):
     """-> (weights tensor [engine dtype], bias tensor fp32, ops with w_off / b_off filled)."""
     import torch
 
     sds = [{(k[7:] if k.startswith("module.") else k): v for k, v in sd.items()} for sd in state_dicts]
-    tdt = {_hip.RCV_F32: torch.float32, _hip.RCV_BF16: torch.bfloat16, _hip.RCV_F16: torch.float16}[dtype]
+    tdt = {_hip.RCV_F32: torch.float32, _hip.RCV_BF16: torch.bfloat16, _hip.RCV_F16: torch.float16,
+           _hip.RCV_F16X3: torch.float16}[dtype]
     wparts, bparts, woff, boff = [], [], 0, 0
     for op, spec in zip(ops, builder.wspecs):
         if spec is None:
@@ -232,9 +270,16 @@ def pack_weights(state_dicts, builder, ops, dtype):
         ws, bs = [], []
         for sd in sds:
             w, b = fold_conv_bn(sd, spec, op["cout"])
-            ws.append(w.reshape(-1))
-            bs.append(b)
+            if dtype == _hip.RCV_F16X3:  # per network: [weights], [bias | scale]
+                flat, scale = pack_split(w, op["kind"])
+                ws.append(flat)
+                bs.append(torch.cat([b.to(torch.float32), scale]))
+            else:
+                ws.append(w.reshape(-1))
+                bs.append(b)
         wcat = torch.cat(ws).to(tdt)
+        if not torch.isfinite(wcat).all():  # (fp16: a folded weight beyond 65504)
+            raise ValueError("weights of %s overflow the engine's storage type" % spec["conv"])
         bcat = torch.cat(bs).to(torch.float32)
         op["w_off"], op["b_off"] = woff, boff
         pad = (-wcat.numel()) % 64  # keep every op's weights 128-byte aligned for 16-byte vector loads
@@ -263,9 +308,10 @@ class FcnEngine:
     """`groups` DenseFCNResNet152 networks (one state dict each) sharing one input image.
 
     forward(x): x float32 [B,3,H,W] on the GPU -> (seg, radial), each float32 [G,B,1,H,W].
-    dtype: storage type of weights and activations (fp32 accumulation throughout): "fp32" (parity mode), "bf16" (the
-    throughput mode BASELINE.json names) or "fp16" (IEEE half: the same kernels and speed as bf16 with 11 instead of 8
-    significand bits).
+    dtype: storage type of weights and activations (fp32 accumulation throughout): "fp32" (parity mode on the fp32 matrix
+    instruction), "f16x3" (the FAST parity mode: half-precision hi / lo pairs, three MFMAs per product -- maps within 1e-4 of
+    the reference like fp32), "bf16" (the throughput mode BASELINE.json names) or "fp16" (IEEE half: the same kernels and
+    speed as bf16 with 11 instead of 8 significand bits).
     """
 
     def __init__(self, state_dicts, H, W, dtype="bf16", device="cuda", reuse_slots=True, arch="dense"):
@@ -274,8 +320,9 @@ class FcnEngine:
         self.lib = _hip.lib()
         self.H, self.W = int(H), int(W)
         self.groups = len(state_dicts)
-        self.dtype = {"bf16": _hip.RCV_BF16, "fp32": _hip.RCV_F32, "f32": _hip.RCV_F32, "fp16": _hip.RCV_F16, "f16": _hip.RCV_F16}[dtype]
-        self.dtype_name = {_hip.RCV_BF16: "bf16", _hip.RCV_F32: "fp32", _hip.RCV_F16: "fp16"}[self.dtype]
+        self.dtype = {"bf16": _hip.RCV_BF16, "fp32": _hip.RCV_F32, "f32": _hip.RCV_F32, "fp16": _hip.RCV_F16, "f16": _hip.RCV_F16,
+                      "f16x3": _hip.RCV_F16X3, "fp16x3": _hip.RCV_F16X3}[dtype]
+        self.dtype_name = {_hip.RCV_BF16: "bf16", _hip.RCV_F32: "fp32", _hip.RCV_F16: "fp16", _hip.RCV_F16X3: "f16x3"}[self.dtype]
         if arch not in ("dense", "res"):
             raise ValueError("arch must be 'dense' (DenseFCNResNet152) or 'res' (ResFCNResNet152)")
         self.arch = arch

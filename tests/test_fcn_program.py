@@ -108,3 +108,59 @@ def test_slots_are_not_recycled_inside_a_fusion_window():
                     if ops[j][key] >= 0:
                         assert ops[j][key] != o["dst"], (i, j, key)
         assert len(slots) <= 24
+
+
+def test_split_weight_packing_roundtrip():
+    """RCV_F16X3 layout: [cout][kh][kw][cin/32][hi 32 | lo 32] halves with a power-of-two scale per output channel; hi + lo,
+    unscaled, reproduces the float64 weight to 2^-21 of the channel's largest magnitude; tiny weights keep normal lo halves."""
+    import torch
+
+    from rcvpose_amd import _hip, fcn_engine
+
+    g = torch.Generator().manual_seed(0)
+    for wsd in (0.03, 1e-4):
+        w = torch.randn(8, 3, 3, 64, generator=g, dtype=torch.float64) * wsd
+        w[3] = 0.0  # an all-zero output channel: scale 1
+        flat, scale = fcn_engine.pack_split(w, _hip.OP_CONV)
+        assert flat.dtype == torch.float16 and flat.numel() == 2 * w.numel() and scale.dtype == torch.float32
+        v = flat.to(torch.float64).reshape(8, 3, 3, 2, 2, 32)
+        back = (v[:, :, :, :, 0] + v[:, :, :, :, 1]).reshape(8, 3, 3, 64) * scale.to(torch.float64).view(-1, 1, 1, 1)
+        mx = w.reshape(8, -1).abs().amax(dim=1).clamp_min(1e-30).view(-1, 1, 1, 1)
+        assert float(((back - w).abs() / mx).max()) <= 2.0 ** -21
+        k = torch.log2(scale.to(torch.float64))
+        assert torch.equal(k, k.round()) and float(scale[3]) == 1.0
+        hi_max = v[:, :, :, :, 0].abs().reshape(8, -1).amax(dim=1)
+        assert all(8192 <= float(m) < 16384 for i, m in enumerate(hi_max) if i != 3)
+    # stem / head: all hi halves, then all lo halves
+    w = torch.randn(64, 7, 7, 3, generator=g, dtype=torch.float64) * 0.05
+    flat, scale = fcn_engine.pack_split(w, _hip.OP_STEM)
+    n = w.numel()
+    back = (flat[:n].to(torch.float64) + flat[n:].to(torch.float64)).reshape(w.shape) * scale.to(torch.float64).view(-1, 1, 1, 1)
+    assert float((back - w).abs().max() / w.abs().max()) <= 2.0 ** -21
+
+
+def test_split_engine_blob_offsets():
+    """pack_weights(RCV_F16X3): two halves per weight, [bias | scale] per network, offsets 128-byte aligned."""
+    import json
+    import os
+
+    import torch
+
+    import fcn_weights
+    from rcvpose_amd import _hip, fcn_engine
+
+    shapes = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "fcn_state_dict_keys.json")))
+    sd = {k: torch.from_numpy(v) for k, v in fcn_weights.make_state_dict_numpy(shapes, seed=0).items()}
+    b = fcn_engine.build_program(64, 96)
+    ops, _ = fcn_engine.assign_slots(b)
+    w, bias, ops = fcn_engine.pack_weights([sd, sd], b, ops, _hip.RCV_F16X3)
+    assert w.dtype == torch.float16 and bias.dtype == torch.float32
+    for op, spec in zip(ops, b.wspecs):
+        if spec is None:
+            continue
+        assert op["w_off"] % 64 == 0 and op["b_off"] % 4 == 0
+        k = op["ksize"] ** 2 * (op["c0"] + (op["c1"] if op["src1"] >= 0 else 0))
+        per_net = 2 * op["cout"] * k
+        assert torch.equal(w[op["w_off"]:op["w_off"] + per_net], w[op["w_off"] + per_net:op["w_off"] + 2 * per_net])
+        sc = bias[op["b_off"] + op["cout"]:op["b_off"] + 2 * op["cout"]]
+        assert torch.equal(torch.log2(sc), torch.log2(sc).round())

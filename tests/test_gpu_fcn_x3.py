@@ -1,0 +1,110 @@
+"""The engine's fast parity mode RCV_F16X3 ("f16x3"): activations and weights as IEEE-half hi / lo pairs, three MFMAs per
+product (hi*hi + hi*lo + lo*hi), fp32 accumulation.  It carries north_star's 1e-4 gate on the radial maps like the fp32
+engine (reference models/fcnresnet.py:121-191 is an fp32 forward) at a third of the fp16 matrix rate instead of a sixteenth."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import fcn_weights
+
+pytestmark = pytest.mark.gpu
+
+REL = 1e-4        # north star: radial maps within 1e-4 relative of the fp32 reference
+REL_TIGHT = 3e-5  # regression guard: measured ~5e-6 (as the fp32 engine)
+
+
+@pytest.fixture(scope="module")
+def shapes(golden_dir):
+    return json.load(open(os.path.join(golden_dir, "fcn_state_dict_keys.json")))
+
+
+def _sd(shapes, seed=0):
+    return {k: torch.from_numpy(v) for k, v in fcn_weights.make_state_dict_numpy(shapes, seed=seed).items()}
+
+
+def _rel(a, b):
+    return float(np.abs(a - b).max() / np.abs(b).max())
+
+
+def test_x3_stages_and_output_vs_golden(shapes, golden_dir):
+    """Every named stage of the reference module's golden forward (64x96) and the output planes, <= 1e-4."""
+    from rcvpose_amd.fcn_engine import FcnEngine
+
+    g = np.load(os.path.join(golden_dir, "fcn1_64x96.npz"))
+    x = torch.from_numpy(fcn_weights.make_input(int(g["input_seed"]), (1, 3, 64, 96))).cuda()
+    eng = FcnEngine([_sd(shapes)], 64, 96, dtype="f16x3", reuse_slots=False)
+    seg, rad = eng.forward(x)
+    worst = 0.0
+    for k in g.files:
+        if not k.startswith("stage_") or k[6:] == "conv8":
+            continue
+        ref = g[k]
+        if k[6:] in ("bn1", "bn6"):
+            ref = np.maximum(ref, 0)
+        got = eng.debug_stage(1, 0, k[6:]).cpu().numpy()
+        assert got.shape == ref.shape, k
+        worst = max(worst, _rel(got, ref))
+        assert _rel(got, ref) <= REL, (k, _rel(got, ref))
+    er, es = _rel(rad[0].cpu().numpy(), g["radial"]), _rel(seg[0].cpu().numpy(), g["seg"])
+    print("f16x3 64x96: worst stage %.2e radial %.2e seg %.2e" % (worst, er, es))
+    assert er <= REL_TIGHT and es <= REL_TIGHT
+
+
+def test_x3_full_size_vs_golden_samples(shapes, golden_dir):
+    """480x640, three networks in one engine: 4096 sampled pixels of the reference's golden forward."""
+    from rcvpose_amd.fcn_engine import FcnEngine
+
+    g = np.load(os.path.join(golden_dir, "fcn2_480x640_samples.npz"))
+    x = torch.from_numpy(fcn_weights.make_input(int(g["input_seed"]), (1, 3, 480, 640))).cuda()
+    seg, rad = FcnEngine([_sd(shapes), _sd(shapes, 1), _sd(shapes, 2)], 480, 640, dtype="f16x3").forward(x)
+    pix = g["pix"]
+    err_r = np.abs(rad[0].cpu().numpy().reshape(-1)[pix] - g["radial"]).max() / float(g["radial_absmax"])
+    err_s = np.abs(seg[0].cpu().numpy().reshape(-1)[pix] - g["seg"]).max() / float(g["seg_absmax"])
+    print("f16x3 480x640 (sampled): radial %.2e seg %.2e" % (err_r, err_s))
+    assert err_r <= REL_TIGHT and err_s <= REL_TIGHT
+
+
+def test_x3_against_fp32_engine_whole_maps(shapes):
+    """Whole 480x640 maps of three networks and four frames against the fp32 engine (v_mfma_f32_16x16x4_f32)."""
+    from rcvpose_amd.fcn_engine import FcnEngine
+
+    sds = [_sd(shapes, s) for s in range(3)]
+    x = torch.from_numpy(fcn_weights.make_input(17, (4, 3, 480, 640))).cuda()
+    seg_a, rad_a = FcnEngine(sds, 480, 640, dtype="f16x3").forward(x)
+    seg_b, rad_b = FcnEngine(sds, 480, 640, dtype="fp32").forward(x)
+    for g in range(3):
+        er = float((rad_a[g] - rad_b[g]).abs().max() / rad_b[g].abs().max())
+        es = float((seg_a[g] - seg_b[g]).abs().max() / seg_b[g].abs().max())
+        print("f16x3 vs fp32 engine, network %d: radial %.2e seg %.2e" % (g, er, es))
+        assert er <= REL_TIGHT and es <= REL_TIGHT
+
+
+def test_x3_kernel_variants_identical(shapes):
+    """The fast kernels of the split engine (engine options on) against the plain register-staged kernels (all off): the
+    same K order and MFMA sequence per output element, so bit-identical maps."""
+    from rcvpose_amd.fcn_engine import FcnEngine
+
+    sds = [_sd(shapes, s) for s in range(3)]
+    for (H, W, B) in ((480, 640, 4), (480, 640, 1), (96, 160, 3)):
+        eng = FcnEngine(sds, H, W, dtype="f16x3")
+        x = torch.from_numpy(fcn_weights.make_input(31, (B, 3, H, W))).cuda()
+        seg_a, rad_a = [t.clone() for t in eng.forward(x)]
+        for key in (1, 2, 3, 4, 5, 6, 7, 9):
+            eng.set_option(key, 0)
+        seg_b, rad_b = eng.forward(x)
+        assert torch.equal(seg_a, seg_b) and torch.equal(rad_a, rad_b), (H, W, B)
+
+
+def test_x3_groups_and_batch(shapes):
+    """A frame's maps do not depend on the batch or the group slot it travels in."""
+    from rcvpose_amd.fcn_engine import FcnEngine
+
+    sds = [_sd(shapes, s) for s in range(3)]
+    x = torch.from_numpy(fcn_weights.make_input(23, (3, 3, 64, 96))).cuda()
+    seg3, rad3 = FcnEngine(sds, 64, 96, dtype="f16x3").forward(x)
+    for g in range(3):
+        seg1, rad1 = FcnEngine([sds[g]], 64, 96, dtype="f16x3").forward(x[1:2])
+        assert torch.equal(rad1[0, 0], rad3[g, 1]) and torch.equal(seg1[0, 0], seg3[g, 1])
