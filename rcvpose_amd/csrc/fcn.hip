@@ -413,17 +413,22 @@ __global__ __launch_bounds__(512) void k_conv_dma(const ConvParams p)
     // kernel is a stream of (operand tile, residual tile, output tile) and this overlaps the first two
     const T *res = p.res ? (const T *)p.res + (long long)g * p.res_gs : nullptr;
     constexpr int E_CPR = DMA_BN / 8, E_PER = (64 * E_CPR) / 512;
-    uint4 rres[4][E_PER];
-    if (res) {
-#pragma unroll
-        for (int round = 0; round < 4; round++)
-#pragma unroll
-            for (int q = 0; q < E_PER; q++) {
-                const int c = q * 512 + tid, row = c / E_CPR, cc = c - row * E_CPR;
-                const int m = m0 + round * 64 + row;
-                rres[round][q] = m < p.M ? *(const uint4 *)(res + (long long)m * p.Cout + n0 + cc * 8) : make_uint4(0u, 0u, 0u, 0u);
-            }
+    constexpr int RV = kX3 ? 2 : 1;  // 16-byte vectors per 8-channel chunk (split storage: hi and lo)
+    uint4 rres[4][E_PER][RV];
+// (split mode: the K loop holds 64 more fragment registers and the residual tile is twice as wide -- it is requested after the
+// loop instead, behind the LDS staging of the accumulators)
+#define RCV_DMA_RESIDUAL()                                                                                     \
+    if (res) {                                                                                                 \
+        _Pragma("unroll") for (int round = 0; round < 4; round++)                                              \
+            _Pragma("unroll") for (int q = 0; q < E_PER; q++) {                                                \
+                const int c = q * 512 + tid, row = c / E_CPR, cc = c - row * E_CPR;                            \
+                const int m = m0 + round * 64 + row;                                                           \
+                const T *rp = res + nhwc_off<T>(m, p.Cout, n0 + cc * 8);                                       \
+                _Pragma("unroll") for (int h = 0; h < RV; h++)                                                 \
+                    rres[round][q][h] = m < p.M ? *(const uint4 *)(rp + 32 * h) : make_uint4(0u, 0u, 0u, 0u);  \
+            }                                                                                                  \
     }
+    if constexpr (!kX3) RCV_DMA_RESIDUAL();
 
     // loader role of this lane: 4 A rows (wave*32 + c*8 + lane/8) and 2 B rows (wave*16 + c*8 + lane/8), 16-byte
     // slot lane%8 of the LDS row, which receives the source chunk slot ^ ((row>>1)&7).
@@ -560,6 +565,50 @@ __global__ __launch_bounds__(512) void k_conv_dma(const ConvParams p)
         stage = stage + 1 == DMA_STAGES ? 0 : stage + 1;                                                       \
     }
 
+// Split precision: the 128-byte K row is [32 hi | 32 lo], so ch0 addresses the hi halves and ch1 the lo halves of both
+// operands, and the step multiplies hi*hi, hi*lo, lo*hi (48 MFMAs instead of 32 on the same LDS bytes -- the step is bound by
+// the matrix pipe, not by LDS reads).  The MFMAs are dealt 24 / 24 over the two phases: first load phase hi of A, hi of B and
+// the lo of B's first two column tiles; per output element the order is always hh, hl, lh (as in k_conv).
+#define RCV_DMA_STEP_X3(ISSUE)                                                                                 \
+    {                                                                                                          \
+        const unsigned char *Ab = smem + stage * DMA_STAGE_BYTES + (wm * 64 + r16) * 128;                      \
+        const unsigned char *Bb = smem + stage * DMA_STAGE_BYTES + BM * 128 + (wn * 64 + r16) * 128;           \
+        const int st2 = stage + 2 >= DMA_STAGES ? stage + 2 - DMA_STAGES : stage + 2;                          \
+        bf16x8 ah[MT], al[MT], bh[NT], bl[NT];                                                                 \
+        _Pragma("unroll") for (int i = 0; i < MT; i++) ah[i] = *(const bf16x8 *)(Ab + i * 16 * 128 + ch0);     \
+        _Pragma("unroll") for (int j = 0; j < NT; j++) bh[j] = *(const bf16x8 *)(Bb + j * 16 * 128 + ch0);     \
+        _Pragma("unroll") for (int j = 0; j < NT / 2; j++) bl[j] = *(const bf16x8 *)(Bb + j * 16 * 128 + ch1); \
+        if (ISSUE) RCV_DMA_ISSUE(st2, 0, 3, false);                                                            \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                     \
+        __builtin_amdgcn_s_barrier();                                                                          \
+        __builtin_amdgcn_s_setprio(1);                                                                         \
+        _Pragma("unroll") for (int i = 0; i < MT; i++)                                                         \
+            _Pragma("unroll") for (int j = 0; j < NT; j++) acc[i][j] = RCV_MFMA16(ah[i], bh[j], acc[i][j], 0, 0, 0); \
+        _Pragma("unroll") for (int i = 0; i < MT; i++)                                                         \
+            _Pragma("unroll") for (int j = 0; j < NT / 2; j++) acc[i][j] = RCV_MFMA16(ah[i], bl[j], acc[i][j], 0, 0, 0); \
+        __builtin_amdgcn_s_setprio(0);                                                                         \
+        __builtin_amdgcn_s_barrier();                                                                          \
+        _Pragma("unroll") for (int i = 0; i < MT; i++) al[i] = *(const bf16x8 *)(Ab + i * 16 * 128 + ch1);     \
+        _Pragma("unroll") for (int j = NT / 2; j < NT; j++) bl[j] = *(const bf16x8 *)(Bb + j * 16 * 128 + ch1); \
+        if (ISSUE) {                                                                                           \
+            RCV_DMA_ISSUE(st2, 3, 6, true);                                                                    \
+            asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");                                        \
+        } else {                                                                                               \
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                        \
+        }                                                                                                      \
+        __builtin_amdgcn_s_barrier();                                                                          \
+        __builtin_amdgcn_s_setprio(1);                                                                         \
+        _Pragma("unroll") for (int i = 0; i < MT; i++)                                                         \
+            _Pragma("unroll") for (int j = NT / 2; j < NT; j++) acc[i][j] = RCV_MFMA16(ah[i], bl[j], acc[i][j], 0, 0, 0); \
+        _Pragma("unroll") for (int i = 0; i < MT; i++)                                                         \
+            _Pragma("unroll") for (int j = 0; j < NT; j++) acc[i][j] = RCV_MFMA16(al[i], bh[j], acc[i][j], 0, 0, 0); \
+        __builtin_amdgcn_s_setprio(0);                                                                         \
+        __builtin_amdgcn_s_barrier();                                                                          \
+        stage = stage + 1 == DMA_STAGES ? 0 : stage + 1;                                                       \
+    }
+#define RCV_DMA_STEP_ANY(ISSUE)                                                                                \
+    { if constexpr (kX3) RCV_DMA_STEP_X3(ISSUE) else RCV_DMA_STEP(ISSUE) }
+
     const int nk = p.K / KE;
     const int grp = wave >> 2;  // waves w and w + 4 share a SIMD
     RCV_DMA_ISSUE(0, 0, 6, true);
@@ -572,10 +621,12 @@ __global__ __launch_bounds__(512) void k_conv_dma(const ConvParams p)
     __builtin_amdgcn_s_barrier();
     if (grp == 1) __builtin_amdgcn_s_barrier();  // the second wave of every SIMD runs one phase behind
     int stage = 0;
-    for (int kt = 0; kt + 2 < nk; kt++) RCV_DMA_STEP(true);
-    if (nk > 1) RCV_DMA_STEP(false);
-    RCV_DMA_STEP(false);
+    for (int kt = 0; kt + 2 < nk; kt++) RCV_DMA_STEP_ANY(true);
+    if (nk > 1) RCV_DMA_STEP_ANY(false);
+    RCV_DMA_STEP_ANY(false);
     if (grp == 0) __builtin_amdgcn_s_barrier();  // match the barrier count of the trailing group
+#undef RCV_DMA_STEP_ANY
+#undef RCV_DMA_STEP_X3
 #undef RCV_DMA_STEP
 #undef RCV_DMA_ISSUE
 
@@ -585,15 +636,19 @@ __global__ __launch_bounds__(512) void k_conv_dma(const ConvParams p)
     const float *bias = p.bias + (long long)g * p.bias_gs;
     constexpr int SROW = BN + 4, CPR = BN / EPV;
     float *stg = (float *)smem;
+    if constexpr (kX3) RCV_DMA_RESIDUAL();
+#undef RCV_DMA_RESIDUAL
     __syncthreads();  // every wave is done reading the last operand tile
 #pragma unroll
     for (int j = 0; j < NT; j++) {
         const int nl = wn * 64 + j * 16 + r16;
         const float bv = bias[n0 + nl];
+        const float sc = kX3 ? bias[p.Cout + n0 + nl] : 1.f;  // (split mode: the weights' power-of-two scale, undone here)
 #pragma unroll
         for (int i = 0; i < MT; i++)
 #pragma unroll
-            for (int e = 0; e < 4; e++) stg[(wm * 64 + i * 16 + kq * 4 + e) * SROW + nl] = acc[i][j][e] + bv;
+            for (int e = 0; e < 4; e++)
+                stg[(wm * 64 + i * 16 + kq * 4 + e) * SROW + nl] = kX3 ? __fmaf_rn(acc[i][j][e], sc, bv) : acc[i][j][e] + bv;
     }
     __syncthreads();
 #pragma unroll
@@ -603,7 +658,7 @@ __global__ __launch_bounds__(512) void k_conv_dma(const ConvParams p)
             const int c = q * 512 + tid, row = c / CPR, cc = c - row * CPR;
             const int m = m0 + round * 64 + row;
             if (m >= p.M) continue;
-            const long long o = (long long)m * p.Cout + n0 + cc * EPV;
+            const long long o = nhwc_off<T>(m, p.Cout, n0 + cc * EPV);
             float v[EPV];
             const float4 *sp4 = (const float4 *)(stg + (round * 64 + row) * SROW + cc * EPV);
 #pragma unroll
@@ -612,19 +667,33 @@ __global__ __launch_bounds__(512) void k_conv_dma(const ConvParams p)
                 v[qq * 4 + 0] = t.x; v[qq * 4 + 1] = t.y; v[qq * 4 + 2] = t.z; v[qq * 4 + 3] = t.w;
             }
             if (res) {
-                const T *rp = (const T *)&rres[round][q];
+                if constexpr (kX3) {
+                    float rv[8];
+                    x3_join8(rres[round][q][0], rres[round][q][RV - 1], rv);
 #pragma unroll
-                for (int qq = 0; qq < EPV; qq++) v[qq] += to_f32(rp[qq]);
+                    for (int qq = 0; qq < EPV; qq++) v[qq] += rv[qq];
+                } else {
+                    const T *rp = (const T *)&rres[round][q][0];
+#pragma unroll
+                    for (int qq = 0; qq < EPV; qq++) v[qq] += to_f32(rp[qq]);
+                }
             }
             if (p.relu) {
 #pragma unroll
                 for (int qq = 0; qq < EPV; qq++) v[qq] = fmaxf(v[qq], 0.f);
             }
-            uint4 outv;
-            T *op = (T *)&outv;
+            if constexpr (kX3) {
+                uint4 oh, ol;
+                x3_split8(v, oh, ol);
+                *(uint4 *)(dst + o) = oh;
+                *(uint4 *)(dst + o + 32) = ol;
+            } else {
+                uint4 outv;
+                T *op = (T *)&outv;
 #pragma unroll
-            for (int qq = 0; qq < EPV; qq++) op[qq] = from_f32<T>(v[qq]);
-            *(uint4 *)(dst + o) = outv;
+                for (int qq = 0; qq < EPV; qq++) op[qq] = from_f32<T>(v[qq]);
+                *(uint4 *)(dst + o) = outv;
+            }
         }
     }
 }
@@ -671,11 +740,15 @@ __global__ __launch_bounds__(512) void k_conv_lat(const ConvParams p)
     const T *wg = (const T *)p.w + (long long)g * p.w_gs;
     const T *res = p.res ? (const T *)p.res + (long long)g * p.res_gs : nullptr;
     // residual tile: 64 rows x 8 chunks of 16 B = 512 chunks, one per thread, requested up front
-    uint4 rres = make_uint4(0u, 0u, 0u, 0u);
+    uint4 rres = make_uint4(0u, 0u, 0u, 0u), rres_lo = make_uint4(0u, 0u, 0u, 0u);
     if (res) {
         const int row = tid >> 3, cc = tid & 7;
         const int m = m0 + row;
-        if (m < p.M) rres = *(const uint4 *)(res + (long long)m * p.Cout + n0 + cc * 8);
+        if (m < p.M) {
+            const T *rp = res + nhwc_off<T>(m, p.Cout, n0 + cc * 8);
+            rres = *(const uint4 *)rp;
+            if constexpr (kX3) rres_lo = *(const uint4 *)(rp + 32);
+        }
     }
     // loader role of this lane: A row wave*8 + lane/8, B row likewise; 16-byte slot lane%8 of the LDS row receives the
     // source chunk slot ^ ((row>>1)&7) (k_conv_dma's scheme)
@@ -763,12 +836,21 @@ __global__ __launch_bounds__(512) void k_conv_lat(const ConvParams p)
             for (int i = 0; i < MT; i++) { af[0][i] = *(const bf16x8 *)(Ab + i * 16 * 128 + ch0); af[1][i] = *(const bf16x8 *)(Ab + i * 16 * 128 + ch1); }
 #pragma unroll
             for (int j = 0; j < NT; j++) { bfr[0][j] = *(const bf16x8 *)(Bb + j * 16 * 128 + ch0); bfr[1][j] = *(const bf16x8 *)(Bb + j * 16 * 128 + ch1); }
+            if constexpr (kX3) {  // [32 hi | 32 lo] K rows: hi*hi, hi*lo, lo*hi
 #pragma unroll
-            for (int kk = 0; kk < 2; kk++)
+                for (int t = 0; t < 3; t++)
 #pragma unroll
-                for (int i = 0; i < MT; i++)
+                    for (int i = 0; i < MT; i++)
 #pragma unroll
-                    for (int j = 0; j < NT; j++) acc[i][j] = RCV_MFMA16(af[kk][i], bfr[kk][j], acc[i][j], 0, 0, 0);
+                        for (int j = 0; j < NT; j++) acc[i][j] = RCV_MFMA16(af[t == 2 ? 1 : 0][i], bfr[t == 1 ? 1 : 0][j], acc[i][j], 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int kk = 0; kk < 2; kk++)
+#pragma unroll
+                    for (int i = 0; i < MT; i++)
+#pragma unroll
+                        for (int j = 0; j < NT; j++) acc[i][j] = RCV_MFMA16(af[kk][i], bfr[kk][j], acc[i][j], 0, 0, 0);
+            }
         }
         stage = stage + 1 == NS ? 0 : stage + 1;
     }
@@ -784,10 +866,12 @@ __global__ __launch_bounds__(512) void k_conv_lat(const ConvParams p)
         for (int j = 0; j < NT; j++) {
             const int nl = wn * 32 + j * 16 + r16;
             const float bv = bias[n0 + nl];
+            const float sc = kX3 ? bias[p.Cout + n0 + nl] : 1.f;
 #pragma unroll
             for (int i = 0; i < MT; i++)
 #pragma unroll
-                for (int e = 0; e < 4; e++) stg[(wm * 32 + i * 16 + kq * 4 + e) * SROW + nl] = acc[i][j][e] + bv;
+                for (int e = 0; e < 4; e++)
+                    stg[(wm * 32 + i * 16 + kq * 4 + e) * SROW + nl] = kX3 ? __fmaf_rn(acc[i][j][e], sc, bv) : acc[i][j][e] + bv;
         }
     }
     __syncthreads();
@@ -803,19 +887,34 @@ __global__ __launch_bounds__(512) void k_conv_lat(const ConvParams p)
                 v[qq * 4 + 0] = t.x; v[qq * 4 + 1] = t.y; v[qq * 4 + 2] = t.z; v[qq * 4 + 3] = t.w;
             }
             if (res) {
-                const T *rp = (const T *)&rres;
+                if constexpr (kX3) {
+                    float rv[8];
+                    x3_join8(rres, rres_lo, rv);
 #pragma unroll
-                for (int qq = 0; qq < EPV; qq++) v[qq] += to_f32(rp[qq]);
+                    for (int qq = 0; qq < EPV; qq++) v[qq] += rv[qq];
+                } else {
+                    const T *rp = (const T *)&rres;
+#pragma unroll
+                    for (int qq = 0; qq < EPV; qq++) v[qq] += to_f32(rp[qq]);
+                }
             }
             if (p.relu) {
 #pragma unroll
                 for (int qq = 0; qq < EPV; qq++) v[qq] = fmaxf(v[qq], 0.f);
             }
-            uint4 outv;
-            T *op = (T *)&outv;
+            T *op_ = dst + nhwc_off<T>(m, p.Cout, n0 + cc * EPV);
+            if constexpr (kX3) {
+                uint4 oh, ol;
+                x3_split8(v, oh, ol);
+                *(uint4 *)op_ = oh;
+                *(uint4 *)(op_ + 32) = ol;
+            } else {
+                uint4 outv;
+                T *op = (T *)&outv;
 #pragma unroll
-            for (int qq = 0; qq < EPV; qq++) op[qq] = from_f32<T>(v[qq]);
-            *(uint4 *)(dst + (long long)m * p.Cout + n0 + cc * EPV) = outv;
+                for (int qq = 0; qq < EPV; qq++) op[qq] = from_f32<T>(v[qq]);
+                *(uint4 *)op_ = outv;
+            }
         }
     }
 }
@@ -1028,6 +1127,94 @@ __global__ __launch_bounds__(512) void k_conv_halo(const HaloParams p)
         stage = stage + 1 == 3 ? 0 : stage + 1;                                                                \
     }
 
+// Split precision (see k_conv_dma): the patch row / weight row is [32 hi | 32 lo]; hi*hi, hi*lo, lo*hi dealt 24 / 24 over the
+// two MFMA phases, per output element always in the order hh, hl, lh.
+#define RCV_HALO_STEP_X3(TAP)                                                                                  \
+    {                                                                                                          \
+        constexpr int T2_ = ((TAP) + 2) % 9, S2_ = ((TAP) + 2) / 9;                                            \
+        const int shift_ = ((TAP) / 3 - 1) * pitch + ((TAP) % 3 - 1);                                          \
+        const unsigned char *Pb = sP + (sl & 1) * HALO_PATCH;                                                  \
+        const unsigned char *Bb = sB + stage * (BN * 128) + (wn * (BN / 2) + r16) * 128;                       \
+        const int st2 = stage + 2 >= 3 ? stage + 2 - 3 : stage + 2;                                            \
+        int ao_[MT];                                                                                           \
+        _Pragma("unroll") for (int i = 0; i < MT; i++) {                                                       \
+            const int prow_ = pr0[i] + shift_;                                                                 \
+            ao_[i] = prow_ * 128 + ((kq ^ (prow_ & 7)) << 4);                                                  \
+        }                                                                                                      \
+        bf16x8 ah[MT], al[MT], bh[NT], bl[NT];                                                                 \
+        _Pragma("unroll") for (int i = 0; i < MT; i++) ah[i] = *(const bf16x8 *)(Pb + ao_[i]);                 \
+        _Pragma("unroll") for (int j = 0; j < NT; j++) bh[j] = *(const bf16x8 *)(Bb + j * 16 * 128 + ch0);     \
+        _Pragma("unroll") for (int j = 0; j < NT / 2; j++) bl[j] = *(const bf16x8 *)(Bb + j * 16 * 128 + ch1); \
+        RCV_HALO_B(sl + S2_, T2_, st2, 0);                                                                     \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                     \
+        __builtin_amdgcn_s_barrier();                                                                          \
+        __builtin_amdgcn_s_setprio(1);                                                                         \
+        _Pragma("unroll") for (int i = 0; i < MT; i++)                                                         \
+            _Pragma("unroll") for (int j = 0; j < NT; j++) acc[i][j] = RCV_MFMA16(ah[i], bh[j], acc[i][j], 0, 0, 0); \
+        _Pragma("unroll") for (int i = 0; i < MT; i++)                                                         \
+            _Pragma("unroll") for (int j = 0; j < NT / 2; j++) acc[i][j] = RCV_MFMA16(ah[i], bl[j], acc[i][j], 0, 0, 0); \
+        __builtin_amdgcn_s_setprio(0);                                                                         \
+        __builtin_amdgcn_s_barrier();                                                                          \
+        _Pragma("unroll") for (int i = 0; i < MT; i++) al[i] = *(const bf16x8 *)(Pb + (ao_[i] ^ 64));          \
+        _Pragma("unroll") for (int j = NT / 2; j < NT; j++) bl[j] = *(const bf16x8 *)(Bb + j * 16 * 128 + ch1); \
+        if constexpr (BPW == 2) RCV_HALO_B(sl + S2_, T2_, st2, 1);                                             \
+        if constexpr ((TAP) < 6) {                                                                             \
+            RCV_HALO_PATCH(sl + 1, TAP);                                                                       \
+            if constexpr (BPW == 2) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");                \
+            else asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");                                   \
+        } else {                                                                                               \
+            if constexpr (BPW == 2) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");                \
+            else asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");                                   \
+        }                                                                                                      \
+        __builtin_amdgcn_s_barrier();                                                                          \
+        __builtin_amdgcn_s_setprio(1);                                                                         \
+        _Pragma("unroll") for (int i = 0; i < MT; i++)                                                         \
+            _Pragma("unroll") for (int j = NT / 2; j < NT; j++) acc[i][j] = RCV_MFMA16(ah[i], bl[j], acc[i][j], 0, 0, 0); \
+        _Pragma("unroll") for (int i = 0; i < MT; i++)                                                         \
+            _Pragma("unroll") for (int j = 0; j < NT; j++) acc[i][j] = RCV_MFMA16(al[i], bh[j], acc[i][j], 0, 0, 0); \
+        __builtin_amdgcn_s_setprio(0);                                                                         \
+        __builtin_amdgcn_s_barrier();                                                                          \
+        stage = stage + 1 == 3 ? 0 : stage + 1;                                                                \
+    }
+// BN = 64, split precision: one load phase, 24 MFMAs
+#define RCV_HALO_STEP2_X3(TAP)                                                                                 \
+    {                                                                                                          \
+        constexpr int T2_ = ((TAP) + 2) % 9, S2_ = ((TAP) + 2) / 9;                                            \
+        const int shift_ = ((TAP) / 3 - 1) * pitch + ((TAP) % 3 - 1);                                          \
+        const unsigned char *Pb = sP + (sl & 1) * HALO_PATCH;                                                  \
+        const unsigned char *Bb = sB + stage * (BN * 128) + (wn * (BN / 2) + r16) * 128;                       \
+        const int st2 = stage + 2 >= 3 ? stage + 2 - 3 : stage + 2;                                            \
+        bf16x8 af[2][MT], bfr[2][NT];                                                                          \
+        _Pragma("unroll") for (int i = 0; i < MT; i++) {                                                       \
+            const int prow_ = pr0[i] + shift_;                                                                 \
+            const int ao_ = prow_ * 128 + ((kq ^ (prow_ & 7)) << 4);                                           \
+            af[0][i] = *(const bf16x8 *)(Pb + ao_);                                                            \
+            af[1][i] = *(const bf16x8 *)(Pb + (ao_ ^ 64));                                                     \
+        }                                                                                                      \
+        _Pragma("unroll") for (int j = 0; j < NT; j++) {                                                       \
+            bfr[0][j] = *(const bf16x8 *)(Bb + j * 16 * 128 + ch0);                                            \
+            bfr[1][j] = *(const bf16x8 *)(Bb + j * 16 * 128 + ch1);                                            \
+        }                                                                                                      \
+        RCV_HALO_B(sl + S2_, T2_, st2, 0);                                                                     \
+        if constexpr ((TAP) < 6) {                                                                             \
+            RCV_HALO_PATCH(sl + 1, TAP);                                                                       \
+            asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");                                        \
+        } else {                                                                                               \
+            asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");                                        \
+        }                                                                                                      \
+        __builtin_amdgcn_s_barrier();                                                                          \
+        __builtin_amdgcn_s_setprio(1);                                                                         \
+        _Pragma("unroll") for (int i = 0; i < MT; i++)                                                         \
+            _Pragma("unroll") for (int j = 0; j < NT; j++) acc[i][j] = RCV_MFMA16(af[0][i], bfr[0][j], acc[i][j], 0, 0, 0); \
+        _Pragma("unroll") for (int i = 0; i < MT; i++)                                                         \
+            _Pragma("unroll") for (int j = 0; j < NT; j++) acc[i][j] = RCV_MFMA16(af[0][i], bfr[1][j], acc[i][j], 0, 0, 0); \
+        _Pragma("unroll") for (int i = 0; i < MT; i++)                                                         \
+            _Pragma("unroll") for (int j = 0; j < NT; j++) acc[i][j] = RCV_MFMA16(af[1][i], bfr[0][j], acc[i][j], 0, 0, 0); \
+        __builtin_amdgcn_s_setprio(0);                                                                         \
+        __builtin_amdgcn_s_barrier();                                                                          \
+        stage = stage + 1 == 3 ? 0 : stage + 1;                                                                \
+    }
+
     const int grp = wave >> 2;
 #pragma unroll
     for (int k = 0; k < 6; k++) RCV_HALO_PATCH(0, k);
@@ -1040,7 +1227,19 @@ __global__ __launch_bounds__(512) void k_conv_halo(const HaloParams p)
     __builtin_amdgcn_s_barrier();
     if (grp == 1) __builtin_amdgcn_s_barrier();
     int stage = 0;
-    if constexpr (BPW == 2) {
+    if constexpr (BPW == 2 && kX3) {
+        for (int sl = 0; sl < nsl; sl++) {
+            RCV_HALO_STEP_X3(0); RCV_HALO_STEP_X3(1); RCV_HALO_STEP_X3(2);
+            RCV_HALO_STEP_X3(3); RCV_HALO_STEP_X3(4); RCV_HALO_STEP_X3(5);
+            RCV_HALO_STEP_X3(6); RCV_HALO_STEP_X3(7); RCV_HALO_STEP_X3(8);
+        }
+    } else if constexpr (kX3) {
+        for (int sl = 0; sl < nsl; sl++) {
+            RCV_HALO_STEP2_X3(0); RCV_HALO_STEP2_X3(1); RCV_HALO_STEP2_X3(2);
+            RCV_HALO_STEP2_X3(3); RCV_HALO_STEP2_X3(4); RCV_HALO_STEP2_X3(5);
+            RCV_HALO_STEP2_X3(6); RCV_HALO_STEP2_X3(7); RCV_HALO_STEP2_X3(8);
+        }
+    } else if constexpr (BPW == 2) {
         for (int sl = 0; sl < nsl; sl++) {
             RCV_HALO_STEP(0); RCV_HALO_STEP(1); RCV_HALO_STEP(2);
             RCV_HALO_STEP(3); RCV_HALO_STEP(4); RCV_HALO_STEP(5);
@@ -1057,6 +1256,8 @@ __global__ __launch_bounds__(512) void k_conv_halo(const HaloParams p)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the zero pieces issued past the end
 #undef RCV_HALO_STEP
 #undef RCV_HALO_STEP2
+#undef RCV_HALO_STEP_X3
+#undef RCV_HALO_STEP2_X3
 #undef RCV_HALO_B
 #undef RCV_HALO_PATCH
 
@@ -1074,10 +1275,12 @@ __global__ __launch_bounds__(512) void k_conv_halo(const HaloParams p)
             for (int j = 0; j < NT; j++) {
                 const int nl = wn * (BN / 2) + j * 16 + r16;
                 const float bv = bias[n0 + nl];
+                const float sc = kX3 ? bias[p.Cout + n0 + nl] : 1.f;  // (split mode: the weights' power-of-two scale, undone here)
 #pragma unroll
                 for (int i = 0; i < MT; i++)
 #pragma unroll
-                    for (int e = 0; e < 4; e++) stg[((wm & 1) * RW + i * 16 + kq * 4 + e) * SROW + nl] = acc[i][j][e] + bv;
+                    for (int e = 0; e < 4; e++)
+                        stg[((wm & 1) * RW + i * 16 + kq * 4 + e) * SROW + nl] = kX3 ? __fmaf_rn(acc[i][j][e], sc, bv) : acc[i][j][e] + bv;
             }
         }
         __syncthreads();
@@ -1088,7 +1291,7 @@ __global__ __launch_bounds__(512) void k_conv_halo(const HaloParams p)
             const int py = (int)(((float)r + 0.5f) * rT), px = r - py * p.tw;
             const int y = y0 + py, x = x0 + px;
             if (lr >= 2 * RW || r >= npx || y >= p.H || x >= p.W) continue;
-            const long long o = ((long long)(img * p.H + y) * p.W + x) * p.Cout + n0 + cc * EPV;
+            const long long o = nhwc_off<T>((long long)(img * p.H + y) * p.W + x, p.Cout, n0 + cc * EPV);
             float v[EPV];
             const float4 *sp4 = (const float4 *)(stg + lr * SROW + cc * EPV);
 #pragma unroll
@@ -1100,11 +1303,18 @@ __global__ __launch_bounds__(512) void k_conv_halo(const HaloParams p)
 #pragma unroll
                 for (int qq = 0; qq < EPV; qq++) v[qq] = fmaxf(v[qq], 0.f);
             }
-            uint4 outv;
-            T *op = (T *)&outv;
+            if constexpr (kX3) {
+                uint4 oh, ol;
+                x3_split8(v, oh, ol);
+                *(uint4 *)(dst + o) = oh;
+                *(uint4 *)(dst + o + 32) = ol;
+            } else {
+                uint4 outv;
+                T *op = (T *)&outv;
 #pragma unroll
-            for (int qq = 0; qq < EPV; qq++) op[qq] = from_f32<T>(v[qq]);
-            *(uint4 *)(dst + o) = outv;
+                for (int qq = 0; qq < EPV; qq++) op[qq] = from_f32<T>(v[qq]);
+                *(uint4 *)(dst + o) = outv;
+            }
         }
         if (half == 0) __syncthreads();
     }
@@ -2640,10 +2850,10 @@ int launch_conv(const ConvParams &p, int groups, hipStream_t st, bool set_attr, 
     if (p.C0 % KE || p.C1 % KE || p.Cout % 32 || p.K % KE) return RCV_E_UNSUPPORTED;
     // few output tiles (a frame or two in flight) and a long K: the layer's time is its chain of K steps -> latency kernel
     // (measured at batch 1: it pays from K = 1024 on; short-K layers keep k_conv, whose tiles are cheaper to set up)
-    if (sizeof(T) == 2 && !kX3 && allow_lat && allow_dma && p.Cout % LAT_BN == 0 && p.K >= 1024 &&
+    if (sizeof(T) == 2 && allow_lat && allow_dma && p.Cout % LAT_BN == 0 && p.K >= 1024 * (kX3 ? 2 : 1) &&
         (long long)((p.M + 127) / 128) * ((p.Cout + 127) / 128) * groups <= 128)
         return launch_conv_lat(p, groups, st);
-    if (sizeof(T) == 2 && !kX3 && allow_dma && p.Cout % DMA_BN == 0 &&
+    if (sizeof(T) == 2 && allow_dma && p.Cout % DMA_BN == 0 &&
         (long long)((p.M + DMA_BM - 1) / DMA_BM) * (p.Cout / DMA_BN) * groups >= 192)
         return launch_conv_dma(p, groups, st, set_attr);
     const int BN = p.Cout % 128 == 0 ? 128 : (p.Cout % 64 == 0 ? 64 : 32);
@@ -2740,7 +2950,7 @@ int run_op(rcv_fcn *h, const rcv_op &op, const float *x, int B, float *seg, floa
         // the LDS-DMA kernels address a tensor through a buffer descriptor with 32-bit byte offsets: only below 2 GiB per group
         auto fits32 = [&](int s) { return s < 0 || (long long)h->slot_elems[s] * B * (long long)sizeof(T) * ES < 0x7fffffffLL; };
         const bool dma_ok = h->use_dma && fits32(op.src0) && fits32(op.src1) && fits32(op.res) && fits32(op.dst);
-        if constexpr (sizeof(T) == 2 && !kX3) {
+        if constexpr (sizeof(T) == 2) {
             int th, tw;
             if (h->use_halo && dma_ok && op.ksize == 3 && op.stride == 1 && op.pad == 1 && op.res < 0 && p.Cout % 64 == 0 &&
                 p.C0 % 64 == 0 && p.C1 % 64 == 0 && op.hin == op.hout && op.win == op.wout && halo_tile(op.hout, op.wout, h->use_halo, th, tw) && (th * tw <= 256 || p.Cout % 128 == 0) &&
