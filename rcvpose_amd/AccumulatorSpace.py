@@ -487,7 +487,7 @@ def estimate_6d_pose_lm(opts, return_details=False):
                 from PIL import Image
 
                 if pipe is None:
-                    pipe = FramePipeline(sds, H, W, dtype=getattr(opts, 'dtype', 'fp32'), frames_per_step=1)
+                    pipe = FramePipeline(sds, H, W, dtype=getattr(opts, 'dtype', 'f16x3'), frames_per_step=1)
                     pipe.set_stage_timing(True)
                 rgb = np.array(Image.open(dataPath + filename).convert('RGB'), dtype=np.uint8)
                 pipe.process(torch.from_numpy(rgb)[None].cuda(), depth_dev[None], max_radii_dm)
@@ -602,7 +602,7 @@ def estimate_6d_pose_lmo(opts, return_details=False):
                 estimated_kpts, statuses = np.zeros((3, 3)), []
                 if opts.using_ckpts:
                     if pipe is None:
-                        pipe = FramePipeline(sds, H, W, dtype=getattr(opts, 'dtype', 'fp32'), frames_per_step=1)
+                        pipe = FramePipeline(sds, H, W, dtype=getattr(opts, 'dtype', 'f16x3'), frames_per_step=1)
                         pipe.set_stage_timing(True)
                         pipe.seg_threshold = seg_thr
                     rgb = np.array(Image.open(jpgPath + filename).convert('RGB'), dtype=np.uint8)
@@ -755,7 +755,7 @@ def estimate_6d_pose_ycb(opts, return_details=False):
             H, W = depth_map1.shape
             depth_dev = _depth_to_u16(depth_map1, "cuda")
             if pipe is None:
-                pipe = FramePipeline(sds, H, W, dtype=getattr(opts, 'dtype', 'fp32'), frames_per_step=1)
+                pipe = FramePipeline(sds, H, W, dtype=getattr(opts, 'dtype', 'f16x3'), frames_per_step=1)
                 pipe.set_stage_timing(True)
                 ws = AccWorkspace(H * W)
             pipe._mark("begin_net")

@@ -77,15 +77,17 @@ class DenseFCNResNet152(nn.Module):
             setattr(self, "up" + name, nn.Upsample(scale_factor=2, mode="bilinear", align_corners=False))
         self.conv7 = _decoder_stage(64, 32)
         self.conv8 = nn.Conv2d(32, output_channels, kernel_size=1, stride=1)
-        # "fp32": exact-fp32 MFMA kernels (matches the reference's fp32 forward to ~1e-5 relative)
-        # "bf16" / "fp16": 16-bit storage / fp32 accumulate (performance modes; fp16 carries 11 significand bits)
-        self.compute_dtype = "fp32"
+        # "f16x3": fp16 hi / lo operand pairs, three MFMAs per product, fp32 accumulate -- matches the reference's fp32 forward to
+        #          ~1e-5 relative like "fp32", several times faster (the default)
+        # "fp32": exact-fp32 MFMA kernels (v_mfma_f32_16x16x4_f32)
+        # "bf16" / "fp16": 16-bit storage / fp32 accumulate (throughput modes outside the 1e-4 tolerance)
+        self.compute_dtype = "f16x3"
         self._engine = None
         self._engine_key = None
 
     def set_compute_dtype(self, name):
-        if name not in ("fp32", "bf16", "fp16"):
-            raise ValueError("compute dtype must be 'fp32', 'bf16' or 'fp16'")
+        if name not in ("f16x3", "fp32", "bf16", "fp16"):
+            raise ValueError("compute dtype must be 'f16x3', 'fp32', 'bf16' or 'fp16'")
         self.compute_dtype = name
         return self
 
@@ -143,6 +145,6 @@ class ResFCNResNet152(DenseFCNResNet152):
             setattr(self, "up" + name, nn.Upsample(scale_factor=2, mode="bilinear", align_corners=False))
         self.conv7 = _decoder_stage(128, 64)
         self.conv8 = nn.Conv2d(64, output_channels, kernel_size=1, stride=1)
-        self.compute_dtype = "fp32"
+        self.compute_dtype = "f16x3"
         self._engine = None
         self._engine_key = None

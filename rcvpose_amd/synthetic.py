@@ -15,7 +15,11 @@ _LM = dict(K=LINEMOD_K, axes=(0.12, 0.10, 0.08), centre=(0.02, -0.03, 0.90))
 _YCB = dict(K=YCB_K, axes=(0.0975, 0.079, 0.065), centre=(0.01, -0.02, 0.75))  # ~50k silhouette pixels
 
 
-def synthetic_frame(frame_idx, H=480, W=640, shape="lm", noise_dm=0.02):
+def synthetic_frame(frame_idx, H=480, W=640, shape="lm", noise_dm=0.02, outlier_frac=0.0, seg_false_pos=0.0):
+    """outlier_frac: fraction of the silhouette pixels whose radius is replaced by a uniform value in (0, max radius] (gross
+    regression errors); seg_false_pos: background pixels (a far plane at 1.3 m, in a band around the silhouette) wrongly
+    segmented as object, as a fraction of the silhouette size, with uniform random radii.  Both default to 0 and then leave the
+    frame exactly as before (the extra random draws come after all others)."""
     cfg = _LM if shape == "lm" else _YCB
     fx, fy, cx, cy = cfg["K"]
     a, b, c = cfg["axes"]
@@ -50,6 +54,23 @@ def synthetic_frame(frame_idx, H=480, W=640, shape="lm", noise_dm=0.02):
         max_radii[k] = r[inside].max()
         noisy = r + rng.normal(0, noise_dm, size=r.shape)
         radial[k] = np.where(inside, np.minimum(noisy, max_radii[k]), 0.0).astype(np.float32)
+    if outlier_frac > 0.0:
+        for k in range(3):
+            bad = inside & (rng.random(size=inside.shape) < outlier_frac)
+            radial[k] = np.where(bad, rng.uniform(0.05, max_radii[k], size=inside.shape), radial[k]).astype(np.float32)
+    if seg_false_pos > 0.0:
+        # band of ~12 pixels around the silhouette (dilation by shifts), background depth = plane at 1.3 m
+        band = np.zeros_like(inside)
+        for dy in (-12, -6, 0, 6, 12):
+            for dx in (-12, -6, 0, 6, 12):
+                band |= np.roll(np.roll(inside, dy, axis=0), dx, axis=1)
+        band &= ~inside
+        p = min(1.0, seg_false_pos * inside.sum() / max(1, band.sum()))
+        fp = band & (rng.random(size=inside.shape) < p)
+        depth = np.where(fp, 1300, depth).astype(np.uint16)
+        seg = np.where(fp, 1.0, seg).astype(np.float32)
+        for k in range(3):
+            radial[k] = np.where(fp, rng.uniform(0.05, max_radii[k], size=inside.shape), radial[k]).astype(np.float32)
     # float32 storage may round the clipped maximum above the float64 bound; keep the bound inclusive
     max_radii = np.maximum(max_radii, radial.reshape(3, -1).max(axis=1).astype(np.float64))
     return {
