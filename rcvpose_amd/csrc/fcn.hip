@@ -1335,30 +1335,37 @@ constexpr int STEM_TH = 8, STEM_TW = 32, STEM_KP = 160, STEM_PITCH = 336;  // by
 constexpr int STEM_IH = STEM_TH * 2 + 5, STEM_IW = STEM_TW * 2 + 5;
 constexpr int STEM_MAXG = 3;   // networks whose weights stay in LDS side by side (more: the kernel is launched per slice of groups)
 constexpr int STEM_RUN = 5;    // consecutive tiles of a tile row per workgroup
-constexpr int STEM_LDS = STEM_MAXG * 64 * STEM_PITCH + 3 * STEM_IH * (STEM_IW + 1) * 2 + STEM_KP * 4;  // weights, input patch (16-bit), tap offsets: 74 KB
+constexpr int STEM_NH = kX3 ? 2 : 1;  // 16-bit planes per value (split precision: hi and lo)
+constexpr int STEM_LDS = STEM_NH * (STEM_MAXG * 64 * STEM_PITCH + 3 * STEM_IH * (STEM_IW + 1) * 2) + STEM_KP * 4;  // weights, input patch (16-bit), tap offsets: 74 KB (split: 147 KB)
 
 // (r02) The im2col tile no longer exists in LDS: every lane builds the MFMA A fragments of its own pixels straight from the
 // input patch (the same bf16 values in the same k order, so the result is unchanged) and keeps them in registers for all
 // groups.  The weights of all groups are laid into LDS ONCE per workgroup, which then walks STEM_RUN tiles of its tile row
 // (before: 21 KB of weights scattered into LDS per group and tile); the patch is stored as 16-bit values -- the rounding the
 // fragments need anyway -- so that two workgroups still share a CU and one's loads / stores overlap the other's MFMAs.
-__global__ __launch_bounds__(256, 2) void k_stem_mfma(const float *x, const H16 *w, const float *bias, H16 *dst, int H, int W,
+// Split precision (kX3): the image and the weights are half hi / lo pairs -- two patch planes, two weight tiles per group
+// ([64*147 hi][64*147 lo] in global memory, scaled per output channel: bias[64 + co] undoes it), three MFMAs per (pixel group,
+// channel tile, K chunk): hi*hi, hi*lo, lo*hi.  147 KB of LDS: one workgroup per CU.
+__global__ __launch_bounds__(256, (kX3 ? 1 : 2)) void k_stem_mfma(const float *x, const H16 *w, const float *bias, H16 *dst, int H, int W,
                                                       int Ho, int Wo, int groups, long long w_gs, int bias_gs, long long dst_gs)
 {
     using T = H16;
+    constexpr int NH = STEM_NH;
+    constexpr int WPLANE = STEM_MAXG * 64 * STEM_PITCH, IPLANE = 3 * STEM_IH * (STEM_IW + 1) * 2;  // bytes of one weight / patch plane
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char *sBall = smem;                                // [groups][64][STEM_PITCH]
-    T(*s_in)[STEM_IH][STEM_IW + 1] = (T(*)[STEM_IH][STEM_IW + 1])(smem + STEM_MAXG * 64 * STEM_PITCH);
-    int *s_koff = (int *)(smem + STEM_MAXG * 64 * STEM_PITCH + 3 * STEM_IH * (STEM_IW + 1) * 2);  // [STEM_KP]
+    unsigned char *sBall = smem;                                // [NH][groups][64][STEM_PITCH]
+    T(*s_in)[STEM_IH][STEM_IW + 1] = (T(*)[STEM_IH][STEM_IW + 1])(smem + NH * WPLANE);  // [NH][3][IH][IW + 1]
+    int *s_koff = (int *)(smem + NH * (WPLANE + IPLANE));  // [STEM_KP]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tiles_x = (Wo + STEM_TW - 1) / STEM_TW, runs_x = (tiles_x + STEM_RUN - 1) / STEM_RUN;
     const int ty = blockIdx.x / runs_x, run = blockIdx.x - ty * runs_x;
     const int img = blockIdx.y;
     const int ho0 = ty * STEM_TH, hi0 = ho0 * 2 - 3;
     // ---- once per workgroup: every group's [64][147] weights into its B tile [64][160] (zero padded)
-    for (int g = 0; g < groups; g++) {
-        const T *wg = w + (long long)g * w_gs;
-        unsigned char *sB = sBall + g * 64 * STEM_PITCH;
+    for (int gh = 0; gh < groups * NH; gh++) {
+        const int g = gh / NH, hp = gh - g * NH;  // group, plane (0: hi, 1: lo)
+        const T *wg = w + (long long)g * w_gs + hp * (64 * 147);
+        unsigned char *sB = sBall + hp * WPLANE + g * 64 * STEM_PITCH;
         // 64 x 147 contiguous weights as 16-byte vectors (1176 of them): all of a thread's loads are issued before the
         // first LDS write; the eight elements of a vector are scattered to their (out channel, k) cells
         constexpr int NV = 64 * 147 / 8, PER = (NV + 255) / 256;
@@ -1424,13 +1431,14 @@ __global__ __launch_bounds__(256, 2) void k_stem_mfma(const float *x, const H16 
                 if (i < NE) {
                     const int c = i / (STEM_IH * STEM_IW), rem = i - c * (STEM_IH * STEM_IW);
                     const int r = rem / STEM_IW, q = rem - r * STEM_IW;
-                    s_in[c][r][q] = (T)pv[u];
+                    if constexpr (kX3) x3_split(pv[u], s_in[c][r][q], s_in[3 + c][r][q]);
+                    else s_in[c][r][q] = (T)pv[u];
                 }
             }
         }
         __syncthreads();
         // A fragments of this lane: pixel group i (pixel wave*64 + i*16 + r16), K chunk ks: k = ks*32 + kq*8 + e
-        bf16x8 afr[4][STEM_KP / 32];
+        bf16x8 afr[NH][4][STEM_KP / 32];
         {
             int koff[STEM_KP / 32][8];
 #pragma unroll
@@ -1438,14 +1446,16 @@ __global__ __launch_bounds__(256, 2) void k_stem_mfma(const float *x, const H16 
 #pragma unroll
                 for (int e = 0; e < 8; e++) koff[ks][e] = s_koff[ks * 32 + kq * 8 + e];
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
-                const int pix = wave * 64 + i * 16 + r16, py = pix >> 5, px = pix & 31;
-                const T *base = &s_in[0][py * 2][px * 2];
+            for (int hp = 0; hp < NH; hp++)
 #pragma unroll
-                for (int ks = 0; ks < STEM_KP / 32; ks++)
+                for (int i = 0; i < 4; i++) {
+                    const int pix = wave * 64 + i * 16 + r16, py = pix >> 5, px = pix & 31;
+                    const T *base = &s_in[3 * hp][py * 2][px * 2];
 #pragma unroll
-                    for (int e = 0; e < 8; e++) afr[i][ks][e] = ks * 32 + kq * 8 + e < 147 ? base[koff[ks][e]] : (T)0.f;
-            }
+                    for (int ks = 0; ks < STEM_KP / 32; ks++)
+#pragma unroll
+                        for (int e = 0; e < 8; e++) afr[hp][i][ks][e] = ks * 32 + kq * 8 + e < 147 ? base[koff[ks][e]] : (T)0.f;
+                }
         }
         for (int g = 0; g < groups; g++) {
             const unsigned char *sB = sBall + g * 64 * STEM_PITCH;
@@ -1456,15 +1466,26 @@ __global__ __launch_bounds__(256, 2) void k_stem_mfma(const float *x, const H16 
                 for (int j = 0; j < 4; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ks = 0; ks < STEM_KP / 32; ks++) {
-                bf16x8 af[4], bfr[4];
+                bf16x8 bfr[NH][4];
 #pragma unroll
-                for (int i = 0; i < 4; i++) af[i] = afr[i][ks];
+                for (int hp = 0; hp < NH; hp++)
 #pragma unroll
-                for (int j = 0; j < 4; j++) bfr[j] = *(const bf16x8 *)(sB + (j * 16 + r16) * STEM_PITCH + (ks * 32 + kq * 8) * 2);
+                    for (int j = 0; j < 4; j++)
+                        bfr[hp][j] = *(const bf16x8 *)(sB + hp * WPLANE + (j * 16 + r16) * STEM_PITCH + (ks * 32 + kq * 8) * 2);
 #pragma unroll
                 for (int i = 0; i < 4; i++)
 #pragma unroll
-                    for (int j = 0; j < 4; j++) acc[i][j] = RCV_MFMA16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < 4; j++) acc[i][j] = RCV_MFMA16(bfr[0][j], afr[0][i][ks], acc[i][j], 0, 0, 0);
+                if constexpr (kX3) {  // image hi x weight lo, image lo x weight hi
+#pragma unroll
+                    for (int i = 0; i < 4; i++)
+#pragma unroll
+                        for (int j = 0; j < 4; j++) acc[i][j] = RCV_MFMA16(bfr[NH - 1][j], afr[0][i][ks], acc[i][j], 0, 0, 0);
+#pragma unroll
+                    for (int i = 0; i < 4; i++)
+#pragma unroll
+                        for (int j = 0; j < 4; j++) acc[i][j] = RCV_MFMA16(bfr[0][j], afr[NH - 1][i][ks], acc[i][j], 0, 0, 0);
+                }
             }
             // acc[i][j][e] = channel j*16 + kq*4 + e of pixel wave*64 + i*16 + r16 (operands swapped); see k_conv_dma's
             // notes on the permlane16 swap: afterwards the lane owns 8 consecutive channels
@@ -1485,6 +1506,17 @@ __global__ __launch_bounds__(256, 2) void k_stem_mfma(const float *x, const H16 
                     }
                     const int ch = e_ch + pr * 32;
                     const float4 b0 = *(const float4 *)(bg + ch), b1 = *(const float4 *)(bg + ch + 4);
+                    if constexpr (kX3) {
+                        const float4 s0 = *(const float4 *)(bg + 64 + ch), s1 = *(const float4 *)(bg + 64 + ch + 4);
+                        v[0] = __fmaf_rn(v[0], s0.x, b0.x); v[1] = __fmaf_rn(v[1], s0.y, b0.y); v[2] = __fmaf_rn(v[2], s0.z, b0.z); v[3] = __fmaf_rn(v[3], s0.w, b0.w);
+                        v[4] = __fmaf_rn(v[4], s1.x, b1.x); v[5] = __fmaf_rn(v[5], s1.y, b1.y); v[6] = __fmaf_rn(v[6], s1.z, b1.z); v[7] = __fmaf_rn(v[7], s1.w, b1.w);
+#pragma unroll
+                        for (int qq = 0; qq < 8; qq++) v[qq] = fmaxf(v[qq], 0.f);
+                        uint4 oh, ol;
+                        x3_split8(v, oh, ol);
+                        T *op_ = out + ((long long)(img * Ho + ho) * Wo + wo) * 128 + x3_off(ch);
+                        if (ho < Ho && wo < Wo) { *(uint4 *)op_ = oh; *(uint4 *)(op_ + 32) = ol; }
+                    } else {
                     v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w;
                     v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
                     uint4 outv;
@@ -1492,6 +1524,7 @@ __global__ __launch_bounds__(256, 2) void k_stem_mfma(const float *x, const H16 
 #pragma unroll
                     for (int qq = 0; qq < 8; qq++) op[qq] = (T)fmaxf(v[qq], 0.f);
                     if (ho < Ho && wo < Wo) *(uint4 *)(out + ((long long)(img * Ho + ho) * Wo + wo) * 64 + ch) = outv;
+                    }
                 }
             }
         }
@@ -2719,6 +2752,190 @@ __global__ __launch_bounds__(256, 2) void k_tail(const H16 *src, const H16 *w7, 
 #undef RCV_TAIL_SOURCE
 }
 
+// ---------------------------------------------------------------------------------------------
+// k_tail_x3 (split precision): the same three layers -- 2x bilinear upsampling of the 64-channel map, conv7 (3x3, 64 -> 32,
+// ReLU) and the 1x1 head -- for the RCV_F16X3 engine.  Unfused they move 17 GB per 72 (frame, network) items through HBM
+// (the 480x640x64 upsampled map alone is 79 MB per item in hi / lo storage); fused only the 240x320x64 source is read.
+// Eight waves: wave = (pixel quarter of the 8 x 32 tile, 16-channel half of conv7's outputs); its 18 x (hi, lo) weight fragments
+// stay in registers (144 VGPRs) for the whole strip, the A fragments (hi and lo of a 32-channel slice) come from the upsampled
+// patch U in LDS: 8 reads per 12 MFMAs and wave.  U's pixel pitch is 288 B (256 + 32): conflict-free for ds_read_b128's lane
+// groups like k_tail's 160.  K order = k_conv's in split mode: channel slice outermost, taps inside, hh / hl / lh per step; the
+// upsampling, conv7's rounding to hi + lo and the head's FMA chain are the unfused kernels' -- identical outputs.
+// ---------------------------------------------------------------------------------------------
+constexpr int TX_UP = 288;                                   // bytes per pixel of the upsampled patch
+constexpr int TX_SPIX = TAIL_SH * TAIL_SW;                   // source pixels per tile (6 x 18)
+constexpr int TX_SPIECES = (TX_SPIX + 3) / 4;                // DMA pieces: 4 pixels x 256 B
+constexpr int TX_HP = 144;                                   // bytes per pixel of the conv7 rows: [32 hi | 32 lo] + 16 (bank spread)
+constexpr int TX_LDS_MAIN = TAIL_UH * TAIL_UW * TX_UP + TX_SPIECES * 1024;
+constexpr int TX_LDS = TX_LDS_MAIN + 64 * 4;
+static_assert(256 * TX_HP <= TAIL_UH * TAIL_UW * TX_UP, "the conv7 rows reuse the upsampled patch's LDS");
+
+__global__ __launch_bounds__(512) void k_tail_x3(const H16 *src, const H16 *w7, const float *b7, const H16 *w8, const float *b8,
+                                                 float *seg, float *radial, int B, int Hin, int Win, long long src_gs, long long w7_gs,
+                                                 int b7_gs, long long w8_gs, int b8_gs, int rad_f16)
+{
+    using T = H16;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char *sU = smem;                                        // [340][TX_UP] upsampled patch ...
+    unsigned char *sH = sU;                                          // ... later [256][TX_HP] conv7 output
+    unsigned char *sS = smem + TAIL_UH * TAIL_UW * TX_UP;            // [108][256 B] source patch of the NEXT tile by LDS-DMA
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r16 = lane & 15, kq = lane >> 4;
+    const int Ho = Hin * 2, Wo = Win * 2;
+    const int ty = blockIdx.x, img = blockIdx.y, g = blockIdx.z;
+    const int ho0 = ty * TAIL_TH;
+    const T *sg = src + (long long)g * src_gs + (long long)img * Hin * Win * 128;
+    const int pq = wave & 3, nt = wave >> 2;
+    // conv7 weights of this wave's 16 output channels: [co][tap][slice][hi 32 | lo 32]
+    bf16x8 bw[2][9][2];  // [slice][tap][hi / lo]
+    {
+        const T *wg = w7 + (long long)g * w7_gs + (long long)(nt * 16 + r16) * 1152;
+#pragma unroll
+        for (int sl = 0; sl < 2; sl++)
+#pragma unroll
+            for (int t = 0; t < 9; t++)
+#pragma unroll
+                for (int h = 0; h < 2; h++) bw[sl][t][h] = *(const bf16x8 *)(wg + (t * 2 + sl) * 64 + h * 32 + kq * 8);
+    }
+    float bias7[4], sc7[4];
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+        bias7[e] = b7[(long long)g * b7_gs + nt * 16 + kq * 4 + e];
+        sc7[e] = b7[(long long)g * b7_gs + 32 + nt * 16 + kq * 4 + e];
+    }
+    float *hw = (float *)(smem + TX_LDS_MAIN);  // head weights [2][32] as fp32 (hi + lo, as k_head forms them)
+    if (tid < 64) hw[tid] = (float)w8[(long long)g * w8_gs + tid] + (float)w8[(long long)g * w8_gs + 64 + tid];
+    const float hb0 = b8[(long long)g * b8_gs], hb1 = b8[(long long)g * b8_gs + 1];
+    const float hs0 = b8[(long long)g * b8_gs + 2], hs1 = b8[(long long)g * b8_gs + 3];
+    int ubase[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int m = pq * 64 + i * 16 + r16;
+        ubase[i] = (m >> 5) * TAIL_UW + (m & 31);
+    }
+    const int sy0 = ho0 / 2 - 1;
+    const int src_bytes = Hin * Win * 256;
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    constexpr int SPW = (TX_SPIECES + 7) / 8;  // pieces per wave
+    int s_row[SPW], s_col[SPW];  // byte offset of the patch row (+ the lane's 16-byte chunk); patch column, or -1
+#pragma unroll
+    for (int k = 0; k < SPW; k++) {
+        const int pp = (k * 8 + wv) * 4 + (lane >> 4);
+        const int a = pp / TAIL_SW, b = pp - a * TAIL_SW;
+        s_row[k] = min(max(sy0 + a, 0), Hin - 1) * Win * 256 + (lane & 15) * 16;
+        s_col[k] = (k * 8 + wv < TX_SPIECES && pp < TX_SPIX) ? b : -1;
+    }
+#define RCV_TX_SOURCE(sx0_)                                                                                    \
+    _Pragma("unroll") for (int k = 0; k < SPW; k++)                                                            \
+        if (k * 8 + wv < TX_SPIECES)                                                                           \
+            tail_dma16(sg, src_bytes, sS + (k * 8 + wv) * 1024,                                                \
+                       s_col[k] >= 0 ? s_row[k] + min(max((sx0_) + s_col[k], 0), Win - 1) * 256 : (int)0x80000000);
+    RCV_TX_SOURCE(-1);
+    for (int tx = 0; tx * TAIL_TW < Wo; tx++) {
+        const int wo0 = tx * TAIL_TW;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();  // the whole source patch is in sS; every thread is done with the previous tile's conv7 rows in sU
+        // ---- upsampled patch: one task = one source cell and one 8-channel chunk -> its 2 x 2 patch pixels (k_upsample2's scheme)
+#pragma unroll 1
+        for (int v = tid; v < (TAIL_UH / 2) * (TAIL_UW / 2) * 8; v += 512) {
+            const int c = v & 7, cell = v >> 3, ai = cell / (TAIL_UW / 2), bi = cell - ai * (TAIL_UW / 2);
+            const int coff = x3_off(c * 8) * 2;  // byte offset of the chunk's hi halves inside a pixel; lo: + 64
+            const unsigned char *r0 = sS + (ai * TAIL_SW + bi) * 256 + coff, *r1 = r0 + TAIL_SW * 256;
+            float f00[8], f01[8], f10[8], f11[8];
+            x3_join8(*(const uint4 *)r0, *(const uint4 *)(r0 + 64), f00);
+            x3_join8(*(const uint4 *)(r0 + 256), *(const uint4 *)(r0 + 256 + 64), f01);
+            x3_join8(*(const uint4 *)r1, *(const uint4 *)(r1 + 64), f10);
+            x3_join8(*(const uint4 *)(r1 + 256), *(const uint4 *)(r1 + 256 + 64), f11);
+#pragma unroll
+            for (int dy = 0; dy < 2; dy++) {
+                const int uy = 2 * ai + dy, y = ho0 - 1 + uy;
+                int y0, y1;
+                float ly, hy;
+                up2_src(y, Hin, y0, y1, ly, hy);
+#pragma unroll
+                for (int dx = 0; dx < 2; dx++) {
+                    const int ux = 2 * bi + dx, x = wo0 - 1 + ux;
+                    int x0, x1;
+                    float lx, hx;
+                    up2_src(x, Win, x0, x1, lx, hx);
+                    uint4 oh = make_uint4(0u, 0u, 0u, 0u), ol = oh;
+                    if ((unsigned)y < (unsigned)Ho && (unsigned)x < (unsigned)Wo) {
+                        float bl[8];
+#pragma unroll
+                        for (int e = 0; e < 8; e++) bl[e] = bilerp(hy, hx, ly, lx, f00[e], f01[e], f10[e], f11[e]);
+                        x3_split8(bl, oh, ol);
+                    }
+                    unsigned char *up = sU + (uy * TAIL_UW + ux) * TX_UP + coff;
+                    *(uint4 *)up = oh;
+                    *(uint4 *)(up + 64) = ol;
+                }
+            }
+        }
+        __syncthreads();  // U is complete, sS is free
+        if ((tx + 1) * TAIL_TW < Wo) RCV_TX_SOURCE((wo0 + TAIL_TW) / 2 - 1);
+        // ---- conv7: K = 2 channel slices x 9 taps x [32 hi | 32 lo]
+        f32x4 acc[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int sl = 0; sl < 2; sl++)
+#pragma unroll
+            for (int t = 0; t < 9; t++) {
+                const int toff = (t / 3) * TAIL_UW + (t % 3);
+                bf16x8 ah[4], al[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++) {  // constant offsets from the lane's pixel: fold into the ds_read immediates
+                    ah[i] = *(const bf16x8 *)(sU + ubase[i] * TX_UP + kq * 16 + (toff * TX_UP + sl * 128));
+                    al[i] = *(const bf16x8 *)(sU + ubase[i] * TX_UP + kq * 16 + (toff * TX_UP + sl * 128 + 64));
+                }
+#pragma unroll
+                for (int i = 0; i < 4; i++) acc[i] = RCV_MFMA16(bw[sl][t][0], ah[i], acc[i], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < 4; i++) acc[i] = RCV_MFMA16(bw[sl][t][1], ah[i], acc[i], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < 4; i++) acc[i] = RCV_MFMA16(bw[sl][t][0], al[i], acc[i], 0, 0, 0);
+                asm volatile("" ::: "memory");  // keep the fragment reads of later K steps from being hoisted (registers)
+            }
+        __syncthreads();  // every wave is done reading U: its LDS takes the conv7 rows
+        // ---- bias + ReLU, stored as hi + lo like the conv7 activation; operands were swapped, so acc[i][e] is channel
+        // nt*16 + kq*4 + e of pixel pq*64 + i*16 + r16
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            uint2 ph, pl;
+            T *vh = (T *)&ph, *vl = (T *)&pl;
+#pragma unroll
+            for (int e = 0; e < 4; e++) x3_split(fmaxf(__fmaf_rn(acc[i][e], sc7[e], bias7[e]), 0.f), vh[e], vl[e]);
+            unsigned char *hp = sH + (pq * 64 + i * 16 + r16) * TX_HP + (nt * 16 + kq * 4) * 2;
+            *(uint2 *)hp = ph;
+            *(uint2 *)(hp + 64) = pl;
+        }
+        __syncthreads();
+        // ---- head: thread = pixel, the sequential FMA chain of k_head
+        if (tid < 256) {
+            const int ho = ho0 + (tid >> 5), wo = wo0 + (tid & 31);
+            float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+            for (int c = 0; c < 32; c += 8) {
+                float f[8];
+                x3_join8(*(const uint4 *)(sH + tid * TX_HP + c * 2), *(const uint4 *)(sH + tid * TX_HP + 64 + c * 2), f);
+#pragma unroll
+                for (int e = 0; e < 8; e++) {
+                    a0 = fmaf(f[e], hw[c + e], a0);
+                    a1 = fmaf(f[e], hw[32 + c + e], a1);
+                }
+            }
+            if (ho < Ho && wo < Wo) {
+                const long long o = ((long long)(g * B + img) * Ho + ho) * Wo + wo;
+                seg[o] = __fmaf_rn(a0, hs0, hb0);
+                const float o1 = __fmaf_rn(a1, hs1, hb1);
+                if (rad_f16) ((_Float16 *)radial)[o] = (_Float16)o1;  // engine option 8
+                else radial[o] = o1;
+            }
+        }
+    }
+#undef RCV_TX_SOURCE
+}
+
 template <typename T>
 __global__ void k_slot_to_f32(const T *src, float *dst, long long n)
 {
@@ -2885,17 +3102,17 @@ int run_op(rcv_fcn *h, const rcv_op &op, const float *x, int B, float *seg, floa
     switch (op.kind) {
     case RCV_OP_STEM: {
         if (op.cout != 64 || op.ksize != 7 || op.stride != 2 || op.pad != 3) return RCV_E_UNSUPPORTED;
-        if constexpr (sizeof(T) == 2 && !kX3) {
-            if (h->use_mfma_stem) {  // MFMA stem (bf16); option 2 = 0 selects the direct fp32-input kernel
+        if constexpr (sizeof(T) == 2) {
+            if (h->use_mfma_stem) {  // MFMA stem (16-bit and split engines); option 2 = 0 selects the direct fp32-input kernel
                 if (!h->attrs_set)
                     RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_stem_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, STEM_LDS));
                 const int tiles_x = (op.wout + STEM_TW - 1) / STEM_TW, runs_x = (tiles_x + STEM_RUN - 1) / STEM_RUN;
                 dim3 grid(((op.hout + STEM_TH - 1) / STEM_TH) * runs_x, B);
                 for (int g0 = 0; g0 < G; g0 += STEM_MAXG) {  // the weights of up to STEM_MAXG networks share the LDS
                     const int gn = std::min(STEM_MAXG, G - g0);
-                    hipLaunchKernelGGL(k_stem_mfma, grid, dim3(256), STEM_LDS, st, x, (const H16 *)w + (long long)g0 * 64 * 147, bias + g0 * 64,
+                    hipLaunchKernelGGL(k_stem_mfma, grid, dim3(256), STEM_LDS, st, x, (const H16 *)w + (long long)g0 * 64 * 147 * ES, bias + g0 * 64 * ES,
                                        (H16 *)slot(op.dst) + (long long)g0 * gstride(op.dst), op.hin, op.win, op.hout, op.wout, gn,
-                                       (long long)64 * 147, 64, gstride(op.dst));
+                                       (long long)64 * 147 * ES, 64 * ES, gstride(op.dst));
                     RCV_LAUNCH_CHECK();
                 }
                 return RCV_OK;
@@ -2996,6 +3213,7 @@ int register_kernel_attributes()
     RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_conv_halo<64, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, halo_lds(64)));
     RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_stem_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, STEM_LDS));
     RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_tail, hipFuncAttributeMaxDynamicSharedMemorySize, TAIL_LDS));
+    RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_tail_x3, hipFuncAttributeMaxDynamicSharedMemorySize, TX_LDS));
     RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_conv_block<64, false>, hipFuncAttributeMaxDynamicSharedMemorySize, blk_lds(64)));
     RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_conv_block<64, true>, hipFuncAttributeMaxDynamicSharedMemorySize, blk_lds(64)));
     RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_conv_block<128, false>, hipFuncAttributeMaxDynamicSharedMemorySize, blk_lds(128)));
@@ -3019,10 +3237,10 @@ int forward_impl(rcv_fcn *h, const float *x, int B, float *seg, float *radial, c
         for (auto &e : h->events) RCV_HIP_CHECK(hipEventCreate(&e));
     }
     for (size_t i = 0; i < h->ops.size(); i++) {
-        if constexpr (sizeof(T) == 2 && !kX3) {
+        if constexpr (sizeof(T) == 2) {
             // 3x3 (-> 256 channels, ReLU) followed by the 1x1 expand to 1024 channels with residual and ReLU: the second
             // half of a layer-3 bottleneck block as one kernel (option 4)
-            if (h->use_block && i + 1 < h->ops.size() && h->ops[i].kind == RCV_OP_CONV && h->ops[i + 1].kind == RCV_OP_CONV &&
+            if (!kX3 && h->use_block && i + 1 < h->ops.size() && h->ops[i].kind == RCV_OP_CONV && h->ops[i + 1].kind == RCV_OP_CONV &&
                 (long long)h->slot_elems[h->ops[i + 1].dst] * B * 2 < 0x7fffffffLL) {  // (the widest tensor it touches; 32-bit DMA offsets)
                 const rcv_op &a = h->ops[i], &b = h->ops[i + 1];
                 const long long M = (long long)B * a.hout * a.wout;
@@ -3091,18 +3309,26 @@ int forward_impl(rcv_fcn *h, const float *x, int B, float *seg, float *radial, c
                 if (u.c0 == 64 && c.src0 == u.dst && c.src1 < 0 && c.res < 0 && c.c0 == 64 && c.cout == 32 && c.ksize == 3 &&
                     c.stride == 1 && c.pad == 1 && c.relu && d.src0 == c.dst && d.c0 == 32 && d.cout == 2 && u.hout == 2 * u.hin &&
                     u.wout == 2 * u.win && c.hin == u.hout && c.win == u.wout) {
-                    if (!h->attrs_set)
+                    if (!h->attrs_set) {
                         RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_tail, hipFuncAttributeMaxDynamicSharedMemorySize, TAIL_LDS));
+                        RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_tail_x3, hipFuncAttributeMaxDynamicSharedMemorySize, TX_LDS));
+                    }
                     if (h->profiling) {  // the fused kernel's time is booked on the convolution
                         RCV_HIP_CHECK(hipEventRecord(h->events[2 * i], st));
                         RCV_HIP_CHECK(hipEventRecord(h->events[2 * i + 1], st));
                         RCV_HIP_CHECK(hipEventRecord(h->events[2 * i + 2], st));
                     }
                     dim3 grid((u.hout + TAIL_TH - 1) / TAIL_TH, B, h->groups);
-                    hipLaunchKernelGGL(k_tail, grid, dim3(256), TAIL_LDS, st, (const H16 *)(ws + off[u.src0]),
-                                       (const H16 *)h->weights + c.w_off, h->bias + c.b_off, (const H16 *)h->weights + d.w_off,
-                                       h->bias + d.b_off, seg, radial, B, u.hin, u.win, (long long)h->slot_elems[u.src0] * B,
-                                       (long long)32 * 576, 32, (long long)64, 2, h->radial_f16 ? 1 : 0);
+                    if constexpr (kX3)
+                        hipLaunchKernelGGL(k_tail_x3, grid, dim3(512), TX_LDS, st, (const H16 *)(ws + off[u.src0]),
+                                           (const H16 *)h->weights + c.w_off, h->bias + c.b_off, (const H16 *)h->weights + d.w_off,
+                                           h->bias + d.b_off, seg, radial, B, u.hin, u.win, (long long)h->slot_elems[u.src0] * B * 2,
+                                           (long long)32 * 576 * 2, 64, (long long)128, 4, h->radial_f16 ? 1 : 0);
+                    else
+                        hipLaunchKernelGGL(k_tail, grid, dim3(256), TAIL_LDS, st, (const H16 *)(ws + off[u.src0]),
+                                           (const H16 *)h->weights + c.w_off, h->bias + c.b_off, (const H16 *)h->weights + d.w_off,
+                                           h->bias + d.b_off, seg, radial, B, u.hin, u.win, (long long)h->slot_elems[u.src0] * B,
+                                           (long long)32 * 576, 32, (long long)64, 2, h->radial_f16 ? 1 : 0);
                     RCV_LAUNCH_CHECK();
                     if (h->profiling) {
                         RCV_HIP_CHECK(hipEventRecord(h->events[2 * i + 3], st));

@@ -241,9 +241,13 @@ def test_module_boundary(state_dict):
     # DataParallel-style checkpoints ("module." prefix, reference README.md:13,52) give the same engine weights
     from rcvpose_amd.fcn_engine import FcnEngine
 
-    eng = FcnEngine([{"module." + k: v for k, v in state_dict.items()}], 64, 96, dtype="fp32")
+    assert model.compute_dtype == "f16x3"  # the default arithmetic: the fast mode within the 1e-4 tolerance
+    eng = FcnEngine([{"module." + k: v for k, v in state_dict.items()}], 64, 96, dtype=model.compute_dtype)
     s2, r2 = eng.forward(x.cuda())
     assert torch.equal(s2[0], seg) and torch.equal(r2[0], rad)
+    model.set_compute_dtype("fp32")
+    s3, r3 = model(x.cuda())
+    assert float((r3 - rad).abs().max() / r3.abs().max()) <= REL_FP32 and float((s3 - seg).abs().max() / s3.abs().max()) <= REL_FP32
     model.train()
     with pytest.raises(NotImplementedError):
         model(x.cuda())
