@@ -96,6 +96,11 @@ size_t rcv_acc_workspace_bytes_min(int max_points);
  *         radii gathered at depth.nonzero(); seg_dev is ignored.
  * mode 2: rgbd_to_point_cloud(K, depth) alone (:77-85): points of depth.nonzero() in MILLIMETRES
  *         (no /1000); seg_dev, radial_dev and radial_list_dev are ignored (may be null).
+ * mode 3: the YCB-Video seam (estimate_6d_pose_ycb, :1050-1057): mask = seg > seg_thr alone (no radius bound),
+ *         depth_map = depth * mask / factor_depth with factor_depth passed in rmax_dm, K = the frame's own intrinsics,
+ *         xyz = rgbd_to_point_cloud(K, depth_map) in the depth map's unit (metres; no /1000), radial_list = radial[mask].
+ * (The Occlusion-LINEMOD seam with pre-computed maps, :849-851,858-864, is mode 0 with seg := (radial > 0) and
+ *  seg_thr = 0.5; both variants are pinned by tests/golden/seam_lmo*.npz / seam_ycb*.npz, generated by the reference.)
  * OR RCV_SEAM_RADIAL_F16 into mode when radial_dev holds float16 (the stress configuration of BASELINE.json); the
  * values then enter the reference arithmetic as the float32 numbers they convert to.
  * seg_dev, radial_dev: float32 [H,W]; depth_dev: uint16 [H,W] (mm); K = {fx, fy, cx, cy}.

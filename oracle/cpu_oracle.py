@@ -106,6 +106,41 @@ def seam_radial_only(radial_est, depth, rmax_dm, K=LINEMOD_K):
     return xyz[: n.value].copy(), rl[: n.value].copy()
 
 
+def seam_lmo_radial(radial_est, depth, rmax_dm, K=LINEMOD_K):
+    """AccumulatorSpace.py:849-851,858-864 (Occlusion-LINEMOD, using_ckpts=False) -> (xyz_m, radial_list) or (None, None) when
+    the thresholded map is all zero (the keypoint is skipped, :858)."""
+    radial_est = np.ascontiguousarray(radial_est, dtype=np.float32)
+    depth = np.ascontiguousarray(depth, dtype=np.uint16)
+    H, W = radial_est.shape
+    xyz = np.empty((H * W, 3), dtype=np.float64)
+    rl = np.empty((H * W,), dtype=np.float32)
+    n, m = ctypes.c_long(), ctypes.c_long()
+    Kd = np.asarray(K, dtype=np.float64)
+    L = lib()
+    L.orc_seam_lmo_radial.restype = ctypes.c_int
+    ok = L.orc_seam_lmo_radial(_p(radial_est), _p(depth), H, W, _p(Kd), ctypes.c_double(rmax_dm), _p(xyz), _p(rl),
+                               ctypes.byref(n), ctypes.byref(m))
+    if not ok:
+        return None, None
+    return xyz[: n.value].copy(), rl[: m.value].copy()
+
+
+def seam_ycb(sem, radial, depth, factor_depth, K, seg_thr=0.8):
+    """AccumulatorSpace.py:1050-1057 (YCB-Video): K = (fx, fy, cx, cy) of the frame's intrinsic matrix ->
+    (xyz in depth / factor_depth units, radial_list)."""
+    sem = np.ascontiguousarray(sem, dtype=np.float32)
+    radial = np.ascontiguousarray(radial, dtype=np.float32)
+    depth = np.ascontiguousarray(depth, dtype=np.uint16)
+    H, W = sem.shape
+    xyz = np.empty((H * W, 3), dtype=np.float64)
+    rl = np.empty((H * W,), dtype=np.float32)
+    n, m = ctypes.c_long(), ctypes.c_long()
+    Kd = np.asarray(K, dtype=np.float64)
+    lib().orc_seam_ycb(_p(sem), _p(radial), _p(depth), H, W, _p(Kd), ctypes.c_double(seg_thr), ctypes.c_double(factor_depth),
+                       _p(xyz), _p(rl), ctypes.byref(n), ctypes.byref(m))
+    return xyz[: n.value].copy(), rl[: m.value].copy()
+
+
 def prepare(xyz_m, radial_dm, acc_unit=5.0):
     """AccumulatorSpace.py:374-401 -> (points_vox [N,3], radius_vox [M] (as f64), GridInfo)."""
     xyz_m = np.ascontiguousarray(xyz_m, dtype=np.float64)

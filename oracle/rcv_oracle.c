@@ -149,6 +149,67 @@ void orc_seam_radial_only(const float *radial_est, const uint16_t *depth, int H,
     *n_points = n;
 }
 
+/* The Occlusion-LINEMOD seam with pre-computed radial maps, AccumulatorSpace.py:849-851 and :858-864:
+ *     radial_out = where(radial_out <= max_radii_dm[k], radial_out, 0);  sem_out = where(radial_out > 0, 1, 0)
+ *     depth_map *= sem_out;  pixel_coor = where(sem_out == 1);  radial_list = radial_out[pixel_coor]
+ *     xyz_mm = rgbd_to_point_cloud(linemod_K, depth_map);  xyz = xyz_mm / 1000
+ * -- radii over the mask, points over mask & depth != 0 (lists may differ in length, as in the LINEMOD seam).
+ * Returns 0 when radial_out.max() == 0 (the frame's keypoint is skipped, :858). */
+int orc_seam_lmo_radial(const float *radial_est, const uint16_t *depth, int H, int W, const double *K, double rmax_dm,
+                        double *xyz_m, float *radial_list, long *n_points, long *n_radii)
+{
+    long np_ = 0, nr = 0;
+    float mx = 0.f;
+    int any = 0;
+    for (long p = 0; p < (long)H * W; p++) {
+        float r = ((double)radial_est[p] <= rmax_dm) ? radial_est[p] : 0.f;
+        if (!any || r > mx) { mx = r; any = 1; }
+    }
+    *n_points = 0;
+    *n_radii = 0;
+    if (!(mx != 0.f)) return 0;
+    for (int v = 0; v < H; v++)
+        for (int u = 0; u < W; u++) {
+            long p = (long)v * W + u;
+            float r = ((double)radial_est[p] <= rmax_dm) ? radial_est[p] : 0.f;
+            if (!(r > 0.f)) continue;
+            radial_list[nr++] = r;
+            if (depth[p] == 0) continue;
+            double zs = (double)depth[p];
+            xyz_m[3 * np_ + 0] = ((((double)u - K[2]) * zs) / K[0]) / 1000.;
+            xyz_m[3 * np_ + 1] = ((((double)v - K[3]) * zs) / K[1]) / 1000.;
+            xyz_m[3 * np_ + 2] = zs / 1000.;
+            np_++;
+        }
+    *n_points = np_;
+    *n_radii = nr;
+    return 1;
+}
+
+/* The YCB-Video seam, AccumulatorSpace.py:1050-1057:
+ *     sem_out = where(sem_out > 0.8, 1, 0);  depth_map = depth_map1 * sem_out / factor_depth
+ *     radial_list = radial_out[where(sem_out == 1)];  xyz = rgbd_to_point_cloud(intrinsic_matrix, depth_map)
+ * -- no radius bound, the frame's own intrinsics, xyz in the unit of depth / factor_depth (metres), NOT divided by 1000. */
+void orc_seam_ycb(const float *sem, const float *radial, const uint16_t *depth, int H, int W, const double *K, double seg_thr,
+                  double factor_depth, double *xyz, float *radial_list, long *n_points, long *n_radii)
+{
+    long np_ = 0, nr = 0;
+    for (int v = 0; v < H; v++)
+        for (int u = 0; u < W; u++) {
+            long p = (long)v * W + u;
+            if (!(sem[p] > (float)seg_thr)) continue;
+            radial_list[nr++] = radial[p];
+            if (depth[p] == 0) continue;
+            double zs = (double)depth[p] / factor_depth;   /* int64 product / uint16 (1,1) array -> float64 */
+            xyz[3 * np_ + 0] = (((double)u - K[2]) * zs) / K[0];
+            xyz[3 * np_ + 1] = (((double)v - K[3]) * zs) / K[1];
+            xyz[3 * np_ + 2] = zs;
+            np_++;
+        }
+    *n_points = np_;
+    *n_radii = nr;
+}
+
 /* Accumulator_3D up to the call of fast_for, AccumulatorSpace.py:374-401.
  * xyz_m [n,3] metres (not modified); radial: float32 or float64 [m] decimetres (m >= n).
  * Outputs: points_vox [n,3] (recentred, shifted, voxel units), radius_vox[m] as double

@@ -196,7 +196,12 @@ def Accumulator_3D(xyz, radial_list, acc_unit=ACC_UNIT_MM, return_votes=False, e
 
 def rgbd_to_point_cloud_no_depth(K, depth):
     """Back-projection of every nonzero pixel at each millimetre of the depth range (reference :100-120).
-    depth: float array [H,W] in metres -> float64 [Z,N,3]."""
+    depth: float array [H,W] in metres -> float64 [Z,N,3].
+
+    The range arithmetic (`int(zs_max*1000)+1-int(zs_min*1000)`, `zs_min+i*0.001`) runs in float64 on the values of the
+    input array.  For float64 depth that is what every numpy does.  For float32 depth it is what the numpy of the reference's
+    environment does (rcvpose.yml pins numpy 1.20.3, whose scalar promotion turns np.float32 * 1000 and np.float32 + 0.001 into
+    float64); numpy >= 2 (NEP 50) would keep those two expressions in float32 and can differ by one hypothesis level."""
     torch = _torch()
     L = _hip.lib()
     d = torch.from_numpy(np.ascontiguousarray(depth, dtype=np.float64)).cuda()
@@ -749,7 +754,8 @@ def estimate_6d_pose_ycb(opts, return_details=False):
                 raise ValueError(class_name + " is not annotated in " + filename)
             RTGT = np.asarray(sceneInfo['poses'], dtype=np.float64)[:, :, hit[0]]
             K = np.asarray(sceneInfo['intrinsic_matrix'], dtype=np.float64)
-            depth_unit_mm = 1000.0 / float(np.asarray(sceneInfo['factor_depth']).reshape(-1)[0])
+            factor_depth = float(np.asarray(sceneInfo['factor_depth']).reshape(-1)[0])
+            depth_unit_mm = 1000.0 / factor_depth
             rgb = np.array(Image.open(opts.root_dataset + 'data/' + cycle + "/" + idx + '-color.png').convert('RGB'), dtype=np.uint8)
             depth_map1 = np.array(Image.open(opts.root_dataset + 'data/' + cycle + "/" + idx + '-depth.png'))
             H, W = depth_map1.shape
@@ -764,10 +770,8 @@ def estimate_6d_pose_ycb(opts, return_details=False):
             seg_maps, rad_maps = pipe.seg[:, 0, 0], pipe.radial[:, 0, 0]
             estimated_kpts = np.zeros((3, 3))
             for k in range(3):
-                # the seam back-projects depth units as millimetres; one device multiply turns them into the metres of
-                # depth / factor_depth (:1053-1059)
-                seam_compact(seg_maps[k], rad_maps[k], depth_dev, np.inf, K=K, mode=0, workspace=ws)
-                ws.xyz.mul_(depth_unit_mm)
+                # mode 3: mask = seg > 0.8 alone, depth / factor_depth, the frame's intrinsics, no /1000 (:1050-1057)
+                seam_compact(seg_maps[k], rad_maps[k], depth_dev, factor_depth, K=K, mode=3, workspace=ws)
                 pipe._mark("seam")
                 accumulate_on_device(ws.xyz, ws.radial, ws.counts, ws.max_points, ws.max_points, ws)
                 pipe._mark("acc")

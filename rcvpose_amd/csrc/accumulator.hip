@@ -95,6 +95,11 @@ struct alignas(16) AccHeader {
     unsigned long long seed;             // 1 + flat index of the least-squares estimate of the keypoint's voxel (k_bb_seed); 0: none
     int32_t probe_skip;                  // the round of exact counts around the seed already found a strong peak: no greedy probe
     int32_t pad2_;
+    // best key (votes << 32 | flat index) as of the END of hill-climb round r, in slot r & 1: round r + 1 centres on it.  Round r
+    // only writes slot r & 1 and only reads the other one, so every workgroup of a round sees the same, frozen centre (r03;
+    // before, each workgroup took the live bb_best_key at its own start and a late one could centre on a voxel found by its
+    // own round -- harmless for exactness, but the lower bound and the list sizes became timing dependent)
+    unsigned long long climb_key[2];
 };
 static_assert(sizeof(AccHeader) <= 512, "AccHeader must fit the 512 bytes reserved in the workspace");
 
@@ -237,6 +242,11 @@ __device__ __forceinline__ void seam_flags(const float *seg, const RT *rad, cons
         m_rad = m_pt = depth[p] != 0;
         return;
     }
+    if (mode == 3) {  // YCB-Video (:1050-1054): the segmentation alone; rmax carries factor_depth
+        m_rad = seg[p] > thr;
+        m_pt = m_rad && depth[p] != 0;
+        return;
+    }
     const float r = (float)rad[p];
     const bool rok = (double)r <= rmax;  // float32 array vs float64 scalar: compared in float64
     if (mode == 0) {
@@ -356,13 +366,15 @@ __device__ __forceinline__ void d_seam_scatter(const float *seg, const RT *rad, 
             int dst = off.x + before_p + pre_p[j];
             if (dst < cap) {
                 // rgbd_to_point_cloud (AccumulatorSpace.py:81-84) then xyz = xyz_mm/1000 (:619)
+                // mode 3 (:1052,1057): depth_map = depth * mask / factor_depth first, and no division by 1000 afterwards
                 const int v = p / W, u = p - v * W;
-                const double zs = (double)depth[p];
+                const double zs = mode == 3 ? (double)depth[p] / rmax : (double)depth[p];
                 const double xs = (((double)u - cx) * zs) / fx;
                 const double ys = (((double)v - cy) * zs) / fy;
-                xyz_m[3 * (size_t)dst + 0] = mode == 2 ? xs : xs / 1000.0;
-                xyz_m[3 * (size_t)dst + 1] = mode == 2 ? ys : ys / 1000.0;
-                xyz_m[3 * (size_t)dst + 2] = mode == 2 ? zs : zs / 1000.0;
+                const bool raw = mode == 2 || mode == 3;
+                xyz_m[3 * (size_t)dst + 0] = raw ? xs : xs / 1000.0;
+                xyz_m[3 * (size_t)dst + 1] = raw ? ys : ys / 1000.0;
+                xyz_m[3 * (size_t)dst + 2] = raw ? zs : zs / 1000.0;
             }
         }
     }
@@ -1506,12 +1518,19 @@ __device__ __forceinline__ void d_bb_climb(AccHeader *hdr, const double *Q, cons
     __shared__ int red[4][NV];
     const AccHeader H = *hdr;
     if (H.status != RCV_OK || !H.bb_enabled) return;
-    const bool from_seed = round == 0 && H.seed != 0;  // the first round looks around the least-squares estimate
-    if (!from_seed && H.bb_best_key == 0) return;
+    // the round's centre: round 0 looks around the least-squares estimate; round r > 0 around the best voxel as of the end of
+    // round r - 1 (climb_key[(r - 1) & 1], which no workgroup of THIS round writes: k_bb_gate folds the probe's finds into slot
+    // 0 before round 1)
+    const bool from_seed = round == 0;
+    if (from_seed && H.seed == 0) return;
+    const unsigned long long frozen = from_seed ? 0ull : H.climb_key[(round - 1) & 1];
+    if (!from_seed && frozen == 0) return;
     const int D = H.dim, n = H.n;
-    const unsigned long long flat = from_seed ? H.seed - 1 : (H.bb_best_key & 0xFFFFFFFFull);
+    const unsigned long long flat = from_seed ? H.seed - 1 : (frozen & 0xFFFFFFFFull);
+    // this round's slot starts from the previous round's best (it still holds round r - 2's, which is not larger)
+    if (!from_seed && threadIdx.x == 0) atomicMax(&hdr->climb_key[round & 1], frozen);
     // converged: the best voxel is the one the previous round was centred on -- its whole neighbourhood has been counted
-    // and nothing in it was better.  (Every workgroup of the round reads the same header; the first one records the centre.)
+    // and nothing in it was better.  (Every workgroup of the round computes the same centre; the first one records it.)
     if (round > 0 && H.climb_center[(round - 1) & 1] == flat + 1) {
         if (blockIdx.x == 0 && threadIdx.x == 0) hdr->climb_center[round & 1] = flat + 1;
         return;
@@ -1559,8 +1578,10 @@ __device__ __forceinline__ void d_bb_climb(AccHeader *hdr, const double *Q, cons
         const int v = threadIdx.x, cj = cj0 + v / W, ck = ck0 + v % W;
         if (cj >= 0 && ck >= 0 && cj < D && ck < D) {
             const int c = red[0][v] + red[1][v] + red[2][v] + red[3][v];
+            const unsigned long long key = ((unsigned long long)c << 32) | (((unsigned long long)ci * D + cj) * D + ck);
             atomicMax(&hdr->bb_best, c);
-            atomicMax(&hdr->bb_best_key, ((unsigned long long)c << 32) | (((unsigned long long)ci * D + cj) * D + ck));
+            atomicMax(&hdr->bb_best_key, key);
+            atomicMax(&hdr->climb_key[round & 1], key);
         }
     }
 }
@@ -2009,10 +2030,13 @@ __global__ __launch_bounds__(256) void k_bb_seed(int cap, SP<unsigned char> ws, 
 // After the round around the seed: a voxel that an eighth of all points vote for is the peak's neighbourhood for every purpose
 // of the search (its count is the lower bound the wide levels prune with) -- the greedy probe, which exists to find such a
 // voxel, is skipped.  Otherwise (no seed, outliers, several weak maxima) the probe runs as before.
-__global__ void k_bb_gate(SP<unsigned char> ws, Layout L)
+__global__ void k_bb_gate(int mode, SP<unsigned char> ws, Layout L)
 {
     AccHeader *hdr = (AccHeader *)(ws.get() + L.header);
-    if (threadIdx.x == 0) hdr->probe_skip = (hdr->seed != 0 && (long long)hdr->bb_best * 8 >= (long long)hdr->n) ? 1 : 0;
+    if (threadIdx.x == 0) {
+        if (mode == 0) hdr->probe_skip = (hdr->seed != 0 && (long long)hdr->bb_best * 8 >= (long long)hdr->n) ? 1 : 0;
+        else if (hdr->bb_best_key > hdr->climb_key[0]) hdr->climb_key[0] = hdr->bb_best_key;  // mode 1, before round 1: the probe's best
+    }
 }
 __global__ __launch_bounds__(256) void k_bb_climb(int cap, int round, SP<unsigned char> ws, Layout L)
 {
@@ -2309,9 +2333,9 @@ static int seam_batch(rcv_strided seg, rcv_strided rad, rcv_strided depth, int H
     if (!depth.ptr || !K || !xyz.ptr || !counts.ptr || !ws.ptr) return RCV_E_INVALID;
     const bool rad_f16 = (mode & RCV_SEAM_RADIAL_F16) != 0;
     mode &= ~RCV_SEAM_RADIAL_F16;
-    if (mode < 0 || mode > 2) return RCV_E_INVALID;
+    if (mode < 0 || mode > 3) return RCV_E_INVALID;
     if (mode != 2 && (!rad.ptr || !rlist.ptr)) return RCV_E_INVALID;
-    if (mode == 0 && !seg.ptr) return RCV_E_INVALID;
+    if ((mode == 0 || mode == 3) && !seg.ptr) return RCV_E_INVALID;
     if (H <= 0 || W <= 0 || cap <= 0 || n_frames <= 0 || n_kp <= 0 || n_frames > 65535 || n_kp > 65535) return RCV_E_INVALID;
     const long long HW = (long long)H * W;
     const int nb = (int)((HW + SEAM_PIX_PER_BLOCK - 1) / SEAM_PIX_PER_BLOCK);
@@ -2364,7 +2388,7 @@ static int run_engines(int cap, int bb_enable, SP<rcv_acc_result> sres, SP<uint3
         RCV_LAUNCH_CHECK();
         hipLaunchKernelGGL(k_bb_climb, grid3(BB_CLIMB_W), dim3(256), 0, st, cap, 0, sws, L);
         RCV_LAUNCH_CHECK();
-        hipLaunchKernelGGL(k_bb_gate, items, dim3(64), 0, st, sws, L);
+        hipLaunchKernelGGL(k_bb_gate, items, dim3(64), 0, st, 0, sws, L);
         RCV_LAUNCH_CHECK();
         // level 0 of the breadth-first search scores the 32-voxel blocks (children of the 64-voxel roots): upper bounds with
         // the wide kernel, then the centre counts that rank them for the probe (r02: was one k_bb_level launch with an exact
@@ -2390,6 +2414,8 @@ static int run_engines(int cap, int bb_enable, SP<rcv_acc_result> sres, SP<uint3
                 RCV_LAUNCH_CHECK();
             }
         }
+        hipLaunchKernelGGL(k_bb_gate, items, dim3(64), 0, st, 1, sws, L);  // freeze the start of round 1 (see AccHeader::climb_key)
+        RCV_LAUNCH_CHECK();
         for (int round = 1; round < BB_CLIMB_ROUNDS; round++) {  // exact hill-climb from the best voxel so far
             hipLaunchKernelGGL(k_bb_climb, grid3(BB_CLIMB_W), dim3(256), 0, st, cap, round, sws, L);
             RCV_LAUNCH_CHECK();

@@ -348,6 +348,9 @@ class FcnEngine:
         self._ws = None
         self._ws_batch = 0
         self.radial_f16 = False
+        # half-precision storage saturates beyond 65504 (f16x3: hi + lo, 131008): with check_finite the forward synchronises and
+        # raises instead of handing inf / nan maps to the seam.  The per-frame drivers switch it on; batched pipelines leave it off.
+        self.check_finite = False
         self.flops_per_image_group = conv_flops(ops)
 
     def __del__(self):
@@ -386,6 +389,9 @@ class FcnEngine:
                 raise ValueError("output planes: seg float32, radial %s" % ("float16 (option 8)" if self.radial_f16 else "float32"))
         _hip.check(self.lib.rcv_fcn_forward(self.handle, _hip.ptr(x), B, _hip.ptr(seg), _hip.ptr(radial), _hip.ptr(ws),
                                             ws.numel(), _hip.current_stream()), "rcv_fcn_forward")
+        if self.check_finite and not (bool(torch.isfinite(seg).all()) and bool(torch.isfinite(radial).all())):
+            raise FloatingPointError("non-finite FCN output in %s mode: an activation left the half-precision range (65504; "
+                                     "131008 for f16x3) -- use dtype='fp32' for this checkpoint" % self.dtype_name)
         return seg, radial
 
     def capture(self, x, out=None):

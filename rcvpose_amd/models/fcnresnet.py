@@ -101,6 +101,8 @@ class DenseFCNResNet152(nn.Module):
         key = (H, W, self.compute_dtype, self._stamp())
         if self._engine is None or self._engine_key != key:
             self._engine = fcn_engine.FcnEngine([self.state_dict()], H, W, dtype=self.compute_dtype, arch=self._arch)
+            # the module is the per-call (synchronous) boundary: half-precision storage modes fail loudly on overflow
+            self._engine.check_finite = self.compute_dtype != "fp32"
             self._engine_key = key
         return self._engine
 

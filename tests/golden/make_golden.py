@@ -290,6 +290,89 @@ def gen_seam(A):
 
 
 # --------------------------------------------------------------------------------------
+# SEAM-LMO / SEAM-YCB: the inline seams of estimate_6d_pose_lmo (AccumulatorSpace.py:835-851, :858-864, its
+# using_ckpts=False branch -- the using_ckpts=True branch cannot run: `radial_out<=max_radii_dm` at :838 compares an [H,W]
+# map with the 3-vector) and of estimate_6d_pose_ycb (:1050-1057), exec'd from the reference file like the LINEMOD seam
+# --------------------------------------------------------------------------------------
+def _ref_lines(first, last, head, tail):
+    with open(os.path.join(REF, "AccumulatorSpace.py")) as f:
+        lines = f.read().split("\n")
+    block = lines[first - 1:last]
+    assert block[0].strip() == head, block[0]
+    assert block[-1].strip() == tail, block[-1]
+    return textwrap.dedent("\n".join(block))
+
+
+def _run_seam_lmo(A, radial_est, depth, max_radii_dm, kp):
+    class _NP:
+        def __getattr__(self, k):
+            return getattr(np, k)
+
+        @staticmethod
+        def load(path):
+            return np.array(radial_est, copy=True)
+
+    ns = {"np": _NP(), "os": os, "opts": types.SimpleNamespace(using_ckpts=False), "rootPath": "", "class_name": "x",
+          "filename": "color_00007.png", "keypoint_count": kp, "max_radii_dm": np.asarray(max_radii_dm, dtype=np.float64),
+          "depth_map": np.array(depth, dtype=np.float64), "rgbd_to_point_cloud": A.rgbd_to_point_cloud, "linemod_K": A.linemod_K}
+    exec(_ref_lines(835, 851, "if opts.using_ckpts:", "depth_map = depth_map*sem_out"), ns)
+    ns["np"] = np
+    exec(_ref_lines(858, 864, "if radial_out.max()!=0:", "xyz = xyz_mm/1000"), ns)
+    return ns.get("xyz"), ns.get("radial_list"), ns.get("xyz_mm")
+
+
+def _run_seam_ycb(A, sem, radial, depth_u16, factor_depth, K):
+    ns = {"np": np, "sem_out": sem, "radial_out": radial, "depth_map1": depth_u16,
+          "sceneInfo": {"factor_depth": np.array([[factor_depth]], dtype=np.uint16), "intrinsic_matrix": np.asarray(K, dtype=np.float64)},
+          "rgbd_to_point_cloud": A.rgbd_to_point_cloud}
+    exec(_ref_lines(1050, 1057, "sem_out = np.where(sem_out>0.8,1,0)", "xyz = rgbd_to_point_cloud(sceneInfo['intrinsic_matrix'],depth_map)"), ns)
+    return ns["xyz"], ns["radial_list"]
+
+
+def gen_seam_variants(A):
+    rng = np.random.default_rng(4711)
+    H, W = 48, 64
+    v, u = np.mgrid[0:H, 0:W]
+    inside = ((u - 33) / 15.0) ** 2 + ((v - 25) / 11.0) ** 2 <= 1.0
+    index = {}
+    # LM-O, pre-computed radial maps: radii above the bound are zeroed, the mask is radial > 0, radii are gathered over the
+    # mask and points over mask & depth != 0 (two depth holes -> misaligned lists); one exact-zero and one negative radius
+    radial = np.where(inside, 2.0 + 0.01 * u + 0.02 * v + rng.normal(0, 0.01, size=(H, W)), 0).astype(np.float32)
+    radial[20:22, 45:47] = 7.5     # above the bound
+    radial[25, 30] = 0.0           # a hole in the radial map
+    radial[26, 31] = -0.25         # not > 0
+    depth = (850 + 3 * u + 2 * v).astype(np.uint16)
+    depth[24, 28:31] = 0
+    depth[30, 36] = 0
+    max_radii = [3.4, 3.3, 2.9]
+    for kp in (1, 3):
+        xyz, rl, xyz_mm = _run_seam_lmo(A, radial, depth, max_radii, kp)
+        np.savez_compressed(os.path.join(HERE, "seam_lmo%d.npz" % kp), radial_est=radial, depth=depth, max_radius_dm=max_radii[kp - 1],
+                            xyz_m=xyz, radial_list=rl, xyz_mm=xyz_mm)
+        index["seam_lmo%d" % kp] = {"n_points": int(len(xyz)), "n_radii": int(len(rl))}
+        assert len(rl) > len(xyz)
+    xyz, rl, _ = _run_seam_lmo(A, np.zeros((H, W), dtype=np.float32), depth, max_radii, 1)   # radial_out.max() == 0: skipped (:858)
+    assert xyz is None and rl is None
+    index["seam_lmo_empty"] = {"skipped": True}
+    # YCB-Video: mask = seg > 0.8 only, depth / factor_depth, the frame's own intrinsic matrix, xyz in the depth map's unit
+    K = np.array([[1066.778, 0.0, 312.9869], [0.0, 1067.487, 241.3109], [0.0, 0.0, 1.0]])
+    sem = np.where(inside, 0.93, 0.1).astype(np.float32) + rng.normal(0, 0.02, size=(H, W)).astype(np.float32)
+    sem[22, 30] = 0.8   # exactly at the threshold: excluded
+    rad = (1.5 + 0.02 * u + 0.01 * v).astype(np.float32)
+    d16 = (7000 + 31 * u + 17 * v).astype(np.uint16)
+    d16[27, 33:36] = 0
+    for name, factor in (("seam_ycb1", 10000), ("seam_ycb2", 7919)):
+        xyz, rl = _run_seam_ycb(A, sem.copy(), rad.copy(), d16.copy(), factor, K)
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), sem=sem, radial=rad, depth=d16, factor_depth=factor, K=K,
+                            xyz=xyz, radial_list=rl)
+        index[name] = {"n_points": int(len(xyz)), "n_radii": int(len(rl))}
+        assert len(rl) > len(xyz)
+    with open(os.path.join(HERE, "seam_variants_index.json"), "w") as f:
+        json.dump(index, f, indent=1, sort_keys=True)
+    print("  seam variants:", index)
+
+
+# --------------------------------------------------------------------------------------
 # FCN-*: models/fcnresnet.py:48-191, FCResBackbone (AccumulatorSpace.py:122-162)
 # --------------------------------------------------------------------------------------
 def gen_fcn(A):
@@ -512,13 +595,15 @@ def gen_nodepth(A):
 
 
 def main():
-    which = set(sys.argv[1:]) or {"acc", "seam", "fcn", "horn", "resfcn", "nd"}
+    which = set(sys.argv[1:]) or {"acc", "seam", "seamv", "fcn", "horn", "resfcn", "nd"}
     A = _import_reference()
     if "acc" in which:
         print("ACC cases (reference fast_for runs as pure Python, ~1 us per point*voxel test)")
         gen_acc(A)
     if "seam" in which:
         gen_seam(A)
+    if "seamv" in which:
+        gen_seam_variants(A)
     if "fcn" in which:
         gen_fcn(A)
     if "horn" in which:

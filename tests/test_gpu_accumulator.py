@@ -138,6 +138,30 @@ def test_seam_golden(A, golden_dir):
     assert np.array_equal(A.rgbd_to_point_cloud(A.linemod_K, g["depth"].astype(np.int64) * mask), g["xyz_mm"])
 
 
+def test_seam_variants_golden(A, golden_dir):
+    """The seams of the Occlusion-LINEMOD (pre-computed radial maps: mode 0 with seg := radial > 0, threshold 0.5, as
+    estimate_6d_pose_lmo calls it) and YCB-Video (mode 3) drivers against the lists the reference's own lines produced
+    (AccumulatorSpace.py:849-851,858-864 and :1050-1057; tests/golden/make_golden.py seamv): bit-exact."""
+    import torch
+
+    for name in ("seam_lmo1", "seam_lmo3"):
+        g = np.load(os.path.join(golden_dir, name + ".npz"))
+        rad = torch.from_numpy(g["radial_est"]).cuda()
+        seg = (rad > 0).to(torch.float32)
+        ws = A.seam_compact(seg, rad, torch.from_numpy(g["depth"].view(np.int16)).cuda(), float(g["max_radius_dm"]), mode=0, seg_thr=0.5)
+        n, m = [int(v) for v in ws.counts.cpu()]
+        assert m > n
+        assert np.array_equal(ws.xyz[:n].cpu().numpy(), g["xyz_m"]), name
+        assert np.array_equal(ws.radial[:m].cpu().numpy(), g["radial_list"]), name
+    for name in ("seam_ycb1", "seam_ycb2"):
+        g = np.load(os.path.join(golden_dir, name + ".npz"))
+        ws = A.seam_compact(torch.from_numpy(g["sem"]).cuda(), torch.from_numpy(g["radial"]).cuda(),
+                            torch.from_numpy(g["depth"].view(np.int16)).cuda(), float(g["factor_depth"]), K=g["K"], mode=3)
+        n, m = [int(v) for v in ws.counts.cpu()]
+        assert np.array_equal(ws.xyz[:n].cpu().numpy(), g["xyz"]), name
+        assert np.array_equal(ws.radial[:m].cpu().numpy(), g["radial_list"]), name
+
+
 def test_seam_to_vote_chain_on_device(A, golden_dir):
     """seam -> Accumulator_3D without touching the host in between (AccumulatorSpace.py:596-654)."""
     import torch

@@ -269,7 +269,7 @@ def test_ycb_driver_end_to_end(tmp_path, golden_dir, oracle):
     assert len(xyz) > 45000
     for k in range(3):
         ref = oracle.accumulator_3d(xyz, np.full(raw.size, radii[k], dtype=np.float32), sparse=True)
-        assert np.abs(d["estimated_kpts"][k] - ref[0]).max() <= 5.0, k    # 1 voxel (the two seams round differently by ~1 ulp)
+        assert np.array_equal(d["estimated_kpts"][k], ref[0]), k    # seam mode 3 divides by factor_depth first, like :1052: identical
     # constant-radius maps put the three peaks nearly on one line: the rotation about it is ill-conditioned, so the pose is
     # checked through what Horn minimises rather than element by element
     kp_mm = kps_obj[1:4] * 1000

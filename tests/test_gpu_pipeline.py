@@ -124,7 +124,10 @@ def test_bf16_keypoints_against_fp32_keypoints(golden_dir, oracle):
         print("network %d: bf16 - fp32 maps, max |delta| / max |map|: radial %.3e seg %.3e" % (k, er, es))
     print("radial perturbation: max %.2f voxels, rms %.2f voxels" % step)
     print("bf16 vs fp32 keypoints: max %.2f voxels, mean %.3f voxels over %d keypoints" % (dev.max(), dev.mean(), dev.size))
-    assert dev.max() <= 15.0 and dev.mean() <= 4.0
+    # regression guards at ~1.3x the measured figures (max 7 voxels, mean 1.7; map error 1.5-5.5e-2; radius perturbation
+    # 0.62 voxel rms): a numeric regression of the 16-bit kernels fails here
+    assert dev.max() <= 9.5 and dev.mean() <= 2.3
+    assert max(er for er, _ in rel) <= 7.5e-2 and step[1] <= 0.85
     for b, k in ((0, 0), (3, 1), (7, 2)):             # the device voted exactly like the oracle on the perturbed maps
         xyz, rl = oracle.seam(ps[k, b, 0], pr[k, b, 0], fr[b]["depth"], rmax[k])
         assert np.array_equal(kb[b, k], oracle.accumulator_3d(xyz, rl, sparse=True)[0])
@@ -138,4 +141,17 @@ def test_fp16_keypoints_against_fp32_keypoints(golden_dir):
         assert er <= 1.2e-2 and es <= 1.2e-2
     print("radial perturbation: max %.2f voxels, rms %.2f voxels" % step)
     print("fp16 vs fp32 keypoints: max %.2f voxels, mean %.3f voxels over %d keypoints" % (dev.max(), dev.mean(), dev.size))
-    assert dev.max() <= 6.0 and dev.mean() <= 1.5
+    assert dev.max() <= 3.0 and dev.mean() <= 0.7   # ~1.3x the measured 2 / 0.5 voxels
+
+
+def test_f16x3_keypoints_against_fp32_keypoints(golden_dir):
+    """The same measurement for the split-precision engine (the drivers' and bench.py's default): its map error is four
+    orders of magnitude below one voxel of radius, and the keypoints stay within north_star's 1 voxel of the fp32 engine's."""
+    dev, rel, step, _, _, _, _ = _keypoints_under_engine_error(golden_dir, "f16x3")
+    for k, (er, es) in enumerate(rel):
+        print("network %d: f16x3 - fp32 maps, max |delta| / max |map|: radial %.3e seg %.3e" % (k, er, es))
+        assert er <= 1e-4 and es <= 1e-4
+    print("radial perturbation: max %.5f voxels, rms %.6f voxels" % step)
+    print("f16x3 vs fp32 keypoints: max %.2f voxels, mean %.3f voxels over %d keypoints, %d identical" %
+          (dev.max(), dev.mean(), dev.size, int((dev == 0).sum())))
+    assert dev.max() <= 1.0

@@ -87,6 +87,23 @@ def test_seam_golden(oracle, golden_dir):
     assert np.array_equal(xyz, g["xyz_m"]) and np.array_equal(rl, g["radial_list"])
 
 
+def test_seam_variants_golden(oracle, golden_dir):
+    """The Occlusion-LINEMOD (pre-computed radial maps, AccumulatorSpace.py:849-851,858-864) and YCB-Video (:1050-1057) seams
+    against outputs of the reference's own lines (tests/golden/make_golden.py seamv): bit-exact lists."""
+    for name in ("seam_lmo1", "seam_lmo3"):
+        g = _load(golden_dir, name)
+        xyz, rl = oracle.seam_lmo_radial(g["radial_est"], g["depth"], float(g["max_radius_dm"]))
+        assert np.array_equal(xyz, g["xyz_m"]) and rl.dtype == g["radial_list"].dtype and np.array_equal(rl, g["radial_list"]), name
+        assert len(rl) > len(xyz)  # radii over the mask, points over mask & depth != 0
+    g = _load(golden_dir, "seam_lmo1")
+    assert oracle.seam_lmo_radial(np.zeros_like(g["radial_est"]), g["depth"], 3.0) == (None, None)  # radial_out.max() == 0 (:858)
+    for name in ("seam_ycb1", "seam_ycb2"):
+        g = _load(golden_dir, name)
+        K = g["K"]
+        xyz, rl = oracle.seam_ycb(g["sem"], g["radial"], g["depth"], float(g["factor_depth"]), (K[0, 0], K[1, 1], K[0, 2], K[1, 2]))
+        assert np.array_equal(xyz, g["xyz"]) and np.array_equal(rl, g["radial_list"]), name
+
+
 def test_backproject_golden(oracle, golden_dir):
     g = _load(golden_dir, "seam1_aligned")
     mask = (g["sem"] > np.float32(0.8)) & (g["radial"].astype(np.float64) <= float(g["max_radius_dm"]))
