@@ -375,7 +375,7 @@ def scene_cloud_of_keypoint_masks(seg_maps, radial_maps, depth_dev, max_radii_dm
 
 
 def _pose_and_add(class_name, xyz_load, keypoints, estimated_kpts, RTGT_mm, seg_maps, rad_maps, depth_dev, max_radii_dm,
-                  mask_mode, criteria, seg_thr=SEG_THRESHOLD, K=linemod_K, syms=lm_syms, scene_scale=1.0, reach_is_mean=False):
+                  mask_mode, criteria, seg_thr=SEG_THRESHOLD, K=linemod_K, syms=lm_syms, scene_scale=1.0, reach_is_mean=False, RT=None):
     """Horn pose from the three keypoints, ADD(-S) before ICP, ICP of the CAD model onto the masked scene points and
     ADD(-S) after ICP (reference AccumulatorSpace.py:655-726 / :899-958 / :1115-1190), everything on the GPU.
 
@@ -386,7 +386,8 @@ def _pose_and_add(class_name, xyz_load, keypoints, estimated_kpts, RTGT_mm, seg_
     from .util.horn import horn_batch
 
     kpts = keypoints[1:4, :] * 1000
-    RT = horn_batch(kpts, torch.from_numpy(np.ascontiguousarray(estimated_kpts[None])).cuda())[0].cpu().numpy()  # :659-661
+    if RT is None:  # (the batched LINEMOD loop fits the poses of a whole batch in one rcv_horn_pose_batch call)
+        RT = horn_batch(kpts, torch.from_numpy(np.ascontiguousarray(estimated_kpts[None])).cuda())[0].cpu().numpy()  # :659-661
     _, est_model = project(xyz_load * 1000, linemod_K, RT[0:3, :])
     _, gt_model = project(xyz_load * 1000, linemod_K, RTGT_mm)
     gt_dev = torch.from_numpy(np.ascontiguousarray(gt_model)).cuda()
@@ -479,47 +480,14 @@ def estimate_6d_pose_lm(opts, return_details=False):
         bf_icp, af_icp, general_counter = 0, 0, 0
         per_frame = {}
         dataPath = rootpvPath + 'JPEGImages/'
+        todo = []
         for filename in sorted(os.listdir(dataPath)):
             stem = os.path.splitext(filename)[0]
-            if not filename.endswith(".jpg") or stem not in test_list:
-                continue
-            print("Evaluating ", filename)
-            RTGT = np.load(rootpvPath + "pose/pose" + str(int(stem)) + '.npy')
-            depth_map1 = read_depth(rootPath + 'data/depth' + str(int(stem)) + '.dpt')
-            H, W = depth_map1.shape
-            depth_dev = _depth_to_u16(depth_map1, "cuda")
-            if opts.using_ckpts:
-                from PIL import Image
+            if filename.endswith(".jpg") and stem in test_list:
+                todo.append((filename, stem))
 
-                if pipe is None:
-                    pipe = FramePipeline(sds, H, W, dtype=getattr(opts, 'dtype', 'f16x3'), frames_per_step=1)
-                    pipe.set_stage_timing(True)
-                rgb = np.array(Image.open(dataPath + filename).convert('RGB'), dtype=np.uint8)
-                pipe.process(torch.from_numpy(rgb)[None].cuda(), depth_dev[None], max_radii_dm)
-                estimated_kpts, res = pipe.read_results()
-                estimated_kpts = estimated_kpts[0]
-                statuses = [r.status for r in res]
-                seg_maps, rad_maps, mask_mode = pipe.seg[:, 0, 0], pipe.radial[:, 0, 0], 0
-            else:
-                estimated_kpts, statuses = np.zeros((3, 3)), []
-                ws = AccWorkspace(H * W)
-                seg_maps, rad_maps, mask_mode = None, torch.empty((3, H, W), dtype=torch.float32, device="cuda"), 1
-                for k in range(1, 4):  # reference :611-618
-                    radial_est = np.load(os.path.join(opts.root_dataset + "LINEMOD_ORIG/", 'estRadialMap', class_name,
-                                                      "Out_pt" + str(k) + "_dm", stem + '.npy'))
-                    rad_dev = torch.from_numpy(np.ascontiguousarray(radial_est, dtype=np.float32)).cuda()
-                    rad_maps[k - 1].copy_(rad_dev)
-                    seam_compact(None, rad_dev, depth_dev, max_radii_dm[k - 1], mode=1, workspace=ws)
-                    accumulate_on_device(ws.xyz, ws.radial, ws.counts, ws.max_points, ws.max_points, ws)
-                    r = ws.read_result()
-                    statuses.append(r.status)
-                    estimated_kpts[k - 1] = r.center_mm[:]
-            for st in statuses:
-                _raise_like_reference(st)
-            RTGT_mm = np.array(RTGT, dtype=np.float64, copy=True)
-            RTGT_mm[:, 3] = RTGT_mm[:, 3] * 1000
-            ev = _pose_and_add(class_name, xyz_load, keypoints, estimated_kpts, RTGT_mm, seg_maps, rad_maps, depth_dev, max_radii_dm,
-                               mask_mode, ICPConvergenceCriteria())
+        def account(stem, ev):
+            nonlocal bf_icp, af_icp, general_counter
             if ev["add_distance_mm"] <= add_threshold[class_name] * 1000:
                 bf_icp += 1
             if ev["add_distance_after_icp_mm"] <= add_threshold[class_name] * 1000:
@@ -528,6 +496,79 @@ def estimate_6d_pose_lm(opts, return_details=False):
             per_frame[stem] = ev
             print('Current ADD\\(s\\) of ' + class_name + ' before ICP: ', bf_icp / general_counter)
             print('Currnet ADD\\(s\\) of ' + class_name + ' after ICP: ', af_icp / general_counter)
+
+        if opts.using_ckpts and todo:
+            # The frames of a class travel through the device pipeline in batches of opts.frames_per_step (default 8): a pool of
+            # host threads decodes the next batch's JPEG / .dpt / pose files while the GPU works on the current one, there is one
+            # result copy and one Horn launch per batch; ADD(-S) / ICP then run per frame.  A frame's maps and keypoints do not
+            # depend on the batch it travels in (tests/test_gpu_fcn_x3.py::test_x3_groups_and_batch), so the results are those
+            # of the frame-by-frame loop of the reference (:553-659).
+            from concurrent.futures import ThreadPoolExecutor
+
+            from PIL import Image
+
+            from .util.horn import horn_batch
+
+            def load(item):
+                filename, stem = item
+                rgb = np.array(Image.open(dataPath + filename).convert('RGB'), dtype=np.uint8)
+                depth = read_depth(rootPath + 'data/depth' + str(int(stem)) + '.dpt')
+                return rgb, _depth_to_u16(depth, "cpu"), np.load(rootpvPath + "pose/pose" + str(int(stem)) + '.npy')
+
+            N = max(1, min(int(getattr(opts, 'frames_per_step', 8)), len(todo)))
+            kpts_model = keypoints[1:4, :] * 1000
+            with ThreadPoolExecutor(max_workers=min(8, N)) as pool:
+                chunks = [todo[i:i + N] for i in range(0, len(todo), N)]
+                pending = [pool.submit(load, it) for it in chunks[0]]
+                for ci, chunk in enumerate(chunks):
+                    loaded = [f.result() for f in pending]
+                    pending = [pool.submit(load, it) for it in chunks[ci + 1]] if ci + 1 < len(chunks) else []
+                    H, W = loaded[0][1].shape
+                    if pipe is None:
+                        pipe = FramePipeline(sds, H, W, dtype=getattr(opts, 'dtype', 'f16x3'), frames_per_step=N)
+                        pipe.set_stage_timing(True)
+                    pad = [loaded[-1]] * (N - len(loaded))  # a short last batch is filled with copies of its last frame
+                    rgb = torch.from_numpy(np.stack([l[0] for l in loaded + pad])).cuda()
+                    depth_dev = torch.stack([l[1] for l in loaded + pad]).cuda()
+                    pipe.process(rgb, depth_dev, max_radii_dm)
+                    kp_all, res = pipe.read_results()          # one copy per batch
+                    RT_all = horn_batch(kpts_model, torch.from_numpy(np.ascontiguousarray(kp_all)).cuda()).cpu().numpy()  # :659-661
+                    for i, (filename, stem) in enumerate(chunk):
+                        print("Evaluating ", filename)
+                        for r in res[3 * i:3 * i + 3]:
+                            _raise_like_reference(r.status)
+                        RTGT_mm = np.array(loaded[i][2], dtype=np.float64, copy=True)
+                        RTGT_mm[:, 3] = RTGT_mm[:, 3] * 1000
+                        ev = _pose_and_add(class_name, xyz_load, keypoints, kp_all[i], RTGT_mm, pipe.seg[:, i, 0], pipe.radial[:, i, 0],
+                                           depth_dev[i], max_radii_dm, 0, ICPConvergenceCriteria(), RT=RT_all[i])
+                        account(stem, ev)
+            todo = []
+        for filename, stem in todo:  # pre-computed radial maps (:611-618): frame by frame
+            print("Evaluating ", filename)
+            RTGT = np.load(rootpvPath + "pose/pose" + str(int(stem)) + '.npy')
+            depth_map1 = read_depth(rootPath + 'data/depth' + str(int(stem)) + '.dpt')
+            H, W = depth_map1.shape
+            depth_dev = _depth_to_u16(depth_map1, "cuda")
+            estimated_kpts, statuses = np.zeros((3, 3)), []
+            ws = AccWorkspace(H * W)
+            seg_maps, rad_maps, mask_mode = None, torch.empty((3, H, W), dtype=torch.float32, device="cuda"), 1
+            for k in range(1, 4):  # reference :611-618
+                radial_est = np.load(os.path.join(opts.root_dataset + "LINEMOD_ORIG/", 'estRadialMap', class_name,
+                                                  "Out_pt" + str(k) + "_dm", stem + '.npy'))
+                rad_dev = torch.from_numpy(np.ascontiguousarray(radial_est, dtype=np.float32)).cuda()
+                rad_maps[k - 1].copy_(rad_dev)
+                seam_compact(None, rad_dev, depth_dev, max_radii_dm[k - 1], mode=1, workspace=ws)
+                accumulate_on_device(ws.xyz, ws.radial, ws.counts, ws.max_points, ws.max_points, ws)
+                r = ws.read_result()
+                statuses.append(r.status)
+                estimated_kpts[k - 1] = r.center_mm[:]
+            for st in statuses:
+                _raise_like_reference(st)
+            RTGT_mm = np.array(RTGT, dtype=np.float64, copy=True)
+            RTGT_mm[:, 3] = RTGT_mm[:, 3] * 1000
+            ev = _pose_and_add(class_name, xyz_load, keypoints, estimated_kpts, RTGT_mm, seg_maps, rad_maps, depth_dev, max_radii_dm,
+                               mask_mode, ICPConvergenceCriteria())
+            account(stem, ev)
         if general_counter:
             tag = 'ADDs' if class_name in lm_syms else 'ADD'
             print(tag + ' of ' + class_name + ' before ICP: ', bf_icp / general_counter)

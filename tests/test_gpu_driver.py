@@ -103,6 +103,65 @@ def test_driver_with_precomputed_radial_maps(tmp_path, oracle):
     assert 0.0 <= results[cls]["add_after_icp"] <= 1.0
 
 
+def _write_lm_checkpoints(root, cls, golden_dir, radii_dm):
+    """Three checkpoints `<class>_pt{1,2,3}.pth.tar` (reference :522) with a zeroed last layer: every network answers seg = 1 and
+    radial = its own constant -- known maps through the real FCN path (no trained weights offline)."""
+    import json
+
+    import torch
+
+    import fcn_weights
+
+    shapes = json.load(open(os.path.join(golden_dir, "fcn_state_dict_keys.json")))
+    for k in range(3):
+        sd = {n: torch.from_numpy(v) for n, v in fcn_weights.make_state_dict_numpy(shapes, seed=k).items()}
+        sd["conv8.weight"] = torch.zeros_like(sd["conv8.weight"])
+        sd["conv8.bias"] = torch.tensor([1.0, radii_dm[k]], dtype=torch.float32)
+        torch.save(dict(epoch=1, model_state_dict=sd, optim_state_dict={}, loss=[]), os.path.join(root, cls + "_pt%d.pth.tar" % (k + 1)))
+
+
+def test_lm_driver_with_checkpoints_batched(tmp_path, golden_dir, oracle):
+    """The north-star branch of estimate_6d_pose_lm (using_ckpts=True, reference :520-530, :596-610): checkpoints -> FCN ->
+    seam (seg > 0.8, radial <= max_radii_dm[k]) -> voting -> Horn -> ADD / ICP, with the frames travelling in batches of
+    three (five frames: one full batch and a short one) -- against the oracle, and identical to the frame-by-frame run."""
+    import time
+
+    from rcvpose_amd import AccumulatorSpace as A
+
+    root = str(tmp_path) + "/"
+    cls, poses = _write_dataset(root, n_frames=5)
+    radii = (3.0, 3.5, 4.0)
+    _write_lm_checkpoints(root, cls, golden_dir, radii)
+    base = dict(root_dataset=root, model_dir=root, using_ckpts=True, demo_mode=False, test_occ=False, class_names=[cls])
+    t0 = time.perf_counter()
+    res_b, det_b = A.estimate_6d_pose_lm(types.SimpleNamespace(frames_per_step=3, **base), return_details=True)
+    t_b = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    res_1, det_1 = A.estimate_6d_pose_lm(types.SimpleNamespace(frames_per_step=1, **base), return_details=True)
+    t_1 = time.perf_counter() - t0
+    print("estimate_6d_pose_lm, 5 frames with checkpoints: %.2f s in batches of 3, %.2f s frame by frame" % (t_b, t_1))
+    assert res_b[cls]["frames"] == 5 and res_1[cls]["frames"] == 5
+    kps_obj = np.load(os.path.join(root, "LINEMOD", cls, "Outside9.npy"))
+    model = A.read_ply_points(os.path.join(root, "LINEMOD", cls, cls + ".ply"))
+    max_radii_dm = [(((model - kps_obj[i + 1]) ** 2).sum(axis=1) ** 0.5).max() * 10 for i in range(3)]
+    assert all(r <= m for r, m in zip(radii, max_radii_dm))
+    for stem in sorted(det_b[cls]):
+        db, d1 = det_b[cls][stem], det_1[cls][stem]
+        for key in ("estimated_kpts", "RT", "icp_transformation"):
+            assert np.array_equal(db[key], d1[key]), (stem, key)
+        for key in ("add_distance_mm", "add_distance_after_icp_mm", "scene_points", "icp_iterations"):
+            assert db[key] == d1[key], (stem, key)
+        fr = frames.synthetic_frame(int(stem))
+        ones = np.ones(fr["depth"].shape, dtype=np.float32)
+        for k in range(3):
+            xyz, rl = oracle.seam(ones, ones * np.float32(radii[k]), fr["depth"], max_radii_dm[k])
+            assert len(rl) == ones.size and len(xyz) == fr["n_silhouette"]    # radii over the whole mask, points where depth != 0
+            ref = oracle.accumulator_3d(xyz, rl, sparse=True)
+            assert np.array_equal(db["estimated_kpts"][k], ref[0]), (stem, k)
+        assert np.array_equal(db["RT"], oracle.horn(kps_obj[1:4] * 1000, db["estimated_kpts"]))
+    assert res_b[cls]["add_before_icp"] == res_1[cls]["add_before_icp"] and res_b[cls]["net_time_ms"] > 0
+
+
 def test_main_entry_runs_the_driver(tmp_path):
     from rcvpose_amd.main import main
 
