@@ -497,6 +497,14 @@ def estimate_6d_pose_lm(opts, return_details=False):
             print('Current ADD\\(s\\) of ' + class_name + ' before ICP: ', bf_icp / general_counter)
             print('Currnet ADD\\(s\\) of ' + class_name + ' after ICP: ', af_icp / general_counter)
 
+        import time as _time
+
+        if opts.using_ckpts and todo:  # the engine (BN folding, weight packing, upload) is built once per class, before the frame loop
+            H, W = read_depth(rootPath + 'data/depth' + str(int(todo[0][1])) + '.dpt').shape
+            n_step = max(1, min(int(getattr(opts, 'frames_per_step', 8)), len(todo)))
+            pipe = FramePipeline(sds, H, W, dtype=getattr(opts, 'dtype', 'f16x3'), frames_per_step=n_step)
+            pipe.set_stage_timing(True)
+        t_loop = _time.perf_counter()
         if opts.using_ckpts and todo:
             # The frames of a class travel through the device pipeline in batches of opts.frames_per_step (default 8): a pool of
             # host threads decodes the next batch's JPEG / .dpt / pose files while the GPU works on the current one, there is one
@@ -515,7 +523,7 @@ def estimate_6d_pose_lm(opts, return_details=False):
                 depth = read_depth(rootPath + 'data/depth' + str(int(stem)) + '.dpt')
                 return rgb, _depth_to_u16(depth, "cpu"), np.load(rootpvPath + "pose/pose" + str(int(stem)) + '.npy')
 
-            N = max(1, min(int(getattr(opts, 'frames_per_step', 8)), len(todo)))
+            N = n_step
             kpts_model = keypoints[1:4, :] * 1000
             with ThreadPoolExecutor(max_workers=min(8, N)) as pool:
                 chunks = [todo[i:i + N] for i in range(0, len(todo), N)]
@@ -523,10 +531,6 @@ def estimate_6d_pose_lm(opts, return_details=False):
                 for ci, chunk in enumerate(chunks):
                     loaded = [f.result() for f in pending]
                     pending = [pool.submit(load, it) for it in chunks[ci + 1]] if ci + 1 < len(chunks) else []
-                    H, W = loaded[0][1].shape
-                    if pipe is None:
-                        pipe = FramePipeline(sds, H, W, dtype=getattr(opts, 'dtype', 'f16x3'), frames_per_step=N)
-                        pipe.set_stage_timing(True)
                     pad = [loaded[-1]] * (N - len(loaded))  # a short last batch is filled with copies of its last frame
                     rgb = torch.from_numpy(np.stack([l[0] for l in loaded + pad])).cuda()
                     depth_dev = torch.stack([l[1] for l in loaded + pad]).cuda()
@@ -574,7 +578,8 @@ def estimate_6d_pose_lm(opts, return_details=False):
             print(tag + ' of ' + class_name + ' before ICP: ', bf_icp / general_counter)
             print(tag + ' of ' + class_name + ' after ICP: ', af_icp / general_counter)
             results[class_name] = dict(frames=general_counter, add_before_icp=bf_icp / general_counter,
-                                       add_after_icp=af_icp / general_counter, **_stage_timers(pipe))
+                                       add_after_icp=af_icp / general_counter, frame_loop_s=_time.perf_counter() - t_loop,
+                                       **_stage_timers(pipe))
             details[class_name] = per_frame
     _require_some_class(results, missing)
     return (results, details) if return_details else results
