@@ -100,6 +100,7 @@ struct alignas(16) AccHeader {
     // before, each workgroup took the live bb_best_key at its own start and a late one could centre on a voxel found by its
     // own round -- harmless for exactness, but the lower bound and the list sizes became timing dependent)
     unsigned long long climb_key[2];
+    unsigned long long restart;  // 1 + flat index of the centre voxel of the candidate block with the largest upper bound (k_bb_restart); 0: none
 };
 static_assert(sizeof(AccHeader) <= 512, "AccHeader must fit the 512 bytes reserved in the workspace");
 
@@ -1431,72 +1432,119 @@ __device__ __forceinline__ void d_bb_wide(AccHeader *hdr, const float *F, size_t
 // round.  One workgroup per item, sums in a fixed order (the start voxel is the same from run to run).
 __device__ __forceinline__ void d_bb_seed(AccHeader *hdr, const double *Q, const double *P, const int32_t *ri, int cap)
 {
-    constexpr int NS = 14;  // upper triangle of A^T A (10) + A^T b (4), rows a_p = (-2x, -2y, -2z, 1), b_p = r^2 - |q|^2
+    constexpr int NS = 15;  // upper triangle of A^T A (10) + A^T b (4), rows a_p = (-2x, -2y, -2z, 1), b_p = r^2 - |q|^2; + the row count
     __shared__ double part[NS][256];
     __shared__ double tot[NS];
+    __shared__ double s_c[3];   // the current estimate (relative to the grid centre)
+    __shared__ int s_have;      // an estimate exists
+    __shared__ int s_hist[512]; // |residual| of the points against the current estimate, 1-voxel bins
+    __shared__ double s_tau;
     const AccHeader H = *hdr;
     if (H.status != RCV_OK || !H.bb_enabled) return;
-    if (threadIdx.x == 0) hdr->seed = 0;
+    if (threadIdx.x == 0) { hdr->seed = 0; s_have = 0; }
     if (H.variant != 0) return;
     const int n = H.n;
     const double t0 = 0.5 * (double)H.dim;
     const double *Phi = P + 4 * (size_t)cap;
-    double sm[NS];
+    // Five passes (r03): the plain least-squares fit, then four trimmed re-fits over the better half of the points -- those whose
+    // shell passes within tau of the current estimate, tau = the median |residual| (from a 1-voxel histogram), at least 3
+    // voxels.  Gross outliers (false-positive segmentation pixels on the background, wrong radii) enter the first fit with
+    // the square of their radius and drag it tens of voxels away -- the hill-climb then starts on a side lobe, the search
+    // prunes with a lower bound of a quarter of the peak and visits 20 x the blocks (tools/vote_sweep.py: 141 instead of 18 ms
+    // per 216 items at 10 % false positives).  A re-fit that fails numerically keeps the previous estimate.
+    for (int pass = 0; pass < 5; pass++) {
+        __syncthreads();  // s_c / s_have of the previous pass
+        const bool trim = pass > 0;
+        if (trim && !s_have) break;
+        const double cx = s_c[0], cy = s_c[1], cz = s_c[2];
+        if (trim) {
+            for (int t = threadIdx.x; t < 512; t += 256) s_hist[t] = 0;
+            __syncthreads();
+            for (int p = threadIdx.x; p < n; p += 256) {
+                if (!(Phi[p] > 0.0)) continue;
+                const double dx = cx - (Q[p] - t0), dy = cy - (Q[(size_t)cap + p] - t0), dz = cz - (Q[2 * (size_t)cap + p] - t0);
+                const double res = fabs(sqrt((dx * dx + dy * dy) + dz * dz) - (double)ri[p]);
+                atomicAdd(&s_hist[res < 511.0 ? (int)res : 511], 1);
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                int total = 0;
+                for (int t = 0; t < 512; t++) total += s_hist[t];
+                int run = 0, t = 0;
+                for (; t < 511; t++) { run += s_hist[t]; if (2 * run >= total) break; }
+                s_tau = fmax(3.0, (double)(t + 1));
+            }
+            __syncthreads();
+        }
+        const double tau = trim ? s_tau : 0.0;
+        double sm[NS];
 #pragma unroll
-    for (int k = 0; k < NS; k++) sm[k] = 0.0;
-#pragma unroll 4
-    for (int p = threadIdx.x; p < n; p += 256) {
-        if (!(Phi[p] > 0.0)) continue;  // never votes
-        const double x = Q[p] - t0, y = Q[(size_t)cap + p] - t0, z = Q[2 * (size_t)cap + p] - t0, r = (double)ri[p];
-        const double a[4] = {-2.0 * x, -2.0 * y, -2.0 * z, 1.0};
-        const double b = r * r - ((x * x + y * y) + z * z);
-        int k = 0;
+        for (int k = 0; k < NS; k++) sm[k] = 0.0;
+#pragma unroll 2
+        for (int p = threadIdx.x; p < n; p += 256) {
+            if (!(Phi[p] > 0.0)) continue;  // never votes
+            const double x = Q[p] - t0, y = Q[(size_t)cap + p] - t0, z = Q[2 * (size_t)cap + p] - t0, r = (double)ri[p];
+            if (trim) {
+                const double dx = cx - x, dy = cy - y, dz = cz - z;
+                if (!(fabs(sqrt((dx * dx + dy * dy) + dz * dz) - r) <= tau)) continue;
+            }
+            const double a[4] = {-2.0 * x, -2.0 * y, -2.0 * z, 1.0};
+            const double b = r * r - ((x * x + y * y) + z * z);
+            int k = 0;
 #pragma unroll
-        for (int u = 0; u < 4; u++)
+            for (int u = 0; u < 4; u++)
 #pragma unroll
-            for (int v = u; v < 4; v++) sm[k++] += a[u] * a[v];
+                for (int v = u; v < 4; v++) sm[k++] += a[u] * a[v];
 #pragma unroll
-        for (int u = 0; u < 4; u++) sm[10 + u] += a[u] * b;
-    }
+            for (int u = 0; u < 4; u++) sm[10 + u] += a[u] * b;
+            sm[14] += 1.0;
+        }
 #pragma unroll
-    for (int k = 0; k < NS; k++) part[k][threadIdx.x] = sm[k];
-    __syncthreads();
-    if (threadIdx.x < NS) {
-        double acc = 0.0;
-        for (int t = 0; t < 256; t++) acc += part[threadIdx.x][t];
-        tot[threadIdx.x] = acc;
-    }
-    __syncthreads();
-    if (threadIdx.x != 0) return;
-    double M[4][5];
-    {
-        int k = 0;
-        for (int u = 0; u < 4; u++)
-            for (int v = u; v < 4; v++) { M[u][v] = tot[k]; M[v][u] = tot[k]; k++; }
-        for (int u = 0; u < 4; u++) M[u][4] = tot[10 + u];
-    }
-    for (int c = 0; c < 4; c++) {  // Gaussian elimination, partial pivoting
-        int piv = c;
-        for (int r = c + 1; r < 4; r++)
-            if (fabs(M[r][c]) > fabs(M[piv][c])) piv = r;
-        if (!(fabs(M[piv][c]) > 0.0)) return;
-        for (int v = 0; v < 5; v++) { const double tmp = M[c][v]; M[c][v] = M[piv][v]; M[piv][v] = tmp; }
-        for (int r = c + 1; r < 4; r++) {
-            const double f = M[r][c] / M[c][c];
-            for (int v = c; v < 5; v++) M[r][v] -= f * M[c][v];
+        for (int k = 0; k < NS; k++) part[k][threadIdx.x] = sm[k];
+        __syncthreads();
+        if (threadIdx.x < NS) {
+            double acc = 0.0;
+            for (int t = 0; t < 256; t++) acc += part[threadIdx.x][t];
+            tot[threadIdx.x] = acc;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            bool ok = !trim || (tot[14] >= 16.0 && tot[14] * 16.0 >= (double)n);
+            double M[4][5];
+            {
+                int k = 0;
+                for (int u = 0; u < 4; u++)
+                    for (int v = u; v < 4; v++) { M[u][v] = tot[k]; M[v][u] = tot[k]; k++; }
+                for (int u = 0; u < 4; u++) M[u][4] = tot[10 + u];
+            }
+            for (int c = 0; c < 4 && ok; c++) {  // Gaussian elimination, partial pivoting
+                int piv = c;
+                for (int r = c + 1; r < 4; r++)
+                    if (fabs(M[r][c]) > fabs(M[piv][c])) piv = r;
+                if (!(fabs(M[piv][c]) > 0.0)) { ok = false; break; }
+                for (int v = 0; v < 5; v++) { const double tmp = M[c][v]; M[c][v] = M[piv][v]; M[piv][v] = tmp; }
+                for (int r = c + 1; r < 4; r++) {
+                    const double f = M[r][c] / M[c][c];
+                    for (int v = c; v < 5; v++) M[r][v] -= f * M[c][v];
+                }
+            }
+            if (ok) {
+                double sol[4];
+                for (int c = 3; c >= 0; c--) {
+                    double v = M[c][4];
+                    for (int u = c + 1; u < 4; u++) v -= M[c][u] * sol[u];
+                    sol[c] = v / M[c][c];
+                }
+                for (int a = 0; a < 3; a++) ok = ok && sol[a] > -1.0e6 && sol[a] < 1.0e6;  // NaN / far outside: not an estimate
+                if (ok) { s_c[0] = sol[0]; s_c[1] = sol[1]; s_c[2] = sol[2]; s_have = 1; }
+            }
         }
     }
-    double sol[4];
-    for (int c = 3; c >= 0; c--) {
-        double v = M[c][4];
-        for (int u = c + 1; u < 4; u++) v -= M[c][u] * sol[u];
-        sol[c] = v / M[c][c];
-    }
+    __syncthreads();
+    if (threadIdx.x != 0 || !s_have) return;
     long long vox[3];
     for (int a = 0; a < 3; a++) {
-        const double c = sol[a] + t0;
-        if (!(c > -1.0e6 && c < 1.0e6)) return;  // NaN / far outside: no seed
-        vox[a] = llrint(c);
+        vox[a] = llrint(s_c[a] + t0);
         vox[a] = vox[a] < 0 ? 0 : (vox[a] >= H.dim ? H.dim - 1 : vox[a]);
     }
     hdr->seed = 1ull + (unsigned long long)((vox[0] * H.dim + vox[1]) * H.dim + vox[2]);
@@ -1584,6 +1632,109 @@ __device__ __forceinline__ void d_bb_climb(AccHeader *hdr, const double *Q, cons
             atomicMax(&hdr->climb_key[round & 1], key);
         }
     }
+}
+
+// Line search along the sheet normal (r03).  The vote landscape around the keypoint is a sheet about one voxel thick, normal
+// to the direction from the points' centroid to the keypoint: an estimate that lies three voxels off the sheet
+// ALONG that normal -- which is where outliers push the least-squares fit -- has nothing but side lobes in its 5 x 5 x 5
+// neighbourhood, and the hill-climb ends on one of them.  When the round around the seed found no strong peak, the exact counts
+// of 125 voxels on the line seed + t * u, t = -62 ... 62, u = unit(seed - centroid), find the sheet crossing; the climb
+// rounds then walk inside the sheet.  Five workgroups of 25 positions; any exact count is a valid lower bound.
+__device__ __forceinline__ void d_bb_line(AccHeader *hdr, const double *Q, const double *P, int cap, int mode)
+{
+    constexpr int NV = 25;
+    __shared__ int red[4][NV];
+    const AccHeader H = *hdr;
+    if (H.status != RCV_OK || !H.bb_enabled || H.variant != 0) return;
+    // mode 0: through the least-squares seed, when its round found no strong peak; mode 1: through the restart voxel (k_bb_restart)
+    if (mode == 0 ? (H.seed == 0 || H.probe_skip) : H.restart == 0) return;
+    const int D = H.dim, n = H.n;
+    const int slot = mode == 0 ? 0 : 1;
+    const unsigned long long flat = mode == 0 ? H.seed - 1 : H.restart - 1;
+    const double s0 = (double)(flat / ((unsigned long long)D * D)), s1 = (double)((flat / D) % D), s2 = (double)(flat % D);
+    // centroid of the recentred points: Q = voxel coordinates - mean - shift
+    const double c0 = -H.shift;
+    double u0 = s0 - c0, u1 = s1 - c0, u2 = s2 - c0;
+    const double nrm = sqrt((u0 * u0 + u1 * u1) + u2 * u2);
+    if (!(nrm >= 1.0)) return;
+    u0 /= nrm; u1 /= nrm; u2 /= nrm;
+    double vi[NV], vj[NV], vk[NV];
+    bool inside[NV];
+#pragma unroll
+    for (int v = 0; v < NV; v++) {
+        const double t = (double)((int)blockIdx.x * NV + v - 62);
+        vi[v] = rint(s0 + t * u0); vj[v] = rint(s1 + t * u1); vk[v] = rint(s2 + t * u2);
+        inside[v] = vi[v] >= 0.0 && vj[v] >= 0.0 && vk[v] >= 0.0 && vi[v] < (double)D && vj[v] < (double)D && vk[v] < (double)D;
+    }
+    const double *Qx = Q, *Qy = Q + (size_t)cap, *Qz = Q + 2 * (size_t)cap;
+    const double *Plo = P + 3 * (size_t)cap, *Phi = P + 4 * (size_t)cap;
+    int cnt[NV];
+#pragma unroll
+    for (int v = 0; v < NV; v++) cnt[v] = 0;
+    for (int p = threadIdx.x; p < n; p += 256) {
+        const double thi = Phi[p];
+        if (!(thi > 0.0)) continue;
+        const double tlo = Plo[p], qx = Qx[p], qy = Qy[p], qz = Qz[p];
+#pragma unroll
+        for (int v = 0; v < NV; v++) {
+            const double dx = vi[v] - qx, dy = vj[v] - qy, dz = vk[v] - qz;
+            const double d2 = (dx * dx + dy * dy) + dz * dz;  // reference operand order (:337)
+            const int below = (int)(__double_as_longlong(d2 - thi) >> 32);
+            const int reach = ~(int)(__double_as_longlong(d2 - tlo) >> 32);
+            cnt[v] += (int)((unsigned)(below & reach) >> 31);
+        }
+    }
+#pragma unroll
+    for (int v = 0; v < NV; v++) {
+        const int c = wave_sum_i32(cnt[v]);
+        if (lane_id() == 0) red[wave_id()][v] = c;
+    }
+    __syncthreads();
+    if (threadIdx.x < NV && inside[threadIdx.x]) {
+        const int v = threadIdx.x;
+        const int c = red[0][v] + red[1][v] + red[2][v] + red[3][v];
+        const unsigned long long key = ((unsigned long long)c << 32) | (((unsigned long long)vi[v] * D + (unsigned long long)vj[v]) * D + (unsigned long long)vk[v]);
+        atomicMax(&hdr->bb_best, c);
+        atomicMax(&hdr->bb_best_key, key);
+        atomicMax(&hdr->climb_key[slot], key);
+    }
+}
+
+// A second start for the lower bound, from the search's own upper bounds (r03).  The seed and the greedy probe can both end on a
+// side lobe (outliers drag the least-squares fit along the viewing direction, tools/vote_sweep.py; the probe ranks 32-voxel blocks
+// whose bounds are all ~N by their centre counts, i.e. by noise).  Once a level has produced 8- or 4-voxel blocks, their bounds
+// do discriminate: the block most shells cross is at the keypoint.  This kernel picks the candidate block with the largest upper
+// bound (first in list order among equals: the list order is deterministic up to the atomics that built it, and any start is
+// valid); the line search through its centre voxel and two climb rounds follow.  If the lower bound already sits on the peak,
+// they find it again.
+__device__ __forceinline__ void d_bb_restart(AccHeader *hdr, const BBEntry *list, uint32_t n_pairs, uint32_t n_singles, int edge)
+{
+    __shared__ unsigned long long s_key[16];
+    const AccHeader H = *hdr;
+    if (H.status != RCV_OK || !H.bb_enabled || H.bb_overflow || H.variant != 0) return;
+    const uint32_t na = min(n_pairs, (uint32_t)BB_HALF), nb = min(n_singles, (uint32_t)BB_HALF), n = na + nb;
+    unsigned long long best = 0;
+    for (uint32_t t = threadIdx.x; t < n; t += 1024) {
+        const uint32_t idx = t < na ? t : (uint32_t)BB_HALF + (t - na);
+        const BBEntry e = list[idx];
+        // ub (31 bits) | inverted position (so that the first entry wins among equals) | + 1: 0 means none
+        const unsigned long long key = ((unsigned long long)(uint32_t)min(e.ub, 0x7FFFFFFF) << 32) | (unsigned long long)(0xFFFFFFu - t);
+        if (key + 1 > best) best = key + 1;
+    }
+    best = wave_max_u64(best);
+    if (lane_id() == 0) s_key[wave_id()] = best;
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    for (int w = 1; w < 16; w++) best = s_key[w] > best ? s_key[w] : best;
+    hdr->climb_key[1] = 0;
+    hdr->climb_center[1] = 0;
+    hdr->restart = 0;
+    if (!best) return;
+    const uint32_t t = 0xFFFFFFu - (uint32_t)((best - 1) & 0xFFFFFFull);
+    const BBEntry e = list[t < na ? t : (uint32_t)BB_HALF + (t - na)];
+    const int D = H.dim;
+    const unsigned long long ci = min((int)e.i + edge / 2, D - 1), cj = min((int)e.j + edge / 2, D - 1), ck = min((int)e.k + edge / 2, D - 1);
+    hdr->restart = 1ull + (ci * D + cj) * D + ck;
 }
 
 // Exact counts of the candidate voxels.  The last wide level (2^3 parents, single-voxel children) leaves the voxels
@@ -2043,6 +2194,19 @@ __global__ __launch_bounds__(256) void k_bb_climb(int cap, int round, SP<unsigne
     unsigned char *w = ws.get();
     d_bb_climb((AccHeader *)(w + L.header), (const double *)(w + L.Q), (const double *)(w + L.P), cap, round);
 }
+__global__ __launch_bounds__(256) void k_bb_line(int cap, int mode, SP<unsigned char> ws, Layout L)
+{
+    unsigned char *w = ws.get();
+    d_bb_line((AccHeader *)(w + L.header), (const double *)(w + L.Q), (const double *)(w + L.P), cap, mode);
+}
+// the candidate list that level `level` is about to consume (blocks of edge BB_ROOT >> level)
+__global__ __launch_bounds__(1024) void k_bb_restart(int level, SP<unsigned char> ws, Layout L)
+{
+    unsigned char *w = ws.get();
+    AccHeader *hdr = (AccHeader *)(w + L.header);
+    BBEntry *la = (BBEntry *)(w + L.bb_lists), *lb = la + BB_CAP;
+    d_bb_restart(hdr, (level & 1) ? lb : la, hdr->bb_count[level], hdr->bs_count[level], BB_ROOT >> level);
+}
 __global__ __launch_bounds__(BBL_THREADS) void k_bb_exact(int cap, SP<unsigned char> ws, Layout L)
 {
     unsigned char *w = ws.get();
@@ -2390,6 +2554,11 @@ static int run_engines(int cap, int bb_enable, SP<rcv_acc_result> sres, SP<uint3
         RCV_LAUNCH_CHECK();
         hipLaunchKernelGGL(k_bb_gate, items, dim3(64), 0, st, 0, sws, L);
         RCV_LAUNCH_CHECK();
+        // no strong peak around the seed: look for the vote sheet along its normal through the seed, and decide again
+        hipLaunchKernelGGL(k_bb_line, grid3(5), dim3(256), 0, st, cap, 0, sws, L);
+        RCV_LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_bb_gate, items, dim3(64), 0, st, 0, sws, L);
+        RCV_LAUNCH_CHECK();
         // level 0 of the breadth-first search scores the 32-voxel blocks (children of the 64-voxel roots): upper bounds with
         // the wide kernel, then the centre counts that rank them for the probe (r02: was one k_bb_level launch with an exact
         // centre count per child, 2.0 ms per 216 items)
@@ -2423,7 +2592,20 @@ static int run_engines(int cap, int bb_enable, SP<rcv_acc_result> sres, SP<uint3
         // the lower bound now sits at (or next to) the peak: the wide levels only need upper bounds
         const int wide_grid = n_items >= 8 ? 256 : 2048 / n_items;
         // (the last of them, on 2^3 parents, bounds single voxels)
+        int extra_round = BB_CLIMB_ROUNDS;  // (even: the restart's line search fills slot 1, which round `extra_round` reads)
+        static_assert(BB_CLIMB_ROUNDS % 2 == 0, "restart rounds read climb_key[1]");
         for (int level = 1; level < BB_LEVELS; level++) {
+            if (level == 3 || level == 4) {  // the 8- and 4-voxel candidates exist: second start of the lower bound (d_bb_restart)
+                hipLaunchKernelGGL(k_bb_restart, items, dim3(1024), 0, st, level, sws, L);
+                RCV_LAUNCH_CHECK();
+                hipLaunchKernelGGL(k_bb_line, grid3(5), dim3(256), 0, st, cap, 1, sws, L);
+                RCV_LAUNCH_CHECK();
+                for (int r = 0; r < 2; r++) {
+                    hipLaunchKernelGGL(k_bb_climb, grid3(BB_CLIMB_W), dim3(256), 0, st, cap, extra_round + r, sws, L);
+                    RCV_LAUNCH_CHECK();
+                }
+                extra_round += 2;
+            }
             // every level list is two regions, x-sibling pairs and single blocks, each with its own launch; the level before
             // the voxel level and the voxel level itself write single entries only
             if (level == BB_LEVELS - 1) {

@@ -1,17 +1,19 @@
 #!/usr/bin/env python3
-"""Candidate-list sizes of the branch-and-bound peak search for the bench workload (debug/tuning aid)."""
+"""Candidate-list sizes of the branch-and-bound peak search for the bench workload (debug/tuning aid).
+    python tools/bb_stats.py [sigma_dm] [outlier_frac] [seg_false_pos]"""
 import json, os, sys
+ARGS = [float(a) for a in sys.argv[1:4]] + [0.02, 0.0, 0.0][len(sys.argv[1:4]):]
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from rcvpose_amd import synthetic, synthetic_weights
 from rcvpose_amd.pipeline import FramePipeline
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-B = 4
+B = 2
 shapes = json.load(open(os.path.join(ROOT, "tests", "golden", "fcn_state_dict_keys.json")))
 sds = [{k: torch.from_numpy(v) for k, v in synthetic_weights.make_state_dict_numpy(shapes, seed=s).items()} for s in range(3)]
 pipe = FramePipeline(sds, 480, 640, dtype="bf16", frames_per_step=B)
-fr = [synthetic.synthetic_frame(i) for i in range(B)]
+fr = [synthetic.synthetic_frame(i, noise_dm=ARGS[0], outlier_frac=ARGS[1], seg_false_pos=ARGS[2]) for i in range(B)]
 rmax = np.max([f["max_radii_dm"] for f in fr], axis=0) + 0.05
 pipe.seg.copy_(torch.from_numpy(np.stack([np.stack([f["seg"] for f in fr])] * 3))[:, :, None].cuda())
 pipe.radial.copy_(torch.from_numpy(np.stack([np.stack([f["radial"][k] for f in fr]) for k in range(3)]))[:, :, None].cuda())
