@@ -2753,6 +2753,252 @@ __global__ __launch_bounds__(256, 2) void k_tail(const H16 *src, const H16 *w7, 
 }
 
 // ---------------------------------------------------------------------------------------------
+// k_chain_x3<CMID> (split precision): the 1x1 expand of a bottleneck block (CMID -> 4*CMID, + residual, ReLU) and the NEXT
+// block's 1x1 reduce (4*CMID -> CMID, ReLU) in one kernel (reference models/fcnresnet.py:30-43 and :24-26 of the following
+// block).  Unfused, the 4*CMID-channel block output is written by the expand kernel and read back twice -- as the reduce's
+// operand and, one block later, as the residual; in hi / lo storage that tensor is 354 MB per launch at 24 frames x 3 networks,
+// and both 1x1 layers sit at the HBM roofline (3.3 TB/s), not at the matrix pipe.  Here the reduce consumes every 128-channel
+// chunk of the block output straight from registers, so the tensor is written once and read once.
+//   Decomposition: a workgroup owns 128 pixels, a wave 16 of them -- all channels of its pixels, so no activation ever crosses
+//   waves.  The wave keeps its rows of the expand's input as MFMA fragments in registers (CMID / 32 slices x (hi, lo)) and the
+//   reduce's accumulators (16 px x CMID channels).  Only the weights travel through LDS: a ring of three 32 KB slots filled
+//   by LDS-DMA two steps ahead, one K slice per step -- [128 out][32 ch (hi | lo)] of the expand for chunk nc, then four slices
+//   [CMID out][32 ch] of the reduce over the chunk just produced.
+//   Per chunk: KE expand steps (8 channel tiles x 3 MFMAs each) -> per 32-channel slice: the accumulators (operands swapped:
+//   lane = pixel, 4 consecutive channels) go through a wave-private LDS transposition as fp32 and come back as 8 consecutive
+//   channels per lane; + bias (x scale) + residual, ReLU, split into hi / lo -- the two 16-byte vectors are the block output
+//   (stored as full 128-byte lines per pixel) AND the reduce's operand fragments -> 3 MFMAs x CMID / 16 tiles.
+//   Every global access is a 16-byte vector; the counted vmcnt of a step covers exactly what was issued since its weights.
+// Results: fp32-grade like every split kernel, but NOT bit-identical to the two separate kernels (the reduce accumulates in
+// the same order; the expand's epilogue adds the residual after the transposition) -- the executor therefore uses this kernel
+// for EVERY batch size, so that a frame's maps do not depend on the batch it travels in.
+// ---------------------------------------------------------------------------------------------
+// LDS accesses the compiler must not see: after an LDS-DMA it guards every visible LDS access that might alias the DMA's
+// destination with s_waitcnt vmcnt(0), which drains the weight prefetch.  The caller waits on lgkmcnt itself.
+__device__ __forceinline__ void lds_st128(unsigned addr, f32x4 v) { asm volatile("ds_write_b128 %0, %1" ::"v"(addr), "v"(v) : "memory"); }
+// (reads come with their wait in ONE asm statement: the compiler may schedule a consumer of the output anywhere after the
+// statement that defines it, also in front of a separate s_waitcnt)
+__device__ __forceinline__ void lds_ld128x2(unsigned a0, unsigned a1, f32x4 &v0, f32x4 &v1)
+{
+    asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %3\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v0), "=&v"(v1) : "v"(a0), "v"(a1) : "memory");
+}
+__device__ __forceinline__ void lds_ld128x4(unsigned a0, unsigned a1, unsigned a2, unsigned a3, f32x4 &v0, f32x4 &v1, f32x4 &v2, f32x4 &v3)
+{
+    asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %5\n\tds_read_b128 %2, %6\n\tds_read_b128 %3, %7\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3) : "v"(a0), "v"(a1), "v"(a2), "v"(a3) : "memory");
+}
+
+constexpr int CH_BM = 128;
+constexpr int CH_SLOT = 32 * 1024, CH_RING = 3;
+constexpr int CH_XP = 144;  // bytes per pixel row of a wave's transposition scratch: 32 fp32 + 16 (bank spread)
+constexpr int CH_BIAS = (2 * 1024 + 2 * 256) * 4;  // [bias | scale] of both layers as fp32 (largest block: 256 -> 1024 -> 256)
+constexpr int CH_LDS = CH_RING * CH_SLOT + 8 * 16 * CH_XP + CH_BIAS;
+
+template <int CMID>
+__global__ __launch_bounds__(512) void k_chain_x3(const BlockParams p)
+{
+    using T = H16;
+    constexpr int COUT = 4 * CMID, NC = COUT / 128, KE = CMID / 32, KR = 4;  // 128-channel chunks; K slices per chunk: expand, reduce
+    constexpr int NTR = CMID / 16;                                            // 16-channel tiles of the reduce's output
+    constexpr int PE = 2, PR = CMID / 64;                                     // DMA pieces (8 rows x 128 B) per wave and slice
+    constexpr int SPC = KE + KR;                                              // steps per chunk
+    static_assert(CMID * 128 <= CH_SLOT, "a reduce-weight slice fills at most one ring slot");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r16 = lane & 15, kq = lane >> 4, lrow = lane >> 3, lpos = lane & 7;
+    const int g = blockIdx.z;
+    const int m0 = blockIdx.x * CH_BM;
+    const T *src = (const T *)p.src + (long long)g * p.src_gs;
+    const T *res = (const T *)p.res + (long long)g * p.res_gs;
+    T *dst = (T *)p.dst + (long long)g * p.dst_gs;
+    T *dst3 = (T *)p.dst3 + (long long)g * p.dst3_gs;
+    const char *w2 = (const char *)((const T *)p.w2 + (long long)g * p.w2_gs);
+    const char *w3 = (const char *)((const T *)p.w3 + (long long)g * p.w3_gs);
+    const float *b2 = p.b2 + (long long)g * p.b2_gs, *b3 = p.b3 + (long long)g * p.b3_gs;  // [bias | scale]
+    const int w2_bytes = COUT * CMID * 4, w3_bytes = CMID * COUT * 4;
+    // (wave-private transposition scratch rows follow the ring: smem + CH_RING * CH_SLOT + wave * 16 * CH_XP)
+    // [bias | scale] of both layers in LDS: read per step as ds_read_b128 (as global loads they would sit in the vector-memory
+    // queue behind the weight pieces issued just before, and waiting for them would drain the prefetch)
+    float *sB2 = (float *)(smem + CH_RING * CH_SLOT + 8 * 16 * CH_XP), *sB3 = sB2 + 2 * COUT;
+    for (int i = tid; i < 2 * COUT; i += 512) sB2[i] = b2[i];
+    for (int i = tid; i < 2 * CMID; i += 512) sB3[i] = b3[i];
+    // LDS byte addresses for the inline-asm accesses (the dynamic LDS block starts at address 0 of the workgroup's allocation)
+    const unsigned aX = (unsigned)(CH_RING * CH_SLOT + wave * 16 * CH_XP + r16 * CH_XP);
+    const unsigned aB2 = (unsigned)(CH_RING * CH_SLOT + 8 * 16 * CH_XP), aB3 = aB2 + 2 * COUT * 4;
+
+    // this lane's pixel (rows beyond M: the last row's data, never stored)
+    const int m = m0 + wave * 16 + r16;
+    const long long mrow = m < p.M ? m : p.M - 1;
+
+    // ---- weights of step (chunk nc, slice q) into ring slot `slot`
+    // expand slice: rows = out channels nc*128 .. +127 of w2 [COUT][KE][64 halves]; reduce slice t: all CMID rows of w3 [CMID][COUT/32][64], K slice nc*4 + t
+    // lane -> (row of the piece, 16-byte position); the source chunk is position ^ ((row >> 1) & 7) (the tiles' bank swizzle)
+    auto issue = [&](int nc, int q, int slot) {
+        unsigned char *sl = smem + slot * CH_SLOT;
+        if (q < KE) {
+#pragma unroll
+            for (int c = 0; c < PE; c++) {
+                const int row = (wave * PE + c) * 8 + lrow;
+                const int off = ((nc * 128 + row) * (2 * CMID) + q * 64 + ((lpos ^ ((row >> 1) & 7)) << 3)) * 2;
+                blk_dma16(w2, w2_bytes, sl + (wave * PE + c) * 1024, off);
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < PR; c++) {
+                const int row = (wave * PR + c) * 8 + lrow;
+                const int off = (row * (2 * COUT) + (nc * 4 + (q - KE)) * 64 + ((lpos ^ ((row >> 1) & 7)) << 3)) * 2;
+                blk_dma16(w3, w3_bytes, sl + (wave * PR + c) * 1024, off);
+            }
+        }
+    };
+    // VM operations the step at position q of a chunk issues at its top: the DMA pieces of the step two ahead, and -- at the first
+    // step of a chunk -- the chunk's residual vectors (4 slices x (hi, lo)), a whole expand phase before they are needed
+    auto pieces_for = [&](int q2) { return q2 < KE ? PE : PR; };
+    auto loads_at = [&](int q_) { return q_ == 0 ? 2 * KR : 0; };
+
+    // ---- prologue: the expand's operand rows of this lane's pixel, the weights of steps 0 and 1
+    bf16x8 aE[KE][2];
+    {
+        const T *sp = src + mrow * (2 * CMID) + kq * 8;
+#pragma unroll
+        for (int s_ = 0; s_ < KE; s_++) {
+            aE[s_][0] = *(const bf16x8 *)(sp + s_ * 64);
+            aE[s_][1] = *(const bf16x8 *)(sp + s_ * 64 + 32);
+        }
+    }
+    issue(0, 0, 0);
+    issue(0, 1, 1);
+    f32x4 accR[NTR];
+#pragma unroll
+    for (int j = 0; j < NTR; j++) accR[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 accE[8];
+    uint4 rres[KR][2];  // the chunk's residual vectors (hi, lo) per reduce step
+    const int swz = (r16 >> 1) & 7;
+    const int fh = ((kq ^ swz) << 4), fl = (((4 + kq) ^ swz) << 4);  // fragment chunks (hi, lo) inside a 128-byte weight row
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // (lgkmcnt: the bias rows written above)
+    __builtin_amdgcn_s_barrier();
+
+    int slot = 0;
+    for (int nc = 0; nc < NC; nc++) {
+        const bool last = nc == NC - 1;
+#pragma unroll
+        for (int q = 0; q < SPC; q++) {
+            // ---- wait for this step's weights (issued two steps ago): everything this wave issued after them may stay in flight
+            if (nc > 0 || q >= 1) {
+                if (nc > 0 || q >= 2) {  // (steps 0 and 1: the prologue waited)
+                    const int qm1 = (q + SPC - 1) % SPC, qm2 = (q + SPC - 2) % SPC;
+                    const int s_m2 = qm2 >= KE ? 2 : 0, s_m1 = qm1 >= KE ? 2 : 0;       // stores of the two previous steps
+                    const bool next_exists = !(last && q == SPC - 1);
+                    const int i_m1 = next_exists ? pieces_for((q + 1) % SPC) : 0;       // pieces step g-1 issued for step g+1
+                    blk_vmwait(loads_at(qm2) + s_m2 + i_m1 + loads_at(qm1) + s_m1);
+                }
+                __builtin_amdgcn_s_barrier();  // every wave's pieces have landed; everybody is done with the slot refilled below
+            }
+            // ---- issue for step g + 2
+            {
+                const int q2 = (q + 2) % SPC, nc2 = nc + (q + 2 >= SPC ? 1 : 0);
+                if (nc2 < NC) issue(nc2, q2, slot + 2 >= CH_RING ? slot + 2 - CH_RING : slot + 2);
+                if (q == 0) {  // this chunk's residual: 8 channels kq*8.. of the slices nc*4 + t (hi, lo)
+#pragma unroll
+                    for (int t2 = 0; t2 < KR; t2++) {
+                        const T *rp = res + mrow * (2 * COUT) + (nc * 4 + t2) * 64 + kq * 8;
+                        rres[t2][0] = *(const uint4 *)rp;
+                        rres[t2][1] = *(const uint4 *)(rp + 32);
+                    }
+                }
+            }
+            const unsigned char *sl = smem + slot * CH_SLOT;
+            if (q < KE) {
+                // ---- expand step: chunk nc, K slice q -- 8 channel tiles, operands swapped (lane = pixel, 4 channels per tile)
+                if (q == 0) {
+#pragma unroll
+                    for (int j = 0; j < 8; j++) accE[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const bf16x8 bh = *(const bf16x8 *)(sl + (j * 16 + r16) * 128 + fh);
+                    const bf16x8 bl = *(const bf16x8 *)(sl + (j * 16 + r16) * 128 + fl);
+                    accE[j] = RCV_MFMA16(bh, aE[q][0], accE[j], 0, 0, 0);
+                    accE[j] = RCV_MFMA16(bl, aE[q][0], accE[j], 0, 0, 0);
+                    accE[j] = RCV_MFMA16(bh, aE[q][1], accE[j], 0, 0, 0);
+                }
+            } else {
+                // ---- reduce step t: the chunk's channels t*32 .. +31 -> transposition, epilogue of the expand, store, 3 x NTR MFMAs
+                const int t = q - KE;
+                // acc[e] = channel (tile)*16 + kq*4 + e of pixel r16, scaled and biased, as fp32 into the scratch row of the pixel
+                f32x4 bv[2], sv[2];
+                {
+                    const int ch = nc * 128 + 2 * t * 16 + kq * 4;
+                    lds_ld128x4(aB2 + ch * 4, aB2 + (ch + 16) * 4, aB2 + (COUT + ch) * 4, aB2 + (COUT + ch + 16) * 4, bv[0], bv[1], sv[0], sv[1]);
+                }
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    const f32x4 a = accE[2 * t + h];
+                    lds_st128(aX + h * 64 + kq * 16, f32x4{__fmaf_rn(a[0], sv[h][0], bv[h][0]), __fmaf_rn(a[1], sv[h][1], bv[h][1]),
+                                                           __fmaf_rn(a[2], sv[h][2], bv[h][2]), __fmaf_rn(a[3], sv[h][3], bv[h][3])});
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (wave-private rows: no barrier)
+                float v[8];
+                {
+                    f32x4 v0, v1;
+                    lds_ld128x2(aX + kq * 32, aX + kq * 32 + 16, v0, v1);
+                    v[0] = v0[0]; v[1] = v0[1]; v[2] = v0[2]; v[3] = v0[3]; v[4] = v1[0]; v[5] = v1[1]; v[6] = v1[2]; v[7] = v1[3];
+                }
+                float rv[8];
+                x3_join8(rres[t][0], rres[t][1], rv);
+#pragma unroll
+                for (int e = 0; e < 8; e++) v[e] = fmaxf(v[e] + rv[e], 0.f);
+                uint4 oh, ol;
+                x3_split8(v, oh, ol);
+                {   // (rows beyond M recompute row M - 1 and store the same values there: every wave issues the same number of
+                    // vector-memory operations, which is what the counted waits rely on)
+                    T *op = dst + mrow * (2 * COUT) + (nc * 4 + t) * 64 + kq * 8;
+                    *(uint4 *)op = oh;
+                    *(uint4 *)(op + 32) = ol;
+                }
+                const bf16x8 ah = *(const bf16x8 *)&oh, al = *(const bf16x8 *)&ol;
+#pragma unroll
+                for (int j = 0; j < NTR; j++) {
+                    const bf16x8 bh = *(const bf16x8 *)(sl + (j * 16 + r16) * 128 + fh);
+                    const bf16x8 bl = *(const bf16x8 *)(sl + (j * 16 + r16) * 128 + fl);
+                    accR[j] = RCV_MFMA16(bh, ah, accR[j], 0, 0, 0);
+                    accR[j] = RCV_MFMA16(bl, ah, accR[j], 0, 0, 0);
+                    accR[j] = RCV_MFMA16(bh, al, accR[j], 0, 0, 0);
+                }
+            }
+            slot = slot + 1 == CH_RING ? 0 : slot + 1;
+        }
+    }
+    // ---- the reduce's epilogue: bias (x scale), ReLU, hi / lo, through the same transposition, 32 channels at a time
+#pragma unroll
+    for (int t = 0; t < NTR / 2; t++) {
+        f32x4 bv[2], sv[2];
+        {
+            const int ch = 2 * t * 16 + kq * 4;
+            lds_ld128x4(aB3 + ch * 4, aB3 + (ch + 16) * 4, aB3 + (CMID + ch) * 4, aB3 + (CMID + ch + 16) * 4, bv[0], bv[1], sv[0], sv[1]);
+        }
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const f32x4 a = accR[2 * t + h];
+            lds_st128(aX + h * 64 + kq * 16, f32x4{fmaxf(__fmaf_rn(a[0], sv[h][0], bv[h][0]), 0.f), fmaxf(__fmaf_rn(a[1], sv[h][1], bv[h][1]), 0.f),
+                                                   fmaxf(__fmaf_rn(a[2], sv[h][2], bv[h][2]), 0.f), fmaxf(__fmaf_rn(a[3], sv[h][3], bv[h][3]), 0.f)});
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        float v[8];
+        {
+            f32x4 v0, v1;
+            lds_ld128x2(aX + kq * 32, aX + kq * 32 + 16, v0, v1);  // (the wait inside also covers the rewrite of the row by the next slice)
+            v[0] = v0[0]; v[1] = v0[1]; v[2] = v0[2]; v[3] = v0[3]; v[4] = v1[0]; v[5] = v1[1]; v[6] = v1[2]; v[7] = v1[3];
+        }
+        uint4 oh, ol;
+        x3_split8(v, oh, ol);
+        T *op = dst3 + mrow * (2 * CMID) + t * 64 + kq * 8;
+        *(uint4 *)op = oh;
+        *(uint4 *)(op + 32) = ol;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // k_tail_x3 (split precision): the same three layers -- 2x bilinear upsampling of the 64-channel map, conv7 (3x3, 64 -> 32,
 // ReLU) and the 1x1 head -- for the RCV_F16X3 engine.  Unfused they move 17 GB per 72 (frame, network) items through HBM
 // (the 480x640x64 upsampled map alone is 79 MB per item in hi / lo storage); fused only the 240x320x64 source is read.
@@ -3214,6 +3460,9 @@ int register_kernel_attributes()
     RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_stem_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, STEM_LDS));
     RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_tail, hipFuncAttributeMaxDynamicSharedMemorySize, TAIL_LDS));
     RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_tail_x3, hipFuncAttributeMaxDynamicSharedMemorySize, TX_LDS));
+    RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_chain_x3<64>, hipFuncAttributeMaxDynamicSharedMemorySize, CH_LDS));
+    RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_chain_x3<128>, hipFuncAttributeMaxDynamicSharedMemorySize, CH_LDS));
+    RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_chain_x3<256>, hipFuncAttributeMaxDynamicSharedMemorySize, CH_LDS));
     RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_conv_block<64, false>, hipFuncAttributeMaxDynamicSharedMemorySize, blk_lds(64)));
     RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_conv_block<64, true>, hipFuncAttributeMaxDynamicSharedMemorySize, blk_lds(64)));
     RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_conv_block<128, false>, hipFuncAttributeMaxDynamicSharedMemorySize, blk_lds(128)));
@@ -3299,6 +3548,39 @@ int forward_impl(rcv_fcn *h, const float *x, int B, float *seg, float *radial, c
                     if (h->profiling)
                         for (int e = 1; e < 2 * fused; e++) RCV_HIP_CHECK(hipEventRecord(h->events[2 * i + e], st));
                     i += fused - 1;
+                    continue;
+                }
+            }
+            // split engine: 1x1 expand (+ residual, ReLU) followed by the next block's 1x1 reduce (ReLU): one kernel (option 4),
+            // at EVERY batch size (its results are not bit-identical to the two kernels': see k_chain_x3)
+            if (kX3 && h->use_block && i + 1 < h->ops.size() && h->ops[i].kind == RCV_OP_CONV && h->ops[i + 1].kind == RCV_OP_CONV) {
+                const rcv_op &a = h->ops[i], &b = h->ops[i + 1];
+                const int cmid = a.c0;
+                const long long M = (long long)B * a.hout * a.wout;
+                if (a.ksize == 1 && a.stride == 1 && a.pad == 0 && a.src1 < 0 && a.res >= 0 && a.relu && a.cout == 4 * cmid &&
+                    (cmid == 64 || cmid == 128 || cmid == 256) && b.ksize == 1 && b.stride == 1 && b.pad == 0 && b.src0 == a.dst &&
+                    b.src1 < 0 && b.res < 0 && b.relu && b.c0 == 4 * cmid && b.cout == cmid && b.hout == a.hout && b.wout == a.wout &&
+                    b.dst != a.src0 && b.dst != a.res && b.dst != a.dst && a.dst != a.src0 && a.dst != a.res &&
+                    M * 4 * cmid * 4 < 0x7fffffffLL) {
+                    auto gs = [&](int s) -> long long { return (long long)h->slot_elems[s] * B * 2; };
+                    BlockParams q;
+                    memset(&q, 0, sizeof(q));
+                    q.src = ws + off[a.src0]; q.res = ws + off[a.res]; q.dst = ws + off[a.dst]; q.dst3 = ws + off[b.dst];
+                    q.w2 = (const H16 *)h->weights + a.w_off; q.w3 = (const H16 *)h->weights + b.w_off;
+                    q.b2 = h->bias + a.b_off; q.b3 = h->bias + b.b_off;
+                    q.src_gs = gs(a.src0); q.res_gs = gs(a.res); q.dst_gs = gs(a.dst); q.dst3_gs = gs(b.dst);
+                    q.w2_gs = (long long)a.cout * a.c0 * 2; q.w3_gs = (long long)b.cout * b.c0 * 2;
+                    q.b2_gs = 2 * a.cout; q.b3_gs = 2 * b.cout;
+                    q.M = (int)M;
+                    if (h->profiling) RCV_HIP_CHECK(hipEventRecord(h->events[2 * i], st));  // time booked on the expand
+                    const dim3 grid((unsigned)((M + CH_BM - 1) / CH_BM), 1, h->groups);
+                    if (cmid == 256) hipLaunchKernelGGL((k_chain_x3<256>), grid, dim3(512), CH_LDS, st, q);
+                    else if (cmid == 128) hipLaunchKernelGGL((k_chain_x3<128>), grid, dim3(512), CH_LDS, st, q);
+                    else hipLaunchKernelGGL((k_chain_x3<64>), grid, dim3(512), CH_LDS, st, q);
+                    RCV_LAUNCH_CHECK();
+                    if (h->profiling)
+                        for (int e = 1; e < 4; e++) RCV_HIP_CHECK(hipEventRecord(h->events[2 * i + e], st));
+                    i += 1;
                     continue;
                 }
             }
