@@ -469,10 +469,10 @@ def main(argv=None):
             "equivalent_votes_note": "sum of 5.44 r^2 shell voxels per point / stage time: the votes a rasteriser would cast; the timed "
                                      "engine (exact branch-and-bound peak search) never casts them",
         }
-        vp = os.path.join(ROOT, "profiles", "r02_vote_pmc.json")
-        if os.path.exists(vp):  # separate rocprofv3 --pmc passes of the voting stage at 72 frames (tools/collect_profiles.sh)
+        vp = next((q for q in (os.path.join(ROOT, "profiles", n) for n in ("r03_vote_pmc.json", "r02_vote_pmc.json")) if os.path.exists(q)), None)
+        if vp:  # separate rocprofv3 --pmc passes of the voting stage at 72 frames (tools/collect_profiles.sh)
             pj = json.load(open(vp))
-            roof_vote["pmc"] = {"source": "profiles/r02_vote_pmc.json: " + pj["source"], "definitions": pj["definitions"],
+            roof_vote["pmc"] = {"source": "profiles/%s: " % os.path.basename(vp) + pj["source"], "definitions": pj["definitions"],
                                 "kernels": {k: {q: v[q] for q in ("ms_per_batch", "valu_issue_frac", "hbm_bytes_per_batch") if q in v}
                                             for k, v in pj["kernels"].items() if v["ms_per_batch"] >= 0.1}}
             if B == 72:
@@ -500,9 +500,9 @@ def main(argv=None):
                          "algorithmic_flop_per_step": conv_flop_step,
                          "mfma_flop_executed_per_algorithmic_flop": 3 if args.dtype == "f16x3" else 1,
                          "frac_of_mode_ceiling": achieved / peak * (3 if args.dtype == "f16x3" else 1),
-                         "kernel": "implicit-GEMM convolution family of the %s engine (k_conv_halo, k_conv_dma, k_conv<..>%s), %d convolutions per "
+                         "kernel": "implicit-GEMM convolution family of the %s engine (k_conv_halo, k_conv_dma, k_conv<..>, %s), %d convolutions per "
                                    "forward, algorithmic 265.568 GFLOP per network forward" %
-                                   (args.dtype, "" if args.dtype in PARITY_DTYPES else ", k_conv_block, k_tail",
+                                   (args.dtype, {"f16x3": "k_chain_x3, k_tail_x3", "fp32": "k_head"}.get(args.dtype, "k_conv_block, k_tail"),
                                     sum(1 for o in pipe.engine.ops if o["kind"] == 3)),
                          "fcn_conv_ms_per_step": prof["conv_ms"], "fcn_other_ms_per_step": prof["other_ms"]},
             "roofline_vote": roof_vote,

@@ -1729,7 +1729,8 @@ __device__ __forceinline__ void d_bb_restart(AccHeader *hdr, const BBEntry *list
     hdr->climb_key[1] = 0;
     hdr->climb_center[1] = 0;
     hdr->restart = 0;
-    if (!best) return;
+    // a lower bound that an eighth of the points vote for sits on the peak's sheet already (the gate of the probe): nothing to restart
+    if (!best || (long long)H.bb_best * 8 >= (long long)H.n) return;
     const uint32_t t = 0xFFFFFFu - (uint32_t)((best - 1) & 0xFFFFFFull);
     const BBEntry e = list[t < na ? t : (uint32_t)BB_HALF + (t - na)];
     const int D = H.dim;

@@ -2769,9 +2769,11 @@ __global__ __launch_bounds__(256, 2) void k_tail(const H16 *src, const H16 *w7, 
 //   channels per lane; + bias (x scale) + residual, ReLU, split into hi / lo -- the two 16-byte vectors are the block output
 //   (stored as full 128-byte lines per pixel) AND the reduce's operand fragments -> 3 MFMAs x CMID / 16 tiles.
 //   Every global access is a 16-byte vector; the counted vmcnt of a step covers exactly what was issued since its weights.
-// Results: fp32-grade like every split kernel, but NOT bit-identical to the two separate kernels (the reduce accumulates in
-// the same order; the expand's epilogue adds the residual after the transposition) -- the executor therefore uses this kernel
-// for EVERY batch size, so that a frame's maps do not depend on the batch it travels in.
+// Results: bit-identical to the two separate kernels -- same K order and MFMA sequence per output element (the operands are
+// swapped, which transposes the product and nothing else), the same fma / add / max in the epilogues
+// (tests/test_gpu_fcn_x3.py::test_x3_kernel_variants_identical), so a frame's maps do not depend on which path its batch takes.
+// Measured: LDS-bound (every wave reads every weight fragment: 2 ds_read_b128 per 3 MFMAs, matrix cores 35 % busy), forward
+// -5 % against the two HBM-bound kernels at 36 frames x 3 networks.
 // ---------------------------------------------------------------------------------------------
 // LDS accesses the compiler must not see: after an LDS-DMA it guards every visible LDS access that might alias the DMA's
 // destination with s_waitcnt vmcnt(0), which drains the weight prefetch.  The caller waits on lgkmcnt itself.
@@ -3551,8 +3553,8 @@ int forward_impl(rcv_fcn *h, const float *x, int B, float *seg, float *radial, c
                     continue;
                 }
             }
-            // split engine: 1x1 expand (+ residual, ReLU) followed by the next block's 1x1 reduce (ReLU): one kernel (option 4),
-            // at EVERY batch size (its results are not bit-identical to the two kernels': see k_chain_x3)
+            // split engine: 1x1 expand (+ residual, ReLU) followed by the next block's 1x1 reduce (ReLU): one kernel (option 4) when
+            // the launch has enough 128-pixel tiles to fill the chip (bit-identical to the two kernels, so the choice is free)
             if (kX3 && h->use_block && i + 1 < h->ops.size() && h->ops[i].kind == RCV_OP_CONV && h->ops[i + 1].kind == RCV_OP_CONV) {
                 const rcv_op &a = h->ops[i], &b = h->ops[i + 1];
                 const int cmid = a.c0;
@@ -3561,7 +3563,7 @@ int forward_impl(rcv_fcn *h, const float *x, int B, float *seg, float *radial, c
                     (cmid == 64 || cmid == 128 || cmid == 256) && b.ksize == 1 && b.stride == 1 && b.pad == 0 && b.src0 == a.dst &&
                     b.src1 < 0 && b.res < 0 && b.relu && b.c0 == 4 * cmid && b.cout == cmid && b.hout == a.hout && b.wout == a.wout &&
                     b.dst != a.src0 && b.dst != a.res && b.dst != a.dst && a.dst != a.src0 && a.dst != a.res &&
-                    M * 4 * cmid * 4 < 0x7fffffffLL) {
+                    (M + CH_BM - 1) / CH_BM * h->groups >= 192 && M * 4 * cmid * 4 < 0x7fffffffLL) {
                     auto gs = [&](int s) -> long long { return (long long)h->slot_elems[s] * B * 2; };
                     BlockParams q;
                     memset(&q, 0, sizeof(q));

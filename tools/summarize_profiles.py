@@ -20,6 +20,8 @@ import sys
 import pandas as pd
 
 SRC, TAG = sys.argv[1], sys.argv[2]
+DT = sys.argv[3] if len(sys.argv) > 3 else "f16x3"   # FCN arithmetic of the traffic / matrix-core passes
+FB = int(sys.argv[4]) if len(sys.argv) > 4 else 36   # their frames per step
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, "profiles")
 N_SIMD = 256 * 4
@@ -28,7 +30,10 @@ N_SIMD = 256 * 4
 def short(n):
     mm = re.search(r'k_convI(\w+?)Li(\d+)ELi(\d+)', n)
     if mm:
-        return 'k_conv<%s,%s,%s>' % ("bf16" if "16b" in mm.group(1) else "f32", mm.group(2), mm.group(3))
+        return 'k_conv<%s,%s,%s>' % ("16-bit" if ("16b" in mm.group(1) or "DF16" in mm.group(1)) else "f32", mm.group(2), mm.group(3))
+    mc = re.search(r'k_chain_x3<(\d+)>', n) or re.search(r'k_chain_x3ILi(\d+)', n)
+    if mc:
+        return 'k_chain_x3<%s>' % mc.group(1)
     mb = re.search(r'k_conv_block<(\d+), (\w+), (\w+)>', n)
     if mb:
         return 'k_conv_block<%s,%s,%s>' % mb.groups()
@@ -66,17 +71,17 @@ if st:
     shutil.copy(st[0], os.path.join(OUT, TAG + "_bench_kernel_stats.csv"))
 
 # ---- 2. HBM traffic of the FCN kernels
-traffic = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 tools/fcn_bench.py --batch B --iters 1 "
-                     "(3 forwards of 3 networks each: 2 warm-up + 1 timed)",
+traffic = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 tools/fcn_bench.py --dtype %s --batch B --iters 1 "
+                     "(3 forwards of 3 networks each: 2 warm-up + 1 timed)" % DT, "dtype": DT,
            "correction": "bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950: FETCH_SIZE counts 64 of every 128 B of wide coalesced reads; both counters in KB)",
            "batches": {}}
-for B in (8, 24, 72):
+for B in (12, FB):
     f, w = counters("fetch_b%d" % B), counters("write_b%d" % B)
     if f is None or w is None:
         continue
     fk, wk = f.groupby("k").FETCH_SIZE.sum(), w.groupby("k").WRITE_SIZE.sum()
-    n_fw = int((f.k == "k_tail").sum())
-    conv = [k for k in fk.index if k.startswith("k_conv") or k == "k_tail"]
+    n_fw = int(f.k.isin(["k_tail", "k_tail_x3"]).sum())
+    conv = [k for k in fk.index if k.startswith("k_conv") or k.startswith("k_chain") or k.startswith("k_tail")]
     allk = [k for k in fk.index if k.startswith("k_")]
     tot = lambda ks: float((2 * fk[ks].sum() + wk.reindex(ks).fillna(0).sum()) * 1024)
     traffic["batches"][str(B)] = {
@@ -85,10 +90,10 @@ for B in (8, 24, 72):
         "all_fcn_kernels_hbm_bytes_per_network_forward": tot(allk) / n_fw / (3 * B),
         "per_kernel_bytes_per_network_forward": {k: float((2 * fk[k] + wk.get(k, 0)) * 1024) / n_fw / (3 * B) for k in allk},
     }
-if "72" in traffic["batches"]:
-    traffic["conv_family"] = {"frames_per_step": 72,
-                              "hbm_bytes_per_network_forward": traffic["batches"]["72"]["conv_family_hbm_bytes_per_network_forward"]}
-    json.dump(traffic, open(os.path.join(OUT, TAG + "_conv_hbm_traffic.json"), "w"), indent=1)
+if str(FB) in traffic["batches"]:
+    traffic["conv_family"] = {"frames_per_step": FB,
+                              "hbm_bytes_per_network_forward": traffic["batches"][str(FB)]["conv_family_hbm_bytes_per_network_forward"]}
+    json.dump(traffic, open(os.path.join(OUT, TAG + "_conv_hbm_traffic_%s.json" % DT), "w"), indent=1)
 
 # ---- 3. matrix-core utilisation of the convolution kernels
 a, b = counters("mfma"), counters("mfma2")
@@ -97,7 +102,7 @@ if a is not None:
     ga = a.groupby("k").mean(numeric_only=True)
     gb = b.groupby("k").mean(numeric_only=True) if b is not None else None
     for k, r in ga.iterrows():
-        if not (k.startswith("k_conv") or k in ("k_tail", "k_stem_mfma")):
+        if not (k.startswith("k_conv") or k.startswith("k_chain") or k in ("k_tail", "k_tail_x3", "k_stem_mfma")):
             continue
         cyc = r.GRBM_GUI_ACTIVE / 8.0
         e = {"dispatches": int((a.k == k).sum()), "avg_us": r.dur_ns / 1e3, "clock_ghz": cyc / r.dur_ns,
@@ -111,8 +116,8 @@ if a is not None:
                       "lds_issue_stall_frac_of_wave_time": q.SQ_WAIT_INST_LDS / r.SQ_WAVE_CYCLES})
         rows[k] = e
     json.dump({"source": "rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE (pass 1) and "
-                         "--pmc SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_MFMA SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_LDS SQ_WAIT_INST_LDS (pass 2) "
-                         "-- python3 tools/fcn_bench.py --batch 72 --iters 1; averages per dispatch",
+                         "--pmc SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_INSTS_MFMA SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_LDS SQ_WAIT_INST_LDS (pass 2) "
+                         "-- python3 tools/fcn_bench.py --dtype %s --batch %d --iters 1; averages per dispatch" % (DT, FB), "dtype": DT,
                "definitions": "mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 * 1024 SIMDs); clock = GRBM_GUI_ACTIVE/8 / duration",
                "tool_output": log_tail("mfma"), "kernels": rows}, open(os.path.join(OUT, TAG + "_conv_mfma_pmc.json"), "w"), indent=1)
 
