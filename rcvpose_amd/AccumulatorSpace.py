@@ -528,14 +528,41 @@ def estimate_6d_pose_lm(opts, return_details=False):
             with ThreadPoolExecutor(max_workers=min(8, N)) as pool:
                 chunks = [todo[i:i + N] for i in range(0, len(todo), N)]
                 pending = [pool.submit(load, it) for it in chunks[0]]
-                for ci, chunk in enumerate(chunks):
+                # Batch ci + 1 is enqueued on the pipeline's own stream (FCN -> seam -> voting -> async copy of the result records
+                # into pinned memory) BEFORE the host turns to ADD(-S) / ICP of batch ci on the default stream: the two overlap.  The
+                # FCN outputs are double buffered inside the pipeline; enqueue_step makes the pipeline wait for everything enqueued
+                # on the default stream so far, i.e. batch ci + 2 cannot overwrite what the ICP of batch ci still reads.
+                rec = ctypes.sizeof(_hip.AccResult)
+                host_res = [torch.empty((N * 3, rec), dtype=torch.uint8).pin_memory() for _ in range(2)]
+                inflight = {}
+
+                def submit(ci):
+                    nonlocal pending
                     loaded = [f.result() for f in pending]
                     pending = [pool.submit(load, it) for it in chunks[ci + 1]] if ci + 1 < len(chunks) else []
                     pad = [loaded[-1]] * (N - len(loaded))  # a short last batch is filled with copies of its last frame
                     rgb = torch.from_numpy(np.stack([l[0] for l in loaded + pad])).cuda()
                     depth_dev = torch.stack([l[1] for l in loaded + pad]).cuda()
-                    pipe.process(rgb, depth_dev, max_radii_dm)
-                    kp_all, res = pipe.read_results()          # one copy per batch
+                    buf = ci & 1
+                    done = torch.cuda.Event()
+
+                    def collect(_kp):  # on the pipeline's voting stream, right after the arg-max
+                        host_res[buf].copy_(pipe.results, non_blocking=True)
+                        done.record()
+
+                    pipe.enqueue_step(rgb, depth_dev, max_radii_dm, collect=collect)
+                    inflight[ci] = (loaded, rgb, depth_dev, pipe.seg, pipe.radial, done)
+
+                submit(0)
+                for ci, chunk in enumerate(chunks):
+                    if ci + 1 < len(chunks):
+                        submit(ci + 1)
+                    loaded, _rgb, depth_dev, seg_b, rad_b, done = inflight.pop(ci)
+                    done.synchronize()                         # one result copy per batch
+                    torch.cuda.current_stream().wait_event(done)
+                    raw = host_res[ci & 1].numpy()
+                    res = [_hip.AccResult.from_buffer_copy(raw[i].tobytes()) for i in range(raw.shape[0])]
+                    kp_all = np.array([[r.center_mm[0], r.center_mm[1], r.center_mm[2]] for r in res]).reshape(N, 3, 3)
                     RT_all = horn_batch(kpts_model, torch.from_numpy(np.ascontiguousarray(kp_all)).cuda()).cpu().numpy()  # :659-661
                     for i, (filename, stem) in enumerate(chunk):
                         print("Evaluating ", filename)
@@ -543,9 +570,10 @@ def estimate_6d_pose_lm(opts, return_details=False):
                             _raise_like_reference(r.status)
                         RTGT_mm = np.array(loaded[i][2], dtype=np.float64, copy=True)
                         RTGT_mm[:, 3] = RTGT_mm[:, 3] * 1000
-                        ev = _pose_and_add(class_name, xyz_load, keypoints, kp_all[i], RTGT_mm, pipe.seg[:, i, 0], pipe.radial[:, i, 0],
+                        ev = _pose_and_add(class_name, xyz_load, keypoints, kp_all[i], RTGT_mm, seg_b[:, i, 0], rad_b[:, i, 0],
                                            depth_dev[i], max_radii_dm, 0, ICPConvergenceCriteria(), RT=RT_all[i])
                         account(stem, ev)
+                pipe.finish()
             todo = []
         for filename, stem in todo:  # pre-computed radial maps (:611-618): frame by frame
             print("Evaluating ", filename)

@@ -1196,11 +1196,14 @@ __global__ __launch_bounds__(512) void k_conv_halo(const HaloParams p)
             bfr[1][j] = *(const bf16x8 *)(Bb + j * 16 * 128 + ch1);                                            \
         }                                                                                                      \
         RCV_HALO_B(sl + S2_, T2_, st2, 0);                                                                     \
+        if constexpr (BPW == 2) RCV_HALO_B(sl + S2_, T2_, st2, 1);                                             \
         if constexpr ((TAP) < 6) {                                                                             \
             RCV_HALO_PATCH(sl + 1, TAP);                                                                       \
-            asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");                                        \
+            if constexpr (BPW == 2) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");                \
+            else asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");                                   \
         } else {                                                                                               \
-            asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");                                        \
+            if constexpr (BPW == 2) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");                \
+            else asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");                                   \
         }                                                                                                      \
         __builtin_amdgcn_s_barrier();                                                                          \
         __builtin_amdgcn_s_setprio(1);                                                                         \
@@ -1227,7 +1230,10 @@ __global__ __launch_bounds__(512) void k_conv_halo(const HaloParams p)
     __builtin_amdgcn_s_barrier();
     if (grp == 1) __builtin_amdgcn_s_barrier();
     int stage = 0;
-    if constexpr (BPW == 2 && kX3) {
+#ifndef RCV_X3_HALO_TWO_PHASE
+#define RCV_X3_HALO_TWO_PHASE 0  // (r03 A-B on one box: 83.9 vs 83.8 ms per 36-frame forward -- the barrier count is not what the kernel waits for)
+#endif
+    if constexpr (BPW == 2 && kX3 && (!RCV_X3_HALO_TWO_PHASE || MT == 5)) {  // (the 320-row tile would spill in the two-phase form)
         for (int sl = 0; sl < nsl; sl++) {
             RCV_HALO_STEP_X3(0); RCV_HALO_STEP_X3(1); RCV_HALO_STEP_X3(2);
             RCV_HALO_STEP_X3(3); RCV_HALO_STEP_X3(4); RCV_HALO_STEP_X3(5);

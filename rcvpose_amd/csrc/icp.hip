@@ -26,8 +26,11 @@ namespace {
 constexpr int NN_THREADS = 256, NN_TILE = 1024, RED_BLOCKS = 256;
 
 // cur[i] = R * src[i] + t  (T row-major 4x4)
-__global__ __launch_bounds__(256) void k_icp_transform(const double *src, int n, const double *T, double *cur)
+// (`done`: the device-side loop control of rcv_icp_point_to_point -- once set, the remaining launches of the iteration chunk
+// return at once; null for callers without one)
+__global__ __launch_bounds__(256) void k_icp_transform(const double *src, int n, const double *T, double *cur, const int *done)
 {
+    if (done && *done) return;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
         const double x = src[3 * i], y = src[3 * i + 1], z = src[3 * i + 2];
         cur[3 * i] = T[0] * x + T[1] * y + T[2] * z + T[3];
@@ -71,8 +74,10 @@ __global__ __launch_bounds__(NN_THREADS) void k_nn(const double *a, int n_a, con
 // (squared distance, index) in part_*[s][i]; k_nn_merge folds the slices in order with the same strict `<`, which is the first
 // index among equal distances again -- identical results.
 constexpr int NN_SLICES = 16;
-__global__ __launch_bounds__(NN_THREADS) void k_nn_sliced(const double *a, int n_a, const double *b, int n_b, double *part_d2, int *part_idx)
+__global__ __launch_bounds__(NN_THREADS) void k_nn_sliced(const double *a, int n_a, const double *b, int n_b, double *part_d2, int *part_idx,
+                                                          const int *done)
 {
+    if (done && *done) return;
     __shared__ double sx[NN_TILE], sy[NN_TILE], sz[NN_TILE];
     const int i = blockIdx.x * NN_THREADS + threadIdx.x;
     const int ii = i < n_a ? i : n_a - 1;
@@ -101,8 +106,9 @@ __global__ __launch_bounds__(NN_THREADS) void k_nn_sliced(const double *a, int n
         part_idx[(size_t)blockIdx.y * n_a + i] = bi;
     }
 }
-__global__ __launch_bounds__(256) void k_nn_merge(const double *part_d2, const int *part_idx, int n_a, double *d2_out, int *idx_out)
+__global__ __launch_bounds__(256) void k_nn_merge(const double *part_d2, const int *part_idx, int n_a, double *d2_out, int *idx_out, const int *done)
 {
+    if (done && *done) return;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < n_a; i += gridDim.x * 256) {
         double best = INFINITY;
         int bi = -1;
@@ -132,8 +138,9 @@ __device__ __forceinline__ double block_sum(double v, double *s)
 // pass 1 over the correspondences (source i <-> target idx[i], d2[i] <= max_d2): count, sum p, sum q, sum d2
 // per block -> part[block][8]; fixed block / thread assignment makes the result reproducible
 __global__ __launch_bounds__(256) void k_icp_sums(const double *cur, const double *tgt, const double *d2, const int *idx, int n,
-                                                  double max_d2, double *part)
+                                                  double max_d2, double *part, const int *done)
 {
+    if (done && *done) return;
     __shared__ double s[4];
     double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
@@ -152,9 +159,9 @@ __global__ __launch_bounds__(256) void k_icp_sums(const double *cur, const doubl
 }
 
 // reduce the partials: stats[0..7] = totals, stats[8..10] = mean p, stats[11..13] = mean q
-__global__ void k_icp_finish_sums(const double *part, int blocks, double *stats)
+__global__ void k_icp_finish_sums(const double *part, int blocks, double *stats, const int *done)
 {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (threadIdx.x != 0 || blockIdx.x != 0 || (done && *done)) return;
     double t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int b = 0; b < blocks; b++)
         for (int k = 0; k < 8; k++) t[k] += part[b * 8 + k];
@@ -165,8 +172,9 @@ __global__ void k_icp_finish_sums(const double *part, int blocks, double *stats)
 
 // pass 2: centred cross-covariance S[a][b] = sum (p - pm)_a (q - qm)_b  -> part[block][9]
 __global__ __launch_bounds__(256) void k_icp_cov(const double *cur, const double *tgt, const double *d2, const int *idx, int n,
-                                                 double max_d2, const double *stats, double *part)
+                                                 double max_d2, const double *stats, double *part, const int *done)
 {
+    if (done && *done) return;
     __shared__ double s[4];
     const double pm[3] = {stats[8], stats[9], stats[10]}, qm[3] = {stats[11], stats[12], stats[13]};
     double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -225,9 +233,9 @@ __device__ void jacobi4(double a[4][4], double d[4], double v[4][4])
 
 // rigid update from the covariance (Horn 1987: the rotation is the unit quaternion that maximises q^T N q) and
 // T <- update * T.  With fewer than 3 correspondences the update is the identity (Open3D returns I for an empty set).
-__global__ void k_icp_update(const double *part, int blocks, const double *stats, double *T)
+__global__ void k_icp_update(const double *part, int blocks, const double *stats, double *T, const int *done)
 {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (threadIdx.x != 0 || blockIdx.x != 0 || (done && *done)) return;
     if (stats[0] < 3.0) return;
     double S[3][3];
     for (int a = 0; a < 3; a++)
@@ -268,6 +276,31 @@ __global__ void k_icp_update(const double *part, int blocks, const double *stats
             Tn[a * 4 + b] = t;
         }
     for (int k = 0; k < 16; k++) T[k] = Tn[k];
+}
+
+// Loop control of the ICP on the device (r03: the host used to read the fitness back after every iteration -- 30 synchronisations
+// of ~0.4 ms per frame).  stats[16..19] = previous / current (fitness, rmse); ctl = (int *)(stats + 24): done, iterations, correspondences.
+// `first`: after the evaluation of the start pose; otherwise after an update + evaluation -- the reference loop's bookkeeping:
+//     it++; converged (|d fitness| < relative_fitness and |d rmse| < relative_rmse) or it == max or no correspondences -> done
+__global__ void k_icp_decide(double *stats, int n_src, double rel_fitness, double rel_rmse, int max_iteration, int first)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    int *ctl = (int *)(stats + 24);
+    if (ctl[0]) return;
+    const int ncorr = (int)stats[0];
+    const double fitness = stats[0] / (double)n_src, rmse = ncorr > 0 ? sqrt(stats[7] / stats[0]) : 0.0;
+    bool done;
+    if (first) {
+        ctl[1] = 0;
+        done = !(0 < max_iteration && ncorr > 0);
+    } else {
+        ctl[1] += 1;
+        const bool conv = fabs(stats[16] - fitness) < rel_fitness && fabs(stats[17] - rmse) < rel_rmse;
+        done = conv || !(ctl[1] < max_iteration && ncorr > 0);
+    }
+    stats[16] = fitness; stats[17] = rmse;
+    ctl[2] = ncorr;
+    ctl[0] = done ? 1 : 0;
 }
 
 struct IcpLayout {
@@ -327,41 +360,50 @@ int rcv_icp_point_to_point(const double *src_dev, int n_src, const double *tgt_d
     const double max_d2 = max_corr_dist * max_corr_dist;
     const int tb = std::min((n_src + 255) / 256, 1024);
     RCV_HIP_CHECK(hipMemcpyAsync(T, T0, 16 * sizeof(double), hipMemcpyHostToDevice, st));
-    double hs[8];
-    auto evaluate = [&](double &fitness, double &rmse, int &ncorr) -> int {
-        hipLaunchKernelGGL(k_icp_transform, dim3(tb), dim3(256), 0, st, src_dev, n_src, (const double *)T, cur);
+    // The whole loop is enqueued in chunks of up to 32 iterations whose kernels test the device-side `done` flag; the host reads
+    // the control words once per chunk (one chunk for Open3D's default of 30 iterations).
+    // blocks of the two-pass reductions: one point per thread at most (the single thread that adds the per-block partials was
+    // most of an iteration when 256 blocks shared 3 000 points)
+    const int rb = std::max(1, std::min(RED_BLOCKS, (n_src + 255) / 256));
+    const int *done = (const int *)(stats + 24);
+    RCV_HIP_CHECK(hipMemsetAsync(stats, 0, 256, st));
+    auto evaluate = [&]() {
+        hipLaunchKernelGGL(k_icp_transform, dim3(tb), dim3(256), 0, st, src_dev, n_src, (const double *)T, cur, done);
         hipLaunchKernelGGL(k_nn_sliced, dim3((n_src + NN_THREADS - 1) / NN_THREADS, NN_SLICES), dim3(NN_THREADS), 0, st, (const double *)cur,
-                           n_src, tgt_dev, n_tgt, nn_d2, nn_idx);
-        hipLaunchKernelGGL(k_nn_merge, dim3(tb), dim3(256), 0, st, (const double *)nn_d2, (const int *)nn_idx, n_src, d2, idx);
-        hipLaunchKernelGGL(k_icp_sums, dim3(RED_BLOCKS), dim3(256), 0, st, (const double *)cur, tgt_dev, (const double *)d2,
-                           (const int *)idx, n_src, max_d2, part);
-        hipLaunchKernelGGL(k_icp_finish_sums, dim3(1), dim3(64), 0, st, (const double *)part, RED_BLOCKS, stats);
-        RCV_LAUNCH_CHECK();
-        RCV_HIP_CHECK(hipMemcpyAsync(hs, stats, sizeof(hs), hipMemcpyDeviceToHost, st));
-        RCV_HIP_CHECK(hipStreamSynchronize(st));
-        ncorr = (int)hs[0];
-        fitness = hs[0] / (double)n_src;
-        rmse = ncorr > 0 ? sqrt(hs[7] / hs[0]) : 0.0;
-        return RCV_OK;
+                           n_src, tgt_dev, n_tgt, nn_d2, nn_idx, done);
+        hipLaunchKernelGGL(k_nn_merge, dim3(tb), dim3(256), 0, st, (const double *)nn_d2, (const int *)nn_idx, n_src, d2, idx, done);
+        hipLaunchKernelGGL(k_icp_sums, dim3(rb), dim3(256), 0, st, (const double *)cur, tgt_dev, (const double *)d2,
+                           (const int *)idx, n_src, max_d2, part, done);
+        hipLaunchKernelGGL(k_icp_finish_sums, dim3(1), dim3(64), 0, st, (const double *)part, rb, stats, done);
     };
-    double fitness, rmse;
-    int ncorr, it = 0;
-    int rc = evaluate(fitness, rmse, ncorr);
-    if (rc != RCV_OK) return rc;
-    for (; it < max_iteration && ncorr > 0; it++) {
-        // the update uses the correspondences of the current evaluation (cur, idx, d2, stats are still in place)
-        hipLaunchKernelGGL(k_icp_cov, dim3(RED_BLOCKS), dim3(256), 0, st, (const double *)cur, tgt_dev, (const double *)d2,
-                           (const int *)idx, n_src, max_d2, (const double *)stats, part);
-        hipLaunchKernelGGL(k_icp_update, dim3(1), dim3(64), 0, st, (const double *)part, RED_BLOCKS, (const double *)stats, T);
+    evaluate();
+    hipLaunchKernelGGL(k_icp_decide, dim3(1), dim3(64), 0, st, stats, n_src, relative_fitness, relative_rmse, max_iteration, 1);
+    RCV_LAUNCH_CHECK();
+    double hstat[4];
+    int hctl[4] = {0, 0, 0, 0};
+    for (int enq = 0; enq < max_iteration;) {
+        const int chunk = std::min(32, max_iteration - enq);
+        for (int c = 0; c < chunk; c++) {
+            // the update uses the correspondences of the current evaluation (cur, idx, d2, stats are still in place)
+            hipLaunchKernelGGL(k_icp_cov, dim3(rb), dim3(256), 0, st, (const double *)cur, tgt_dev, (const double *)d2,
+                               (const int *)idx, n_src, max_d2, (const double *)stats, part, done);
+            hipLaunchKernelGGL(k_icp_update, dim3(1), dim3(64), 0, st, (const double *)part, rb, (const double *)stats, T, done);
+            evaluate();
+            hipLaunchKernelGGL(k_icp_decide, dim3(1), dim3(64), 0, st, stats, n_src, relative_fitness, relative_rmse, max_iteration, 0);
+        }
         RCV_LAUNCH_CHECK();
-        const double pf = fitness, pr = rmse;
-        rc = evaluate(fitness, rmse, ncorr);
-        if (rc != RCV_OK) return rc;
-        if (fabs(pf - fitness) < relative_fitness && fabs(pr - rmse) < relative_rmse) { it++; break; }
+        enq += chunk;
+        RCV_HIP_CHECK(hipMemcpyAsync(hctl, stats + 24, sizeof(hctl), hipMemcpyDeviceToHost, st));
+        RCV_HIP_CHECK(hipStreamSynchronize(st));
+        if (hctl[0]) break;
     }
     memset(out, 0, sizeof(*out));
+    RCV_HIP_CHECK(hipMemcpyAsync(hctl, stats + 24, sizeof(hctl), hipMemcpyDeviceToHost, st));
+    RCV_HIP_CHECK(hipMemcpyAsync(hstat, stats + 16, sizeof(hstat), hipMemcpyDeviceToHost, st));
     RCV_HIP_CHECK(hipMemcpyAsync(out->transformation, T, 16 * sizeof(double), hipMemcpyDeviceToHost, st));
     RCV_HIP_CHECK(hipStreamSynchronize(st));
+    const double fitness = hstat[0], rmse = hstat[1];
+    const int ncorr = hctl[2], it = hctl[1];
     out->fitness = fitness;
     out->inlier_rmse = rmse;
     out->n_correspondences = ncorr;
