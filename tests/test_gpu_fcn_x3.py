@@ -90,7 +90,9 @@ def test_x3_kernel_variants_identical(shapes):
     from rcvpose_amd.fcn_engine import FcnEngine
 
     sds = [_sd(shapes, s) for s in range(3)]
-    for (H, W, B) in ((480, 640, 4), (480, 640, 1), (96, 160, 3)):
+    # 7 frames: the smallest batch at which every fused kernel is active at 480x640 -- k_chain_x3<256> needs 192 tiles of 128
+    # pixels (7 x 1200 px x 3 networks = 197, the last tile of each network partial: 80 of 128 rows)
+    for (H, W, B) in ((480, 640, 7), (480, 640, 1), (96, 160, 3)):
         eng = FcnEngine(sds, H, W, dtype="f16x3")
         x = torch.from_numpy(fcn_weights.make_input(31, (B, 3, H, W))).cuda()
         seg_a, rad_a = [t.clone() for t in eng.forward(x)]
