@@ -129,3 +129,25 @@ def test_x3_groups_and_batch(shapes):
     for g in range(3):
         seg1, rad1 = FcnEngine([sds[g]], 64, 96, dtype="f16x3").forward(x[1:2])
         assert torch.equal(rad1[0, 0], rad3[g, 1]) and torch.equal(seg1[0, 0], seg3[g, 1])
+
+
+def test_half_precision_range_is_guarded(shapes):
+    """Half-precision storage has a range: f16x3 saturates (hi and lo clamp at 65504) instead of producing inf - inf = NaN, and
+    the module boundary (`check_finite`) refuses non-finite maps of the plain fp16 engine instead of handing them to the seam."""
+    from rcvpose_amd.fcn_engine import FcnEngine
+
+    sd = _sd(shapes)
+    x = torch.from_numpy(fcn_weights.make_input(3, (1, 3, 64, 96))).cuda() * 3.0e5   # activations far beyond 65504
+    seg, rad = FcnEngine([sd], 64, 96, dtype="f16x3").forward(x)
+    assert bool(torch.isfinite(seg).all()) and bool(torch.isfinite(rad).all())
+    # (a ReLU turns NaN into 0, so an overflow inside the network does not always reach the maps; what does reach them is refused)
+    bad = dict(sd)
+    bad["conv8.bias"] = torch.tensor([float("inf"), 0.0])
+    eng = FcnEngine([bad], 64, 96, dtype="fp16")
+    eng.check_finite = True
+    with pytest.raises(FloatingPointError):
+        eng.forward(x / 3.0e5)
+    eng = FcnEngine([sd], 64, 96, dtype="fp16")
+    eng.check_finite = True
+    seg, rad = eng.forward(x / 3.0e5)   # an ordinary image passes
+    assert bool(torch.isfinite(rad).all())
