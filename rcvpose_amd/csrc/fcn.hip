@@ -931,6 +931,21 @@ __global__ __launch_bounds__(512) void k_conv_lat(const ConvParams p)
 // per output element as k_conv_dma: bit-identical results.  Four-phase step, wave groups one barrier apart, as there.
 // Every step issues the same number of pieces (beyond the end: out-of-range offsets), so one counted vmcnt serves all.
 // ---------------------------------------------------------------------------------------------
+#ifdef RCV_HALO_STAMPS
+// diagnostic build only (tools/halo_stamps.py): cycle stamps of ONE K step (slice 2, tap 4) of the split-precision halo kernel,
+// waves 0 and 4 (the two wave groups of SIMD 0) of one workgroup in the middle of the launch
+__device__ unsigned g_halo_stamps[2][16];
+#define RCV_HSTAMP(idx)                                                                                        \
+    if (stamp_on) {                                                                                            \
+        unsigned long long t_;                                                                                 \
+        __builtin_amdgcn_sched_barrier(0);                                                                     \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                         \
+        __builtin_amdgcn_sched_barrier(0);                                                                     \
+        hst[idx] = (unsigned)t_;                                                                               \
+    }
+#else
+#define RCV_HSTAMP(idx)
+#endif
 struct HaloParams {
     const void *src0, *src1, *w;
     void *dst;
@@ -1129,9 +1144,15 @@ __global__ __launch_bounds__(512) void k_conv_halo(const HaloParams p)
 
 // Split precision (see k_conv_dma): the patch row / weight row is [32 hi | 32 lo]; hi*hi, hi*lo, lo*hi dealt 24 / 24 over the
 // two MFMA phases, per output element always in the order hh, hl, lh.
+#ifdef RCV_HALO_STAMPS
+#define RCV_HSTAMP_X(TAP, idx) if constexpr ((TAP) == 4) { RCV_HSTAMP(idx) }
+#else
+#define RCV_HSTAMP_X(TAP, idx)
+#endif
 #define RCV_HALO_STEP_X3(TAP)                                                                                  \
     {                                                                                                          \
         constexpr int T2_ = ((TAP) + 2) % 9, S2_ = ((TAP) + 2) / 9;                                            \
+        RCV_HSTAMP_X(TAP, 0);                                                                                  \
         const int shift_ = ((TAP) / 3 - 1) * pitch + ((TAP) % 3 - 1);                                          \
         const unsigned char *Pb = sP + (sl & 1) * HALO_PATCH;                                                  \
         const unsigned char *Bb = sB + stage * (BN * 128) + (wn * (BN / 2) + r16) * 128;                       \
@@ -1147,14 +1168,18 @@ __global__ __launch_bounds__(512) void k_conv_halo(const HaloParams p)
         _Pragma("unroll") for (int j = 0; j < NT / 2; j++) bl[j] = *(const bf16x8 *)(Bb + j * 16 * 128 + ch1); \
         RCV_HALO_B(sl + S2_, T2_, st2, 0);                                                                     \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                     \
+        RCV_HSTAMP_X(TAP, 1);                                                                                  \
         __builtin_amdgcn_s_barrier();                                                                          \
+        RCV_HSTAMP_X(TAP, 2);                                                                                  \
         __builtin_amdgcn_s_setprio(1);                                                                         \
         _Pragma("unroll") for (int i = 0; i < MT; i++)                                                         \
             _Pragma("unroll") for (int j = 0; j < NT; j++) acc[i][j] = RCV_MFMA16(ah[i], bh[j], acc[i][j], 0, 0, 0); \
         _Pragma("unroll") for (int i = 0; i < MT; i++)                                                         \
             _Pragma("unroll") for (int j = 0; j < NT / 2; j++) acc[i][j] = RCV_MFMA16(ah[i], bl[j], acc[i][j], 0, 0, 0); \
         __builtin_amdgcn_s_setprio(0);                                                                         \
+        RCV_HSTAMP_X(TAP, 3);                                                                                  \
         __builtin_amdgcn_s_barrier();                                                                          \
+        RCV_HSTAMP_X(TAP, 4);                                                                                  \
         _Pragma("unroll") for (int i = 0; i < MT; i++) al[i] = *(const bf16x8 *)(Pb + (ao_[i] ^ 64));          \
         _Pragma("unroll") for (int j = NT / 2; j < NT; j++) bl[j] = *(const bf16x8 *)(Bb + j * 16 * 128 + ch1); \
         if constexpr (BPW == 2) RCV_HALO_B(sl + S2_, T2_, st2, 1);                                             \
@@ -1166,14 +1191,18 @@ __global__ __launch_bounds__(512) void k_conv_halo(const HaloParams p)
             if constexpr (BPW == 2) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");                \
             else asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");                                   \
         }                                                                                                      \
+        RCV_HSTAMP_X(TAP, 5);                                                                                  \
         __builtin_amdgcn_s_barrier();                                                                          \
+        RCV_HSTAMP_X(TAP, 6);                                                                                  \
         __builtin_amdgcn_s_setprio(1);                                                                         \
         _Pragma("unroll") for (int i = 0; i < MT; i++)                                                         \
             _Pragma("unroll") for (int j = NT / 2; j < NT; j++) acc[i][j] = RCV_MFMA16(ah[i], bl[j], acc[i][j], 0, 0, 0); \
         _Pragma("unroll") for (int i = 0; i < MT; i++)                                                         \
             _Pragma("unroll") for (int j = 0; j < NT; j++) acc[i][j] = RCV_MFMA16(al[i], bh[j], acc[i][j], 0, 0, 0); \
         __builtin_amdgcn_s_setprio(0);                                                                         \
+        RCV_HSTAMP_X(TAP, 7);                                                                                  \
         __builtin_amdgcn_s_barrier();                                                                          \
+        RCV_HSTAMP_X(TAP, 8);                                                                                  \
         stage = stage + 1 == 3 ? 0 : stage + 1;                                                                \
     }
 // BN = 64, split precision: one load phase, 24 MFMAs
@@ -1219,6 +1248,12 @@ __global__ __launch_bounds__(512) void k_conv_halo(const HaloParams p)
     }
 
     const int grp = wave >> 2;
+#ifdef RCV_HALO_STAMPS
+    unsigned hst[16];
+    for (int k = 0; k < 16; k++) hst[k] = 0u;
+    const bool stamp_blk = blockIdx.x + gridDim.x * blockIdx.y == (gridDim.x * gridDim.y) / 2 && blockIdx.z == 0 && (wave & 3) == 0;
+    bool stamp_on = false;
+#endif
 #pragma unroll
     for (int k = 0; k < 6; k++) RCV_HALO_PATCH(0, k);
     RCV_HALO_B(0, 0, 0, 0);
@@ -1235,6 +1270,9 @@ __global__ __launch_bounds__(512) void k_conv_halo(const HaloParams p)
 #endif
     if constexpr (BPW == 2 && kX3 && (!RCV_X3_HALO_TWO_PHASE || MT == 5)) {  // (the 320-row tile would spill in the two-phase form)
         for (int sl = 0; sl < nsl; sl++) {
+#ifdef RCV_HALO_STAMPS
+            stamp_on = stamp_blk && sl == 2;
+#endif
             RCV_HALO_STEP_X3(0); RCV_HALO_STEP_X3(1); RCV_HALO_STEP_X3(2);
             RCV_HALO_STEP_X3(3); RCV_HALO_STEP_X3(4); RCV_HALO_STEP_X3(5);
             RCV_HALO_STEP_X3(6); RCV_HALO_STEP_X3(7); RCV_HALO_STEP_X3(8);
@@ -1260,6 +1298,10 @@ __global__ __launch_bounds__(512) void k_conv_halo(const HaloParams p)
     }
     if (grp == 0) __builtin_amdgcn_s_barrier();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the zero pieces issued past the end
+#ifdef RCV_HALO_STAMPS
+    if (stamp_blk && BN == 128 && MT == 4 && lane == 0)
+        for (int k = 0; k < 16; k++) g_halo_stamps[wave >> 2][k] = hst[k];
+#endif
 #undef RCV_HALO_STEP
 #undef RCV_HALO_STEP2
 #undef RCV_HALO_STEP_X3
@@ -3663,6 +3705,16 @@ int RCV_TU_SUFFIX(fcn_debug_slot)(const void *src, float *out_dev, long long n, 
     RCV_LAUNCH_CHECK();
     return RCV_OK;
 }
+#if defined(RCV_HALO_STAMPS) && defined(RCV_FCN_X3)
+}  // namespace rcv
+extern "C" int rcv_debug_halo_stamps(unsigned *out32)
+{
+    RCV_HIP_CHECK(hipDeviceSynchronize());
+    RCV_HIP_CHECK(hipMemcpyFromSymbol(out32, HIP_SYMBOL(rcv::g_halo_stamps), sizeof(unsigned) * 32));
+    return RCV_OK;
+}
+namespace rcv {
+#endif
 #else
 int fcn_forward_f16(rcv_fcn *h, const float *x, int B, float *seg, float *radial, char *ws, hipStream_t st);
 int fcn_register_f16();

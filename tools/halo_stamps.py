@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""Diagnostic: where one K step of the split-precision k_conv_halo<128,4> spends its cycles (s_memtime stamps of waves 0 and 4 of
+one workgroup; a separate build: `tools/ab_build.sh -DRCV_HALO_STAMPS`, then
+    RCV_LIB_PATH=$PWD/tools/probe/ab/librcvpose_hip_a.so python tools/halo_stamps.py [--batch 36]
+The stamps of the LAST <128,4> launch of the forward survive (conv_up2, 512 -> 128 at 120x160).  Read shares, not totals."""
+import argparse, ctypes, json, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+from rcvpose_amd import _hip, synthetic_weights
+from rcvpose_amd.fcn_engine import FcnEngine
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--batch", type=int, default=36)
+args = ap.parse_args()
+shapes = json.load(open(os.path.join(ROOT, "tests", "golden", "fcn_state_dict_keys.json")))
+sds = [{k: torch.from_numpy(v) for k, v in synthetic_weights.make_state_dict_numpy(shapes, seed=s).items()} for s in range(3)]
+eng = FcnEngine(sds, 480, 640, dtype="f16x3")
+x = torch.randn(args.batch, 3, 480, 640, device="cuda")
+for _ in range(3):
+    eng.forward(x)
+torch.cuda.synchronize()
+out = (ctypes.c_uint * 32)()
+L = ctypes.CDLL(_hip.LIB_PATH)
+assert L.rcv_debug_halo_stamps(out) == 0
+st = np.array(out[:], dtype=np.int64).reshape(2, 16)
+names = ["L1 (10 reads + 1 DMA + lgkm wait)", "barrier 1", "M1 (24 MFMAs issued)", "barrier 2", "L2 (6 reads + DMAs + vmcnt/lgkm wait)", "barrier 3",
+         "M2 (24 MFMAs issued)", "barrier 4"]
+for w in range(2):
+    s = st[w]
+    print("wave %d (group %d): step = %d cycles of the s_memtime clock (100 MHz x ... see guide; shares matter); starts %d after wave 0's" %
+          (4 * w, w, s[8] - s[0], s[0] - st[0][0]))
+    for k, nm in enumerate(names):
+        print("  %-42s %6d" % (nm, s[k + 1] - s[k]))
