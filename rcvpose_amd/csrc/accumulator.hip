@@ -101,6 +101,7 @@ struct alignas(16) AccHeader {
     // own round -- harmless for exactness, but the lower bound and the list sizes became timing dependent)
     unsigned long long climb_key[2];
     unsigned long long restart;  // 1 + flat index of the centre voxel of the candidate block with the largest upper bound (k_bb_restart); 0: none
+    int32_t box[2][6];           // diagnostics (tools/bb_stats.py): bounding box (i0, i1, j0, j1, k0, k1) of the 8- and 4-voxel candidates
 };
 static_assert(sizeof(AccHeader) <= 512, "AccHeader must fit the 512 bytes reserved in the workspace");
 
@@ -1714,16 +1715,30 @@ __device__ __forceinline__ void d_bb_restart(AccHeader *hdr, const BBEntry *list
     if (H.status != RCV_OK || !H.bb_enabled || H.bb_overflow || H.variant != 0) return;
     const uint32_t na = min(n_pairs, (uint32_t)BB_HALF), nb = min(n_singles, (uint32_t)BB_HALF), n = na + nb;
     unsigned long long best = 0;
+    __shared__ int s_box[6];
+    if (threadIdx.x < 6) s_box[threadIdx.x] = (threadIdx.x & 1) ? -1 : 0x7fffffff;
+    __syncthreads();
+    int bx[6] = {0x7fffffff, -1, 0x7fffffff, -1, 0x7fffffff, -1};
     for (uint32_t t = threadIdx.x; t < n; t += 1024) {
         const uint32_t idx = t < na ? t : (uint32_t)BB_HALF + (t - na);
         const BBEntry e = list[idx];
+        if (e.ub >= H.bb_best) {  // (stale entries below the current bound would be skipped by the level kernel)
+            bx[0] = min(bx[0], (int)e.i); bx[1] = max(bx[1], (int)e.i + edge - 1);
+            bx[2] = min(bx[2], (int)e.j); bx[3] = max(bx[3], (int)e.j + edge - 1);
+            bx[4] = min(bx[4], (int)e.k); bx[5] = max(bx[5], (int)e.k + edge - 1);
+        }
         // ub (31 bits) | inverted position (so that the first entry wins among equals) | + 1: 0 means none
         const unsigned long long key = ((unsigned long long)(uint32_t)min(e.ub, 0x7FFFFFFF) << 32) | (unsigned long long)(0xFFFFFFu - t);
         if (key + 1 > best) best = key + 1;
     }
     best = wave_max_u64(best);
     if (lane_id() == 0) s_key[wave_id()] = best;
+    for (int a = 0; a < 6; a++) {
+        if (a & 1) atomicMax(&s_box[a], bx[a]);
+        else atomicMin(&s_box[a], bx[a]);
+    }
     __syncthreads();
+    if (threadIdx.x < 6) hdr->box[edge == 8 ? 0 : 1][threadIdx.x] = s_box[threadIdx.x];
     if (threadIdx.x != 0) return;
     for (int w = 1; w < 16; w++) best = s_key[w] > best ? s_key[w] : best;
     hdr->climb_key[1] = 0;

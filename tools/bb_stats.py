@@ -9,6 +9,7 @@ from rcvpose_amd import synthetic, synthetic_weights
 from rcvpose_amd.pipeline import FramePipeline
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BOX_OFF = 352  # offsetof(AccHeader, box)
 B = 2
 shapes = json.load(open(os.path.join(ROOT, "tests", "golden", "fcn_state_dict_keys.json")))
 sds = [{k: torch.from_numpy(v) for k, v in synthetic_weights.make_state_dict_numpy(shapes, seed=s).items()} for s in range(3)]
@@ -25,6 +26,12 @@ for i in range(B * 3):
     ints = pipe.ws[i, 48:288].cpu().numpy().view(np.int32)
     # AccHeader after the six doubles: n, m, zb, dim, tile geometry (8), wide, nparts, status, tile_counter, bb_enabled, bb_done,
     # bb_best, bb_overflow, bb_count[8] (pair regions), bs_count[8] (single regions), pb_count[8], sel_count[8]
+    hb = pipe.ws[i, :512].cpu().numpy()
+    import struct
+    # AccHeader::box sits at the end of the header: find it by layout (after `restart`): offsets computed from the struct in accumulator.hip
+    box = np.frombuffer(hb[BOX_OFF:BOX_OFF + 48].tobytes(), dtype=np.int32).reshape(2, 6)
+    dims = [(int(b[1] - b[0] + 1), int(b[3] - b[2] + 1), int(b[5] - b[4] + 1)) for b in box]
+    print("   candidate boxes (i, j, k extent): edge 8 %s, edge 4 %s" % (dims[0], dims[1]))
     print("item %2d (frame %d kp %d) n %d dim %d peak %d | bb done %d best %d | pair entries %s | single entries %s | probe %s" %
           (i, i // 3, i % 3, ints[0], ints[3], res[i].peak_votes, ints[17], ints[18], [int(v) for v in ints[20:27]],
            [int(v) for v in ints[28:35]], [int(v) for v in ints[36:42]]))
