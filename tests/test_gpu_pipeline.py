@@ -155,3 +155,32 @@ def test_f16x3_keypoints_against_fp32_keypoints(golden_dir):
     print("f16x3 vs fp32 keypoints: max %.2f voxels, mean %.3f voxels over %d keypoints, %d identical" %
           (dev.max(), dev.mean(), dev.size, int((dev == 0).sum())))
     assert dev.max() <= 1.0
+
+
+def test_keypoints_under_false_positives_and_noise_equal_the_oracle(golden_dir, oracle):
+    """The peak search's second start (robust seed, line search along the sheet normal, restart of the lower bound from the
+    candidate block with the largest upper bound -- DESIGN 4.2, r03) is only a place to start counting: on frames with
+    false-positive segmentation on a background plane, gross radius outliers and one voxel of radial noise the keypoints are
+    still the oracle's, bit for bit, and the search (not the rasteriser) decides them."""
+    from rcvpose_amd.pipeline import FramePipeline
+
+    cases = [dict(noise_dm=0.02, outlier_frac=0.0, seg_false_pos=0.1), dict(noise_dm=0.05, outlier_frac=0.2, seg_false_pos=0.1)]
+    fr = [frames.synthetic_frame(300 + i, **cases[i]) for i in range(2)]
+    B, G, H, W = 2, 3, 480, 640
+    pipe = FramePipeline(_state_dicts(golden_dir), H, W, dtype="bf16", frames_per_step=B)   # (only the voting half is used)
+    pipe.seg.copy_(torch.from_numpy(np.stack([np.stack([f["seg"] for f in fr])] * G))[:, :, None].cuda())
+    pipe.radial.copy_(torch.from_numpy(np.stack([np.stack([f["radial"][k] for f in fr]) for k in range(G)]))[:, :, None].cuda())
+    depth = torch.from_numpy(np.stack([f["depth"] for f in fr]).view(np.int16)).cuda()
+    rmax = torch.tensor(np.stack([f["max_radii_dm"] for f in fr]), dtype=torch.float64, device="cuda")
+    pipe.vote(depth, rmax)
+    kp, res = pipe.read_results()
+    hdr = pipe.ws[:, :512].cpu().numpy().view(np.int32)
+    for b in range(B):
+        assert fr[b]["depth"].astype(bool).sum() > fr[b]["n_silhouette"]  # the false positives are in the cloud
+        for k in range(G):
+            r = res[b * G + k]
+            assert r.status == 0 and int(hdr[b * G + k, 116 // 4]) == 1   # AccHeader::bb_done: decided by the search
+            xyz, rl = oracle.seam(fr[b]["seg"], fr[b]["radial"][k], fr[b]["depth"], fr[b]["max_radii_dm"][k])
+            ref, _, info, _ = oracle.accumulator_3d(xyz, rl, sparse=True, return_all=True)
+            assert np.array_equal(kp[b, k], ref[0]), (b, k)
+            assert r.dim == info.dim and r.n_points == len(xyz)
