@@ -315,7 +315,10 @@ int rcv_fcn_debug_slot(rcv_fcn *h, const void *ws, int B, int g, int slot, float
 /* Name and average device time (ms, HIP events on `stream`) of the slowest op kind in the last
  * profiled forward; used by bench.py for the roofline line.  Enable with rcv_fcn_set_profiling. */
 int rcv_fcn_set_profiling(rcv_fcn *h, int enable);
-/* Engine options (A-B tests; all default 1, bf16 engines only): key 1 = LDS-DMA convolution kernel where it applies
+/* Engine options (A-B tests; all default 1; 16-bit and split-precision engines -- in an RCV_F16X3 engine key 3 selects
+ * k_tail_x3, key 4 the fused 1x1 expand + next 1x1 reduce kernel k_chain_x3 (keys 5 and 6 have no effect there), key 2 the
+ * split-precision MFMA stem; every fused / fast kernel of that engine is bit-identical to the plain kernels as well, except the
+ * MFMA stem against the direct fp32-input stem (5e-7)): key 1 = LDS-DMA convolution kernel where it applies
  * (k_conv_dma), key 2 = MFMA stem (k_stem_mfma; 0: direct kernel with fp32 input), key 3 = fused last upsampling + conv7
  * + head (k_tail; 0: three kernels, bit-identical output), key 4 = fused 3x3 + expand 1x1 of the stride-1 bottleneck blocks (layers 1-3)
  * (k_conv_block; 0: two kernels, bit-identical output), key 5 = chain the next block's 1x1 reduce into k_conv_block where it
