@@ -2964,13 +2964,21 @@ __global__ __launch_bounds__(512) void k_chain_x3(const BlockParams p)
 #pragma unroll
                     for (int j = 0; j < 8; j++) accE[j] = f32x4{0.f, 0.f, 0.f, 0.f};
                 }
+                // (the weight fragments of tile j + 1 are requested before the three MFMAs of tile j: left to itself hipcc reuses one
+                // register set and the wave sits out an LDS round trip per pair of tiles -- matrix cores 0.35 busy)
+                bf16x8 wh[2], wl[2];
+                wh[0] = *(const bf16x8 *)(sl + r16 * 128 + fh);
+                wl[0] = *(const bf16x8 *)(sl + r16 * 128 + fl);
 #pragma unroll
                 for (int j = 0; j < 8; j++) {
-                    const bf16x8 bh = *(const bf16x8 *)(sl + (j * 16 + r16) * 128 + fh);
-                    const bf16x8 bl = *(const bf16x8 *)(sl + (j * 16 + r16) * 128 + fl);
-                    accE[j] = RCV_MFMA16(bh, aE[q][0], accE[j], 0, 0, 0);
-                    accE[j] = RCV_MFMA16(bl, aE[q][0], accE[j], 0, 0, 0);
-                    accE[j] = RCV_MFMA16(bh, aE[q][1], accE[j], 0, 0, 0);
+                    if (j + 1 < 8) {
+                        wh[(j + 1) & 1] = *(const bf16x8 *)(sl + ((j + 1) * 16 + r16) * 128 + fh);
+                        wl[(j + 1) & 1] = *(const bf16x8 *)(sl + ((j + 1) * 16 + r16) * 128 + fl);
+                    }
+                    accE[j] = RCV_MFMA16(wh[j & 1], aE[q][0], accE[j], 0, 0, 0);
+                    accE[j] = RCV_MFMA16(wl[j & 1], aE[q][0], accE[j], 0, 0, 0);
+                    accE[j] = RCV_MFMA16(wh[j & 1], aE[q][1], accE[j], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);  // keep the order: reads of j + 1, then the MFMAs of j
                 }
             } else {
                 // ---- reduce step t: the chunk's channels t*32 .. +31 -> transposition, epilogue of the expand, store, 3 x NTR MFMAs
@@ -3007,13 +3015,19 @@ __global__ __launch_bounds__(512) void k_chain_x3(const BlockParams p)
                     *(uint4 *)(op + 32) = ol;
                 }
                 const bf16x8 ah = *(const bf16x8 *)&oh, al = *(const bf16x8 *)&ol;
+                bf16x8 wh[2], wl[2];
+                wh[0] = *(const bf16x8 *)(sl + r16 * 128 + fh);
+                wl[0] = *(const bf16x8 *)(sl + r16 * 128 + fl);
 #pragma unroll
                 for (int j = 0; j < NTR; j++) {
-                    const bf16x8 bh = *(const bf16x8 *)(sl + (j * 16 + r16) * 128 + fh);
-                    const bf16x8 bl = *(const bf16x8 *)(sl + (j * 16 + r16) * 128 + fl);
-                    accR[j] = RCV_MFMA16(bh, ah, accR[j], 0, 0, 0);
-                    accR[j] = RCV_MFMA16(bl, ah, accR[j], 0, 0, 0);
-                    accR[j] = RCV_MFMA16(bh, al, accR[j], 0, 0, 0);
+                    if (j + 1 < NTR) {
+                        wh[(j + 1) & 1] = *(const bf16x8 *)(sl + ((j + 1) * 16 + r16) * 128 + fh);
+                        wl[(j + 1) & 1] = *(const bf16x8 *)(sl + ((j + 1) * 16 + r16) * 128 + fl);
+                    }
+                    accR[j] = RCV_MFMA16(wh[j & 1], ah, accR[j], 0, 0, 0);
+                    accR[j] = RCV_MFMA16(wl[j & 1], ah, accR[j], 0, 0, 0);
+                    accR[j] = RCV_MFMA16(wh[j & 1], al, accR[j], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
             slot = slot + 1 == CH_RING ? 0 : slot + 1;
