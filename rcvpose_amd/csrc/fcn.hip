@@ -1298,7 +1298,7 @@ __global__ __launch_bounds__(512) void k_conv_halo(const HaloParams p)
     }
     if (grp == 0) __builtin_amdgcn_s_barrier();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the zero pieces issued past the end
-#ifdef RCV_HALO_STAMPS
+#if defined(RCV_HALO_STAMPS) && !defined(RCV_CHAIN_STAMPS)
     if (stamp_blk && BN == 128 && MT == 4 && lane == 0)
         for (int k = 0; k < 16; k++) g_halo_stamps[wave >> 2][k] = hst[k];
 #endif
@@ -2928,12 +2928,25 @@ __global__ __launch_bounds__(512) void k_chain_x3(const BlockParams p)
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // (lgkmcnt: the bias rows written above)
     __builtin_amdgcn_s_barrier();
 
+#ifdef RCV_HALO_STAMPS
+    unsigned hst[16];
+    for (int k = 0; k < 16; k++) hst[k] = 0u;
+    const bool stamp_blk = blockIdx.x == gridDim.x / 2 && blockIdx.z == 0 && (wave & 3) == 0 && CMID == 256;
+    bool stamp_on = false;
+#define RCV_CSTAMP(cond, idx) if (cond) { RCV_HSTAMP(idx) }
+#else
+#define RCV_CSTAMP(cond, idx)
+#endif
     int slot = 0;
     for (int nc = 0; nc < NC; nc++) {
         const bool last = nc == NC - 1;
+#ifdef RCV_HALO_STAMPS
+        stamp_on = stamp_blk && nc == 3;
+#endif
 #pragma unroll
         for (int q = 0; q < SPC; q++) {
             // ---- wait for this step's weights (issued two steps ago): everything this wave issued after them may stay in flight
+            RCV_CSTAMP(q == 3, 0) RCV_CSTAMP(q == KE + 1, 5)
             if (nc > 0 || q >= 1) {
                 if (nc > 0 || q >= 2) {  // (steps 0 and 1: the prologue waited)
                     const int qm1 = (q + SPC - 1) % SPC, qm2 = (q + SPC - 2) % SPC;
@@ -2942,7 +2955,9 @@ __global__ __launch_bounds__(512) void k_chain_x3(const BlockParams p)
                     const int i_m1 = next_exists ? pieces_for((q + 1) % SPC) : 0;       // pieces step g-1 issued for step g+1
                     blk_vmwait(loads_at(qm2) + s_m2 + i_m1 + loads_at(qm1) + s_m1);
                 }
+                RCV_CSTAMP(q == 3, 1) RCV_CSTAMP(q == KE + 1, 6)
                 __builtin_amdgcn_s_barrier();  // every wave's pieces have landed; everybody is done with the slot refilled below
+                RCV_CSTAMP(q == 3, 2) RCV_CSTAMP(q == KE + 1, 7)
             }
             // ---- issue for step g + 2
             {
@@ -2957,6 +2972,7 @@ __global__ __launch_bounds__(512) void k_chain_x3(const BlockParams p)
                     }
                 }
             }
+            RCV_CSTAMP(q == 3, 3) RCV_CSTAMP(q == KE + 1, 8)
             const unsigned char *sl = smem + slot * CH_SLOT;
             if (q < KE) {
                 // ---- expand step: chunk nc, K slice q -- 8 channel tiles, operands swapped (lane = pixel, 4 channels per tile)
@@ -3030,9 +3046,14 @@ __global__ __launch_bounds__(512) void k_chain_x3(const BlockParams p)
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
+            RCV_CSTAMP(q == 3, 4) RCV_CSTAMP(q == KE + 1, 9)
             slot = slot + 1 == CH_RING ? 0 : slot + 1;
         }
     }
+#if defined(RCV_HALO_STAMPS) && defined(RCV_CHAIN_STAMPS)
+    if (stamp_blk && lane == 0)
+        for (int k = 0; k < 16; k++) g_halo_stamps[wave >> 2][k] = hst[k];
+#endif
     // ---- the reduce's epilogue: bias (x scale), ReLU, hi / lo, through the same transposition, 32 channels at a time
 #pragma unroll
     for (int t = 0; t < NTR / 2; t++) {

@@ -13,6 +13,7 @@ from rcvpose_amd.fcn_engine import FcnEngine
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=36)
+ap.add_argument("--chain", action="store_true", help="the build was made with -DRCV_HALO_STAMPS -DRCV_CHAIN_STAMPS: stamps of k_chain_x3<256> (chunk 3: expand step 3, reduce step 1)")
 args = ap.parse_args()
 shapes = json.load(open(os.path.join(ROOT, "tests", "golden", "fcn_state_dict_keys.json")))
 sds = [{k: torch.from_numpy(v) for k, v in synthetic_weights.make_state_dict_numpy(shapes, seed=s).items()} for s in range(3)]
@@ -25,6 +26,13 @@ out = (ctypes.c_uint * 32)()
 L = ctypes.CDLL(_hip.LIB_PATH)
 assert L.rcv_debug_halo_stamps(out) == 0
 st = np.array(out[:], dtype=np.int64).reshape(2, 16)
+if args.chain:
+    for w in range(2):
+        s = st[w]
+        for tag, o in (("expand step (8 tiles x 3 MFMAs)", 0), ("reduce step (transposition, epilogue, store, 16 tiles x 3 MFMAs)", 5)):
+            print("wave %d %s: counted vmcnt wait %d, barrier %d, DMA issue (+ residual loads) %d, compute %d  (total %d)" %
+                  (4 * w, tag, s[o + 1] - s[o], s[o + 2] - s[o + 1], s[o + 3] - s[o + 2], s[o + 4] - s[o + 3], s[o + 4] - s[o]))
+    sys.exit(0)
 names = ["L1 (10 reads + 1 DMA + lgkm wait)", "barrier 1", "M1 (24 MFMAs issued)", "barrier 2", "L2 (6 reads + DMAs + vmcnt/lgkm wait)", "barrier 3",
          "M2 (24 MFMAs issued)", "barrier 4"]
 for w in range(2):
