@@ -935,6 +935,7 @@ __global__ __launch_bounds__(512) void k_conv_lat(const ConvParams p)
 // diagnostic build only (tools/halo_stamps.py): cycle stamps of ONE K step (slice 2, tap 4) of the split-precision halo kernel,
 // waves 0 and 4 (the two wave groups of SIMD 0) of one workgroup in the middle of the launch
 __device__ unsigned g_halo_stamps[2][16];
+__device__ unsigned g_chain_stamps[2][64];  // k_chain_x3<256>, chunk 3: four stamps per step (top, after the counted wait, after the barrier, after the issue) + the end
 #define RCV_HSTAMP(idx)                                                                                        \
     if (stamp_on) {                                                                                            \
         unsigned long long t_;                                                                                 \
@@ -2928,25 +2929,25 @@ __global__ __launch_bounds__(512) void k_chain_x3(const BlockParams p)
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // (lgkmcnt: the bias rows written above)
     __builtin_amdgcn_s_barrier();
 
-#ifdef RCV_HALO_STAMPS
-    unsigned hst[16];
-    for (int k = 0; k < 16; k++) hst[k] = 0u;
+#if defined(RCV_HALO_STAMPS) && defined(RCV_CHAIN_STAMPS)
+    unsigned hst[64];
+    for (int k = 0; k < 64; k++) hst[k] = 0u;
     const bool stamp_blk = blockIdx.x == gridDim.x / 2 && blockIdx.z == 0 && (wave & 3) == 0 && CMID == 256;
     bool stamp_on = false;
-#define RCV_CSTAMP(cond, idx) if (cond) { RCV_HSTAMP(idx) }
+#define RCV_CSTAMP(idx) RCV_HSTAMP(idx)
 #else
-#define RCV_CSTAMP(cond, idx)
+#define RCV_CSTAMP(idx)
 #endif
     int slot = 0;
     for (int nc = 0; nc < NC; nc++) {
         const bool last = nc == NC - 1;
-#ifdef RCV_HALO_STAMPS
+#if defined(RCV_HALO_STAMPS) && defined(RCV_CHAIN_STAMPS)
         stamp_on = stamp_blk && nc == 3;
 #endif
 #pragma unroll
         for (int q = 0; q < SPC; q++) {
             // ---- wait for this step's weights (issued two steps ago): everything this wave issued after them may stay in flight
-            RCV_CSTAMP(q == 3, 0) RCV_CSTAMP(q == KE + 1, 5)
+            RCV_CSTAMP(q * 4 + 0)
             if (nc > 0 || q >= 1) {
                 if (nc > 0 || q >= 2) {  // (steps 0 and 1: the prologue waited)
                     const int qm1 = (q + SPC - 1) % SPC, qm2 = (q + SPC - 2) % SPC;
@@ -2955,9 +2956,9 @@ __global__ __launch_bounds__(512) void k_chain_x3(const BlockParams p)
                     const int i_m1 = next_exists ? pieces_for((q + 1) % SPC) : 0;       // pieces step g-1 issued for step g+1
                     blk_vmwait(loads_at(qm2) + s_m2 + i_m1 + loads_at(qm1) + s_m1);
                 }
-                RCV_CSTAMP(q == 3, 1) RCV_CSTAMP(q == KE + 1, 6)
+                RCV_CSTAMP(q * 4 + 1)
                 __builtin_amdgcn_s_barrier();  // every wave's pieces have landed; everybody is done with the slot refilled below
-                RCV_CSTAMP(q == 3, 2) RCV_CSTAMP(q == KE + 1, 7)
+                RCV_CSTAMP(q * 4 + 2)
             }
             // ---- issue for step g + 2
             {
@@ -2972,7 +2973,7 @@ __global__ __launch_bounds__(512) void k_chain_x3(const BlockParams p)
                     }
                 }
             }
-            RCV_CSTAMP(q == 3, 3) RCV_CSTAMP(q == KE + 1, 8)
+            RCV_CSTAMP(q * 4 + 3)
             const unsigned char *sl = smem + slot * CH_SLOT;
             if (q < KE) {
                 // ---- expand step: chunk nc, K slice q -- 8 channel tiles, operands swapped (lane = pixel, 4 channels per tile)
@@ -3046,13 +3047,13 @@ __global__ __launch_bounds__(512) void k_chain_x3(const BlockParams p)
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
-            RCV_CSTAMP(q == 3, 4) RCV_CSTAMP(q == KE + 1, 9)
+            if (q == SPC - 1) { RCV_CSTAMP(SPC * 4) }
             slot = slot + 1 == CH_RING ? 0 : slot + 1;
         }
     }
 #if defined(RCV_HALO_STAMPS) && defined(RCV_CHAIN_STAMPS)
     if (stamp_blk && lane == 0)
-        for (int k = 0; k < 16; k++) g_halo_stamps[wave >> 2][k] = hst[k];
+        for (int k = 0; k < 64; k++) g_chain_stamps[wave >> 2][k] = hst[k];
 #endif
     // ---- the reduce's epilogue: bias (x scale), ReLU, hi / lo, through the same transposition, 32 channels at a time
 #pragma unroll
@@ -3746,6 +3747,12 @@ extern "C" int rcv_debug_halo_stamps(unsigned *out32)
 {
     RCV_HIP_CHECK(hipDeviceSynchronize());
     RCV_HIP_CHECK(hipMemcpyFromSymbol(out32, HIP_SYMBOL(rcv::g_halo_stamps), sizeof(unsigned) * 32));
+    return RCV_OK;
+}
+extern "C" int rcv_debug_chain_stamps(unsigned *out128)
+{
+    RCV_HIP_CHECK(hipDeviceSynchronize());
+    RCV_HIP_CHECK(hipMemcpyFromSymbol(out128, HIP_SYMBOL(rcv::g_chain_stamps), sizeof(unsigned) * 128));
     return RCV_OK;
 }
 namespace rcv {

@@ -22,17 +22,22 @@ x = torch.randn(args.batch, 3, 480, 640, device="cuda")
 for _ in range(3):
     eng.forward(x)
 torch.cuda.synchronize()
-out = (ctypes.c_uint * 32)()
 L = ctypes.CDLL(_hip.LIB_PATH)
-assert L.rcv_debug_halo_stamps(out) == 0
-st = np.array(out[:], dtype=np.int64).reshape(2, 16)
 if args.chain:
+    out = (ctypes.c_uint * 128)()
+    assert L.rcv_debug_chain_stamps(out) == 0
+    st = np.array(out[:], dtype=np.int64).reshape(2, 64)
     for w in range(2):
         s = st[w]
-        for tag, o in (("expand step (8 tiles x 3 MFMAs)", 0), ("reduce step (transposition, epilogue, store, 16 tiles x 3 MFMAs)", 5)):
-            print("wave %d %s: counted vmcnt wait %d, barrier %d, DMA issue (+ residual loads) %d, compute %d  (total %d)" %
-                  (4 * w, tag, s[o + 1] - s[o], s[o + 2] - s[o + 1], s[o + 3] - s[o + 2], s[o + 4] - s[o + 3], s[o + 4] - s[o]))
+        print("wave %d: chunk 3 = %d cycles; per step (E = expand slice, R = reduce slice): counted vmcnt wait / barrier / DMA issue / compute" % (4 * w, s[48] - s[0]))
+        for q in range(12):
+            e = s[4 * q + 4] if q < 11 else s[48]
+            print("   %s%d  %5d %5d %5d %5d   = %5d" % ("E" if q < 8 else "R", q if q < 8 else q - 8, s[4 * q + 1] - s[4 * q], s[4 * q + 2] - s[4 * q + 1],
+                                                   s[4 * q + 3] - s[4 * q + 2], e - s[4 * q + 3], e - s[4 * q]))
     sys.exit(0)
+out = (ctypes.c_uint * 32)()
+assert L.rcv_debug_halo_stamps(out) == 0
+st = np.array(out[:], dtype=np.int64).reshape(2, 16)
 names = ["L1 (10 reads + 1 DMA + lgkm wait)", "barrier 1", "M1 (24 MFMAs issued)", "barrier 2", "L2 (6 reads + DMAs + vmcnt/lgkm wait)", "barrier 3",
          "M2 (24 MFMAs issued)", "barrier 4"]
 for w in range(2):
