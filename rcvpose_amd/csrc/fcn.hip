@@ -97,7 +97,37 @@ __device__ __forceinline__ void x3_split(float v, H16 &hi, H16 &lo)
     hi = (H16)h;
     lo = (H16)__builtin_amdgcn_fmed3f(v - (float)hi, -65504.f, 65504.f);
 }
-// eight consecutive channels as two 16-byte vectors
+// eight consecutive channels as two 16-byte vectors.  Written on pairs: gfx950 converts two floats to packed halves in one
+// instruction (v_cvt_pk_f16_f32) and subtracts / adds two floats in one (v_pk_add_f32) -- 36 VALU instructions per eight
+// elements instead of 56 + 8 to pack; element for element the same IEEE operations as x3_split.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+#ifdef RCV_FCN_X3
+typedef _Float16 x3_h2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void x3_split8(const float *v, uint4 &hi, uint4 &lo)
+{
+    unsigned *wh = (unsigned *)&hi, *wl = (unsigned *)&lo;
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+        const f32x2 c = {__builtin_amdgcn_fmed3f(v[2 * e], -65504.f, 65504.f), __builtin_amdgcn_fmed3f(v[2 * e + 1], -65504.f, 65504.f)};
+        const x3_h2 h = __builtin_convertvector(c, x3_h2);
+        const f32x2 r = (f32x2){v[2 * e], v[2 * e + 1]} - __builtin_convertvector(h, f32x2);
+        const f32x2 rc = {__builtin_amdgcn_fmed3f(r[0], -65504.f, 65504.f), __builtin_amdgcn_fmed3f(r[1], -65504.f, 65504.f)};
+        const x3_h2 l = __builtin_convertvector(rc, x3_h2);
+        wh[e] = __builtin_bit_cast(unsigned, h);
+        wl[e] = __builtin_bit_cast(unsigned, l);
+    }
+}
+__device__ __forceinline__ void x3_join8(const uint4 &hi, const uint4 &lo, float *v)
+{
+    const unsigned *wh = (const unsigned *)&hi, *wl = (const unsigned *)&lo;
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+        const f32x2 s = __builtin_convertvector(__builtin_bit_cast(x3_h2, wh[e]), f32x2) + __builtin_convertvector(__builtin_bit_cast(x3_h2, wl[e]), f32x2);
+        v[2 * e] = s[0];
+        v[2 * e + 1] = s[1];
+    }
+}
+#else
 __device__ __forceinline__ void x3_split8(const float *v, uint4 &hi, uint4 &lo)
 {
     H16 *ph = (H16 *)&hi, *pl = (H16 *)&lo;
@@ -110,6 +140,7 @@ __device__ __forceinline__ void x3_join8(const uint4 &hi, const uint4 &lo, float
 #pragma unroll
     for (int e = 0; e < 8; e++) v[e] = (float)ph[e] + (float)pl[e];
 }
+#endif
 
 struct ConvParams {
     const void *src0, *src1, *res, *w;
@@ -1590,6 +1621,28 @@ __device__ __forceinline__ float bilerp(float hy, float hx, float ly, float lx, 
     const float t1 = __fmaf_rn(lx, p11, __fmul_rn(hx, p10));
     return __fmaf_rn(hy, t0, __fmul_rn(ly, t1));
 }
+// the same on eight channels, two per instruction (v_pk_mul_f32 / v_pk_fma_f32), in two stages so that the horizontal blends
+// of a source cell are formed once per destination column: element for element bilerp's operations
+__device__ __forceinline__ void bilerp8_rows(float hx, float lx, const float *p00, const float *p01, const float *p10, const float *p11,
+                                             f32x2 *t0, f32x2 *t1)
+{
+    const f32x2 hx2 = {hx, hx}, lx2 = {lx, lx};
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+        t0[e] = __builtin_elementwise_fma(lx2, (f32x2){p01[2 * e], p01[2 * e + 1]}, hx2 * (f32x2){p00[2 * e], p00[2 * e + 1]});
+        t1[e] = __builtin_elementwise_fma(lx2, (f32x2){p11[2 * e], p11[2 * e + 1]}, hx2 * (f32x2){p10[2 * e], p10[2 * e + 1]});
+    }
+}
+__device__ __forceinline__ void bilerp8_col(float hy, float ly, const f32x2 *t0, const f32x2 *t1, float *out)
+{
+    const f32x2 hy2 = {hy, hy}, ly2 = {ly, ly};
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+        const f32x2 r = __builtin_elementwise_fma(hy2, t0[e], ly2 * t1[e]);
+        out[2 * e] = r[0];
+        out[2 * e + 1] = r[1];
+    }
+}
 // source row/column and weights of destination index d for the 2x upsampling: ATen's area_pixel_compute_source_index
 // (align_corners = False): s = max(0.5 * (d + 0.5) - 0.5, 0)
 __device__ __forceinline__ void up2_src(int d, int n_in, int &i0, int &i1, float &l, float &h)
@@ -2531,8 +2584,9 @@ __global__ __launch_bounds__(256) void k_upsample2(const T *src, T *dst, int C, 
                 T *op = out + ((long long)y * Wout + x) * C * PS;
                 if constexpr (is_x3<T>()) {
                     float bl[8];
-#pragma unroll
-                    for (int e = 0; e < EPV; e++) bl[e] = bilerp(hy, hx, ly, lx, f00[e], f01[e], f10[e], f11[e]);
+                    f32x2 t0[4], t1[4];
+                    bilerp8_rows(hx, lx, f00, f01, f10, f11, t0, t1);
+                    bilerp8_col(hy, ly, t0, t1, bl);
                     uint4 oh, ol;
                     x3_split8(bl, oh, ol);
                     *(uint4 *)op = oh;
@@ -3088,36 +3142,49 @@ __global__ __launch_bounds__(512) void k_chain_x3(const BlockParams p)
 // k_tail_x3 (split precision): the same three layers -- 2x bilinear upsampling of the 64-channel map, conv7 (3x3, 64 -> 32,
 // ReLU) and the 1x1 head -- for the RCV_F16X3 engine.  Unfused they move 17 GB per 72 (frame, network) items through HBM
 // (the 480x640x64 upsampled map alone is 79 MB per item in hi / lo storage); fused only the 240x320x64 source is read.
-// Eight waves: wave = (pixel quarter of the 8 x 32 tile, 16-channel half of conv7's outputs); its 18 x (hi, lo) weight fragments
-// stay in registers (144 VGPRs) for the whole strip, the A fragments (hi and lo of a 32-channel slice) come from the upsampled
-// patch U in LDS: 8 reads per 12 MFMAs and wave.  U's pixel pitch is 288 B (256 + 32): conflict-free for ds_read_b128's lane
+// Four waves on a 4 x 32 tile: wave = (pixel half of the tile, 16-channel half of conv7's outputs); its 18 x (hi, lo) weight
+// fragments stay in registers (144 VGPRs) for the whole strip, the A fragments (hi and lo of a 32-channel slice) come from the
+// upsampled patch U in LDS: 8 reads per 12 MFMAs and wave.  The kernel's phases are serial inside a workgroup -- building U is
+// ~400 VALU instructions per (cell, 8 channels), as long as the tile's MFMAs -- so the tile is sized for TWO workgroups per CU
+// (77 KB of LDS each) and the head runs on all four waves (thread = (pixel, plane)).  Measured at 153 items: 6.2 ms for the
+// 8 x 32 tile / 512 threads / one workgroup per CU, 5.8 ms now, for 2.1 ms of MFMAs: the stamps (tools/halo_stamps.py --tail)
+// show one wave's build phase and the other's MFMA phase on the same SIMD slowing each other down about as much as running
+// one after the other -- a SIMD issues one vector instruction at a time, and the kernel's VALU work (join, blend, split:
+// inherent to hi / lo storage) is as long as its matrix work.  Starting the CU's second workgroup half a tile late: no change.  U's pixel pitch is 288 B (256 + 32): conflict-free for ds_read_b128's lane
 // groups like k_tail's 160.  K order = k_conv's in split mode: channel slice outermost, taps inside, hh / hl / lh per step; the
 // upsampling, conv7's rounding to hi + lo and the head's FMA chain are the unfused kernels' -- identical outputs.
 // ---------------------------------------------------------------------------------------------
+#ifndef RCV_TX_PIPE
+#define RCV_TX_PIPE 0  // 1: conv7's fragments of K step s + 1 requested before the MFMAs of step s (measured: 5.8 -> 6.3-6.4 ms, off)
+#endif
 constexpr int TX_UP = 288;                                   // bytes per pixel of the upsampled patch
-constexpr int TX_SPIX = TAIL_SH * TAIL_SW;                   // source pixels per tile (6 x 18)
+constexpr int TX_TH = 4, TX_TW = 32, TX_UH = TX_TH + 2, TX_UW = TX_TW + 2, TX_SH = TX_TH / 2 + 2, TX_SW = TX_TW / 2 + 2;
+constexpr int TX_NPX = TX_TH * TX_TW;                        // output pixels per tile
+constexpr int TX_SPIX = TX_SH * TX_SW;                       // source pixels per tile (4 x 18)
 constexpr int TX_SPIECES = (TX_SPIX + 3) / 4;                // DMA pieces: 4 pixels x 256 B
 constexpr int TX_HP = 144;                                   // bytes per pixel of the conv7 rows: [32 hi | 32 lo] + 16 (bank spread)
-constexpr int TX_LDS_MAIN = TAIL_UH * TAIL_UW * TX_UP + TX_SPIECES * 1024;
+constexpr int TX_LDS_MAIN = TX_UH * TX_UW * TX_UP + TX_SPIECES * 1024;
 constexpr int TX_LDS = TX_LDS_MAIN + 64 * 4;
-static_assert(256 * TX_HP <= TAIL_UH * TAIL_UW * TX_UP, "the conv7 rows reuse the upsampled patch's LDS");
+static_assert(TX_NPX == 128, "the head maps thread -> (pixel, plane) with 128 pixels per tile");
+static_assert(TX_NPX * TX_HP <= TX_UH * TX_UW * TX_UP, "the conv7 rows reuse the upsampled patch's LDS");
+static_assert(2 * TX_LDS <= 160 * 1024, "two workgroups per CU");
 
-__global__ __launch_bounds__(512) void k_tail_x3(const H16 *src, const H16 *w7, const float *b7, const H16 *w8, const float *b8,
+__global__ __launch_bounds__(256, 2) void k_tail_x3(const H16 *src, const H16 *w7, const float *b7, const H16 *w8, const float *b8,
                                                  float *seg, float *radial, int B, int Hin, int Win, long long src_gs, long long w7_gs,
                                                  int b7_gs, long long w8_gs, int b8_gs, int rad_f16)
 {
     using T = H16;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char *sU = smem;                                        // [340][TX_UP] upsampled patch ...
-    unsigned char *sH = sU;                                          // ... later [256][TX_HP] conv7 output
-    unsigned char *sS = smem + TAIL_UH * TAIL_UW * TX_UP;            // [108][256 B] source patch of the NEXT tile by LDS-DMA
+    unsigned char *sU = smem;                                        // [6 x 34][TX_UP] upsampled patch ...
+    unsigned char *sH = sU;                                          // ... later [128][TX_HP] conv7 output
+    unsigned char *sS = smem + TX_UH * TX_UW * TX_UP;                // [72][256 B] source patch of the NEXT tile by LDS-DMA
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r16 = lane & 15, kq = lane >> 4;
     const int Ho = Hin * 2, Wo = Win * 2;
     const int ty = blockIdx.x, img = blockIdx.y, g = blockIdx.z;
-    const int ho0 = ty * TAIL_TH;
+    const int ho0 = ty * TX_TH;
     const T *sg = src + (long long)g * src_gs + (long long)img * Hin * Win * 128;
-    const int pq = wave & 3, nt = wave >> 2;
+    const int pq = wave & 1, nt = wave >> 1;
     // conv7 weights of this wave's 16 output channels: [co][tap][slice][hi 32 | lo 32]
     bf16x8 bw[2][9][2];  // [slice][tap][hi / lo]
     {
@@ -3143,92 +3210,125 @@ __global__ __launch_bounds__(512) void k_tail_x3(const H16 *src, const H16 *w7, 
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         const int m = pq * 64 + i * 16 + r16;
-        ubase[i] = (m >> 5) * TAIL_UW + (m & 31);
+        ubase[i] = (m >> 5) * TX_UW + (m & 31);
     }
     const int sy0 = ho0 / 2 - 1;
     const int src_bytes = Hin * Win * 256;
     const int wv = __builtin_amdgcn_readfirstlane(wave);
-    constexpr int SPW = (TX_SPIECES + 7) / 8;  // pieces per wave
+    constexpr int SPW = (TX_SPIECES + 3) / 4;  // pieces per wave
     int s_row[SPW], s_col[SPW];  // byte offset of the patch row (+ the lane's 16-byte chunk); patch column, or -1
 #pragma unroll
     for (int k = 0; k < SPW; k++) {
-        const int pp = (k * 8 + wv) * 4 + (lane >> 4);
-        const int a = pp / TAIL_SW, b = pp - a * TAIL_SW;
+        const int pp = (k * 4 + wv) * 4 + (lane >> 4);
+        const int a = pp / TX_SW, b = pp - a * TX_SW;
         s_row[k] = min(max(sy0 + a, 0), Hin - 1) * Win * 256 + (lane & 15) * 16;
-        s_col[k] = (k * 8 + wv < TX_SPIECES && pp < TX_SPIX) ? b : -1;
+        s_col[k] = (k * 4 + wv < TX_SPIECES && pp < TX_SPIX) ? b : -1;
     }
 #define RCV_TX_SOURCE(sx0_)                                                                                    \
     _Pragma("unroll") for (int k = 0; k < SPW; k++)                                                            \
-        if (k * 8 + wv < TX_SPIECES)                                                                           \
-            tail_dma16(sg, src_bytes, sS + (k * 8 + wv) * 1024,                                                \
+        if (k * 4 + wv < TX_SPIECES)                                                                           \
+            tail_dma16(sg, src_bytes, sS + (k * 4 + wv) * 1024,                                                \
                        s_col[k] >= 0 ? s_row[k] + min(max((sx0_) + s_col[k], 0), Win - 1) * 256 : (int)0x80000000);
+#if defined(RCV_HALO_STAMPS) && defined(RCV_TAIL_STAMPS)
+    unsigned hst[16];
+    for (int k = 0; k < 16; k++) hst[k] = 0u;
+    const bool stamp_blk = blockIdx.x == gridDim.x / 2 && blockIdx.y == gridDim.y / 2 && blockIdx.z == 0 && (wave == 0 || wave == 3);
+    bool stamp_on = false;
+#define RCV_TSTAMP(idx) RCV_HSTAMP(idx)
+#else
+#define RCV_TSTAMP(idx)
+#endif
     RCV_TX_SOURCE(-1);
-    for (int tx = 0; tx * TAIL_TW < Wo; tx++) {
-        const int wo0 = tx * TAIL_TW;
+    for (int tx = 0; tx * TX_TW < Wo; tx++) {
+        const int wo0 = tx * TX_TW;
+#if defined(RCV_HALO_STAMPS) && defined(RCV_TAIL_STAMPS)
+        stamp_on = stamp_blk && tx == 10;
+#endif
+        RCV_TSTAMP(0)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        RCV_TSTAMP(1)
         __syncthreads();  // the whole source patch is in sS; every thread is done with the previous tile's conv7 rows in sU
+        RCV_TSTAMP(2)
         // ---- upsampled patch: one task = one source cell and one 8-channel chunk -> its 2 x 2 patch pixels (k_upsample2's scheme)
 #pragma unroll 1
-        for (int v = tid; v < (TAIL_UH / 2) * (TAIL_UW / 2) * 8; v += 512) {
-            const int c = v & 7, cell = v >> 3, ai = cell / (TAIL_UW / 2), bi = cell - ai * (TAIL_UW / 2);
+        for (int v = tid; v < (TX_UH / 2) * (TX_UW / 2) * 8; v += 256) {
+            const int c = v & 7, cell = v >> 3, ai = cell / (TX_UW / 2), bi = cell - ai * (TX_UW / 2);
             const int coff = x3_off(c * 8) * 2;  // byte offset of the chunk's hi halves inside a pixel; lo: + 64
-            const unsigned char *r0 = sS + (ai * TAIL_SW + bi) * 256 + coff, *r1 = r0 + TAIL_SW * 256;
+            const unsigned char *r0 = sS + (ai * TX_SW + bi) * 256 + coff, *r1 = r0 + TX_SW * 256;
             float f00[8], f01[8], f10[8], f11[8];
             x3_join8(*(const uint4 *)r0, *(const uint4 *)(r0 + 64), f00);
             x3_join8(*(const uint4 *)(r0 + 256), *(const uint4 *)(r0 + 256 + 64), f01);
             x3_join8(*(const uint4 *)r1, *(const uint4 *)(r1 + 64), f10);
             x3_join8(*(const uint4 *)(r1 + 256), *(const uint4 *)(r1 + 256 + 64), f11);
 #pragma unroll
-            for (int dy = 0; dy < 2; dy++) {
-                const int uy = 2 * ai + dy, y = ho0 - 1 + uy;
-                int y0, y1;
-                float ly, hy;
-                up2_src(y, Hin, y0, y1, ly, hy);
+            for (int dx = 0; dx < 2; dx++) {
+                const int ux = 2 * bi + dx, x = wo0 - 1 + ux;
+                int x0, x1;
+                float lx, hx;
+                up2_src(x, Win, x0, x1, lx, hx);
+                f32x2 t0[4], t1[4];
+                bilerp8_rows(hx, lx, f00, f01, f10, f11, t0, t1);
 #pragma unroll
-                for (int dx = 0; dx < 2; dx++) {
-                    const int ux = 2 * bi + dx, x = wo0 - 1 + ux;
-                    int x0, x1;
-                    float lx, hx;
-                    up2_src(x, Win, x0, x1, lx, hx);
-                    uint4 oh = make_uint4(0u, 0u, 0u, 0u), ol = oh;
+                for (int dy = 0; dy < 2; dy++) {
+                    const int uy = 2 * ai + dy, y = ho0 - 1 + uy;
+                    int y0, y1;
+                    float ly, hy;
+                    up2_src(y, Hin, y0, y1, ly, hy);
+                    unsigned char *up = sU + (uy * TX_UW + ux) * TX_UP + coff;
                     if ((unsigned)y < (unsigned)Ho && (unsigned)x < (unsigned)Wo) {
                         float bl[8];
-#pragma unroll
-                        for (int e = 0; e < 8; e++) bl[e] = bilerp(hy, hx, ly, lx, f00[e], f01[e], f10[e], f11[e]);
+                        bilerp8_col(hy, ly, t0, t1, bl);
+                        uint4 oh, ol;
                         x3_split8(bl, oh, ol);
+                        *(uint4 *)up = oh;
+                        *(uint4 *)(up + 64) = ol;
+                    } else {  // conv7's zero padding (rare: a branch of its own, skipped by whole waves inside the image)
+                        *(uint4 *)up = make_uint4(0u, 0u, 0u, 0u);
+                        *(uint4 *)(up + 64) = make_uint4(0u, 0u, 0u, 0u);
                     }
-                    unsigned char *up = sU + (uy * TAIL_UW + ux) * TX_UP + coff;
-                    *(uint4 *)up = oh;
-                    *(uint4 *)(up + 64) = ol;
                 }
             }
         }
+        RCV_TSTAMP(3)
         __syncthreads();  // U is complete, sS is free
-        if ((tx + 1) * TAIL_TW < Wo) RCV_TX_SOURCE((wo0 + TAIL_TW) / 2 - 1);
+        RCV_TSTAMP(4)
+        if ((tx + 1) * TX_TW < Wo) RCV_TX_SOURCE((wo0 + TX_TW) / 2 - 1);
         // ---- conv7: K = 2 channel slices x 9 taps x [32 hi | 32 lo]
         f32x4 acc[4];
 #pragma unroll
         for (int i = 0; i < 4; i++) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int sl = 0; sl < 2; sl++)
-#pragma unroll
-            for (int t = 0; t < 9; t++) {
-                const int toff = (t / 3) * TAIL_UW + (t % 3);
-                bf16x8 ah[4], al[4];
-#pragma unroll
-                for (int i = 0; i < 4; i++) {  // constant offsets from the lane's pixel: fold into the ds_read immediates
-                    ah[i] = *(const bf16x8 *)(sU + ubase[i] * TX_UP + kq * 16 + (toff * TX_UP + sl * 128));
-                    al[i] = *(const bf16x8 *)(sU + ubase[i] * TX_UP + kq * 16 + (toff * TX_UP + sl * 128 + 64));
-                }
-#pragma unroll
-                for (int i = 0; i < 4; i++) acc[i] = RCV_MFMA16(bw[sl][t][0], ah[i], acc[i], 0, 0, 0);
-#pragma unroll
-                for (int i = 0; i < 4; i++) acc[i] = RCV_MFMA16(bw[sl][t][1], ah[i], acc[i], 0, 0, 0);
-#pragma unroll
-                for (int i = 0; i < 4; i++) acc[i] = RCV_MFMA16(bw[sl][t][0], al[i], acc[i], 0, 0, 0);
-                asm volatile("" ::: "memory");  // keep the fragment reads of later K steps from being hoisted (registers)
-            }
+        // (RCV_TX_PIPE: the fragments of K step s + 1 requested before the MFMAs of step s, two register sets.  The stamps show
+        // 500 cycles per step for 192 of MFMAs either way: the step is not waiting for its own reads -- the SIMD's other wave, of
+        // the CU's second workgroup, is issuing VALU instructions of its build phase -- and the pipelined form lost 8 %)
+        bf16x8 ah[2][4], al[2][4];
+#define RCV_TX_FRAGS(st_)                                                                                      \
+    {                                                                                                          \
+        constexpr int sl_ = (st_) / 9, t_ = (st_) % 9, toff_ = (t_ / 3) * TX_UW + (t_ % 3);                   \
+        _Pragma("unroll") for (int i = 0; i < 4; i++) {                                                        \
+            ah[(st_) & 1][i] = *(const bf16x8 *)(sU + ubase[i] * TX_UP + kq * 16 + (toff_ * TX_UP + sl_ * 128));      \
+            al[(st_) & 1][i] = *(const bf16x8 *)(sU + ubase[i] * TX_UP + kq * 16 + (toff_ * TX_UP + sl_ * 128 + 64)); \
+        }                                                                                                      \
+    }
+#define RCV_TX_STEP(st_)                                                                                       \
+    {                                                                                                          \
+        if constexpr (RCV_TX_PIPE && (st_) + 1 < 18) RCV_TX_FRAGS((st_) + 1 < 18 ? (st_) + 1 : 0)              \
+        if constexpr (!RCV_TX_PIPE) RCV_TX_FRAGS(st_)                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                                     \
+        constexpr int sl_ = (st_) / 9, t_ = (st_) % 9, b_ = (st_) & 1;                                         \
+        _Pragma("unroll") for (int i = 0; i < 4; i++) acc[i] = RCV_MFMA16(bw[sl_][t_][0], ah[b_][i], acc[i], 0, 0, 0); \
+        _Pragma("unroll") for (int i = 0; i < 4; i++) acc[i] = RCV_MFMA16(bw[sl_][t_][1], ah[b_][i], acc[i], 0, 0, 0); \
+        _Pragma("unroll") for (int i = 0; i < 4; i++) acc[i] = RCV_MFMA16(bw[sl_][t_][0], al[b_][i], acc[i], 0, 0, 0); \
+        __builtin_amdgcn_sched_barrier(0);                                                                     \
+    }
+        if constexpr (RCV_TX_PIPE) RCV_TX_FRAGS(0)
+        RCV_TX_STEP(0) RCV_TX_STEP(1) RCV_TX_STEP(2) RCV_TX_STEP(3) RCV_TX_STEP(4) RCV_TX_STEP(5)
+        RCV_TX_STEP(6) RCV_TX_STEP(7) RCV_TX_STEP(8) RCV_TX_STEP(9) RCV_TX_STEP(10) RCV_TX_STEP(11)
+        RCV_TX_STEP(12) RCV_TX_STEP(13) RCV_TX_STEP(14) RCV_TX_STEP(15) RCV_TX_STEP(16) RCV_TX_STEP(17)
+#undef RCV_TX_STEP
+#undef RCV_TX_FRAGS
+        RCV_TSTAMP(5)
         __syncthreads();  // every wave is done reading U: its LDS takes the conv7 rows
+        RCV_TSTAMP(6)
         // ---- bias + ReLU, stored as hi + lo like the conv7 activation; operands were swapped, so acc[i][e] is channel
         // nt*16 + kq*4 + e of pixel pq*64 + i*16 + r16
 #pragma unroll
@@ -3241,29 +3341,36 @@ __global__ __launch_bounds__(512) void k_tail_x3(const H16 *src, const H16 *w7, 
             *(uint2 *)hp = ph;
             *(uint2 *)(hp + 64) = pl;
         }
+        RCV_TSTAMP(7)
         __syncthreads();
+        RCV_TSTAMP(8)
         // ---- head: thread = pixel, the sequential FMA chain of k_head
-        if (tid < 256) {
-            const int ho = ho0 + (tid >> 5), wo = wo0 + (tid & 31);
-            float a0 = 0.f, a1 = 0.f;
+        {   // thread = (pixel, output plane): waves 0-1 the seg plane, waves 2-3 the radial plane
+            const int px = tid & (TX_NPX - 1), oc = tid >> 7;
+            const int ho = ho0 + (px >> 5), wo = wo0 + (px & 31);
+            float a = 0.f;
 #pragma unroll
             for (int c = 0; c < 32; c += 8) {
                 float f[8];
-                x3_join8(*(const uint4 *)(sH + tid * TX_HP + c * 2), *(const uint4 *)(sH + tid * TX_HP + 64 + c * 2), f);
+                x3_join8(*(const uint4 *)(sH + px * TX_HP + c * 2), *(const uint4 *)(sH + px * TX_HP + 64 + c * 2), f);
 #pragma unroll
-                for (int e = 0; e < 8; e++) {
-                    a0 = fmaf(f[e], hw[c + e], a0);
-                    a1 = fmaf(f[e], hw[32 + c + e], a1);
-                }
+                for (int e = 0; e < 8; e++) a = fmaf(f[e], hw[oc * 32 + c + e], a);
             }
             if (ho < Ho && wo < Wo) {
                 const long long o = ((long long)(g * B + img) * Ho + ho) * Wo + wo;
-                seg[o] = __fmaf_rn(a0, hs0, hb0);
-                const float o1 = __fmaf_rn(a1, hs1, hb1);
-                if (rad_f16) ((_Float16 *)radial)[o] = (_Float16)o1;  // engine option 8
-                else radial[o] = o1;
+                if (oc == 0) seg[o] = __fmaf_rn(a, hs0, hb0);
+                else {
+                    const float o1 = __fmaf_rn(a, hs1, hb1);
+                    if (rad_f16) ((_Float16 *)radial)[o] = (_Float16)o1;  // engine option 8
+                    else radial[o] = o1;
+                }
             }
         }
+        RCV_TSTAMP(9)
+#if defined(RCV_HALO_STAMPS) && defined(RCV_TAIL_STAMPS)
+        if (stamp_on && lane == 0)
+            for (int k = 0; k < 16; k++) g_chain_stamps[wave == 0 ? 0 : 1][k] = hst[k];
+#endif
     }
 #undef RCV_TX_SOURCE
 }
@@ -3546,6 +3653,11 @@ int register_kernel_attributes()
     RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_stem_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, STEM_LDS));
     RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_tail, hipFuncAttributeMaxDynamicSharedMemorySize, TAIL_LDS));
     RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_tail_x3, hipFuncAttributeMaxDynamicSharedMemorySize, TX_LDS));
+    if (getenv("RCV_DEBUG_OCCUPANCY")) {
+        int nb = -1;
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)k_tail_x3, 256, TX_LDS);
+        fprintf(stderr, "k_tail_x3: %d workgroups per CU (LDS %d B)\n", nb, TX_LDS);
+    }
     RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_chain_x3<64>, hipFuncAttributeMaxDynamicSharedMemorySize, CH_LDS));
     RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_chain_x3<128>, hipFuncAttributeMaxDynamicSharedMemorySize, CH_LDS));
     RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_chain_x3<256>, hipFuncAttributeMaxDynamicSharedMemorySize, CH_LDS));
@@ -3688,7 +3800,7 @@ int forward_impl(rcv_fcn *h, const float *x, int B, float *seg, float *radial, c
                     }
                     dim3 grid((u.hout + TAIL_TH - 1) / TAIL_TH, B, h->groups);
                     if constexpr (kX3)
-                        hipLaunchKernelGGL(k_tail_x3, grid, dim3(512), TX_LDS, st, (const H16 *)(ws + off[u.src0]),
+                        hipLaunchKernelGGL(k_tail_x3, dim3((u.hout + TX_TH - 1) / TX_TH, B, h->groups), dim3(256), TX_LDS, st, (const H16 *)(ws + off[u.src0]),
                                            (const H16 *)h->weights + c.w_off, h->bias + c.b_off, (const H16 *)h->weights + d.w_off,
                                            h->bias + d.b_off, seg, radial, B, u.hin, u.win, (long long)h->slot_elems[u.src0] * B * 2,
                                            (long long)32 * 576 * 2, 64, (long long)128, 4, h->radial_f16 ? 1 : 0);

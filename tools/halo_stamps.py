@@ -13,6 +13,7 @@ from rcvpose_amd.fcn_engine import FcnEngine
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=36)
+ap.add_argument("--tail", action="store_true", help="the build was made with -DRCV_HALO_STAMPS -DRCV_TAIL_STAMPS: phases of one tile of k_tail_x3")
 ap.add_argument("--chain", action="store_true", help="the build was made with -DRCV_HALO_STAMPS -DRCV_CHAIN_STAMPS: stamps of k_chain_x3<256> (chunk 3: expand step 3, reduce step 1)")
 args = ap.parse_args()
 shapes = json.load(open(os.path.join(ROOT, "tests", "golden", "fcn_state_dict_keys.json")))
@@ -23,6 +24,18 @@ for _ in range(3):
     eng.forward(x)
 torch.cuda.synchronize()
 L = ctypes.CDLL(_hip.LIB_PATH)
+if args.tail:
+    out = (ctypes.c_uint * 128)()
+    assert L.rcv_debug_chain_stamps(out) == 0
+    st = np.array(out[:], dtype=np.int64).reshape(2, 64)
+    names = ["wait for the source patch (vmcnt)", "barrier", "build U (upsample: join, blend, split)", "barrier", "conv7 MFMAs (+ next patch's DMA issue)",
+             "barrier", "conv7 epilogue", "barrier", "head + stores"]
+    for w in range(2):
+        s = st[w]
+        print("wave %d: tile = %d cycles" % (0 if w == 0 else 3, s[9] - s[0]))
+        for k, nm in enumerate(names):
+            print("   %-46s %6d" % (nm, s[k + 1] - s[k]))
+    sys.exit(0)
 if args.chain:
     out = (ctypes.c_uint * 128)()
     assert L.rcv_debug_chain_stamps(out) == 0
