@@ -25,20 +25,6 @@ namespace {
 
 constexpr int NN_THREADS = 256, NN_TILE = 1024, RED_BLOCKS = 256;
 
-// cur[i] = R * src[i] + t  (T row-major 4x4)
-// (`done`: the device-side loop control of rcv_icp_point_to_point -- once set, the remaining launches of the iteration chunk
-// return at once; null for callers without one)
-__global__ __launch_bounds__(256) void k_icp_transform(const double *src, int n, const double *T, double *cur, const int *done)
-{
-    if (done && *done) return;
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-        const double x = src[3 * i], y = src[3 * i + 1], z = src[3 * i + 2];
-        cur[3 * i] = T[0] * x + T[1] * y + T[2] * z + T[3];
-        cur[3 * i + 1] = T[4] * x + T[5] * y + T[6] * z + T[7];
-        cur[3 * i + 2] = T[8] * x + T[9] * y + T[10] * z + T[11];
-    }
-}
-
 // nearest b for every a: squared distance and index (first index among equal distances)
 __global__ __launch_bounds__(NN_THREADS) void k_nn(const double *a, int n_a, const double *b, int n_b, double *d2_out, int *idx_out)
 {
@@ -71,11 +57,13 @@ __global__ __launch_bounds__(NN_THREADS) void k_nn(const double *a, int n_a, con
 
 // The same search with the target cloud cut into gridDim.y slices (r03: 3 000 model points against 15 000 scene points kept
 // 12 workgroups busy for 0.2 ms per ICP iteration): slice s scans targets [s * per, (s + 1) * per) and leaves its best
-// (squared distance, index) in part_*[s][i]; k_nn_merge folds the slices in order with the same strict `<`, which is the first
+// (squared distance, index) in part_*[s][i]; k_icp_merge_sums folds the slices in order with the same strict `<`, which is the first
 // index among equal distances again -- identical results.
 constexpr int NN_SLICES = 16;
-__global__ __launch_bounds__(NN_THREADS) void k_nn_sliced(const double *a, int n_a, const double *b, int n_b, double *part_d2, int *part_idx,
-                                                          const int *done)
+// T (row-major 4x4, may be null: identity) is applied to the source point on the fly; slice 0 also leaves the transformed points
+// in `cur` for the reductions that follow (r03: one launch less per ICP iteration).
+__global__ __launch_bounds__(NN_THREADS) void k_nn_sliced(const double *a, int n_a, const double *T, double *cur, const double *b, int n_b,
+                                                          double *part_d2, int *part_idx, const int *done)
 {
     if (done && *done) return;
     __shared__ double sx[NN_TILE], sy[NN_TILE], sz[NN_TILE];
@@ -83,7 +71,14 @@ __global__ __launch_bounds__(NN_THREADS) void k_nn_sliced(const double *a, int n
     const int ii = i < n_a ? i : n_a - 1;
     const int per = (n_b + NN_SLICES - 1) / NN_SLICES;
     const int lo = blockIdx.y * per, hi = min(n_b, lo + per);
-    const double px = a[3 * ii], py = a[3 * ii + 1], pz = a[3 * ii + 2];
+    double px = a[3 * ii], py = a[3 * ii + 1], pz = a[3 * ii + 2];
+    if (T) {
+        const double x = px, y = py, z = pz;
+        px = T[0] * x + T[1] * y + T[2] * z + T[3];
+        py = T[4] * x + T[5] * y + T[6] * z + T[7];
+        pz = T[8] * x + T[9] * y + T[10] * z + T[11];
+        if (blockIdx.y == 0 && i < n_a) { cur[3 * i] = px; cur[3 * i + 1] = py; cur[3 * i + 2] = pz; }
+    }
     double best = INFINITY;
     int bi = -1;
     for (int base = lo; base < hi; base += NN_TILE) {
@@ -106,20 +101,6 @@ __global__ __launch_bounds__(NN_THREADS) void k_nn_sliced(const double *a, int n
         part_idx[(size_t)blockIdx.y * n_a + i] = bi;
     }
 }
-__global__ __launch_bounds__(256) void k_nn_merge(const double *part_d2, const int *part_idx, int n_a, double *d2_out, int *idx_out, const int *done)
-{
-    if (done && *done) return;
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < n_a; i += gridDim.x * 256) {
-        double best = INFINITY;
-        int bi = -1;
-        for (int s = 0; s < NN_SLICES; s++) {
-            const double d2 = part_d2[(size_t)s * n_a + i];
-            if (d2 < best) { best = d2; bi = part_idx[(size_t)s * n_a + i]; }
-        }
-        d2_out[i] = best;
-        idx_out[i] = bi;
-    }
-}
 
 __global__ __launch_bounds__(256) void k_sqrt(const double *d2, int n, double *d)
 {
@@ -135,160 +116,137 @@ __device__ __forceinline__ double block_sum(double v, double *s)
     return s[0] + s[1] + s[2] + s[3];
 }
 
-// pass 1 over the correspondences (source i <-> target idx[i], d2[i] <= max_d2): count, sum p, sum q, sum d2
-// per block -> part[block][8]; fixed block / thread assignment makes the result reproducible
-__global__ __launch_bounds__(256) void k_icp_sums(const double *cur, const double *tgt, const double *d2, const int *idx, int n,
-                                                  double max_d2, double *part, const int *done)
+// Fold the slices of the nearest-neighbour search (in order, strict `<`: the first index among equal distances) and, in the same
+// pass, the sums over the correspondences (source i <-> target idx[i], d2[i] <= max_d2) that evaluation and update need:
+//   part[block][0] = count, [1..3] = sum (p - a), [4..6] = sum (q - b), [7] = sum d2, [8..16] = sum (p - a)(q - b)^T
+// with a, b = ref[0..2], ref[3..5]: the correspondence means of the previous evaluation (zeros at first), so that the centred
+// covariance S = sum (p - a)(q - b)^T - n (pm - a)(qm - b)^T comes out of ONE pass without cancellation.  Fixed block / thread
+// assignment: reproducible.
+constexpr int ICP_NSUM = 17;
+__global__ __launch_bounds__(256) void k_icp_merge_sums(const double *part_d2, const int *part_idx, const double *cur, const double *tgt, int n,
+                                                        double max_d2, const double *ref, double *d2_out, int *idx_out, double *part,
+                                                        const int *done)
 {
     if (done && *done) return;
     __shared__ double s[4];
-    double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const double a[3] = {ref[0], ref[1], ref[2]}, b[3] = {ref[3], ref[4], ref[5]};
+    double acc[ICP_NSUM];
+#pragma unroll
+    for (int k = 0; k < ICP_NSUM; k++) acc[k] = 0.0;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-        if (idx[i] >= 0 && d2[i] <= max_d2) {
-            const int j = idx[i];
+        double best = INFINITY;
+        int bi = -1;
+        for (int sl = 0; sl < NN_SLICES; sl++) {
+            const double d2 = part_d2[(size_t)sl * n + i];
+            if (d2 < best) { best = d2; bi = part_idx[(size_t)sl * n + i]; }
+        }
+        d2_out[i] = best;
+        idx_out[i] = bi;
+        if (bi >= 0 && best <= max_d2) {
+            const double p[3] = {cur[3 * i] - a[0], cur[3 * i + 1] - a[1], cur[3 * i + 2] - a[2]};
+            const double q[3] = {tgt[3 * bi] - b[0], tgt[3 * bi + 1] - b[1], tgt[3 * bi + 2] - b[2]};
             acc[0] += 1.0;
-            acc[1] += cur[3 * i]; acc[2] += cur[3 * i + 1]; acc[3] += cur[3 * i + 2];
-            acc[4] += tgt[3 * j]; acc[5] += tgt[3 * j + 1]; acc[6] += tgt[3 * j + 2];
-            acc[7] += d2[i];
+            acc[1] += p[0]; acc[2] += p[1]; acc[3] += p[2];
+            acc[4] += q[0]; acc[5] += q[1]; acc[6] += q[2];
+            acc[7] += best;
+#pragma unroll
+            for (int u = 0; u < 3; u++)
+#pragma unroll
+                for (int v = 0; v < 3; v++) acc[8 + u * 3 + v] += p[u] * q[v];
         }
     }
-    for (int k = 0; k < 8; k++) {
+#pragma unroll
+    for (int k = 0; k < ICP_NSUM; k++) {
         const double v = block_sum(acc[k], s);
-        if (threadIdx.x == 0) part[blockIdx.x * 8 + k] = v;
+        if (threadIdx.x == 0) part[blockIdx.x * ICP_NSUM + k] = v;
     }
 }
 
-// reduce the partials: stats[0..7] = totals, stats[8..10] = mean p, stats[11..13] = mean q
-__global__ void k_icp_finish_sums(const double *part, int blocks, double *stats, const int *done)
+// cyclic Jacobi for a symmetric 4x4 matrix: eigenvalues d, eigenvectors in the columns of v (every loop over matrix indices
+// unrolled: the arrays stay in registers -- with run-time indices they lived in scratch memory and the one-lane kernel took 155 us)
+__device__ __forceinline__ void jacobi4(double a[4][4], double d[4], double v[4][4])
 {
-    if (threadIdx.x != 0 || blockIdx.x != 0 || (done && *done)) return;
-    double t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int b = 0; b < blocks; b++)
-        for (int k = 0; k < 8; k++) t[k] += part[b * 8 + k];
-    for (int k = 0; k < 8; k++) stats[k] = t[k];
-    const double n = t[0] > 0 ? t[0] : 1.0;
-    for (int k = 0; k < 3; k++) { stats[8 + k] = t[1 + k] / n; stats[11 + k] = t[4 + k] / n; }
-}
-
-// pass 2: centred cross-covariance S[a][b] = sum (p - pm)_a (q - qm)_b  -> part[block][9]
-__global__ __launch_bounds__(256) void k_icp_cov(const double *cur, const double *tgt, const double *d2, const int *idx, int n,
-                                                 double max_d2, const double *stats, double *part, const int *done)
-{
-    if (done && *done) return;
-    __shared__ double s[4];
-    const double pm[3] = {stats[8], stats[9], stats[10]}, qm[3] = {stats[11], stats[12], stats[13]};
-    double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-        if (idx[i] >= 0 && d2[i] <= max_d2) {
-            const int j = idx[i];
-            const double p[3] = {cur[3 * i] - pm[0], cur[3 * i + 1] - pm[1], cur[3 * i + 2] - pm[2]};
-            const double q[3] = {tgt[3 * j] - qm[0], tgt[3 * j + 1] - qm[1], tgt[3 * j + 2] - qm[2]};
-            for (int a = 0; a < 3; a++)
-                for (int b = 0; b < 3; b++) acc[a * 3 + b] += p[a] * q[b];
-        }
-    }
-    for (int k = 0; k < 9; k++) {
-        const double v = block_sum(acc[k], s);
-        if (threadIdx.x == 0) part[blockIdx.x * 9 + k] = v;
-    }
-}
-
-// cyclic Jacobi for a symmetric 4x4 matrix: eigenvalues d, eigenvectors in the columns of v
-__device__ void jacobi4(double a[4][4], double d[4], double v[4][4])
-{
-    for (int i = 0; i < 4; i++) {
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
         for (int j = 0; j < 4; j++) v[i][j] = i == j ? 1.0 : 0.0;
-        d[i] = a[i][i];
-    }
     for (int sweep = 0; sweep < 60; sweep++) {
-        double off = 0.0;
-        for (int i = 0; i < 4; i++)
+        double off = 0.0, diag = 0.0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            diag += a[i][i] * a[i][i];
+#pragma unroll
             for (int j = i + 1; j < 4; j++) off += a[i][j] * a[i][j];
-        if (off < 1e-300) break;
+        }
+        // (relative: the off-diagonal part stalls near eps * |A| and never reaches an absolute 1e-300 -- the loop used to run all
+        // 60 sweeps, 150 us on one lane; converged sweeps only rotate by angles below eps)
+        if (off <= 1e-32 * diag || off < 1e-300) break;
+#pragma unroll
         for (int p = 0; p < 4; p++)
+#pragma unroll
             for (int q = p + 1; q < 4; q++) {
                 if (fabs(a[p][q]) < 1e-300) continue;
                 const double theta = (a[q][q] - a[p][p]) / (2.0 * a[p][q]);
                 const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
-                const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+                const double c = 1.0 / sqrt(t * t + 1.0), sn = t * c;
+#pragma unroll
                 for (int k = 0; k < 4; k++) {  // A <- A * J
                     const double akp = a[k][p], akq = a[k][q];
-                    a[k][p] = c * akp - s * akq;
-                    a[k][q] = s * akp + c * akq;
+                    a[k][p] = c * akp - sn * akq;
+                    a[k][q] = sn * akp + c * akq;
                 }
+#pragma unroll
                 for (int k = 0; k < 4; k++) {  // A <- J^T * A
                     const double apk = a[p][k], aqk = a[q][k];
-                    a[p][k] = c * apk - s * aqk;
-                    a[q][k] = s * apk + c * aqk;
+                    a[p][k] = c * apk - sn * aqk;
+                    a[q][k] = sn * apk + c * aqk;
                 }
+#pragma unroll
                 for (int k = 0; k < 4; k++) {
                     const double vkp = v[k][p], vkq = v[k][q];
-                    v[k][p] = c * vkp - s * vkq;
-                    v[k][q] = s * vkp + c * vkq;
+                    v[k][p] = c * vkp - sn * vkq;
+                    v[k][q] = sn * vkp + c * vkq;
                 }
             }
     }
+#pragma unroll
     for (int i = 0; i < 4; i++) d[i] = a[i][i];
 }
 
-// rigid update from the covariance (Horn 1987: the rotation is the unit quaternion that maximises q^T N q) and
-// T <- update * T.  With fewer than 3 correspondences the update is the identity (Open3D returns I for an empty set).
-__global__ void k_icp_update(const double *part, int blocks, const double *stats, double *T, const int *done)
+// One wave closes an evaluation (r03: this was k_icp_finish_sums, k_icp_decide, k_icp_cov and k_icp_update -- the host used to
+// read the fitness back after every iteration, 30 synchronisations of ~0.4 ms per frame, and a single lane added the partials):
+//   * the per-block partials, one per lane and stride 64, then a butterfly over the wave: stats[0] = count, stats[7] = sum d2,
+//     stats[8..10] / [11..13] = mean p / mean q of the correspondences (the next pass's reference points);
+//   * the reference loop's bookkeeping -- stats[16..19] = previous / current (fitness, rmse); ctl = (int *)(stats + 24): done,
+//     iterations, correspondences.  `first`: the evaluation of the start pose; otherwise one after an update:
+//         it++; converged (|d fitness| < relative_fitness and |d rmse| < relative_rmse) or it == max or no correspondences -> done
+//   * unless done: the rigid update from the centred covariance (Horn 1987: the rotation is the unit quaternion that maximises
+//     q^T N q) and T <- update * T.  With fewer than 3 correspondences the update is the identity (Open3D returns I for an empty set).
+__global__ __launch_bounds__(64) void k_icp_finish(const double *part, int blocks, double *stats, double *T, int n_src, double rel_fitness,
+                                                   double rel_rmse, int max_iteration, int first)
 {
-    if (threadIdx.x != 0 || blockIdx.x != 0 || (done && *done)) return;
-    if (stats[0] < 3.0) return;
-    double S[3][3];
-    for (int a = 0; a < 3; a++)
-        for (int b = 0; b < 3; b++) {
-            double t = 0.0;
-            for (int k = 0; k < blocks; k++) t += part[k * 9 + a * 3 + b];
-            S[a][b] = t;
-        }
-    double N[4][4] = {
-        {S[0][0] + S[1][1] + S[2][2], S[1][2] - S[2][1], S[2][0] - S[0][2], S[0][1] - S[1][0]},
-        {S[1][2] - S[2][1], S[0][0] - S[1][1] - S[2][2], S[0][1] + S[1][0], S[2][0] + S[0][2]},
-        {S[2][0] - S[0][2], S[0][1] + S[1][0], -S[0][0] + S[1][1] - S[2][2], S[1][2] + S[2][1]},
-        {S[0][1] - S[1][0], S[2][0] + S[0][2], S[1][2] + S[2][1], -S[0][0] - S[1][1] + S[2][2]}};
-    double d[4], v[4][4];
-    jacobi4(N, d, v);
-    int m = 0;
-    for (int i = 1; i < 4; i++)
-        if (d[i] > d[m]) m = i;
-    double q0 = v[0][m], qx = v[1][m], qy = v[2][m], qz = v[3][m];
-    const double nq = sqrt(q0 * q0 + qx * qx + qy * qy + qz * qz);
-    q0 /= nq; qx /= nq; qy /= nq; qz /= nq;
-    const double R[3][3] = {
-        {q0 * q0 + qx * qx - qy * qy - qz * qz, 2 * (qx * qy - q0 * qz), 2 * (qx * qz + q0 * qy)},
-        {2 * (qy * qx + q0 * qz), q0 * q0 - qx * qx + qy * qy - qz * qz, 2 * (qy * qz - q0 * qx)},
-        {2 * (qz * qx - q0 * qy), 2 * (qz * qy + q0 * qx), q0 * q0 - qx * qx - qy * qy + qz * qz}};
-    const double pm[3] = {stats[8], stats[9], stats[10]}, qm[3] = {stats[11], stats[12], stats[13]};
-    double U[4][4] = {{0}};
-    for (int a = 0; a < 3; a++) {
-        for (int b = 0; b < 3; b++) U[a][b] = R[a][b];
-        U[a][3] = qm[a] - (R[a][0] * pm[0] + R[a][1] * pm[1] + R[a][2] * pm[2]);
-    }
-    U[3][3] = 1.0;
-    double Tn[16];
-    for (int a = 0; a < 4; a++)
-        for (int b = 0; b < 4; b++) {
-            double t = 0.0;
-            for (int k = 0; k < 4; k++) t += U[a][k] * T[k * 4 + b];
-            Tn[a * 4 + b] = t;
-        }
-    for (int k = 0; k < 16; k++) T[k] = Tn[k];
-}
-
-// Loop control of the ICP on the device (r03: the host used to read the fitness back after every iteration -- 30 synchronisations
-// of ~0.4 ms per frame).  stats[16..19] = previous / current (fitness, rmse); ctl = (int *)(stats + 24): done, iterations, correspondences.
-// `first`: after the evaluation of the start pose; otherwise after an update + evaluation -- the reference loop's bookkeeping:
-//     it++; converged (|d fitness| < relative_fitness and |d rmse| < relative_rmse) or it == max or no correspondences -> done
-__global__ void k_icp_decide(double *stats, int n_src, double rel_fitness, double rel_rmse, int max_iteration, int first)
-{
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
     int *ctl = (int *)(stats + 24);
     if (ctl[0]) return;
-    const int ncorr = (int)stats[0];
-    const double fitness = stats[0] / (double)n_src, rmse = ncorr > 0 ? sqrt(stats[7] / stats[0]) : 0.0;
+    const int lane = threadIdx.x;
+    double t[ICP_NSUM];
+#pragma unroll
+    for (int k = 0; k < ICP_NSUM; k++) {
+        double v = 0.0;
+        for (int b = lane; b < blocks; b += 64) v += part[b * ICP_NSUM + k];
+        for (int m = 32; m; m >>= 1) v += __shfl_xor(v, m);
+        t[k] = v;
+    }
+    if (lane != 0) return;
+    const double a[3] = {stats[8], stats[9], stats[10]}, b[3] = {stats[11], stats[12], stats[13]};  // this pass's reference points
+    const double n = t[0] > 0 ? t[0] : 1.0;
+    const double dp[3] = {t[1] / n, t[2] / n, t[3] / n}, dq[3] = {t[4] / n, t[5] / n, t[6] / n};  // means relative to them
+    const double pm[3] = {a[0] + dp[0], a[1] + dp[1], a[2] + dp[2]}, qm[3] = {b[0] + dq[0], b[1] + dq[1], b[2] + dq[2]};
+    stats[0] = t[0];
+    stats[7] = t[7];
+    for (int k = 0; k < 3; k++) { stats[8 + k] = pm[k]; stats[11 + k] = qm[k]; }
+    // ---- loop control
+    const int ncorr = (int)t[0];
+    const double fitness = t[0] / (double)n_src, rmse = ncorr > 0 ? sqrt(t[7] / t[0]) : 0.0;
     bool done;
     if (first) {
         ctl[1] = 0;
@@ -301,6 +259,51 @@ __global__ void k_icp_decide(double *stats, int n_src, double rel_fitness, doubl
     stats[16] = fitness; stats[17] = rmse;
     ctl[2] = ncorr;
     ctl[0] = done ? 1 : 0;
+    if (done || t[0] < 3.0) return;
+    // ---- the update from this evaluation's correspondences
+    double S[3][3];
+#pragma unroll
+    for (int u = 0; u < 3; u++)
+#pragma unroll
+        for (int v = 0; v < 3; v++) S[u][v] = t[8 + u * 3 + v] - t[0] * dp[u] * dq[v];
+    double N[4][4] = {
+        {S[0][0] + S[1][1] + S[2][2], S[1][2] - S[2][1], S[2][0] - S[0][2], S[0][1] - S[1][0]},
+        {S[1][2] - S[2][1], S[0][0] - S[1][1] - S[2][2], S[0][1] + S[1][0], S[2][0] + S[0][2]},
+        {S[2][0] - S[0][2], S[0][1] + S[1][0], -S[0][0] + S[1][1] - S[2][2], S[1][2] + S[2][1]},
+        {S[0][1] - S[1][0], S[2][0] + S[0][2], S[1][2] + S[2][1], -S[0][0] - S[1][1] + S[2][2]}};
+    double d[4], v[4][4];
+    jacobi4(N, d, v);
+    double q0 = v[0][0], qx = v[1][0], qy = v[2][0], qz = v[3][0], dm = d[0];
+#pragma unroll
+    for (int i = 1; i < 4; i++)
+        if (d[i] > dm) { dm = d[i]; q0 = v[0][i]; qx = v[1][i]; qy = v[2][i]; qz = v[3][i]; }
+    const double nq = sqrt(q0 * q0 + qx * qx + qy * qy + qz * qz);
+    q0 /= nq; qx /= nq; qy /= nq; qz /= nq;
+    const double R[3][3] = {
+        {q0 * q0 + qx * qx - qy * qy - qz * qz, 2 * (qx * qy - q0 * qz), 2 * (qx * qz + q0 * qy)},
+        {2 * (qy * qx + q0 * qz), q0 * q0 - qx * qx + qy * qy - qz * qz, 2 * (qy * qz - q0 * qx)},
+        {2 * (qz * qx - q0 * qy), 2 * (qz * qy + q0 * qx), q0 * q0 - qx * qx - qy * qy + qz * qz}};
+    double U[4][4];
+#pragma unroll
+    for (int u = 0; u < 3; u++) {
+#pragma unroll
+        for (int w = 0; w < 3; w++) U[u][w] = R[u][w];
+        U[u][3] = qm[u] - (R[u][0] * pm[0] + R[u][1] * pm[1] + R[u][2] * pm[2]);
+    }
+    U[3][0] = U[3][1] = U[3][2] = 0.0;
+    U[3][3] = 1.0;
+    double Tn[16];
+#pragma unroll
+    for (int u = 0; u < 4; u++)
+#pragma unroll
+        for (int w = 0; w < 4; w++) {
+            double acc = 0.0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) acc += U[u][k] * T[k * 4 + w];
+            Tn[u * 4 + w] = acc;
+        }
+#pragma unroll
+    for (int k = 0; k < 16; k++) T[k] = Tn[k];
 }
 
 struct IcpLayout {
@@ -313,7 +316,7 @@ IcpLayout icp_layout(int n_src)
     L.cur = o;   o += align_up(sizeof(double) * 3 * (size_t)n_src, 256);
     L.d2 = o;    o += align_up(sizeof(double) * (size_t)n_src, 256);
     L.idx = o;   o += align_up(sizeof(int) * (size_t)n_src, 256);
-    L.part = o;  o += align_up(sizeof(double) * 9 * RED_BLOCKS, 256);
+    L.part = o;  o += align_up(sizeof(double) * ICP_NSUM * RED_BLOCKS, 256);
     L.stats = o; o += 256;
     L.T = o;     o += 256;
     L.nn_d2 = o;  o += align_up(sizeof(double) * NN_SLICES * (size_t)n_src, 256);
@@ -358,39 +361,30 @@ int rcv_icp_point_to_point(const double *src_dev, int n_src, const double *tgt_d
     int *idx = (int *)(w + L.idx), *nn_idx = (int *)(w + L.nn_idx);
     double *nn_d2 = (double *)(w + L.nn_d2);
     const double max_d2 = max_corr_dist * max_corr_dist;
-    const int tb = std::min((n_src + 255) / 256, 1024);
     RCV_HIP_CHECK(hipMemcpyAsync(T, T0, 16 * sizeof(double), hipMemcpyHostToDevice, st));
-    // The whole loop is enqueued in chunks of up to 32 iterations whose kernels test the device-side `done` flag; the host reads
-    // the control words once per chunk (one chunk for Open3D's default of 30 iterations).
-    // blocks of the two-pass reductions: one point per thread at most (the single thread that adds the per-block partials was
-    // most of an iteration when 256 blocks shared 3 000 points)
+    // One evaluation = three launches: nearest neighbours of the transformed source points (16 target slices), merge + the sums
+    // over the correspondences, and a one-wave kernel that closes the evaluation, decides and -- unless done -- updates T.  The
+    // loop is enqueued in chunks of up to 32 iterations whose kernels test the device-side `done` flag; the host reads the control
+    // words once per chunk (one chunk for Open3D's default of 30 iterations).
+    // blocks of the reductions: one point per thread at most
     const int rb = std::max(1, std::min(RED_BLOCKS, (n_src + 255) / 256));
     const int *done = (const int *)(stats + 24);
     RCV_HIP_CHECK(hipMemsetAsync(stats, 0, 256, st));
-    auto evaluate = [&]() {
-        hipLaunchKernelGGL(k_icp_transform, dim3(tb), dim3(256), 0, st, src_dev, n_src, (const double *)T, cur, done);
-        hipLaunchKernelGGL(k_nn_sliced, dim3((n_src + NN_THREADS - 1) / NN_THREADS, NN_SLICES), dim3(NN_THREADS), 0, st, (const double *)cur,
-                           n_src, tgt_dev, n_tgt, nn_d2, nn_idx, done);
-        hipLaunchKernelGGL(k_nn_merge, dim3(tb), dim3(256), 0, st, (const double *)nn_d2, (const int *)nn_idx, n_src, d2, idx, done);
-        hipLaunchKernelGGL(k_icp_sums, dim3(rb), dim3(256), 0, st, (const double *)cur, tgt_dev, (const double *)d2,
-                           (const int *)idx, n_src, max_d2, part, done);
-        hipLaunchKernelGGL(k_icp_finish_sums, dim3(1), dim3(64), 0, st, (const double *)part, rb, stats, done);
+    auto evaluate = [&](int first) {
+        hipLaunchKernelGGL(k_nn_sliced, dim3((n_src + NN_THREADS - 1) / NN_THREADS, NN_SLICES), dim3(NN_THREADS), 0, st, src_dev, n_src,
+                           (const double *)T, cur, tgt_dev, n_tgt, nn_d2, nn_idx, done);
+        hipLaunchKernelGGL(k_icp_merge_sums, dim3(rb), dim3(256), 0, st, (const double *)nn_d2, (const int *)nn_idx, (const double *)cur,
+                           tgt_dev, n_src, max_d2, (const double *)(stats + 8), d2, idx, part, done);
+        hipLaunchKernelGGL(k_icp_finish, dim3(1), dim3(64), 0, st, (const double *)part, rb, stats, T, n_src, relative_fitness,
+                           relative_rmse, max_iteration, first);
     };
-    evaluate();
-    hipLaunchKernelGGL(k_icp_decide, dim3(1), dim3(64), 0, st, stats, n_src, relative_fitness, relative_rmse, max_iteration, 1);
+    evaluate(1);
     RCV_LAUNCH_CHECK();
     double hstat[4];
     int hctl[4] = {0, 0, 0, 0};
     for (int enq = 0; enq < max_iteration;) {
         const int chunk = std::min(32, max_iteration - enq);
-        for (int c = 0; c < chunk; c++) {
-            // the update uses the correspondences of the current evaluation (cur, idx, d2, stats are still in place)
-            hipLaunchKernelGGL(k_icp_cov, dim3(rb), dim3(256), 0, st, (const double *)cur, tgt_dev, (const double *)d2,
-                               (const int *)idx, n_src, max_d2, (const double *)stats, part, done);
-            hipLaunchKernelGGL(k_icp_update, dim3(1), dim3(64), 0, st, (const double *)part, rb, (const double *)stats, T, done);
-            evaluate();
-            hipLaunchKernelGGL(k_icp_decide, dim3(1), dim3(64), 0, st, stats, n_src, relative_fitness, relative_rmse, max_iteration, 0);
-        }
+        for (int c = 0; c < chunk; c++) evaluate(0);
         RCV_LAUNCH_CHECK();
         enq += chunk;
         RCV_HIP_CHECK(hipMemcpyAsync(hctl, stats + 24, sizeof(hctl), hipMemcpyDeviceToHost, st));
