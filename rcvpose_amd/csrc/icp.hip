@@ -14,6 +14,8 @@
 // Nearest neighbours are exact (float64 brute force, target streamed through LDS; ties -> lowest index), the rigid
 // update is Horn's quaternion solution of the same least-squares problem as Umeyama's SVD.
 #include <math.h>
+#include <stdlib.h>
+#include <cmath>
 #include <string.h>
 
 #include <vector>
@@ -123,6 +125,7 @@ __device__ __forceinline__ double block_sum(double v, double *s)
 // covariance S = sum (p - a)(q - b)^T - n (pm - a)(qm - b)^T comes out of ONE pass without cancellation.  Fixed block / thread
 // assignment: reproducible.
 constexpr int ICP_NSUM = 17;
+template <int SL>
 __global__ __launch_bounds__(256) void k_icp_merge_sums(const double *part_d2, const int *part_idx, const double *cur, const double *tgt, int n,
                                                         double max_d2, const double *ref, double *d2_out, int *idx_out, double *part,
                                                         const int *done)
@@ -136,12 +139,14 @@ __global__ __launch_bounds__(256) void k_icp_merge_sums(const double *part_d2, c
     for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
         double best = INFINITY;
         int bi = -1;
-        for (int sl = 0; sl < NN_SLICES; sl++) {
+        for (int sl = 0; sl < SL; sl++) {
             const double d2 = part_d2[(size_t)sl * n + i];
             if (d2 < best) { best = d2; bi = part_idx[(size_t)sl * n + i]; }
         }
-        d2_out[i] = best;
-        idx_out[i] = bi;
+        if (SL > 1) {  // (SL == 1: the grid search wrote d2_out / idx_out itself, part_* alias them)
+            d2_out[i] = best;
+            idx_out[i] = bi;
+        }
         if (bi >= 0 && best <= max_d2) {
             const double p[3] = {cur[3 * i] - a[0], cur[3 * i + 1] - a[1], cur[3 * i + 2] - a[2]};
             const double q[3] = {tgt[3 * bi] - b[0], tgt[3 * bi + 1] - b[1], tgt[3 * bi + 2] - b[2]};
@@ -159,6 +164,105 @@ __global__ __launch_bounds__(256) void k_icp_merge_sums(const double *part_d2, c
     for (int k = 0; k < ICP_NSUM; k++) {
         const double v = block_sum(acc[k], s);
         if (threadIdx.x == 0) part[blockIdx.x * ICP_NSUM + k] = v;
+    }
+}
+
+// ---- nearest neighbour within the correspondence distance through a hashed uniform grid (r03).  The ICP only uses neighbours
+// within max_correspondence_distance h: with the target points binned into cells of edge h, the nearest target within h of a
+// point lies in the 27 cells around the point's own.  Cells are hashed into M = 2^k >= 2 n_tgt buckets (collisions only add
+// candidates); every candidate's squared distance is the brute-force kernel's expression, the minimum is taken with the same
+// rule (smaller distance, then smaller target index), so correspondences -- and everything computed from them -- are those of
+// the exhaustive search.  Points without a target within h report whatever the 27 cells held (never a correspondence).
+__device__ __forceinline__ unsigned grid_hash(long long ix, long long iy, long long iz, unsigned mask)
+{
+    unsigned long long h = (unsigned long long)ix * 73856093ULL ^ (unsigned long long)iy * 19349663ULL ^ (unsigned long long)iz * 83492791ULL;
+    h ^= h >> 29;
+    return (unsigned)h & mask;
+}
+__global__ __launch_bounds__(256) void k_grid_count(const double *b, int n_b, double inv_h, unsigned mask, int *counts, int *max_count)
+{
+    for (int j = blockIdx.x * 256 + threadIdx.x; j < n_b; j += gridDim.x * 256) {
+        const unsigned h = grid_hash((long long)floor(b[3 * j] * inv_h), (long long)floor(b[3 * j + 1] * inv_h), (long long)floor(b[3 * j + 2] * inv_h), mask);
+        const int c = atomicAdd(&counts[h], 1) + 1;
+        atomicMax(max_count, c);
+    }
+}
+// exclusive scan of counts[M] into starts[M + 1], one workgroup (M is a power of two >= 1024)
+__global__ __launch_bounds__(1024) void k_grid_scan(const int *counts, int M, int *starts, unsigned long long *sumsq)
+{
+    __shared__ int s[1024];
+    const int per = M / 1024, t = threadIdx.x;
+    int sum = 0;
+    unsigned long long sq = 0;
+    for (int k = 0; k < per; k++) {
+        const int c = counts[t * per + k];
+        sum += c;
+        sq += (unsigned long long)c * (unsigned long long)c;
+    }
+    atomicAdd(sumsq, sq);  // sum of squared bucket counts / n = the occupancy a target point sees in its own bucket
+    s[t] = sum;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const int v = t >= off ? s[t - off] : 0;
+        __syncthreads();
+        s[t] += v;
+        __syncthreads();
+    }
+    int run = s[t] - sum;
+    for (int k = 0; k < per; k++) {
+        starts[t * per + k] = run;
+        run += counts[t * per + k];
+    }
+    if (t == 1023) starts[M] = run;
+}
+__global__ __launch_bounds__(256) void k_grid_fill(const double *b, int n_b, double inv_h, unsigned mask, const int *starts, int *cursor,
+                                                   double *sorted, int *sorted_idx)
+{
+    for (int j = blockIdx.x * 256 + threadIdx.x; j < n_b; j += gridDim.x * 256) {
+        const double x = b[3 * j], y = b[3 * j + 1], z = b[3 * j + 2];
+        const unsigned h = grid_hash((long long)floor(x * inv_h), (long long)floor(y * inv_h), (long long)floor(z * inv_h), mask);
+        const int pos = starts[h] + atomicAdd(&cursor[h], 1);
+        sorted[3 * pos] = x; sorted[3 * pos + 1] = y; sorted[3 * pos + 2] = z;
+        sorted_idx[pos] = j;
+    }
+}
+// 32 lanes per source point, one per neighbouring cell (27 of them work): with a thread per point the 6 000-point model gave the
+// chip 94 waves that each walked 27 dependent bucket lookups -- 45 us of latency for 600 k distance evaluations.  Two cells that
+// hash to one bucket make two lanes scan the same points; the minimum does not care.
+__global__ __launch_bounds__(256) void k_nn_grid(const double *a, int n_a, const double *T, double *cur, const double *sorted, const int *sorted_idx,
+                                                 const int *starts, double inv_h, unsigned mask, double *d2_out, int *idx_out, const int *done)
+{
+    if (done && *done) return;
+    const int c = threadIdx.x & 31;
+    int i = blockIdx.x * 8 + (threadIdx.x >> 5);
+    const bool live = i < n_a;
+    i = live ? i : n_a - 1;
+    const double x = a[3 * i], y = a[3 * i + 1], z = a[3 * i + 2];
+    const double px = T[0] * x + T[1] * y + T[2] * z + T[3];
+    const double py = T[4] * x + T[5] * y + T[6] * z + T[7];
+    const double pz = T[8] * x + T[9] * y + T[10] * z + T[11];
+    double best = INFINITY;
+    int bi = -1;
+    if (c < 27) {
+        const int dx = c % 3 - 1, dy = (c / 3) % 3 - 1, dz = c / 9 - 1;
+        const unsigned h = grid_hash((long long)floor(px * inv_h) + dx, (long long)floor(py * inv_h) + dy, (long long)floor(pz * inv_h) + dz, mask);
+        const int e = starts[h + 1];
+        for (int j = starts[h]; j < e; j++) {
+            const double ex = px - sorted[3 * j], ey = py - sorted[3 * j + 1], ez = pz - sorted[3 * j + 2];
+            const double d2 = ex * ex + ey * ey + ez * ez;
+            const int oj = sorted_idx[j];
+            if (d2 < best || (d2 == best && oj < bi)) { best = d2; bi = oj; }
+        }
+    }
+    for (int m = 16; m; m >>= 1) {  // (xor masks below 32 stay inside the point's half of the wave)
+        const double ob = __shfl_xor(best, m);
+        const int oi = __shfl_xor(bi, m);
+        if (ob < best || (ob == best && oi >= 0 && (bi < 0 || oi < bi))) { best = ob; bi = oi; }
+    }
+    if (live && c == 0) {
+        cur[3 * i] = px; cur[3 * i + 1] = py; cur[3 * i + 2] = pz;
+        d2_out[i] = best;
+        idx_out[i] = bi;
     }
 }
 
@@ -370,11 +474,55 @@ int rcv_icp_point_to_point(const double *src_dev, int n_src, const double *tgt_d
     const int rb = std::max(1, std::min(RED_BLOCKS, (n_src + 255) / 256));
     const int *done = (const int *)(stats + 24);
     RCV_HIP_CHECK(hipMemsetAsync(stats, 0, 256, st));
+    // ---- the neighbour search: hashed grid of cell edge max_corr_dist where that bins the target finely, else the sliced scan
+    bool use_grid = false;
+    char *gmem = nullptr;
+    int *g_starts = nullptr, *g_sorted_idx = nullptr;
+    double *g_sorted = nullptr;
+    unsigned g_mask = 0;
+    const double inv_h = max_corr_dist > 0.0 ? 1.0 / max_corr_dist : 0.0;
+    const char *no_grid = getenv("RCV_ICP_NO_GRID");  // (tests: the exhaustive search for comparison)
+    if (max_corr_dist > 1e-9 && std::isfinite(inv_h) && n_tgt >= 2048 && !(no_grid && no_grid[0] == '1')) {
+        int M = 1024;
+        while (M < 2 * n_tgt) M <<= 1;
+        const size_t o_counts = 0, o_starts = o_counts + align_up(sizeof(int) * (size_t)M, 256);
+        const size_t o_cursor = o_starts + align_up(sizeof(int) * ((size_t)M + 1), 256), o_max = o_cursor + align_up(sizeof(int) * (size_t)M, 256);
+        const size_t o_sorted = o_max + 256, o_sidx = o_sorted + align_up(sizeof(double) * 3 * (size_t)n_tgt, 256);
+        const size_t g_total = o_sidx + align_up(sizeof(int) * (size_t)n_tgt, 256);
+        RCV_HIP_CHECK(hipMallocAsync((void **)&gmem, g_total, st));
+        int *counts = (int *)(gmem + o_counts), *cursor = (int *)(gmem + o_cursor), *maxc = (int *)(gmem + o_max);
+        g_starts = (int *)(gmem + o_starts);
+        g_sorted = (double *)(gmem + o_sorted);
+        g_sorted_idx = (int *)(gmem + o_sidx);
+        g_mask = (unsigned)(M - 1);
+        RCV_HIP_CHECK(hipMemsetAsync(gmem, 0, o_sorted, st));
+        const int gb = std::min((n_tgt + 255) / 256, 1024);
+        hipLaunchKernelGGL(k_grid_count, dim3(gb), dim3(256), 0, st, tgt_dev, n_tgt, inv_h, g_mask, counts, maxc);
+        hipLaunchKernelGGL(k_grid_scan, dim3(1), dim3(1024), 0, st, (const int *)counts, M, g_starts, (unsigned long long *)(maxc + 2));
+        hipLaunchKernelGGL(k_grid_fill, dim3(gb), dim3(256), 0, st, tgt_dev, n_tgt, inv_h, g_mask, (const int *)g_starts, cursor, g_sorted,
+                           g_sorted_idx);
+        RCV_LAUNCH_CHECK();
+        int hgrid[4] = {0, 0, 0, 0};  // largest bucket, -, sum of squared bucket counts (64 bits)
+        RCV_HIP_CHECK(hipMemcpyAsync(hgrid, maxc, sizeof(hgrid), hipMemcpyDeviceToHost, st));
+        RCV_HIP_CHECK(hipStreamSynchronize(st));
+        unsigned long long sumsq;
+        memcpy(&sumsq, hgrid + 2, sizeof(sumsq));
+        // a fine binning only: the occupancy a point meets in a bucket stays small (a lane scans one bucket from global memory;
+        // a reach of the size of the object would scan most of the cloud without the LDS tiles of the exhaustive kernel)
+        use_grid = hgrid[0] <= 1024 && (double)sumsq <= 48.0 * (double)n_tgt;
+    }
     auto evaluate = [&](int first) {
-        hipLaunchKernelGGL(k_nn_sliced, dim3((n_src + NN_THREADS - 1) / NN_THREADS, NN_SLICES), dim3(NN_THREADS), 0, st, src_dev, n_src,
-                           (const double *)T, cur, tgt_dev, n_tgt, nn_d2, nn_idx, done);
-        hipLaunchKernelGGL(k_icp_merge_sums, dim3(rb), dim3(256), 0, st, (const double *)nn_d2, (const int *)nn_idx, (const double *)cur,
-                           tgt_dev, n_src, max_d2, (const double *)(stats + 8), d2, idx, part, done);
+        if (use_grid) {
+            hipLaunchKernelGGL(k_nn_grid, dim3((n_src + 7) / 8), dim3(256), 0, st, src_dev, n_src, (const double *)T, cur,
+                               (const double *)g_sorted, (const int *)g_sorted_idx, (const int *)g_starts, inv_h, g_mask, d2, idx, done);
+            hipLaunchKernelGGL(k_icp_merge_sums<1>, dim3(rb), dim3(256), 0, st, (const double *)d2, (const int *)idx, (const double *)cur,
+                               tgt_dev, n_src, max_d2, (const double *)(stats + 8), d2, idx, part, done);
+        } else {
+            hipLaunchKernelGGL(k_nn_sliced, dim3((n_src + NN_THREADS - 1) / NN_THREADS, NN_SLICES), dim3(NN_THREADS), 0, st, src_dev, n_src,
+                               (const double *)T, cur, tgt_dev, n_tgt, nn_d2, nn_idx, done);
+            hipLaunchKernelGGL(k_icp_merge_sums<NN_SLICES>, dim3(rb), dim3(256), 0, st, (const double *)nn_d2, (const int *)nn_idx,
+                               (const double *)cur, tgt_dev, n_src, max_d2, (const double *)(stats + 8), d2, idx, part, done);
+        }
         hipLaunchKernelGGL(k_icp_finish, dim3(1), dim3(64), 0, st, (const double *)part, rb, stats, T, n_src, relative_fitness,
                            relative_rmse, max_iteration, first);
     };
@@ -403,6 +551,7 @@ int rcv_icp_point_to_point(const double *src_dev, int n_src, const double *tgt_d
     out->n_correspondences = ncorr;
     out->iterations = it;
     out->status = RCV_OK;
+    if (gmem) RCV_HIP_CHECK(hipFreeAsync(gmem, st));
     return RCV_OK;
 }
 

@@ -73,3 +73,33 @@ def test_icp_degenerate_inputs():
     assert far.n_correspondences == 0 and far.iterations == 0 and np.array_equal(far.transformation, np.eye(4))
     same = registration_icp(a, a, 0.5)
     assert same.fitness == 1.0 and same.inlier_rmse < 1e-9 and np.allclose(same.transformation, np.eye(4), atol=1e-9)
+
+
+@pytest.mark.parametrize("seed,reach", [(3, 4.0), (4, 9.0), (5, 60.0)])
+def test_icp_grid_search_equals_exhaustive_search(seed, reach, monkeypatch):
+    """The hashed-grid neighbour search (targets binned at the correspondence distance; taken when that bins the cloud finely)
+    must give the exhaustive search's correspondences, hence bit-identical ICP results -- also with duplicate target points
+    (ties go to the lower index in both) and against the oracle."""
+    from rcvpose_amd.registration import ICPConvergenceCriteria, registration_icp
+
+    rng = np.random.default_rng(seed)
+    model = _model(rng, 6000)
+    Rg, tg = _rot(rng, 40), np.array([20.0, -30.0, 900.0])
+    vis = (model @ Rg.T)[:, 2] < 25
+    scene = model[vis] @ Rg.T + tg + rng.normal(size=(vis.sum(), 3)) * 0.3
+    scene = np.concatenate([scene, scene[:200], rng.uniform(-300, 300, size=(500, 3)) + tg])  # duplicates + clutter
+    assert scene.shape[0] >= 2048
+    init = np.eye(4)
+    init[:3, :3] = _rot(rng, 2.0) @ Rg
+    init[:3, 3] = tg + rng.normal(size=3) * 2.0
+    crit = ICPConvergenceCriteria()
+    got = registration_icp(model, scene, reach, init, crit)
+    monkeypatch.setenv("RCV_ICP_NO_GRID", "1")
+    full = registration_icp(model, scene, reach, init, crit)
+    monkeypatch.delenv("RCV_ICP_NO_GRID")
+    assert got.iterations == full.iterations and got.n_correspondences == full.n_correspondences
+    assert got.fitness == full.fitness and got.inlier_rmse == full.inlier_rmse
+    assert np.array_equal(got.transformation, full.transformation)
+    ref = icp_oracle.registration_icp(model, scene, reach, init, crit.relative_fitness, crit.relative_rmse, crit.max_iteration)
+    assert got.iterations == ref["iterations"] and got.n_correspondences == ref["n_correspondences"]
+    assert np.allclose(got.transformation, ref["transformation"], rtol=0, atol=1e-6)
