@@ -223,8 +223,12 @@ typedef struct rcv_icp_result {
 /*
  * open3d.pipelines.registration.registration_icp(source, target, max_correspondence_distance, init,
  * TransformationEstimationPointToPoint(), ICPConvergenceCriteria(relative_fitness, relative_rmse, max_iteration)),
- * AccumulatorSpace.py:706-712 (defaults 1e-6, 1e-6, 30) and :935-943.  Synchronous: the convergence test runs on the
- * host once per iteration; `out` is host memory.  Workspace: rcv_icp_workspace_bytes(n_src) device bytes.
+ * AccumulatorSpace.py:706-712 (defaults 1e-6, 1e-6, 30) and :935-943.  Synchronous (`out` is host memory): the convergence
+ * test runs on the device, the host reads the loop's control words once per 32 enqueued iterations.  The neighbour search is a
+ * hashed grid at max_corr_dist when that bins the target finely (its buckets come from the stream's memory pool,
+ * hipMallocAsync / hipFreeAsync) and an exhaustive scan otherwise -- same correspondences either way; the environment variable
+ * RCV_ICP_NO_GRID=1 forces the exhaustive scan (used by the tests to compare the two).
+ * Workspace: rcv_icp_workspace_bytes(n_src) device bytes.
  */
 size_t rcv_icp_workspace_bytes(int n_src);
 int rcv_icp_point_to_point(const double *src_dev, int n_src, const double *tgt_dev, int n_tgt, double max_corr_dist,
