@@ -101,7 +101,8 @@ __device__ __forceinline__ void x3_split(float v, H16 &hi, H16 &lo)
 // instruction (v_cvt_pk_f16_f32) and subtracts / adds two floats in one (v_pk_add_f32) -- 36 VALU instructions per eight
 // elements instead of 56 + 8 to pack; element for element the same IEEE operations as x3_split.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-#ifdef RCV_FCN_X3
+// (-DRCV_X3_SCALAR_HELPERS: the element-by-element forms, for an A-B check of the outputs' hash -- tools/fcn_hash.py)
+#if defined(RCV_FCN_X3) && !defined(RCV_X3_SCALAR_HELPERS)
 typedef _Float16 x3_h2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void x3_split8(const float *v, uint4 &hi, uint4 &lo)
 {
@@ -1626,15 +1627,27 @@ __device__ __forceinline__ float bilerp(float hy, float hx, float ly, float lx, 
 __device__ __forceinline__ void bilerp8_rows(float hx, float lx, const float *p00, const float *p01, const float *p10, const float *p11,
                                              f32x2 *t0, f32x2 *t1)
 {
+#ifdef RCV_X3_SCALAR_HELPERS
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+        t0[e >> 1][e & 1] = __fmaf_rn(lx, p01[e], __fmul_rn(hx, p00[e]));
+        t1[e >> 1][e & 1] = __fmaf_rn(lx, p11[e], __fmul_rn(hx, p10[e]));
+    }
+#else
     const f32x2 hx2 = {hx, hx}, lx2 = {lx, lx};
 #pragma unroll
     for (int e = 0; e < 4; e++) {
         t0[e] = __builtin_elementwise_fma(lx2, (f32x2){p01[2 * e], p01[2 * e + 1]}, hx2 * (f32x2){p00[2 * e], p00[2 * e + 1]});
         t1[e] = __builtin_elementwise_fma(lx2, (f32x2){p11[2 * e], p11[2 * e + 1]}, hx2 * (f32x2){p10[2 * e], p10[2 * e + 1]});
     }
+#endif
 }
 __device__ __forceinline__ void bilerp8_col(float hy, float ly, const f32x2 *t0, const f32x2 *t1, float *out)
 {
+#ifdef RCV_X3_SCALAR_HELPERS
+#pragma unroll
+    for (int e = 0; e < 8; e++) out[e] = __fmaf_rn(hy, t0[e >> 1][e & 1], __fmul_rn(ly, t1[e >> 1][e & 1]));
+#else
     const f32x2 hy2 = {hy, hy}, ly2 = {ly, ly};
 #pragma unroll
     for (int e = 0; e < 4; e++) {
@@ -1642,6 +1655,7 @@ __device__ __forceinline__ void bilerp8_col(float hy, float ly, const f32x2 *t0,
         out[2 * e] = r[0];
         out[2 * e + 1] = r[1];
     }
+#endif
 }
 // source row/column and weights of destination index d for the 2x upsampling: ATen's area_pixel_compute_source_index
 // (align_corners = False): s = max(0.5 * (d + 0.5) - 0.5, 0)
