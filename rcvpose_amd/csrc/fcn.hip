@@ -956,7 +956,7 @@ __global__ __launch_bounds__(512) void k_conv_lat(const ConvParams p)
 // k_conv_dma brings the [256 px][64 ch] A tile of a channel slice in nine times, once per tap (32 KB per K step through
 // the CU's 64 B/clk vector-memory path, next to 16 KB of weights).  Here a workgroup owns a th x tw pixel rectangle of one
 // image (th * tw <= 256) and keeps, per 64-channel slice, the (th+2) x (tw+2) patch around it in LDS (<= 48 rows-of-8 =
-// 48 KB, double buffered, filled by LDS-DMA during the previous slice's nine steps, six pieces per wave); the A fragments of
+// 56 KB, double buffered, filled by LDS-DMA during the previous slice's nine steps, seven pieces per wave); the A fragments of
 // tap (dh, dw) are ds_read_b128 at the patch row of the pixel shifted by (dh-1) * (tw+2) + (dw-1).  Pixels outside the
 // image are out-of-range buffer offsets (zeros), per patch row and independent of the tap.  Weights: k_conv_dma's ring of
 // three 16 KB stages, two pieces per wave and step.  Same K order (channel-slice-major, taps innermost) and MFMA sequence
@@ -988,7 +988,8 @@ struct HaloParams {
     int C0, C1, Cout, H, W, n_img, relu, K;
     int th, tw, tiles_y, tiles_x;
 };
-constexpr int HALO_PIECES = 48;                               // patch rows / 8 (six pieces per wave)
+constexpr int HALO_PPW = 7;                                   // patch pieces per wave and slice (one per tap 0 .. HALO_PPW - 1)
+constexpr int HALO_PIECES = 8 * HALO_PPW;                     // patch rows / 8: 448 rows -- a 320-pixel rectangle with its halo (10 x 42)
 constexpr int HALO_PATCH = HALO_PIECES * 1024;                // bytes per patch buffer
 constexpr int halo_lds(int bn) { return 2 * HALO_PATCH + 3 * bn * 128; }  // 144 KB for BN = 128
 
@@ -1028,9 +1029,9 @@ __global__ __launch_bounds__(512) void k_conv_halo(const HaloParams p)
     const float rP = 1.0f / (float)pitch, rT = 1.0f / (float)p.tw;
 
     // loader: patch piece k of this wave = patch rows (k * 8 + wave) * 8 + lrow; pixel index in the image or -1
-    int lin[6];
+    int lin[HALO_PPW];
 #pragma unroll
-    for (int k = 0; k < 6; k++) {
+    for (int k = 0; k < HALO_PPW; k++) {
         const int pr = (k * 8 + wave) * 8 + lrow;
         const int py = (int)(((float)pr + 0.5f) * rP), px = pr - py * pitch;
         const int y = y0 - 1 + py, x = x0 - 1 + px;
@@ -1087,8 +1088,8 @@ __global__ __launch_bounds__(512) void k_conv_halo(const HaloParams p)
     const int ch0 = ((0 * 4 + kq) ^ ((r16 >> 1) & 7)) << 4, ch1 = ((1 * 4 + kq) ^ ((r16 >> 1) & 7)) << 4;
 
 // One K step = (slice sl, tap TAP), four phases as in k_conv_dma.  Pieces issued: first load phase the first weight piece
-// of step + 2, second load phase its second piece and (taps 0..5) one patch piece of slice sl + 1; the counted wait of the
-// second load phase leaves exactly those in flight, so the weights of step + 1 (and by tap 6 the whole next patch) have
+// of step + 2, second load phase its second piece and (taps 0..6) one patch piece of slice sl + 1; the counted wait of the
+// second load phase leaves exactly those in flight, so the weights of step + 1 (and by tap 7 the whole next patch) have
 // landed at least one barrier before anybody reads them.  The patch buffer refilled during slice sl was last read in the
 // second load phase of slice sl - 1's last step, two barriers before the first piece goes out.
 #define RCV_HALO_STEP(TAP)                                                                                     \
@@ -1118,7 +1119,7 @@ __global__ __launch_bounds__(512) void k_conv_halo(const HaloParams p)
         _Pragma("unroll") for (int i = 0; i < MT; i++) af[i] = *(const bf16x8 *)(Pb + (ao_[i] ^ 64));          \
         _Pragma("unroll") for (int j = 0; j < NT; j++) bfr[j] = *(const bf16x8 *)(Bb + j * 16 * 128 + ch1);    \
         if constexpr (BPW == 2) RCV_HALO_B(sl + S2_, T2_, st2, 1);                                             \
-        if constexpr ((TAP) < 6) {                                                                             \
+        if constexpr ((TAP) < HALO_PPW) {                                                                             \
             RCV_HALO_PATCH(sl + 1, TAP);                                                                       \
             if constexpr (BPW == 2) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");                \
             else asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");                                   \
@@ -1158,7 +1159,7 @@ __global__ __launch_bounds__(512) void k_conv_halo(const HaloParams p)
             bfr[1][j] = *(const bf16x8 *)(Bb + j * 16 * 128 + ch1);                                            \
         }                                                                                                      \
         RCV_HALO_B(sl + S2_, T2_, st2, 0);                                                                     \
-        if constexpr ((TAP) < 6) {                                                                             \
+        if constexpr ((TAP) < HALO_PPW) {                                                                             \
             RCV_HALO_PATCH(sl + 1, TAP);                                                                       \
             asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");                                        \
         } else {                                                                                               \
@@ -1216,7 +1217,7 @@ __global__ __launch_bounds__(512) void k_conv_halo(const HaloParams p)
         _Pragma("unroll") for (int i = 0; i < MT; i++) al[i] = *(const bf16x8 *)(Pb + (ao_[i] ^ 64));          \
         _Pragma("unroll") for (int j = NT / 2; j < NT; j++) bl[j] = *(const bf16x8 *)(Bb + j * 16 * 128 + ch1); \
         if constexpr (BPW == 2) RCV_HALO_B(sl + S2_, T2_, st2, 1);                                             \
-        if constexpr ((TAP) < 6) {                                                                             \
+        if constexpr ((TAP) < HALO_PPW) {                                                                             \
             RCV_HALO_PATCH(sl + 1, TAP);                                                                       \
             if constexpr (BPW == 2) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");                \
             else asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");                                   \
@@ -1259,7 +1260,7 @@ __global__ __launch_bounds__(512) void k_conv_halo(const HaloParams p)
         }                                                                                                      \
         RCV_HALO_B(sl + S2_, T2_, st2, 0);                                                                     \
         if constexpr (BPW == 2) RCV_HALO_B(sl + S2_, T2_, st2, 1);                                             \
-        if constexpr ((TAP) < 6) {                                                                             \
+        if constexpr ((TAP) < HALO_PPW) {                                                                             \
             RCV_HALO_PATCH(sl + 1, TAP);                                                                       \
             if constexpr (BPW == 2) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");                \
             else asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");                                   \
@@ -1288,7 +1289,7 @@ __global__ __launch_bounds__(512) void k_conv_halo(const HaloParams p)
     bool stamp_on = false;
 #endif
 #pragma unroll
-    for (int k = 0; k < 6; k++) RCV_HALO_PATCH(0, k);
+    for (int k = 0; k < HALO_PPW; k++) RCV_HALO_PATCH(0, k);
     RCV_HALO_B(0, 0, 0, 0);
     if constexpr (BPW == 2) RCV_HALO_B(0, 0, 0, 1);
     RCV_HALO_B(0, 1, 1, 0);
@@ -3469,32 +3470,42 @@ int launch_conv_dma(const ConvParams &p, int groups, hipStream_t st, bool set_at
     return RCV_OK;
 }
 
-// k_conv_halo where it applies: 3x3 / stride 1 / pad 1, bf16, Cout a multiple of 128, a pixel rectangle of <= 256 pixels
-// whose halo'd patch fits 48 DMA pieces and that covers the image with little waste, and enough workgroups
-bool halo_tile(int H, int W, int mode, int &th, int &tw)
+// k_conv_halo where it applies: 3x3 / stride 1 / pad 1, 16-bit operands, a pixel rectangle of <= 256 pixels -- or of 320 for
+// Cout % 128 == 0 -- whose halo'd patch fits the DMA pieces and that covers the image with little waste.  Among the rectangles
+// that do, the one with the least modelled time: rounds of 256 workgroups x rows per tile / the kernel's matrix-core rate at
+// that tile height (r03 counters: 0.73 busy with 256 rows, 0.83 with 320 -- 60 MFMAs per phase pair instead of 48 against the
+// same barriers).  `units` = workgroups per tile position (images x networks x output-channel tiles).
+bool halo_tile(int H, int W, int mode, int bn, long long units, int &th, int &tw)
 {
-    // rectangles of <= 256 pixels, and 15 x 20 (a whole 15 x 20 image: the 320-row tile, 128 output channels only)
-    const int cand[5][2] = {{8, 32}, {6, 40}, {12, 20}, {16, 16}, {15, 20}};
+    const int cand[9][2] = {{8, 32}, {6, 40}, {12, 20}, {16, 16}, {15, 20}, {8, 40}, {20, 16}, {10, 32}, {16, 20}};
+    const double thr = mode == 2 ? 0.3 : 0.9;  // mode 2 (tests): also where rectangles hang over the image edge a lot
     double best = 0.0;
+    bool found = false;
     for (auto &c : cand) {
         if ((c[0] + 2) * (c[1] + 2) > HALO_PIECES * 8) continue;
-        const double rows = c[0] * c[1] > 256 ? 320.0 : 256.0;
-        const double util = (double)H * W / ((double)((H + c[0] - 1) / c[0]) * ((W + c[1] - 1) / c[1]) * rows);
-        if (util > best) { best = util; th = c[0]; tw = c[1]; }
+        const bool tall = c[0] * c[1] > 256;
+        if (tall && bn != 128) continue;
+        const double rows = tall ? 320.0 : 256.0;
+        const long long tiles = (long long)((H + c[0] - 1) / c[0]) * ((W + c[1] - 1) / c[1]);
+        const double util = (double)H * W / ((double)tiles * rows);
+        if (util < thr) continue;
+        const double rounds = (double)((tiles * units + 255) / 256);
+        const double cost = rounds * rows / (tall ? 0.83 : 0.73);
+        if (!found || cost < best) { best = cost; th = c[0]; tw = c[1]; found = true; }
     }
-    return best >= (mode == 2 ? 0.3 : 0.9);  // mode 2 (tests): also where rectangles hang over the image edge a lot
+    return found;
 }
 
 int launch_conv_halo(const ConvParams &p, int B, int groups, int mode, hipStream_t st)
 {
     HaloParams q;
     memset(&q, 0, sizeof(q));
-    if (!halo_tile(p.Hout, p.Wout, mode, q.th, q.tw)) return RCV_E_UNSUPPORTED;
+    const int bn = p.Cout % 128 == 0 ? 128 : 64;
+    if (!halo_tile(p.Hout, p.Wout, mode, bn, (long long)B * groups * (p.Cout / bn), q.th, q.tw)) return RCV_E_UNSUPPORTED;
     q.src0 = p.src0; q.src1 = p.src1; q.w = p.w; q.dst = p.dst; q.bias = p.bias;
     q.src0_gs = p.src0_gs; q.src1_gs = p.src1_gs; q.dst_gs = p.dst_gs; q.w_gs = p.w_gs; q.bias_gs = p.bias_gs;
     q.C0 = p.C0; q.C1 = p.C1; q.Cout = p.Cout; q.H = p.Hout; q.W = p.Wout; q.n_img = B; q.relu = p.relu; q.K = p.K;
     q.tiles_y = (q.H + q.th - 1) / q.th; q.tiles_x = (q.W + q.tw - 1) / q.tw;
-    const int bn = p.Cout % 128 == 0 ? 128 : 64;
     dim3 grid(p.Cout / bn, (unsigned)(B * q.tiles_y * q.tiles_x), groups);
     if (q.th * q.tw > 256) {
         if (bn != 128) return RCV_E_UNSUPPORTED;
@@ -3622,9 +3633,11 @@ int run_op(rcv_fcn *h, const rcv_op &op, const float *x, int B, float *seg, floa
         const bool dma_ok = h->use_dma && fits32(op.src0) && fits32(op.src1) && fits32(op.res) && fits32(op.dst);
         if constexpr (sizeof(T) == 2) {
             int th, tw;
+            const int hbn = p.Cout % 128 == 0 ? 128 : 64;
             if (h->use_halo && dma_ok && op.ksize == 3 && op.stride == 1 && op.pad == 1 && op.res < 0 && p.Cout % 64 == 0 &&
-                p.C0 % 64 == 0 && p.C1 % 64 == 0 && op.hin == op.hout && op.win == op.wout && halo_tile(op.hout, op.wout, h->use_halo, th, tw) && (th * tw <= 256 || p.Cout % 128 == 0) &&
-                (long long)B * ((op.hout + th - 1) / th) * ((op.wout + tw - 1) / tw) * (p.Cout / (p.Cout % 128 == 0 ? 128 : 64)) * G >= 192)
+                p.C0 % 64 == 0 && p.C1 % 64 == 0 && op.hin == op.hout && op.win == op.wout &&
+                halo_tile(op.hout, op.wout, h->use_halo, hbn, (long long)B * G * (p.Cout / hbn), th, tw) &&
+                (long long)B * ((op.hout + th - 1) / th) * ((op.wout + tw - 1) / tw) * (p.Cout / hbn) * G >= 192)
                 return launch_conv_halo(p, B, G, h->use_halo, st);
         }
         return launch_conv<T>(p, G, st, !h->attrs_set, dma_ok, h->use_lat);
