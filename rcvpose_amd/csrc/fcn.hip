@@ -988,10 +988,13 @@ struct HaloParams {
     int C0, C1, Cout, H, W, n_img, relu, K;
     int th, tw, tiles_y, tiles_x;
 };
-constexpr int HALO_PPW = 7;                                   // patch pieces per wave and slice (one per tap 0 .. HALO_PPW - 1)
-constexpr int HALO_PIECES = 8 * HALO_PPW;                     // patch rows / 8: 448 rows -- a 320-pixel rectangle with its halo (10 x 42)
-constexpr int HALO_PATCH = HALO_PIECES * 1024;                // bytes per patch buffer
-constexpr int halo_lds(int bn) { return 2 * HALO_PATCH + 3 * bn * 128; }  // 144 KB for BN = 128
+// patch pieces (8 rows x 128 B) per wave and slice, one per tap 0 .. PPW - 1.  BN = 128: 7 -> 448 patch rows, a 320-pixel rectangle
+// with its halo (10 x 42); BN = 64 (half the weight stages): 8 -> 512 rows, a 384-pixel rectangle (14 x 34)
+constexpr int halo_ppw(int bn) { return bn == 64 ? 8 : 7; }
+constexpr int halo_patch_rows(int bn) { return halo_ppw(bn) * 64; }
+constexpr int halo_patch(int bn) { return halo_ppw(bn) * 8 * 1024; }  // bytes per patch buffer
+constexpr int halo_lds(int bn) { return 2 * halo_patch(bn) + 3 * bn * 128; }  // 160 KB for BN = 128, 152 KB for BN = 64
+static_assert(halo_lds(128) <= 160 * 1024 && halo_lds(64) <= 160 * 1024, "k_conv_halo's LDS plan");
 
 // (plain function: the buffer builtins are device-only and a template kernel's body is also instantiated for the host)
 __device__ __forceinline__ void halo_dma16(const void *base, int num_bytes, unsigned char *lds_wave_base, int voffset)
@@ -1008,6 +1011,7 @@ __global__ __launch_bounds__(512) void k_conv_halo(const HaloParams p)
     constexpr int BPW = BN / 64;                             // weight pieces per wave and K step
     constexpr int OOB = (int)0x80000000;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int HALO_PPW = halo_ppw(BN), HALO_PATCH = halo_patch(BN);
     unsigned char *sP = smem;                    // [2][HALO_PATCH]
     unsigned char *sB = smem + 2 * HALO_PATCH;   // [3][BN][128 B]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -3474,23 +3478,27 @@ int launch_conv_dma(const ConvParams &p, int groups, hipStream_t st, bool set_at
 // Cout % 128 == 0 -- whose halo'd patch fits the DMA pieces and that covers the image with little waste.  Among the rectangles
 // that do, the one with the least modelled time: rounds of 256 workgroups x rows per tile / the kernel's matrix-core rate at
 // that tile height (r03 counters: 0.73 busy with 256 rows, 0.83 with 320 -- 60 MFMAs per phase pair instead of 48 against the
-// same barriers).  `units` = workgroups per tile position (images x networks x output-channel tiles).
+// same barriers; BN = 64: 24 MFMAs per step with 256 rows, 36 with 384).  `units` = workgroups per tile position (images x
+// networks x output-channel tiles).
 bool halo_tile(int H, int W, int mode, int bn, long long units, int &th, int &tw)
 {
-    const int cand[9][2] = {{8, 32}, {6, 40}, {12, 20}, {16, 16}, {15, 20}, {8, 40}, {20, 16}, {10, 32}, {16, 20}};
+    const int cand[13][2] = {{8, 32}, {6, 40}, {12, 20}, {16, 16}, {15, 20}, {8, 40}, {20, 16}, {10, 32}, {16, 20}, {12, 32}, {16, 24}, {8, 48}, {24, 16}};
+    const int tall_px = bn == 128 ? 320 : 384;  // pixels of the tall tile (five / six 16-row tiles per wave row)
     const double thr = mode == 2 ? 0.3 : 0.9;  // mode 2 (tests): also where rectangles hang over the image edge a lot
     double best = 0.0;
     bool found = false;
     for (auto &c : cand) {
-        if ((c[0] + 2) * (c[1] + 2) > HALO_PIECES * 8) continue;
-        const bool tall = c[0] * c[1] > 256;
-        if (tall && bn != 128) continue;
-        const double rows = tall ? 320.0 : 256.0;
+        const int px = c[0] * c[1];
+        if ((c[0] + 2) * (c[1] + 2) > halo_patch_rows(bn) || px > tall_px) continue;
+        const bool tall = px > 256;
+        const double rows = tall ? (double)tall_px : 256.0;
         const long long tiles = (long long)((H + c[0] - 1) / c[0]) * ((W + c[1] - 1) / c[1]);
         const double util = (double)H * W / ((double)tiles * rows);
         if (util < thr) continue;
         const double rounds = (double)((tiles * units + 255) / 256);
-        const double cost = rounds * rows / (tall ? 0.83 : 0.73);
+        // matrix-core busy fractions of the four forms (r03 counters; the 384-row form of BN = 64 estimated from its step)
+        const double rate = bn == 128 ? (tall ? 0.83 : 0.73) : (tall ? 0.62 : 0.52);
+        const double cost = rounds * rows / rate;
         if (!found || cost < best) { best = cost; th = c[0]; tw = c[1]; found = true; }
     }
     return found;
@@ -3508,8 +3516,8 @@ int launch_conv_halo(const ConvParams &p, int B, int groups, int mode, hipStream
     q.tiles_y = (q.H + q.th - 1) / q.th; q.tiles_x = (q.W + q.tw - 1) / q.tw;
     dim3 grid(p.Cout / bn, (unsigned)(B * q.tiles_y * q.tiles_x), groups);
     if (q.th * q.tw > 256) {
-        if (bn != 128) return RCV_E_UNSUPPORTED;
-        hipLaunchKernelGGL((k_conv_halo<128, 5>), grid, dim3(512), halo_lds(128), st, q);
+        if (bn == 128) hipLaunchKernelGGL((k_conv_halo<128, 5>), grid, dim3(512), halo_lds(128), st, q);
+        else hipLaunchKernelGGL((k_conv_halo<64, 6>), grid, dim3(512), halo_lds(64), st, q);
     } else if (bn == 128) hipLaunchKernelGGL((k_conv_halo<128, 4>), grid, dim3(512), halo_lds(128), st, q);
     else hipLaunchKernelGGL((k_conv_halo<64, 4>), grid, dim3(512), halo_lds(64), st, q);
     RCV_LAUNCH_CHECK();
@@ -3677,6 +3685,7 @@ int register_kernel_attributes()
     RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_conv_halo<128, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, halo_lds(128)));
     RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_conv_halo<128, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, halo_lds(128)));
     RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_conv_halo<64, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, halo_lds(64)));
+    RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_conv_halo<64, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, halo_lds(64)));
     RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_stem_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, STEM_LDS));
     RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_tail, hipFuncAttributeMaxDynamicSharedMemorySize, TAIL_LDS));
     RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_tail_x3, hipFuncAttributeMaxDynamicSharedMemorySize, TX_LDS));
