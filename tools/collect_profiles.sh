@@ -4,7 +4,7 @@
 #   tools/collect_profiles.sh <tag>          -> gpurun_out/<tag>/...
 TAG=${1:-r03}
 DT=${2:-f16x3}     # FCN arithmetic of the traffic / matrix-core passes (bench.py's default)
-FB=${3:-51}
+FB=${3:-53}
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT

@@ -21,7 +21,7 @@ import pandas as pd
 
 SRC, TAG = sys.argv[1], sys.argv[2]
 DT = sys.argv[3] if len(sys.argv) > 3 else "f16x3"   # FCN arithmetic of the traffic / matrix-core passes
-FB = int(sys.argv[4]) if len(sys.argv) > 4 else 51   # their frames per step
+FB = int(sys.argv[4]) if len(sys.argv) > 4 else 53   # their frames per step
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, "profiles")
 N_SIMD = 256 * 4
