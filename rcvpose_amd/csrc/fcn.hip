@@ -955,8 +955,9 @@ __global__ __launch_bounds__(512) void k_conv_lat(const ConvParams p)
 // k_conv_halo (bf16): 3x3 / stride 1 / pad 1 convolutions with the A operand read from a halo'd pixel patch.
 // k_conv_dma brings the [256 px][64 ch] A tile of a channel slice in nine times, once per tap (32 KB per K step through
 // the CU's 64 B/clk vector-memory path, next to 16 KB of weights).  Here a workgroup owns a th x tw pixel rectangle of one
-// image (th * tw <= 256) and keeps, per 64-channel slice, the (th+2) x (tw+2) patch around it in LDS (<= 48 rows-of-8 =
-// 56 KB, double buffered, filled by LDS-DMA during the previous slice's nine steps, seven pieces per wave); the A fragments of
+// image (th * tw = 64 * MT pixels at most: 256, 320 with BN = 128 or 384 with BN = 64 -- the taller the tile, the more MFMAs
+// behind each barrier) and keeps, per 64-channel slice, the (th+2) x (tw+2) patch around it in LDS (<= 56 / 64 rows-of-8,
+// double buffered, filled by LDS-DMA during the previous slice's nine steps, seven / eight pieces per wave); the A fragments of
 // tap (dh, dw) are ds_read_b128 at the patch row of the pixel shifted by (dh-1) * (tw+2) + (dw-1).  Pixels outside the
 // image are out-of-range buffer offsets (zeros), per patch row and independent of the tap.  Weights: k_conv_dma's ring of
 // three 16 KB stages, two pieces per wave and step.  Same K order (channel-slice-major, taps innermost) and MFMA sequence
