@@ -476,7 +476,13 @@ int rcv_icp_point_to_point(const double *src_dev, int n_src, const double *tgt_d
     RCV_HIP_CHECK(hipMemsetAsync(stats, 0, 256, st));
     // ---- the neighbour search: hashed grid of cell edge max_corr_dist where that bins the target finely, else the sliced scan
     bool use_grid = false;
-    char *gmem = nullptr;
+    struct PoolBlock {  // the grid's buckets: back to the stream's pool on every way out of this function
+        char *p = nullptr;
+        hipStream_t st;
+        ~PoolBlock() { if (p) (void)hipFreeAsync(p, st); }
+    } gblock;
+    gblock.st = st;
+    char *&gmem = gblock.p;
     int *g_starts = nullptr, *g_sorted_idx = nullptr;
     double *g_sorted = nullptr;
     unsigned g_mask = 0;
@@ -551,7 +557,6 @@ int rcv_icp_point_to_point(const double *src_dev, int n_src, const double *tgt_d
     out->n_correspondences = ncorr;
     out->iterations = it;
     out->status = RCV_OK;
-    if (gmem) RCV_HIP_CHECK(hipFreeAsync(gmem, st));
     return RCV_OK;
 }
 
