@@ -37,7 +37,10 @@ typedef enum rcv_status {
     RCV_E_BADGRID = -5,       /* grid dimension <= 0: reference raises ValueError (AccumulatorSpace.py:401,406) */
     RCV_E_TOO_LARGE = -6,     /* grid dimension, radius or tile count beyond what this build supports */
     RCV_E_GRID_BUFFER = -7,   /* vote_grid_dev given but smaller than dim^3 cells (votes still counted) */
-    RCV_E_UNSUPPORTED = -8    /* layer shape / dtype not supported by the FCN engine */
+    RCV_E_UNSUPPORTED = -8,   /* layer shape / dtype not supported by the FCN engine */
+    RCV_E_RANGE = -9          /* FCN engine, half-precision storage (RCV_F16X3 / RCV_F16): an activation left the half range
+                                 (|v| > 65504) in a forward that has completed -- its maps were clipped (RCV_F16X3) or hold
+                                 infinities (RCV_F16), not the reference's fp32 values.  Sticky: see rcv_fcn_range_status */
 } rcv_status;
 
 const char *rcv_strerror(int status);
@@ -261,8 +264,8 @@ int rcv_preprocess_rgb(const uint8_t *rgb_dev, int B, int H, int W, float *x_dev
  *             fp32 forward (measured ~5e-6, like RCV_F32) at a third of the fp16 matrix rate instead of a sixteenth.
  *             Storage: 4 bytes per element, NHWC with channels in groups of 32 as [32 hi | 32 lo]; weights per op
  *             [G][cout][kh][kw][cin/32][hi 32 | lo 32], each output channel scaled by a power of two 2^k (so that the lo
- *             halves are normal numbers) and biases per op [G][cout bias | cout scale 2^-k]; magnitudes beyond 131008
- *             saturate.  Packing: rcvpose_amd/fcn_engine.py::pack_weights. */
+ *             halves are normal numbers) and biases per op [G][cout bias | cout scale 2^-k]; magnitudes beyond 65504 are
+ *             clamped and reported (RCV_E_RANGE, rcv_fcn_range_status).  Packing: rcvpose_amd/fcn_engine.py::pack_weights. */
 typedef enum rcv_dtype { RCV_F32 = 0, RCV_BF16 = 1, RCV_F16 = 2, RCV_F16X3 = 3 } rcv_dtype;
 
 typedef enum rcv_op_kind {
@@ -299,7 +302,10 @@ typedef struct rcv_fcn rcv_fcn; /* opaque engine handle */
  *   n_slots, slot_elems[n_slots]: activation slots, sizes in elements PER GROUP AND PER IMAGE
  *   weights_dev      packed weights, dtype `dtype`, BN folded, layout per op [G][cout][kh][kw][cin]
  *   bias_dev         fp32 biases (BN folded), per op [G][cout]
- * The handle only stores pointers and the program; it owns no device memory.
+ * The handle stores pointers and the program; the only device memory it owns is the 256-byte range-flag word of the
+ * half-precision engines (below), allocated here, not on the hot path.
+ * RCV_F16X3 engines need every tensor of the program to have a multiple of 32 channels (the network input and the head's two
+ * planes excepted): RCV_E_UNSUPPORTED otherwise.
  */
 int rcv_fcn_create(const rcv_op *ops, int n_ops, int n_slots, const int64_t *slot_elems, int groups, int dtype,
                    const void *weights_dev, const float *bias_dev, rcv_fcn **out);
@@ -313,6 +319,19 @@ size_t rcv_fcn_workspace_bytes(const rcv_fcn *h, int B);
  */
 int rcv_fcn_forward(rcv_fcn *h, const float *x_dev, int B, float *seg_dev, float *radial_dev, void *ws,
                     size_t ws_bytes, void *stream);
+/*
+ * Range guard of the half-precision engines.  The reference's forward is fp32 (models/fcnresnet.py:121-191) and has fp32's
+ * range; RCV_F16X3 stores every activation as a pair of halves and CLAMPS magnitudes beyond 65504 (the stored pair is finite
+ * and wrong), RCV_F16 turns them into infinities.  Every kernel that rounds to halves therefore ORs a bit into a flag word of
+ * the engine when it stored such a value (bit 0: an RCV_F16X3 pair was clamped; bit 1: an RCV_F16 store overflowed):
+ *   - rcv_fcn_forward copies the word to the host at the end of each forward (asynchronously, on `stream`) and returns
+ *     RCV_E_RANGE without enqueuing anything once a COMPLETED forward has set it -- sticky until cleared;
+ *   - rcv_fcn_range_status waits for `stream`, writes the word to *flags_out (may be null), clears it when `clear` != 0 and
+ *     returns RCV_E_RANGE if it was set, RCV_OK otherwise.  Call it after a forward whose maps must be trusted (the Python
+ *     mirrors do: models.fcnresnet forward, FCResBackbone, FramePipeline.read_results); use RCV_F32 for such a checkpoint.
+ * RCV_F32 / RCV_BF16 engines have fp32's exponent range: always RCV_OK, flags 0.
+ */
+int rcv_fcn_range_status(rcv_fcn *h, unsigned *flags_out, int clear, void *stream);
 /* Test hook: copy activation slot `slot` of group g (as stored: NHWC, engine dtype) to out_dev as fp32. */
 int rcv_fcn_debug_slot(rcv_fcn *h, const void *ws, int B, int g, int slot, float *out_dev, void *stream);
 

@@ -18,6 +18,7 @@ RCV_E_BADGRID = -5
 RCV_E_TOO_LARGE = -6
 RCV_E_GRID_BUFFER = -7
 RCV_E_UNSUPPORTED = -8
+RCV_E_RANGE = -9
 
 RCV_SEAM_RADIAL_F16 = 256
 RCV_VOTE_AUTO, RCV_VOTE_RASTER = 0, 1
@@ -109,6 +110,7 @@ SYMBOLS = {
     "rcv_fcn_destroy": (None, [_vp]),
     "rcv_fcn_workspace_bytes": (_sz, [_vp, _i]),
     "rcv_fcn_forward": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _sz, _vp]),
+    "rcv_fcn_range_status": (_i, [_vp, ctypes.POINTER(ctypes.c_uint), _i, _vp]),
     "rcv_fcn_debug_slot": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "rcv_fcn_set_profiling": (_i, [_vp, _i]),
     "rcv_fcn_set_option": (_i, [_vp, _i, _i]),
@@ -125,6 +127,10 @@ _lib = None
 
 class HipLibraryError(RuntimeError):
     pass
+
+
+class HalfRangeError(HipLibraryError, FloatingPointError):
+    """RCV_E_RANGE: an activation left the half-precision range of an f16x3 / fp16 engine (the maps are clipped, not exact)."""
 
 
 def load_library():
@@ -174,6 +180,8 @@ def check(rc, what=""):
         msg = L.rcv_strerror(rc).decode()
         if rc == RCV_E_HIP:
             msg += ": " + L.rcv_last_hip_error().decode()
+        if rc == RCV_E_RANGE:
+            raise HalfRangeError("%s failed: %s (%d)" % (what or "librcvpose_hip call", msg, rc))
         raise HipLibraryError("%s failed: %s (%d)" % (what or "librcvpose_hip call", msg, rc))
 
 

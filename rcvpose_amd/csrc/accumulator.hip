@@ -1741,6 +1741,9 @@ __device__ __forceinline__ void d_bb_restart(AccHeader *hdr, const BBEntry *list
     if (threadIdx.x < 6) hdr->box[edge == 8 ? 0 : 1][threadIdx.x] = s_box[threadIdx.x];
     if (threadIdx.x != 0) return;
     for (int w = 1; w < 16; w++) best = s_key[w] > best ? s_key[w] : best;
+    // both slots start empty: the restart's first round (even) folds its neighbourhood into slot 0, and the round after it must
+    // re-centre on THIS restart's best, not on the older side lobe still standing there (bb_best / bb_best_key keep the bound)
+    hdr->climb_key[0] = 0;
     hdr->climb_key[1] = 0;
     hdr->climb_center[1] = 0;
     hdr->restart = 0;

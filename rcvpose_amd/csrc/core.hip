@@ -33,6 +33,7 @@ const char *rcv_strerror(int status)
     case RCV_E_TOO_LARGE: return "grid, radius or tile count beyond supported range";
     case RCV_E_GRID_BUFFER: return "vote grid buffer smaller than dim^3";
     case RCV_E_UNSUPPORTED: return "unsupported layer shape or dtype";
+    case RCV_E_RANGE: return "an activation left the half-precision range of the engine's storage (maps clipped); use RCV_F32";
     default: return "unknown status";
     }
 }

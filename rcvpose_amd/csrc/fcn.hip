@@ -143,6 +143,33 @@ __device__ __forceinline__ void x3_join8(const uint4 &hi, const uint4 &lo, float
 }
 #endif
 
+// ---- range guard of the half-precision stores (RCV_F16X3 and RCV_F16).  A magnitude beyond 65504 is clamped by x3_split (the
+// stored pair is finite and wrong) or becomes an infinity in RCV_F16: every epilogue that rounds to halves keeps the largest
+// magnitude it stored in one register (v_max3_f32 with |.| modifiers: four instructions per eight values) and ORs a bit into the
+// engine's sticky flag word at its end when that exceeded the half range -- rcv_fcn_forward / rcv_fcn_range_status report it as
+// RCV_E_RANGE.  bf16 has fp32's range: no guard there.
+#if defined(RCV_FCN_X3) || defined(RCV_FCN_FP16)
+constexpr bool kHalfRange = true;
+#else
+constexpr bool kHalfRange = false;
+#endif
+constexpr unsigned RNG_BIT = kX3 ? 1u : 2u;  // bit 0: an f16x3 pair was clamped, bit 1: an RCV_F16 store overflowed to infinity
+template <int N> __device__ __forceinline__ float rng_see(float m, const float *v)
+{
+    if constexpr (kHalfRange) {
+#pragma unroll
+        for (int e = 0; e + 1 < N; e += 2) m = fmaxf(fmaxf(m, fabsf(v[e])), fabsf(v[e + 1]));
+        if constexpr (N & 1) m = fmaxf(m, fabsf(v[N - 1]));
+    }
+    return m;
+}
+__device__ __forceinline__ void rng_flush(unsigned *flag, float m)
+{
+    if constexpr (kHalfRange) {
+        if (m > 65504.f && flag) atomicOr(flag, RNG_BIT);
+    }
+}
+
 struct ConvParams {
     const void *src0, *src1, *res, *w;
     void *dst;
@@ -153,6 +180,7 @@ struct ConvParams {
     int Hin, Win, Hout, Wout;
     int KS, stride, pad, relu;
     int M, K;  // GEMM sizes per group
+    unsigned *range;  // the engine's sticky range-flag word (half-precision engines), or null
 };
 
 // Tile order.  Blocks are numbered so that the N tiles of one M tile are neighbours (they share the gathered
@@ -350,6 +378,7 @@ __global__ __launch_bounds__(256) void k_conv(const ConvParams p)
                 for (int h = 0; h < RV; h++) rres[round][q][h] = live ? *(const uint4 *)(rp + 32 * h) : make_uint4(0u, 0u, 0u, 0u);
             }
     }
+    float rmax = 0.f;  // largest magnitude stored (range guard of the half-precision engines)
 #pragma unroll
     for (int round = 0; round < 2; round++) {
         __syncthreads();  // K loop (round 0) / previous round's readers are done with LDS
@@ -396,6 +425,7 @@ __global__ __launch_bounds__(256) void k_conv(const ConvParams p)
 #pragma unroll
                 for (int qq = 0; qq < EPV; qq++) v[qq] = fmaxf(v[qq], 0.f);
             }
+            if constexpr (sizeof(T) == 2) rmax = rng_see<EPV>(rmax, v);
             if constexpr (is_x3<T>()) {
                 uint4 oh, ol;
                 x3_split8(v, oh, ol);
@@ -410,6 +440,7 @@ __global__ __launch_bounds__(256) void k_conv(const ConvParams p)
             }
         }
     }
+    if constexpr (sizeof(T) == 2) rng_flush(p.range, rmax);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -683,6 +714,7 @@ __global__ __launch_bounds__(512) void k_conv_dma(const ConvParams p)
                 stg[(wm * 64 + i * 16 + kq * 4 + e) * SROW + nl] = kX3 ? __fmaf_rn(acc[i][j][e], sc, bv) : acc[i][j][e] + bv;
     }
     __syncthreads();
+    float rmax = 0.f;
 #pragma unroll
     for (int round = 0; round < 4; round++) {
 #pragma unroll
@@ -714,6 +746,7 @@ __global__ __launch_bounds__(512) void k_conv_dma(const ConvParams p)
 #pragma unroll
                 for (int qq = 0; qq < EPV; qq++) v[qq] = fmaxf(v[qq], 0.f);
             }
+            rmax = rng_see<EPV>(rmax, v);
             if constexpr (kX3) {
                 uint4 oh, ol;
                 x3_split8(v, oh, ol);
@@ -728,6 +761,7 @@ __global__ __launch_bounds__(512) void k_conv_dma(const ConvParams p)
             }
         }
     }
+    rng_flush(p.range, rmax);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -907,6 +941,7 @@ __global__ __launch_bounds__(512) void k_conv_lat(const ConvParams p)
         }
     }
     __syncthreads();
+    float rmax = 0.f;
     {
         const int row = tid >> 3, cc = tid & 7;
         const int m = m0 + row;
@@ -935,6 +970,7 @@ __global__ __launch_bounds__(512) void k_conv_lat(const ConvParams p)
                 for (int qq = 0; qq < EPV; qq++) v[qq] = fmaxf(v[qq], 0.f);
             }
             T *op_ = dst + nhwc_off<T>(m, p.Cout, n0 + cc * EPV);
+            rmax = rng_see<EPV>(rmax, v);
             if constexpr (kX3) {
                 uint4 oh, ol;
                 x3_split8(v, oh, ol);
@@ -949,6 +985,7 @@ __global__ __launch_bounds__(512) void k_conv_lat(const ConvParams p)
             }
         }
     }
+    rng_flush(p.range, rmax);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -988,6 +1025,7 @@ struct HaloParams {
     int bias_gs;
     int C0, C1, Cout, H, W, n_img, relu, K;
     int th, tw, tiles_y, tiles_x;
+    unsigned *range;  // sticky range-flag word (ConvParams::range)
 };
 // patch pieces (8 rows x 128 B) per wave and slice, one per tap 0 .. PPW - 1.  BN = 128: 7 -> 448 patch rows, a 320-pixel rectangle
 // with its halo (10 x 42); BN = 64 (half the weight stages): 8 -> 512 rows, a 384-pixel rectangle (14 x 34)
@@ -1354,6 +1392,7 @@ __global__ __launch_bounds__(512) void k_conv_halo(const HaloParams p)
     const float *bias = p.bias + (long long)g * p.bias_gs;
     constexpr int SROW = BN + 4, CPR = BN / EPV, RPR = 512 / CPR;  // rows per pass of the 512 threads
     float *stg = (float *)smem;
+    float rmax = 0.f;
     __syncthreads();
 #pragma unroll
     for (int half = 0; half < 2; half++) {
@@ -1390,6 +1429,7 @@ __global__ __launch_bounds__(512) void k_conv_halo(const HaloParams p)
 #pragma unroll
                 for (int qq = 0; qq < EPV; qq++) v[qq] = fmaxf(v[qq], 0.f);
             }
+            rmax = rng_see<EPV>(rmax, v);
             if constexpr (kX3) {
                 uint4 oh, ol;
                 x3_split8(v, oh, ol);
@@ -1405,6 +1445,7 @@ __global__ __launch_bounds__(512) void k_conv_halo(const HaloParams p)
         }
         if (half == 0) __syncthreads();
     }
+    rng_flush(p.range, rmax);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1434,9 +1475,10 @@ constexpr int STEM_LDS = STEM_NH * (STEM_MAXG * 64 * STEM_PITCH + 3 * STEM_IH * 
 // ([64*147 hi][64*147 lo] in global memory, scaled per output channel: bias[64 + co] undoes it), three MFMAs per (pixel group,
 // channel tile, K chunk): hi*hi, hi*lo, lo*hi.  147 KB of LDS: one workgroup per CU.
 __global__ __launch_bounds__(256, (kX3 ? 1 : 2)) void k_stem_mfma(const float *x, const H16 *w, const float *bias, H16 *dst, int H, int W,
-                                                      int Ho, int Wo, int groups, long long w_gs, int bias_gs, long long dst_gs)
+                                                      int Ho, int Wo, int groups, long long w_gs, int bias_gs, long long dst_gs, unsigned *range)
 {
     using T = H16;
+    float rmax = 0.f;  // range guard
     constexpr int NH = STEM_NH;
     constexpr int WPLANE = STEM_MAXG * 64 * STEM_PITCH, IPLANE = 3 * STEM_IH * (STEM_IW + 1) * 2;  // bytes of one weight / patch plane
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1599,6 +1641,7 @@ __global__ __launch_bounds__(256, (kX3 ? 1 : 2)) void k_stem_mfma(const float *x
                         v[4] = __fmaf_rn(v[4], s1.x, b1.x); v[5] = __fmaf_rn(v[5], s1.y, b1.y); v[6] = __fmaf_rn(v[6], s1.z, b1.z); v[7] = __fmaf_rn(v[7], s1.w, b1.w);
 #pragma unroll
                         for (int qq = 0; qq < 8; qq++) v[qq] = fmaxf(v[qq], 0.f);
+                        rmax = rng_see<8>(rmax, v);
                         uint4 oh, ol;
                         x3_split8(v, oh, ol);
                         T *op_ = out + ((long long)(img * Ho + ho) * Wo + wo) * 128 + x3_off(ch);
@@ -1606,6 +1649,7 @@ __global__ __launch_bounds__(256, (kX3 ? 1 : 2)) void k_stem_mfma(const float *x
                     } else {
                     v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w;
                     v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+                    rmax = rng_see<8>(rmax, v);
                     uint4 outv;
                     T *op = (T *)&outv;
 #pragma unroll
@@ -1617,6 +1661,7 @@ __global__ __launch_bounds__(256, (kX3 ? 1 : 2)) void k_stem_mfma(const float *x
         }
     }
 #undef RCV_STEM_PATCH
+    rng_flush(range, rmax);
 }
 
 // bilinear blend shared by k_upsample2 and the fused tail kernel: hy * (hx * p00 + lx * p01) + ly * (hx * p10 + lx * p11)
@@ -1715,6 +1760,7 @@ struct BlockParams {
     const float *b3;
     long long w3_gs, dst3_gs;
     int b3_gs;
+    unsigned *range;  // sticky range-flag word (ConvParams::range)
 };
 constexpr int BLK_BM = 128;
 constexpr int BLK_RING = 3, BLK_SLOT = 128 * 128;  // expand-weight ring: 16 KB slots (128 out channels x 64 K)
@@ -2436,8 +2482,9 @@ __global__ __launch_bounds__(512, (CMID == 64 ? 4 : 2)) void k_conv_block(const 
 // ---------------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void k_stem(const float *x, const T *w, const float *bias, T *dst, int B, int H, int W,
-                                              int Ho, int Wo, long long w_gs, int bias_gs, long long dst_gs)
+                                              int Ho, int Wo, long long w_gs, int bias_gs, long long dst_gs, unsigned *range)
 {
+    float rmax = 0.f;  // range guard (half-precision engines)
     constexpr int TP = 16, IN = TP * 2 + 5;  // 37 x 37 input patch per channel
     __shared__ float s_in[3][IN][IN + 1];
     __shared__ __attribute__((aligned(16))) float s_w[147][64];  // [tap*3 + c][cout]
@@ -2489,14 +2536,20 @@ __global__ __launch_bounds__(256) void k_stem(const float *x, const T *w, const 
 #pragma unroll
                 for (int q = 0; q < 16; q++) {
                     const float v = fmaxf(__fmaf_rn(acc[q], bg[64 + cb + q], bg[cb + q]), 0.f);
+                    rmax = fmaxf(rmax, v);
                     x3_split(v, out[x3_off(cb + q)], out[x3_off(cb + q) + 32]);
                 }
             } else {
 #pragma unroll
-                for (int q = 0; q < 16; q++) out[cb + q] = from_f32<T>(fmaxf(acc[q] + bg[cb + q], 0.f));
+                for (int q = 0; q < 16; q++) {
+                    const float v = fmaxf(acc[q] + bg[cb + q], 0.f);
+                    if constexpr (sizeof(T) == 2) rmax = fmaxf(rmax, v);
+                    out[cb + q] = from_f32<T>(v);
+                }
             }
         }
     }
+    if constexpr (sizeof(T) == 2) rng_flush(range, rmax);
 }
 
 // maxpool 3x3 stride 2 pad 1, NHWC; one thread = EPV channels of one output pixel
@@ -2710,7 +2763,7 @@ __device__ __forceinline__ void tail_dma16(const void *base, int num_bytes, unsi
 
 __global__ __launch_bounds__(256, 2) void k_tail(const H16 *src, const H16 *w7, const float *b7, const H16 *w8, const float *b8,
                                                  float *seg, float *radial, int B, int Hin, int Win, long long src_gs, long long w7_gs,
-                                                 int b7_gs, long long w8_gs, int b8_gs, int rad_f16)
+                                                 int b7_gs, long long w8_gs, int b8_gs, int rad_f16, unsigned *range)
 {
     using T = H16;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -3097,6 +3150,7 @@ __global__ __launch_bounds__(512) void k_chain_x3(const BlockParams p)
                 x3_join8(rres[t][0], rres[t][1], rv);
 #pragma unroll
                 for (int e = 0; e < 8; e++) v[e] = fmaxf(v[e] + rv[e], 0.f);
+                rng_flush(p.range, rng_see<8>(0.f, v));  // (checked on the spot: the kernel has no register to carry a maximum)
                 uint4 oh, ol;
                 x3_split8(v, oh, ol);
                 {   // (rows beyond M recompute row M - 1 and store the same values there: every wave issues the same number of
@@ -3150,6 +3204,7 @@ __global__ __launch_bounds__(512) void k_chain_x3(const BlockParams p)
             lds_ld128x2(aX + kq * 32, aX + kq * 32 + 16, v0, v1);  // (the wait inside also covers the rewrite of the row by the next slice)
             v[0] = v0[0]; v[1] = v0[1]; v[2] = v0[2]; v[3] = v0[3]; v[4] = v1[0]; v[5] = v1[1]; v[6] = v1[2]; v[7] = v1[3];
         }
+        rng_flush(p.range, rng_see<8>(0.f, v));
         uint4 oh, ol;
         x3_split8(v, oh, ol);
         T *op = dst3 + mrow * (2 * CMID) + t * 64 + kq * 8;
@@ -3191,7 +3246,7 @@ static_assert(2 * TX_LDS <= 160 * 1024, "two workgroups per CU");
 
 __global__ __launch_bounds__(256, 2) void k_tail_x3(const H16 *src, const H16 *w7, const float *b7, const H16 *w8, const float *b8,
                                                  float *seg, float *radial, int B, int Hin, int Win, long long src_gs, long long w7_gs,
-                                                 int b7_gs, long long w8_gs, int b8_gs, int rad_f16)
+                                                 int b7_gs, long long w8_gs, int b8_gs, int rad_f16, unsigned *range)
 {
     using T = H16;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -3205,6 +3260,7 @@ __global__ __launch_bounds__(256, 2) void k_tail_x3(const H16 *src, const H16 *w
     const int ho0 = ty * TX_TH;
     const T *sg = src + (long long)g * src_gs + (long long)img * Hin * Win * 128;
     const int pq = wave & 1, nt = wave >> 1;
+    float rmax = 0.f;  // range guard: the largest conv7 activation stored as hi + lo
     // conv7 weights of this wave's 16 output channels: [co][tap][slice][hi 32 | lo 32]
     bf16x8 bw[2][9][2];  // [slice][tap][hi / lo]
     {
@@ -3356,7 +3412,11 @@ __global__ __launch_bounds__(256, 2) void k_tail_x3(const H16 *src, const H16 *w
             uint2 ph, pl;
             T *vh = (T *)&ph, *vl = (T *)&pl;
 #pragma unroll
-            for (int e = 0; e < 4; e++) x3_split(fmaxf(__fmaf_rn(acc[i][e], sc7[e], bias7[e]), 0.f), vh[e], vl[e]);
+            for (int e = 0; e < 4; e++) {
+                const float v7 = fmaxf(__fmaf_rn(acc[i][e], sc7[e], bias7[e]), 0.f);
+                rmax = fmaxf(rmax, v7);
+                x3_split(v7, vh[e], vl[e]);
+            }
             unsigned char *hp = sH + (pq * 64 + i * 16 + r16) * TX_HP + (nt * 16 + kq * 4) * 2;
             *(uint2 *)hp = ph;
             *(uint2 *)(hp + 64) = pl;
@@ -3393,6 +3453,7 @@ __global__ __launch_bounds__(256, 2) void k_tail_x3(const H16 *src, const H16 *w
 #endif
     }
 #undef RCV_TX_SOURCE
+    rng_flush(range, rmax);
 }
 
 template <typename T>
@@ -3434,6 +3495,10 @@ struct rcv_fcn {
     bool use_dma = true;  // LDS-DMA conv kernel for the shapes it covers (bf16, Cout % 128 == 0, enough tiles)
     bool radial_f16 = false;  // the radial plane leaves the head as float16 (BASELINE.json stress configuration)
     bool use_lat = true;      // latency kernel (k_conv_lat) for launches with few tiles (small batches)
+    // range guard of the half-precision engines: one sticky flag word on the device (kernels OR bits into it), mirrored into
+    // pinned host memory by a 4-byte copy at the end of every forward
+    unsigned *range_dev = nullptr;
+    volatile unsigned *range_host = nullptr;
 };
 
 namespace {
@@ -3515,6 +3580,7 @@ int launch_conv_halo(const ConvParams &p, int B, int groups, int mode, hipStream
     q.src0_gs = p.src0_gs; q.src1_gs = p.src1_gs; q.dst_gs = p.dst_gs; q.w_gs = p.w_gs; q.bias_gs = p.bias_gs;
     q.C0 = p.C0; q.C1 = p.C1; q.Cout = p.Cout; q.H = p.Hout; q.W = p.Wout; q.n_img = B; q.relu = p.relu; q.K = p.K;
     q.tiles_y = (q.H + q.th - 1) / q.th; q.tiles_x = (q.W + q.tw - 1) / q.tw;
+    q.range = p.range;
     dim3 grid(p.Cout / bn, (unsigned)(B * q.tiles_y * q.tiles_x), groups);
     if (q.th * q.tw > 256) {
         if (bn == 128) hipLaunchKernelGGL((k_conv_halo<128, 5>), grid, dim3(512), halo_lds(128), st, q);
@@ -3585,7 +3651,7 @@ int run_op(rcv_fcn *h, const rcv_op &op, const float *x, int B, float *seg, floa
                     const int gn = std::min(STEM_MAXG, G - g0);
                     hipLaunchKernelGGL(k_stem_mfma, grid, dim3(256), STEM_LDS, st, x, (const H16 *)w + (long long)g0 * 64 * 147 * ES, bias + g0 * 64 * ES,
                                        (H16 *)slot(op.dst) + (long long)g0 * gstride(op.dst), op.hin, op.win, op.hout, op.wout, gn,
-                                       (long long)64 * 147 * ES, 64 * ES, gstride(op.dst));
+                                       (long long)64 * 147 * ES, 64 * ES, gstride(op.dst), h->range_dev);
                     RCV_LAUNCH_CHECK();
                 }
                 return RCV_OK;
@@ -3593,7 +3659,7 @@ int run_op(rcv_fcn *h, const rcv_op &op, const float *x, int B, float *seg, floa
         }
         dim3 grid(((op.hout + 15) / 16) * ((op.wout + 15) / 16), B, G);
         hipLaunchKernelGGL((k_stem<T>), grid, dim3(256), 0, st, x, w, bias, slot(op.dst), B, op.hin, op.win, op.hout,
-                           op.wout, (long long)64 * 147 * ES, 64 * ES, gstride(op.dst));
+                           op.wout, (long long)64 * 147 * ES, 64 * ES, gstride(op.dst), h->range_dev);
         RCV_LAUNCH_CHECK();
         return RCV_OK;
     }
@@ -3637,6 +3703,7 @@ int run_op(rcv_fcn *h, const rcv_op &op, const float *x, int B, float *seg, floa
         p.K = op.ksize * op.ksize * (p.C0 + p.C1);
         p.w_gs = (long long)op.cout * p.K;
         p.bias_gs = op.cout * ES;  // (split: [bias | scale] per group)
+        p.range = h->range_dev;
         // the LDS-DMA kernels address a tensor through a buffer descriptor with 32-bit byte offsets: only below 2 GiB per group
         auto fits32 = [&](int s) { return s < 0 || (long long)h->slot_elems[s] * B * (long long)sizeof(T) * ES < 0x7fffffffLL; };
         const bool dma_ok = h->use_dma && fits32(op.src0) && fits32(op.src1) && fits32(op.res) && fits32(op.dst);
@@ -3752,6 +3819,7 @@ int forward_impl(rcv_fcn *h, const float *x, int B, float *seg, float *radial, c
                     q.w1_gs = (long long)a.cout * 9 * a.c0; q.w2_gs = (long long)b.cout * b.c0;
                     q.b1_gs = a.cout; q.b2_gs = b.cout;
                     q.C0 = a.c0; q.Hin = a.hin; q.Win = a.win; q.Hout = a.hout; q.Wout = a.wout; q.stride = a.stride; q.M = (int)M;
+                    q.range = h->range_dev;
                     // the next block's 1x1 reduce (1024 -> 256, ReLU) reads exactly the tile this kernel produces: chained in
                     bool chain = false;
                     if (h->use_chain && i + 2 < h->ops.size() && h->ops[i + 2].kind == RCV_OP_CONV) {
@@ -3807,6 +3875,7 @@ int forward_impl(rcv_fcn *h, const float *x, int B, float *seg, float *radial, c
                     q.w2_gs = (long long)a.cout * a.c0 * 2; q.w3_gs = (long long)b.cout * b.c0 * 2;
                     q.b2_gs = 2 * a.cout; q.b3_gs = 2 * b.cout;
                     q.M = (int)M;
+                    q.range = h->range_dev;
                     if (h->profiling) RCV_HIP_CHECK(hipEventRecord(h->events[2 * i], st));  // time booked on the expand
                     const dim3 grid((unsigned)((M + CH_BM - 1) / CH_BM), 1, h->groups);
                     if (cmid == 256) hipLaunchKernelGGL((k_chain_x3<256>), grid, dim3(512), CH_LDS, st, q);
@@ -3840,12 +3909,12 @@ int forward_impl(rcv_fcn *h, const float *x, int B, float *seg, float *radial, c
                         hipLaunchKernelGGL(k_tail_x3, dim3((u.hout + TX_TH - 1) / TX_TH, B, h->groups), dim3(256), TX_LDS, st, (const H16 *)(ws + off[u.src0]),
                                            (const H16 *)h->weights + c.w_off, h->bias + c.b_off, (const H16 *)h->weights + d.w_off,
                                            h->bias + d.b_off, seg, radial, B, u.hin, u.win, (long long)h->slot_elems[u.src0] * B * 2,
-                                           (long long)32 * 576 * 2, 64, (long long)128, 4, h->radial_f16 ? 1 : 0);
+                                           (long long)32 * 576 * 2, 64, (long long)128, 4, h->radial_f16 ? 1 : 0, h->range_dev);
                     else
                         hipLaunchKernelGGL(k_tail, grid, dim3(256), TAIL_LDS, st, (const H16 *)(ws + off[u.src0]),
                                            (const H16 *)h->weights + c.w_off, h->bias + c.b_off, (const H16 *)h->weights + d.w_off,
                                            h->bias + d.b_off, seg, radial, B, u.hin, u.win, (long long)h->slot_elems[u.src0] * B,
-                                           (long long)32 * 576, 32, (long long)64, 2, h->radial_f16 ? 1 : 0);
+                                           (long long)32 * 576, 32, (long long)64, 2, h->radial_f16 ? 1 : 0, h->range_dev);
                     RCV_LAUNCH_CHECK();
                     if (h->profiling) {
                         RCV_HIP_CHECK(hipEventRecord(h->events[2 * i + 3], st));
@@ -3947,7 +4016,29 @@ int rcv_fcn_create(const rcv_op *ops, int n_ops, int n_slots, const int64_t *slo
         if (rc == RCV_OK && dtype == RCV_F16X3) rc = rcv::fcn_register_x3();
         if (rc != RCV_OK) return rc;
     }
+    if (dtype == RCV_F16X3) {
+        // split storage keeps the channels in groups of [32 hi | 32 lo]: every tensor an op touches needs a multiple of 32
+        // channels (the network input and the two-plane head output excepted) -- anything else would be mis-indexed silently
+        for (int i = 0; i < n_ops; i++) {
+            const rcv_op &o = ops[i];
+            const bool in_ok = o.kind == RCV_OP_STEM || (o.c0 % 32 == 0 && (o.src1 < 0 || o.c1 % 32 == 0));
+            const bool out_ok = o.kind == RCV_OP_HEAD || o.cout % 32 == 0;
+            if (!in_ok || !out_ok) return RCV_E_UNSUPPORTED;
+        }
+    }
     rcv_fcn *h = new rcv_fcn();
+    if (dtype == RCV_F16 || dtype == RCV_F16X3) {  // the range guard's flag word and its pinned mirror (not on the hot path)
+        hipError_t e = hipMalloc((void **)&h->range_dev, 256);
+        if (e == hipSuccess) e = hipMemset(h->range_dev, 0, 256);
+        if (e == hipSuccess) e = hipHostMalloc((void **)&h->range_host, 256, hipHostMallocDefault);
+        if (e != hipSuccess) {
+            rcv::set_hip_error(e, "range-flag allocation", __FILE__, __LINE__);
+            if (h->range_dev) (void)hipFree(h->range_dev);
+            delete h;
+            return RCV_E_HIP;
+        }
+        *h->range_host = 0u;
+    }
     h->ops.assign(ops, ops + n_ops);
     h->slot_elems.assign(slot_elems, slot_elems + n_slots);
     h->groups = groups;
@@ -3962,6 +4053,8 @@ void rcv_fcn_destroy(rcv_fcn *h)
 {
     if (!h) return;
     for (auto e : h->events) (void)hipEventDestroy(e);
+    if (h->range_dev) (void)hipFree(h->range_dev);
+    if (h->range_host) (void)hipHostFree((void *)h->range_host);
     delete h;
 }
 
@@ -3980,9 +4073,31 @@ int rcv_fcn_forward(rcv_fcn *h, const float *x_dev, int B, float *seg_dev, float
     if (!h || !x_dev || !seg_dev || !radial_dev || !ws || B <= 0) return RCV_E_INVALID;
     if (ws_bytes < rcv_fcn_workspace_bytes(h, B)) return RCV_E_WORKSPACE;
     if (h->dtype == RCV_F32) return forward_impl<float>(h, x_dev, B, seg_dev, radial_dev, (char *)ws, (hipStream_t)stream);
-    if (h->dtype == RCV_F16) return rcv::fcn_forward_f16(h, x_dev, B, seg_dev, radial_dev, (char *)ws, (hipStream_t)stream);
-    if (h->dtype == RCV_F16X3) return rcv::fcn_forward_x3(h, x_dev, B, seg_dev, radial_dev, (char *)ws, (hipStream_t)stream);
-    return forward_impl<H16>(h, x_dev, B, seg_dev, radial_dev, (char *)ws, (hipStream_t)stream);
+    if (h->dtype == RCV_BF16) return forward_impl<H16>(h, x_dev, B, seg_dev, radial_dev, (char *)ws, (hipStream_t)stream);
+    // half-precision storage: a forward that already COMPLETED with a value beyond the half range makes every later call fail
+    // (sticky, like a HIP error) until rcv_fcn_range_status clears it -- its maps were clipped, not exact
+    if (h->range_host && *h->range_host) return RCV_E_RANGE;
+    int rc = h->dtype == RCV_F16 ? rcv::fcn_forward_f16(h, x_dev, B, seg_dev, radial_dev, (char *)ws, (hipStream_t)stream)
+                                 : rcv::fcn_forward_x3(h, x_dev, B, seg_dev, radial_dev, (char *)ws, (hipStream_t)stream);
+    if (rc == RCV_OK && h->range_dev)
+        RCV_HIP_CHECK(hipMemcpyAsync((void *)h->range_host, h->range_dev, sizeof(unsigned), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    return rc;
+}
+
+int rcv_fcn_range_status(rcv_fcn *h, unsigned *flags_out, int clear, void *stream)
+{
+    if (!h) return RCV_E_INVALID;
+    unsigned f = 0u;
+    if (h->range_dev) {
+        RCV_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+        RCV_HIP_CHECK(hipMemcpy(&f, h->range_dev, sizeof(unsigned), hipMemcpyDeviceToHost));
+        if (clear) {
+            RCV_HIP_CHECK(hipMemset(h->range_dev, 0, sizeof(unsigned)));
+            *h->range_host = 0u;
+        } else *h->range_host = f;
+    }
+    if (flags_out) *flags_out = f;
+    return f ? RCV_E_RANGE : RCV_OK;
 }
 
 int rcv_fcn_debug_slot(rcv_fcn *h, const void *ws, int B, int g, int slot, float *out_dev, void *stream)

@@ -24,6 +24,7 @@
 
 namespace rcv {
 namespace {
+static_assert(WAVE == 64, "the butterfly reductions below (__shfl_xor from 32 down) assume 64-lane wavefronts (gfx950)");
 
 constexpr int NN_THREADS = 256, NN_TILE = 1024, RED_BLOCKS = 256;
 
@@ -486,7 +487,10 @@ int rcv_icp_point_to_point(const double *src_dev, int n_src, const double *tgt_d
     int *g_starts = nullptr, *g_sorted_idx = nullptr;
     double *g_sorted = nullptr;
     unsigned g_mask = 0;
-    const double inv_h = max_corr_dist > 0.0 ? 1.0 / max_corr_dist : 0.0;
+    // cells a shade wider than the reach (1 + 2^-30): two points within max_corr_dist of each other then provably fall into
+    // neighbouring cells whatever the rounding of x * inv_h does (coordinates up to 10^6 cells from the origin), so the 27 scanned
+    // cells hold every target the exhaustive search would accept -- identical correspondences, not just almost always
+    const double inv_h = max_corr_dist > 0.0 ? 1.0 / (max_corr_dist * (1.0 + 9.313225746154785e-10)) : 0.0;
     const char *no_grid = getenv("RCV_ICP_NO_GRID");  // (tests: the exhaustive search for comparison)
     if (max_corr_dist > 1e-9 && std::isfinite(inv_h) && n_tgt >= 2048 && !(no_grid && no_grid[0] == '1')) {
         int M = 1024;
@@ -495,7 +499,27 @@ int rcv_icp_point_to_point(const double *src_dev, int n_src, const double *tgt_d
         const size_t o_cursor = o_starts + align_up(sizeof(int) * ((size_t)M + 1), 256), o_max = o_cursor + align_up(sizeof(int) * (size_t)M, 256);
         const size_t o_sorted = o_max + 256, o_sidx = o_sorted + align_up(sizeof(double) * 3 * (size_t)n_tgt, 256);
         const size_t g_total = o_sidx + align_up(sizeof(int) * (size_t)n_tgt, 256);
-        RCV_HIP_CHECK(hipMallocAsync((void **)&gmem, g_total, st));
+        {   // the stream's pool keeps what it has handed out once (default: everything goes back to the OS at each synchronise)
+            static bool pool_set = false;
+            hipMemPool_t pool;
+            int dev = 0;
+            if (!pool_set && hipGetDevice(&dev) == hipSuccess && hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess) {
+                uint64_t keep = 1ull << 30;
+                (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
+                pool_set = true;
+            }
+        }
+        if (hipMallocAsync((void **)&gmem, g_total, st) != hipSuccess) {
+            (void)hipGetLastError();  // no room next to the caller's allocator: the exhaustive scan needs no extra memory
+            gmem = nullptr;
+        }
+    }
+    if (gmem) {
+        int M = 1024;
+        while (M < 2 * n_tgt) M <<= 1;
+        const size_t o_counts = 0, o_starts = o_counts + align_up(sizeof(int) * (size_t)M, 256);
+        const size_t o_cursor = o_starts + align_up(sizeof(int) * ((size_t)M + 1), 256), o_max = o_cursor + align_up(sizeof(int) * (size_t)M, 256);
+        const size_t o_sorted = o_max + 256, o_sidx = o_sorted + align_up(sizeof(double) * 3 * (size_t)n_tgt, 256);
         int *counts = (int *)(gmem + o_counts), *cursor = (int *)(gmem + o_cursor), *maxc = (int *)(gmem + o_max);
         g_starts = (int *)(gmem + o_starts);
         g_sorted = (double *)(gmem + o_sorted);
@@ -537,7 +561,8 @@ int rcv_icp_point_to_point(const double *src_dev, int n_src, const double *tgt_d
     double hstat[4];
     int hctl[4] = {0, 0, 0, 0};
     for (int enq = 0; enq < max_iteration;) {
-        const int chunk = std::min(32, max_iteration - enq);
+        // (after the first read-back the chunks are short: once `done` is set the remaining kernels of a chunk are empty launches)
+        const int chunk = std::min(enq == 0 ? 16 : 8, max_iteration - enq);
         for (int c = 0; c < chunk; c++) evaluate(0);
         RCV_LAUNCH_CHECK();
         enq += chunk;

@@ -349,8 +349,11 @@ class FcnEngine:
         self._ws = None
         self._ws_batch = 0
         self.radial_f16 = False
-        # half-precision storage saturates beyond 65504 (f16x3: hi + lo, 131008): with check_finite the forward synchronises and
-        # raises instead of handing inf / nan maps to the seam.  The per-frame drivers switch it on; batched pipelines leave it off.
+        # half-precision storage has a range: f16x3 clamps magnitudes beyond 65504 (finite and wrong), fp16 turns them into
+        # infinities.  The kernels record both in the engine's sticky flag word (RCV_E_RANGE, include/rcvpose_hip.h).  With
+        # check_finite the forward synchronises, reads that word (range_status) and the maps' finiteness, and raises; the
+        # module boundary (models.fcnresnet, FCResBackbone) switches it on.  Batched pipelines stay asynchronous: the next
+        # forward after a flagged one fails with RCV_E_RANGE, and FramePipeline.read_results() checks the word itself.
         self.check_finite = False
         self.flops_per_image_group = conv_flops(ops)
 
@@ -390,10 +393,25 @@ class FcnEngine:
                 raise ValueError("output planes: seg float32, radial %s" % ("float16 (option 8)" if self.radial_f16 else "float32"))
         _hip.check(self.lib.rcv_fcn_forward(self.handle, _hip.ptr(x), B, _hip.ptr(seg), _hip.ptr(radial), _hip.ptr(ws),
                                             ws.numel(), _hip.current_stream()), "rcv_fcn_forward")
-        if self.check_finite and not (bool(torch.isfinite(seg).all()) and bool(torch.isfinite(radial).all())):
-            raise FloatingPointError("non-finite FCN output in %s mode: an activation left the half-precision range (65504; "
-                                     "131008 for f16x3) -- use dtype='fp32' for this checkpoint" % self.dtype_name)
+        if self.check_finite:
+            self.range_status(clear=True, raise_on_flag=True)
+            if not (bool(torch.isfinite(seg).all()) and bool(torch.isfinite(radial).all())):
+                raise FloatingPointError("non-finite FCN output in %s mode -- use dtype='fp32' for this checkpoint / input" % self.dtype_name)
         return seg, radial
+
+    def range_status(self, clear=True, raise_on_flag=False):
+        """Waits for the current stream and returns the engine's range-flag word (0 = every stored activation stayed inside the
+        half range; bit 0: an f16x3 pair was clamped at 65504, bit 1: an fp16 store overflowed to infinity); fp32 / bf16 engines
+        always return 0.  raise_on_flag: raise _hip.HalfRangeError (a FloatingPointError) instead."""
+        flags = ctypes.c_uint(0)
+        rc = self.lib.rcv_fcn_range_status(self.handle, ctypes.byref(flags), int(bool(clear)), _hip.current_stream())
+        if rc not in (_hip.RCV_OK, _hip.RCV_E_RANGE):
+            _hip.check(rc, "rcv_fcn_range_status")
+        if flags.value and raise_on_flag:
+            raise _hip.HalfRangeError("an activation left the half-precision range (|v| > 65504) in %s mode: the maps of that forward are "
+                                      "clipped, not the reference's fp32 values (flags %d) -- use dtype='fp32' for this checkpoint"
+                                      % (self.dtype_name, flags.value))
+        return int(flags.value)
 
     def capture(self, x, out=None):
         """One forward for fixed buffers as a HIP graph (the ~170 launches of a forward are launch-bound at small batches).

@@ -15,7 +15,7 @@ from . import _hip, fcn_engine
 
 
 class FramePipeline:
-    def __init__(self, state_dicts, H=480, W=640, dtype="bf16", frames_per_step=1, K=A.linemod_K, acc_unit=A.ACC_UNIT_MM,
+    def __init__(self, state_dicts, H=480, W=640, dtype="f16x3", frames_per_step=1, K=A.linemod_K, acc_unit=A.ACC_UNIT_MM,
                  device="cuda", overlap=False, radial_f16=False, engine="auto"):
         """acc_unit: voxel edge in mm (the reference hard-codes 5, AccumulatorSpace.py:374).  radial_f16: the FCN head
         writes the radial maps as float16 and the seam reads them as such (the stress configuration of BASELINE.json).
@@ -133,8 +133,11 @@ class FramePipeline:
         self._mark("acc")
 
     def read_results(self):
-        """One D2H copy -> (estimated_kpts float64 [B,G,3] mm, list of AccResult)."""
+        """One D2H copy -> (estimated_kpts float64 [B,G,3] mm, list of AccResult).  Raises _hip.HalfRangeError when a forward
+        since the last call stored an activation beyond the half-precision range (f16x3 / fp16 engines: clipped maps)."""
         raw = self.results.cpu().numpy()
+        self.finish()
+        self.engine.range_status(clear=True, raise_on_flag=True)
         res = [_hip.AccResult.from_buffer_copy(raw[i].tobytes()) for i in range(raw.shape[0])]
         kpts = np.array([[r.center_mm[0], r.center_mm[1], r.center_mm[2]] for r in res]).reshape(self.B, self.G, 3)
         return kpts, res

@@ -164,3 +164,34 @@ def test_split_engine_blob_offsets():
         assert torch.equal(w[op["w_off"]:op["w_off"] + per_net], w[op["w_off"] + per_net:op["w_off"] + 2 * per_net])
         sc = bias[op["b_off"] + op["cout"]:op["b_off"] + 2 * op["cout"]]
         assert torch.equal(torch.log2(sc), torch.log2(sc).round())
+
+
+def test_hostile_state_dict_is_the_same_function():
+    """tests/fcn_weights.make_hostile_state_dict (the weights of the GPU range / precision tests) re-parametrises the network
+    without changing what it computes: checked with the torch oracle in float64; its statistics span the advertised ranges."""
+    import json
+    import os
+
+    import torch
+
+    import fcn_weights
+    from oracle import fcn_torch
+
+    shapes = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fcn_state_dict_keys.json")))
+    sd = {k: torch.from_numpy(v) for k, v in fcn_weights.make_state_dict_numpy(shapes, seed=0).items()}
+    hs = fcn_weights.make_hostile_state_dict(sd, seed=1)
+    x = torch.from_numpy(fcn_weights.make_input(3, (1, 3, 32, 64))).double()
+    d = lambda s: {k: (v.double() if v.dtype == torch.float32 else v) for k, v in s.items()}
+    (s0, r0), (s1, r1) = fcn_torch.forward(d(sd), x), fcn_torch.forward(d(hs), x)
+    assert float((r1 - r0).abs().max() / r0.abs().max()) < 2e-6 and float((s1 - s0).abs().max() / s0.abs().max()) < 2e-6
+    var = torch.cat([v.flatten() for k, v in hs.items() if k.endswith("bn1.running_var") or k.endswith("bn2.running_var")])
+    gam = torch.cat([v.flatten().abs() for k, v in hs.items() if k.startswith("block") and (k.endswith("bn1.weight") or k.endswith("bn2.weight"))])
+    assert float(var.min()) < 2e-6 and float(var.max()) > 50 and float(gam.max() / gam.min()) > 1e4
+
+
+def test_range_status_in_header_and_strerror():
+    from rcvpose_amd import _hip
+
+    L = _hip.load_library()
+    assert _hip.RCV_E_RANGE == -9 and b"range" in L.rcv_strerror(_hip.RCV_E_RANGE)
+    assert issubclass(_hip.HalfRangeError, FloatingPointError) and issubclass(_hip.HalfRangeError, _hip.HipLibraryError)

@@ -25,7 +25,7 @@ def test_full_frames_three_keypoints(golden_dir, oracle):
 
     B = 2
     fr = [frames.synthetic_frame(i) for i in range(B)]
-    pipe = FramePipeline(_state_dicts(golden_dir), 480, 640, dtype="bf16", frames_per_step=B)
+    pipe = FramePipeline(_state_dicts(golden_dir), 480, 640, frames_per_step=B)  # (default arithmetic: f16x3)
     rgb = torch.from_numpy(np.stack([f["rgb"] for f in fr])).cuda()
     depth = torch.from_numpy(np.stack([f["depth"] for f in fr]).view(np.int16)).cuda()
     seg = torch.from_numpy(np.stack([np.stack([f["seg"] for f in fr])] * 3))[:, :, None].contiguous().cuda()

@@ -42,7 +42,7 @@ def test_configs4_eight_frames_fp16_radial_one_millimetre_against_oracle(oracle,
     fr = [frames.synthetic_frame(300 + i, shape="ycb") for i in range(B)]
     shapes = json.load(open(os.path.join(golden_dir, "fcn_state_dict_keys.json")))
     sds = [{k: torch.from_numpy(v) for k, v in fcn_weights.make_state_dict_numpy(shapes, seed=s).items()} for s in range(G)]
-    pipe = FramePipeline(sds, H, W, dtype="bf16", frames_per_step=B, K=_K(fr[0]), acc_unit=1.0, radial_f16=True)
+    pipe = FramePipeline(sds, H, W, frames_per_step=B, K=_K(fr[0]), acc_unit=1.0, radial_f16=True)  # (default arithmetic: f16x3)
     assert pipe.radial.dtype == torch.float16
     rgb = torch.from_numpy(np.stack([f["rgb"] for f in fr])).cuda()
     depth = torch.from_numpy(np.stack([f["depth"] for f in fr]).view(np.int16)).cuda()
