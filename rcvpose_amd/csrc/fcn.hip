@@ -102,8 +102,8 @@ __device__ __forceinline__ void x3_split(float v, H16 &hi, H16 &lo)
 // elements instead of 56 + 8 to pack; element for element the same IEEE operations as x3_split.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 // (-DRCV_X3_SCALAR_HELPERS: the element-by-element forms, for an A-B check of the outputs' hash -- tools/fcn_hash.py)
-#if defined(RCV_FCN_X3) && !defined(RCV_X3_SCALAR_HELPERS)
 typedef _Float16 x3_h2 __attribute__((ext_vector_type(2)));
+#if defined(RCV_FCN_X3) && !defined(RCV_X3_SCALAR_HELPERS)
 __device__ __forceinline__ void x3_split8(const float *v, uint4 &hi, uint4 &lo)
 {
     unsigned *wh = (unsigned *)&hi, *wl = (unsigned *)&lo;
@@ -3214,6 +3214,306 @@ __global__ __launch_bounds__(512) void k_chain_x3(const BlockParams p)
 }
 
 // ---------------------------------------------------------------------------------------------
+// k_chain2_x3<CMID> (split precision, r04): the same two layers as k_chain_x3 -- a bottleneck's 1x1 expand (+ residual, ReLU)
+// and the next block's 1x1 reduce -- with the same decomposition (a workgroup owns 128 pixels, a wave 16 of them with all their
+// channels; only weights travel through LDS, by LDS-DMA two steps ahead) and the same arithmetic per output element (K order,
+// hh / hl / lh per slice, fma / add / max of the epilogue): bit-identical outputs.  What changed is where the time went:
+//   * No transposition.  With the operands swapped the accumulator of a 16-channel tile holds, per lane (pixel r16, quarter
+//     kq), the four output channels of MFMA rows kq*4 .. +3 -- while the next MFMA (and a 16-byte store) wants eight CONSECUTIVE
+//     channels kq*8 .. +7 per lane.  k_chain_x3 sent every 32-channel slice through a wave-private fp32 LDS round trip (three
+//     dependent LDS latencies per reduce step, in front of its MFMAs).  Which weight row feeds which MFMA row is free, though:
+//     lane r16 of tile jj of a 32-channel slice reads the weights of output channel (r16 >> 2) * 8 + jj * 4 + (r16 & 3), so the
+//     two tiles' accumulators of a lane ARE channels kq*8 .. +3 and kq*8+4 .. +7 of its pixel.  Nothing moves; the per-element
+//     sums are the same MFMAs on the same operands.  The weight image's bank swizzle follows the new row pattern
+//     (c2_key: 16 lanes of a ds_read_b128 group -> 16 distinct 16-byte columns), and every fragment read of a step is one
+//     base register + an immediate offset.
+//   * Half chunks.  A chunk is 64 output channels of the expand (two K slices of the reduce) instead of 128: 16 accumulator and
+//     16 residual registers less, which pay for a second weight-fragment set in flight, and the residual arrives as four loads
+//     per wave eight times per block instead of eight loads four times (the stalls of k_chain_x3 sat where those bursts met
+//     the queued stores).  An expand step multiplies two K slices (2 x [64 out][32 ch] = 16 KB of weights) so that a step
+//     still carries 24 MFMAs per wave behind its barrier.
+//   * The epilogue of slice t + 1 (scale, bias, residual, ReLU, split, store -- ~90 VALU instructions per lane) is in program
+//     order BEFORE the MFMAs of reduce step t and free of LDS round trips, so the scheduler interleaves it with those MFMAs
+//     instead of both waves of a SIMD doing VALU work while the matrix pipe idles; slice 0's sits in the last expand step.
+// ---------------------------------------------------------------------------------------------
+constexpr int c2_slot(int cmid) { return cmid * 128 > 16384 ? cmid * 128 : 16384; }       // ring slot: the larger of the two step images
+constexpr int c2_lds(int cmid) { return 3 * c2_slot(cmid) + (2 * 4 * cmid + 2 * cmid) * 4; }  // ring + [bias | scale] of both layers
+static_assert(c2_lds(256) <= 160 * 1024, "k_chain2_x3's LDS plan");
+// bank swizzle of the weight images: 16-byte column c of row r lives at column c ^ c2_key(r).  A fragment read takes, for its 16
+// lanes, the rows (r16 >> 2) * 8 + (r16 & 3) (+ multiples of 4 and 32): bits 1, 3 and 4 of the row separate them into eight
+// keys x two row parities = sixteen distinct 16-byte columns of the 256-byte bank row.
+__device__ __forceinline__ int c2_key(int row) { return ((row >> 1) & 1) | (((row >> 3) & 3) << 1); }
+// LDS reads by inline asm (not tracked by the compiler's lgkmcnt model; its own counted waits only get stricter): the bias /
+// scale vectors of an epilogue are requested at the top of a step and waited for where they are used
+__device__ __forceinline__ void lds_req128(unsigned a, f32x4 &v) { asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(a)); }
+__device__ __forceinline__ void lds_arrive4(f32x4 &a, f32x4 &b, f32x4 &c, f32x4 &d)
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+}
+
+template <int CMID>
+__global__ __launch_bounds__(512) void k_chain2_x3(const BlockParams p)
+{
+    using T = H16;
+    constexpr int COUT = 4 * CMID, HC = COUT / 64, KE = CMID / 32;  // half chunks of 64 output channels; K slices of the expand
+    constexpr int ES = KE / 2, SPC = ES + 2;                        // expand steps (two K slices each) + two reduce steps per half chunk
+    constexpr int NTR = CMID / 16;                                  // 16-channel tiles of the reduce's output
+    constexpr int PE = 2, PR = CMID / 64;                           // DMA pieces (8 rows x 128 B) per wave: expand step, reduce step
+    constexpr int SLOT = c2_slot(CMID);
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r16 = lane & 15, kq = lane >> 4, lrow = lane >> 3, lpos = lane & 7;
+    const int g = blockIdx.z;
+    const int m0 = blockIdx.x * CH_BM;
+    const T *src = (const T *)p.src + (long long)g * p.src_gs;
+    const T *res = (const T *)p.res + (long long)g * p.res_gs;
+    T *dst = (T *)p.dst + (long long)g * p.dst_gs;
+    T *dst3 = (T *)p.dst3 + (long long)g * p.dst3_gs;
+    const char *w2 = (const char *)((const T *)p.w2 + (long long)g * p.w2_gs);
+    const char *w3 = (const char *)((const T *)p.w3 + (long long)g * p.w3_gs);
+    const float *b2 = p.b2 + (long long)g * p.b2_gs, *b3 = p.b3 + (long long)g * p.b3_gs;  // [bias | scale]
+    const int w2_bytes = COUT * CMID * 4, w3_bytes = CMID * COUT * 4;
+    float *sB2 = (float *)(smem + 3 * SLOT), *sB3 = sB2 + 2 * COUT;
+    for (int i = tid; i < 2 * COUT; i += 512) sB2[i] = b2[i];
+    for (int i = tid; i < 2 * CMID; i += 512) sB3[i] = b3[i];
+    const unsigned aB2 = (unsigned)(3 * SLOT) + kq * 32, aB3 = (unsigned)(3 * SLOT + 2 * COUT * 4) + kq * 32;  // this lane's 8 channels
+
+    const int m = m0 + wave * 16 + r16;
+    const long long mrow = m < p.M ? m : p.M - 1;  // (rows beyond M recompute and re-store row M - 1: equal VM operation counts)
+
+    // ---- weights of step (half chunk h, position q) into ring slot `slot`: lane -> (row of the piece, 16-byte column)
+    auto issue = [&](int h, int q, int slot) {
+        unsigned char *sl = smem + slot * SLOT;
+        if (q < ES) {  // [2 K slices][64 out channels h*64 ..][32 ch (hi | lo)] of w2 [COUT][KE][64 halves]
+#pragma unroll
+            for (int c = 0; c < PE; c++) {
+                const int pid = wave * PE + c, ks = pid >> 3, row = (pid & 7) * 8 + lrow;
+                const int off = ((h * 64 + row) * (2 * CMID) + (2 * q + ks) * 64 + ((lpos ^ c2_key(row)) << 3)) * 2;
+                blk_dma16(w2, w2_bytes, sl + pid * 1024, off);
+            }
+        } else {       // [CMID out channels][32 ch] of w3 [CMID][COUT / 32][64 halves], K slice h*2 + t
+#pragma unroll
+            for (int c = 0; c < PR; c++) {
+                const int pid = wave * PR + c, row = pid * 8 + lrow;
+                const int off = (row * (2 * COUT) + (h * 2 + (q - ES)) * 64 + ((lpos ^ c2_key(row)) << 3)) * 2;
+                blk_dma16(w3, w3_bytes, sl + pid * 1024, off);
+            }
+        }
+    };
+    // vector-memory operations a step issues besides the weights of the step two ahead: the half chunk's residual vectors
+    // (2 slices x (hi, lo)) at its first step; the stores of slice 0 in the last expand step and of slice 1 in reduce step 0
+    auto pieces_for = [&](int q2) { return q2 < ES ? PE : PR; };
+    auto extra_at = [&](int q_) { return (q_ == 0 ? 4 : 0) + (q_ == ES - 1 || q_ == ES ? 2 : 0); };
+
+    bf16x8 aE[KE][2];
+    {
+        const T *sp = src + mrow * (2 * CMID) + kq * 8;
+#pragma unroll
+        for (int s_ = 0; s_ < KE; s_++) {
+            aE[s_][0] = *(const bf16x8 *)(sp + s_ * 64);
+            aE[s_][1] = *(const bf16x8 *)(sp + s_ * 64 + 32);
+        }
+    }
+    issue(0, 0, 0);
+    issue(0, 1 % SPC, 1);
+    f32x4 accR[NTR];
+#pragma unroll
+    for (int j = 0; j < NTR; j++) accR[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 accE[4];
+    uint4 rres[2][2];
+    bf16x8 ah, al;        // operand fragments of the reduce step in flight (slice t of the half chunk, hi / lo)
+    float rmax = 0.f;     // range guard: largest magnitude stored
+    // fragment addressing: row (r16 >> 2) * 8 + (r16 & 3) of a 32-row group, columns kq (hi) and 4 + kq (lo) under the row's key
+    const int fkey = ((r16 >> 1) & 1) | ((r16 >> 2) << 1);
+    const unsigned frow = (unsigned)(((r16 >> 2) * 8 + (r16 & 3)) * 128);
+    const unsigned fhi = frow + ((kq ^ fkey) << 4), flo = frow + (((4 + kq) ^ fkey) << 4);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    // The epilogue of slice t of half chunk h (accumulators of tiles 2t, 2t + 1 -> eight consecutive channels of this lane's pixel:
+    // scale, bias, + residual, ReLU, split, store; the two 16-byte vectors are also the reduce's operand fragments), cut into
+    // EP_N pieces of a few VALU instructions.  The steps hand them out one or three per tile, between the MFMAs, each slot
+    // closed by a scheduling fence: both waves of a SIMD then alternate matrix and vector work instead of doing ~90 VALU
+    // instructions side by side while the matrix pipe idles.  Element for element the operations of k_chain_x3's epilogue.
+    constexpr int EP_N = 12;
+    float ev[8], erv[8];
+    f32x4 ebi0, ebi1, esc0, esc1;
+    uint4 eoh, eol;
+    auto ep_request = [&](int h, int t) {  // bias / scale of the slice's eight channels: LDS reads left in flight
+        const unsigned a = aB2 + (unsigned)(h * 64 + t * 32) * 4;
+        lds_req128(a, ebi0); lds_req128(a + 16, ebi1); lds_req128(a + COUT * 4, esc0); lds_req128(a + COUT * 4 + 16, esc1);
+    };
+    auto ep_piece = [&](int h, int t, int k) {
+        unsigned *wh_ = (unsigned *)&eoh, *wl_ = (unsigned *)&eol;
+        const unsigned *rh = (const unsigned *)&rres[t][0], *rl = (const unsigned *)&rres[t][1];
+        switch (k) {
+        case 0:  // (LDS reads complete in order: the fragment reads issued after the request have been consumed by now)
+            asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(ebi0), "+v"(ebi1), "+v"(esc0), "+v"(esc1));  // (at most two tiles' fragments are newer)
+#pragma unroll
+            for (int e = 0; e < 4; e++) ev[e] = __fmaf_rn(accE[2 * t][e], esc0[e], ebi0[e]);
+            break;
+        case 1:
+#pragma unroll
+            for (int e = 0; e < 4; e++) ev[4 + e] = __fmaf_rn(accE[2 * t + 1][e], esc1[e], ebi1[e]);
+            break;
+        case 2: case 3: {  // residual: hi + lo of channels 4(k-2) .. +3
+            const int b = (k - 2) * 2;
+#pragma unroll
+            for (int e = 0; e < 2; e++) {
+                const f32x2 s2 = __builtin_convertvector(__builtin_bit_cast(x3_h2, rh[b + e]), f32x2) + __builtin_convertvector(__builtin_bit_cast(x3_h2, rl[b + e]), f32x2);
+                erv[2 * (b + e)] = s2[0];
+                erv[2 * (b + e) + 1] = s2[1];
+            }
+            break;
+        }
+        case 4: case 5: {
+            const int b = (k - 4) * 4;
+#pragma unroll
+            for (int e = 0; e < 4; e++) ev[b + e] = fmaxf(ev[b + e] + erv[b + e], 0.f);
+            break;
+        }
+        case 6: rmax = rng_see<8>(rmax, ev); break;
+        case 7: case 8: case 9: case 10: {  // split of elements 2(k-7), 2(k-7) + 1 (x3_split8's operations)
+            const int e = k - 7;
+            const f32x2 c = {__builtin_amdgcn_fmed3f(ev[2 * e], -65504.f, 65504.f), __builtin_amdgcn_fmed3f(ev[2 * e + 1], -65504.f, 65504.f)};
+            const x3_h2 hh = __builtin_convertvector(c, x3_h2);
+            const f32x2 r = (f32x2){ev[2 * e], ev[2 * e + 1]} - __builtin_convertvector(hh, f32x2);
+            const f32x2 rc = {__builtin_amdgcn_fmed3f(r[0], -65504.f, 65504.f), __builtin_amdgcn_fmed3f(r[1], -65504.f, 65504.f)};
+            const x3_h2 ll = __builtin_convertvector(rc, x3_h2);
+            wh_[e] = __builtin_bit_cast(unsigned, hh);
+            wl_[e] = __builtin_bit_cast(unsigned, ll);
+            break;
+        }
+        default: {  // 11: the block output (full 128-byte lines per pixel over the wave's two stores)
+            T *op = dst + mrow * (2 * COUT) + (h * 2 + t) * 64 + kq * 8;
+            *(uint4 *)op = eoh;
+            *(uint4 *)(op + 32) = eol;
+            break;
+        }
+        }
+    };
+
+    bf16x8 fwh[3], fwl[3];  // weight fragments (hi, lo) of three tiles: two in flight ahead of the one being multiplied
+    int slot = 0;
+    for (int h = 0; h < HC; h++) {
+        const bool last = h == HC - 1;
+#pragma unroll
+        for (int q = 0; q < SPC; q++) {
+            // ---- this step's weights (issued two steps ago) have landed in every wave's share; the slot refilled below is free
+            if (h > 0 || q >= 1) {
+                if (h > 0 || q >= 2) {  // (steps 0 and 1: the prologue waited)
+                    const int qm1 = (q + SPC - 1) % SPC, qm2 = (q + SPC - 2) % SPC;
+                    const bool next_exists = !(last && q == SPC - 1);
+                    const int i_m1 = next_exists ? pieces_for((q + 1) % SPC) : 0;  // pieces step g-1 issued for step g+1
+                    blk_vmwait(extra_at(qm2) + i_m1 + extra_at(qm1));
+                }
+                __builtin_amdgcn_s_barrier();
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            {
+                const int q2 = (q + 2) % SPC, h2 = h + (q + 2 >= SPC ? 1 : 0);
+                if (h2 < HC) issue(h2, q2, slot + 2 >= 3 ? slot + 2 - 3 : slot + 2);
+                if (q == 0) {  // this half chunk's residual: channels kq*8 .. +7 of the slices h*2 + t (hi, lo)
+#pragma unroll
+                    for (int t2 = 0; t2 < 2; t2++) {
+                        const T *rp = res + mrow * (2 * COUT) + (h * 2 + t2) * 64 + kq * 8;
+                        rres[t2][0] = *(const uint4 *)rp;
+                        rres[t2][1] = *(const uint4 *)(rp + 32);
+                    }
+                }
+            }
+            const unsigned sbase = (unsigned)(slot * SLOT);
+            const unsigned char *slh = smem + sbase + fhi, *sll = smem + sbase + flo;
+            auto rd = [&](int buf, int o) {
+                fwh[buf] = *(const bf16x8 *)(slh + o);
+                fwl[buf] = *(const bf16x8 *)(sll + o);
+            };
+            if (q < ES) {
+                // ---- expand step: K slices 2q, 2q + 1 x four 16-channel tiles, tile pair (= slice of the half chunk) outermost, so
+                // that slice 0's accumulators are final half a step before the step ends and its epilogue rides on the second half
+                if (q == 0) {
+#pragma unroll
+                    for (int j = 0; j < 4; j++) accE[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+                auto off = [](int i) { return ((i >> 1) & 1) * 8192 + (i >> 2) * 4096 + (i & 1) * 512; };
+                if (q == ES - 1) ep_request(h, 0);
+                __builtin_amdgcn_sched_barrier(0);  // (the requests stay older than every fragment read of the step)
+                rd(0, off(0));
+                rd(1, off(1));
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    if (i + 2 < 8) rd((i + 2) % 3, off(i + 2));
+                    const int ks = (i >> 1) & 1;
+                    f32x4 &a = accE[(i >> 2) * 2 + (i & 1)];
+                    a = RCV_MFMA16(fwh[i % 3], aE[2 * q + ks][0], a, 0, 0, 0);
+                    a = RCV_MFMA16(fwl[i % 3], aE[2 * q + ks][0], a, 0, 0, 0);
+                    a = RCV_MFMA16(fwh[i % 3], aE[2 * q + ks][1], a, 0, 0, 0);
+                    if (q == ES - 1 && i >= 4) {
+#pragma unroll
+                        for (int k = 0; k < 3; k++) ep_piece(h, 0, (i - 4) * 3 + k);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (q == ES - 1) {
+                    ah = *(const bf16x8 *)&eoh;
+                    al = *(const bf16x8 *)&eol;
+                }
+            } else {
+                // ---- reduce step t: 3 x NTR MFMAs on slice t's fragments; beside them, in step 0, the epilogue of slice 1
+                const int t = q - ES;
+                auto off = [](int j) { return (j >> 1) * 4096 + (j & 1) * 512; };
+                if (t == 0) ep_request(h, 1);
+                __builtin_amdgcn_sched_barrier(0);
+                rd(0, off(0));
+                rd(1, off(1));
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < NTR; j++) {
+                    if (j + 2 < NTR) rd((j + 2) % 3, off(j + 2));
+                    accR[j] = RCV_MFMA16(fwh[j % 3], ah, accR[j], 0, 0, 0);
+                    accR[j] = RCV_MFMA16(fwl[j % 3], ah, accR[j], 0, 0, 0);
+                    accR[j] = RCV_MFMA16(fwh[j % 3], al, accR[j], 0, 0, 0);
+                    if (t == 0) {  // EP_N pieces over the tiles from the second on (the bias reads are older than tile 2's fragments)
+                        constexpr int PPT = (EP_N + NTR - 2) / (NTR - 1);
+#pragma unroll
+                        for (int k = 0; k < PPT; k++)
+                            if (j >= 1 && (j - 1) * PPT + k < EP_N) ep_piece(h, 1, (j - 1) * PPT + k);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (t == 0) {
+                    ah = *(const bf16x8 *)&eoh;
+                    al = *(const bf16x8 *)&eol;
+                }
+            }
+            slot = slot + 1 == 3 ? 0 : slot + 1;
+        }
+    }
+    // ---- the reduce's epilogue: scale, bias, ReLU, hi / lo; tiles 2t, 2t + 1 are channels t*32 + kq*8 .. +7 of this lane's pixel
+#pragma unroll
+    for (int t = 0; t < NTR / 2; t++) {
+        f32x4 bi0, bi1, sc0, sc1;
+        const unsigned a = aB3 + (unsigned)(t * 32) * 4;
+        lds_req128(a, bi0); lds_req128(a + 16, bi1); lds_req128(a + CMID * 4, sc0); lds_req128(a + CMID * 4 + 16, sc1);
+        lds_arrive4(bi0, bi1, sc0, sc1);
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            v[e] = fmaxf(__fmaf_rn(accR[2 * t][e], sc0[e], bi0[e]), 0.f);
+            v[4 + e] = fmaxf(__fmaf_rn(accR[2 * t + 1][e], sc1[e], bi1[e]), 0.f);
+        }
+        rmax = rng_see<8>(rmax, v);
+        uint4 oh, ol;
+        x3_split8(v, oh, ol);
+        T *op = dst3 + mrow * (2 * CMID) + t * 64 + kq * 8;
+        *(uint4 *)op = oh;
+        *(uint4 *)(op + 32) = ol;
+    }
+    rng_flush(p.range, rmax);
+}
+
+// ---------------------------------------------------------------------------------------------
 // k_tail_x3 (split precision): the same three layers -- 2x bilinear upsampling of the 64-channel map, conv7 (3x3, 64 -> 32,
 // ReLU) and the 1x1 head -- for the RCV_F16X3 engine.  Unfused they move 17 GB per 72 (frame, network) items through HBM
 // (the 480x640x64 upsampled map alone is 79 MB per item in hi / lo storage); fused only the 240x320x64 source is read.
@@ -3495,6 +3795,7 @@ struct rcv_fcn {
     bool use_dma = true;  // LDS-DMA conv kernel for the shapes it covers (bf16, Cout % 128 == 0, enough tiles)
     bool radial_f16 = false;  // the radial plane leaves the head as float16 (BASELINE.json stress configuration)
     bool use_lat = true;      // latency kernel (k_conv_lat) for launches with few tiles (small batches)
+    bool use_chain2 = true;   // split engine: k_chain2_x3 (r04) instead of k_chain_x3
     // range guard of the half-precision engines: one sticky flag word on the device (kernels OR bits into it), mirrored into
     // pinned host memory by a 4-byte copy at the end of every forward
     unsigned *range_dev = nullptr;
@@ -3765,6 +4066,9 @@ int register_kernel_attributes()
     RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_chain_x3<64>, hipFuncAttributeMaxDynamicSharedMemorySize, CH_LDS));
     RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_chain_x3<128>, hipFuncAttributeMaxDynamicSharedMemorySize, CH_LDS));
     RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_chain_x3<256>, hipFuncAttributeMaxDynamicSharedMemorySize, CH_LDS));
+    RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_chain2_x3<64>, hipFuncAttributeMaxDynamicSharedMemorySize, c2_lds(64)));
+    RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_chain2_x3<128>, hipFuncAttributeMaxDynamicSharedMemorySize, c2_lds(128)));
+    RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_chain2_x3<256>, hipFuncAttributeMaxDynamicSharedMemorySize, c2_lds(256)));
     RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_conv_block<64, false>, hipFuncAttributeMaxDynamicSharedMemorySize, blk_lds(64)));
     RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_conv_block<64, true>, hipFuncAttributeMaxDynamicSharedMemorySize, blk_lds(64)));
     RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_conv_block<128, false>, hipFuncAttributeMaxDynamicSharedMemorySize, blk_lds(128)));
@@ -3878,7 +4182,11 @@ int forward_impl(rcv_fcn *h, const float *x, int B, float *seg, float *radial, c
                     q.range = h->range_dev;
                     if (h->profiling) RCV_HIP_CHECK(hipEventRecord(h->events[2 * i], st));  // time booked on the expand
                     const dim3 grid((unsigned)((M + CH_BM - 1) / CH_BM), 1, h->groups);
-                    if (cmid == 256) hipLaunchKernelGGL((k_chain_x3<256>), grid, dim3(512), CH_LDS, st, q);
+                    if (h->use_chain2) {  // (option 10: the r04 form; 0: k_chain_x3, bit-identical output)
+                        if (cmid == 256) hipLaunchKernelGGL((k_chain2_x3<256>), grid, dim3(512), c2_lds(256), st, q);
+                        else if (cmid == 128) hipLaunchKernelGGL((k_chain2_x3<128>), grid, dim3(512), c2_lds(128), st, q);
+                        else hipLaunchKernelGGL((k_chain2_x3<64>), grid, dim3(512), c2_lds(64), st, q);
+                    } else if (cmid == 256) hipLaunchKernelGGL((k_chain_x3<256>), grid, dim3(512), CH_LDS, st, q);
                     else if (cmid == 128) hipLaunchKernelGGL((k_chain_x3<128>), grid, dim3(512), CH_LDS, st, q);
                     else hipLaunchKernelGGL((k_chain_x3<64>), grid, dim3(512), CH_LDS, st, q);
                     RCV_LAUNCH_CHECK();
@@ -4142,6 +4450,7 @@ int rcv_fcn_set_option(rcv_fcn *h, int key, int value)
     if (key == 7) { h->use_halo = value; h->attrs_set = false; return RCV_OK; }
     if (key == 8) { h->radial_f16 = value != 0; return RCV_OK; }
     if (key == 9) { h->use_lat = value != 0; return RCV_OK; }
+    if (key == 10) { h->use_chain2 = value != 0; return RCV_OK; }
     return RCV_E_INVALID;
 }
 
