@@ -3237,7 +3237,14 @@ __global__ __launch_bounds__(512) void k_chain_x3(const BlockParams p)
 //     instead of both waves of a SIMD doing VALU work while the matrix pipe idles; slice 0's sits in the last expand step.
 // ---------------------------------------------------------------------------------------------
 constexpr int c2_slot(int cmid) { return cmid * 128 > 16384 ? cmid * 128 : 16384; }       // ring slot: the larger of the two step images
-constexpr int c2_lds(int cmid) { return 3 * c2_slot(cmid) + (2 * 4 * cmid + 2 * cmid) * 4; }  // ring + [bias | scale] of both layers
+#ifndef RCV_C2_DIST
+#define RCV_C2_DIST 2  // steps between the issue of a step's weights and their use (ring slots = RCV_C2_DIST + 1)
+#endif
+#ifndef RCV_C2_DEPHASE
+#define RCV_C2_DEPHASE 0  // cycles per phase unit of the start-up delay (blockIdx.x % 6 units): spreads the workgroups' store / load bursts
+#endif
+constexpr int C2_DIST = RCV_C2_DIST, C2_RING = C2_DIST + 1;
+constexpr int c2_lds(int cmid) { return C2_RING * c2_slot(cmid) + (2 * 4 * cmid + 2 * cmid) * 4; }  // ring + [bias | scale] of both layers
 static_assert(c2_lds(256) <= 160 * 1024, "k_chain2_x3's LDS plan");
 // bank swizzle of the weight images: 16-byte column c of row r lives at column c ^ c2_key(r).  A fragment read takes, for its 16
 // lanes, the rows (r16 >> 2) * 8 + (r16 & 3) (+ multiples of 4 and 32): bits 1, 3 and 4 of the row separate them into eight
@@ -3265,6 +3272,14 @@ __global__ __launch_bounds__(512) void k_chain2_x3(const BlockParams p)
     const int r16 = lane & 15, kq = lane >> 4, lrow = lane >> 3, lpos = lane & 7;
     const int g = blockIdx.z;
     const int m0 = blockIdx.x * CH_BM;
+    if constexpr (RCV_C2_DEPHASE > 0) {
+        // Workgroups that start together run their half chunks in step: every CU stores, then every CU loads, and the memory
+        // system sees bursts it takes microseconds to drain -- which the in-order vmcnt then charges to the weight stream.  A start-up
+        // delay of blockIdx.x % 6 units spreads the phases over the half chunk's period (placement only: results unchanged).
+        const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+        const unsigned long long wait = (unsigned long long)(blockIdx.x % 6u) * RCV_C2_DEPHASE;
+        while (__builtin_amdgcn_s_memtime() - t0 < wait) __builtin_amdgcn_s_sleep(8);
+    }
     const T *src = (const T *)p.src + (long long)g * p.src_gs;
     const T *res = (const T *)p.res + (long long)g * p.res_gs;
     T *dst = (T *)p.dst + (long long)g * p.dst_gs;
@@ -3273,10 +3288,10 @@ __global__ __launch_bounds__(512) void k_chain2_x3(const BlockParams p)
     const char *w3 = (const char *)((const T *)p.w3 + (long long)g * p.w3_gs);
     const float *b2 = p.b2 + (long long)g * p.b2_gs, *b3 = p.b3 + (long long)g * p.b3_gs;  // [bias | scale]
     const int w2_bytes = COUT * CMID * 4, w3_bytes = CMID * COUT * 4;
-    float *sB2 = (float *)(smem + 3 * SLOT), *sB3 = sB2 + 2 * COUT;
+    float *sB2 = (float *)(smem + C2_RING * SLOT), *sB3 = sB2 + 2 * COUT;
     for (int i = tid; i < 2 * COUT; i += 512) sB2[i] = b2[i];
     for (int i = tid; i < 2 * CMID; i += 512) sB3[i] = b3[i];
-    const unsigned aB2 = (unsigned)(3 * SLOT) + kq * 32, aB3 = (unsigned)(3 * SLOT + 2 * COUT * 4) + kq * 32;  // this lane's 8 channels
+    const unsigned aB2 = (unsigned)(C2_RING * SLOT) + kq * 32, aB3 = (unsigned)(C2_RING * SLOT + 2 * COUT * 4) + kq * 32;  // this lane's 8 channels
 
     const int m = m0 + wave * 16 + r16;
     const long long mrow = m < p.M ? m : p.M - 1;  // (rows beyond M recompute and re-store row M - 1: equal VM operation counts)
@@ -3314,8 +3329,8 @@ __global__ __launch_bounds__(512) void k_chain2_x3(const BlockParams p)
             aE[s_][1] = *(const bf16x8 *)(sp + s_ * 64 + 32);
         }
     }
-    issue(0, 0, 0);
-    issue(0, 1 % SPC, 1);
+#pragma unroll
+    for (int k = 0; k < C2_DIST; k++) issue(k / SPC, k % SPC, k);
     f32x4 accR[NTR];
 #pragma unroll
     for (int j = 0; j < NTR; j++) accR[j] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -3394,25 +3409,47 @@ __global__ __launch_bounds__(512) void k_chain2_x3(const BlockParams p)
     };
 
     bf16x8 fwh[3], fwl[3];  // weight fragments (hi, lo) of three tiles: two in flight ahead of the one being multiplied
+#if defined(RCV_HALO_STAMPS) && defined(RCV_CHAIN2_STAMPS)
+    // diagnostic build (tools/halo_stamps.py --chain2): four stamps per step over half chunks 6 and 7 of one workgroup in the
+    // middle of the launch -- step top, after the counted vmcnt wait, after the barrier, after the issue (DMA pieces, residual)
+    unsigned hst[64];
+    for (int k = 0; k < 64; k++) hst[k] = 0u;
+    const bool stamp_blk = blockIdx.x == gridDim.x / 2 && blockIdx.z == 0 && (wave & 3) == 0 && CMID == 256;
+    bool stamp_on = false;
+#define RCV_C2STAMP(k) RCV_HSTAMP(((h - 6) * SPC + q) * 4 + (k))
+#else
+#define RCV_C2STAMP(k)
+#endif
     int slot = 0;
     for (int h = 0; h < HC; h++) {
         const bool last = h == HC - 1;
+#if defined(RCV_HALO_STAMPS) && defined(RCV_CHAIN2_STAMPS)
+        stamp_on = stamp_blk && (h == 6 || h == 7);
+#endif
 #pragma unroll
         for (int q = 0; q < SPC; q++) {
+            RCV_C2STAMP(0)
             // ---- this step's weights (issued two steps ago) have landed in every wave's share; the slot refilled below is free
             if (h > 0 || q >= 1) {
-                if (h > 0 || q >= 2) {  // (steps 0 and 1: the prologue waited)
-                    const int qm1 = (q + SPC - 1) % SPC, qm2 = (q + SPC - 2) % SPC;
-                    const bool next_exists = !(last && q == SPC - 1);
-                    const int i_m1 = next_exists ? pieces_for((q + 1) % SPC) : 0;  // pieces step g-1 issued for step g+1
-                    blk_vmwait(extra_at(qm2) + i_m1 + extra_at(qm1));
+                if (h > 0 || q >= C2_DIST) {  // (the first C2_DIST steps: the prologue waited)
+                    // younger than this step's weights (issued C2_DIST steps ago, first thing of that step): that step's loads and
+                    // stores, then per step since: the pieces for the step C2_DIST ahead of it (if there is one) and its loads / stores
+                    int n = extra_at((q + 2 * SPC - C2_DIST) % SPC);
+#pragma unroll
+                    for (int k = 1; k < C2_DIST; k++) {
+                        const bool exists = h * SPC + q + k < HC * SPC;
+                        n += (exists ? pieces_for((q + k) % SPC) : 0) + extra_at((q + 2 * SPC - C2_DIST + k) % SPC);
+                    }
+                    blk_vmwait(n);
                 }
+                RCV_C2STAMP(1)
                 __builtin_amdgcn_s_barrier();
             }
+            RCV_C2STAMP(2)
             __builtin_amdgcn_sched_barrier(0);
             {
-                const int q2 = (q + 2) % SPC, h2 = h + (q + 2 >= SPC ? 1 : 0);
-                if (h2 < HC) issue(h2, q2, slot + 2 >= 3 ? slot + 2 - 3 : slot + 2);
+                const int q2 = (q + C2_DIST) % SPC, h2 = h + (q + C2_DIST) / SPC;
+                if (h2 < HC) issue(h2, q2, slot + C2_DIST >= C2_RING ? slot + C2_DIST - C2_RING : slot + C2_DIST);
                 if (q == 0) {  // this half chunk's residual: channels kq*8 .. +7 of the slices h*2 + t (hi, lo)
 #pragma unroll
                     for (int t2 = 0; t2 < 2; t2++) {
@@ -3422,6 +3459,7 @@ __global__ __launch_bounds__(512) void k_chain2_x3(const BlockParams p)
                     }
                 }
             }
+            RCV_C2STAMP(3)
             const unsigned sbase = (unsigned)(slot * SLOT);
             const unsigned char *slh = smem + sbase + fhi, *sll = smem + sbase + flo;
             auto rd = [&](int buf, int o) {
@@ -3487,9 +3525,20 @@ __global__ __launch_bounds__(512) void k_chain2_x3(const BlockParams p)
                     al = *(const bf16x8 *)&eol;
                 }
             }
-            slot = slot + 1 == 3 ? 0 : slot + 1;
+            slot = slot + 1 == C2_RING ? 0 : slot + 1;
         }
+#if defined(RCV_HALO_STAMPS) && defined(RCV_CHAIN2_STAMPS)
+        if (stamp_on && h == 7) {
+            const int q = SPC;  // (the end of the second stamped half chunk)
+            RCV_C2STAMP(0)
+        }
+#endif
     }
+#if defined(RCV_HALO_STAMPS) && defined(RCV_CHAIN2_STAMPS)
+    if (stamp_blk && lane == 0)
+        for (int k = 0; k < 64; k++) g_chain_stamps[wave >> 2][k] = hst[k];
+#endif
+#undef RCV_C2STAMP
     // ---- the reduce's epilogue: scale, bias, ReLU, hi / lo; tiles 2t, 2t + 1 are channels t*32 + kq*8 .. +7 of this lane's pixel
 #pragma unroll
     for (int t = 0; t < NTR / 2; t++) {

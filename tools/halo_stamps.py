@@ -14,6 +14,7 @@ from rcvpose_amd.fcn_engine import FcnEngine
 ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=36)
 ap.add_argument("--tail", action="store_true", help="the build was made with -DRCV_HALO_STAMPS -DRCV_TAIL_STAMPS: phases of one tile of k_tail_x3")
+ap.add_argument("--chain2", action="store_true", help="the build was made with -DRCV_HALO_STAMPS -DRCV_CHAIN2_STAMPS: stamps of k_chain2_x3<256> (half chunks 6 and 7)")
 ap.add_argument("--chain", action="store_true", help="the build was made with -DRCV_HALO_STAMPS -DRCV_CHAIN_STAMPS: stamps of k_chain_x3<256> (chunk 3: expand step 3, reduce step 1)")
 args = ap.parse_args()
 shapes = json.load(open(os.path.join(ROOT, "tests", "golden", "fcn_state_dict_keys.json")))
@@ -35,6 +36,17 @@ if args.tail:
         print("wave %d: tile = %d cycles" % (0 if w == 0 else 3, s[9] - s[0]))
         for k, nm in enumerate(names):
             print("   %-46s %6d" % (nm, s[k + 1] - s[k]))
+    sys.exit(0)
+if args.chain2:
+    out = (ctypes.c_uint * 128)()
+    assert L.rcv_debug_chain_stamps(out) == 0
+    st = np.array(out[:], dtype=np.int64).reshape(2, 64)
+    for w in range(2):
+        s = st[w]
+        print("wave %d: half chunks 6 + 7 = %d cycles; per step (E = expand step of two K slices, R = reduce step): counted vmcnt wait / barrier / issue / compute" % (4 * w, s[48] - s[0]))
+        for q in range(12):
+            print("   %s%d  %5d %5d %5d %5d   = %5d" % ("E" if q % 6 < 4 else "R", q % 6 if q % 6 < 4 else q % 6 - 4, s[4 * q + 1] - s[4 * q], s[4 * q + 2] - s[4 * q + 1],
+                                                   s[4 * q + 3] - s[4 * q + 2], s[4 * q + 4] - s[4 * q + 3], s[4 * q + 4] - s[4 * q]))
     sys.exit(0)
 if args.chain:
     out = (ctypes.c_uint * 128)()
