@@ -36,6 +36,7 @@ add_threshold = {
     'holepuncher': 0.019606109985, 'benchvise': .033091264970068, 'iron': .03172344425531, 'lamp': .03165980764376,
     'phone': .02543407135792}
 
+DEFAULT_FRAMES_PER_STEP = 53  # frames per device batch of the evaluation drivers (bench.py's optimum for the f16x3 forward)
 ACC_UNIT_MM = 5.0  # reference AccumulatorSpace.py:374 hard-codes 5 mm voxels
 SEG_THRESHOLD = 0.8  # reference AccumulatorSpace.py:603
 
@@ -501,14 +502,16 @@ def estimate_6d_pose_lm(opts, return_details=False):
 
         if opts.using_ckpts and todo:  # the engine (BN folding, weight packing, upload) is built once per class, before the frame loop
             H, W = read_depth(rootPath + 'data/depth' + str(int(todo[0][1])) + '.dpt').shape
-            n_step = max(1, min(int(getattr(opts, 'frames_per_step', 8)), len(todo)))
+            n_step = max(1, min(int(getattr(opts, 'frames_per_step', DEFAULT_FRAMES_PER_STEP)), len(todo)))
             pipe = FramePipeline(sds, H, W, dtype=getattr(opts, 'dtype', 'f16x3'), frames_per_step=n_step)
             pipe.set_stage_timing(True)
         t_loop = _time.perf_counter()
         if opts.using_ckpts and todo:
-            # The frames of a class travel through the device pipeline in batches of opts.frames_per_step (default 8): a pool of
-            # host threads decodes the next batch's JPEG / .dpt / pose files while the GPU works on the current one, there is one
-            # result copy and one Horn launch per batch; ADD(-S) / ICP then run per frame.  A frame's maps and keypoints do not
+            # The frames of a class travel through the device pipeline in batches of opts.frames_per_step (default: bench.py's 53):
+            # a pool of host threads decodes the next batch's JPEG / .dpt / pose files while the GPU works on the current one, there
+            # is one result copy and one Horn launch per batch; ADD(-S) / ICP of the batch's frames then run on opts.eval_threads
+            # host threads, each on its own HIP stream (a frame's evaluation is a chain of small launches and a few
+            # synchronisations: one thread spends it waiting, sixteen overlap).  A frame's maps and keypoints do not
             # depend on the batch it travels in (tests/test_gpu_fcn_x3.py::test_x3_groups_and_batch), so the results are those
             # of the frame-by-frame loop of the reference (:553-659).
             from concurrent.futures import ThreadPoolExecutor
@@ -525,7 +528,17 @@ def estimate_6d_pose_lm(opts, return_details=False):
 
             N = n_step
             kpts_model = keypoints[1:4, :] * 1000
-            with ThreadPoolExecutor(max_workers=min(8, N)) as pool:
+            import threading
+
+            n_eval = max(1, int(getattr(opts, 'eval_threads', min(16, os.cpu_count() or 8))))
+            tls = threading.local()
+
+            def worker_stream():
+                if getattr(tls, "stream", None) is None:
+                    tls.stream = torch.cuda.Stream()
+                return tls.stream
+
+            with ThreadPoolExecutor(max_workers=min(16, N)) as pool, ThreadPoolExecutor(max_workers=n_eval) as eval_pool:
                 chunks = [todo[i:i + N] for i in range(0, len(todo), N)]
                 pending = [pool.submit(load, it) for it in chunks[0]]
                 # Batch ci + 1 is enqueued on the pipeline's own stream (FCN -> seam -> voting -> async copy of the result records
@@ -564,15 +577,24 @@ def estimate_6d_pose_lm(opts, return_details=False):
                     res = [_hip.AccResult.from_buffer_copy(raw[i].tobytes()) for i in range(raw.shape[0])]
                     kp_all = np.array([[r.center_mm[0], r.center_mm[1], r.center_mm[2]] for r in res]).reshape(N, 3, 3)
                     RT_all = horn_batch(kpts_model, torch.from_numpy(np.ascontiguousarray(kp_all)).cuda()).cpu().numpy()  # :659-661
-                    for i, (filename, stem) in enumerate(chunk):
-                        print("Evaluating ", filename)
+
+                    def evaluate(i):  # Horn pose -> ADD(-S) -> ICP -> ADD(-S) of frame i of the batch, on this thread's stream
                         for r in res[3 * i:3 * i + 3]:
                             _raise_like_reference(r.status)
                         RTGT_mm = np.array(loaded[i][2], dtype=np.float64, copy=True)
                         RTGT_mm[:, 3] = RTGT_mm[:, 3] * 1000
-                        ev = _pose_and_add(class_name, xyz_load, keypoints, kp_all[i], RTGT_mm, seg_b[:, i, 0], rad_b[:, i, 0],
-                                           depth_dev[i], max_radii_dm, 0, ICPConvergenceCriteria(), RT=RT_all[i])
-                        account(stem, ev)
+                        with torch.cuda.stream(worker_stream()):
+                            torch.cuda.current_stream().wait_event(done)  # (maps, depth and keypoints of the batch are complete)
+                            ev = _pose_and_add(class_name, xyz_load, keypoints, kp_all[i], RTGT_mm, seg_b[:, i, 0], rad_b[:, i, 0],
+                                               depth_dev[i], max_radii_dm, 0, ICPConvergenceCriteria(), RT=RT_all[i])
+                            torch.cuda.current_stream().synchronize()
+                        return ev
+
+                    # (every frame of the batch is joined here, before the next iteration lets batch ci + 2 overwrite these maps)
+                    futures = [eval_pool.submit(evaluate, i) for i in range(len(chunk))]
+                    for (filename, stem), fut in zip(chunk, futures):
+                        print("Evaluating ", filename)
+                        account(stem, fut.result())
                 pipe.finish()
             todo = []
         for filename, stem in todo:  # pre-computed radial maps (:611-618): frame by frame

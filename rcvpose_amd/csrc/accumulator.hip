@@ -94,7 +94,7 @@ struct alignas(16) AccHeader {
     unsigned long long climb_center[2];  // 1 + flat index of the voxel the hill-climb round (parity) was centred on; 0: none
     unsigned long long seed;             // 1 + flat index of the least-squares estimate of the keypoint's voxel (k_bb_seed); 0: none
     int32_t probe_skip;                  // the round of exact counts around the seed already found a strong peak: no greedy probe
-    int32_t pad2_;
+    int32_t bb_handover;                 // the search gave up on cost (d_bb_restart): the rasteriser decides (diagnostics)
     // best key (votes << 32 | flat index) as of the END of hill-climb round r, in slot r & 1: round r + 1 centres on it.  Round r
     // only writes slot r & 1 and only reads the other one, so every workgroup of a round sees the same, frozen centre (r03;
     // before, each workgroup took the live bb_best_key at its own start and a late one could centre on a voxel found by its
@@ -1714,6 +1714,21 @@ __device__ __forceinline__ void d_bb_restart(AccHeader *hdr, const BBEntry *list
     const AccHeader H = *hdr;
     if (H.status != RCV_OK || !H.bb_enabled || H.bb_overflow || H.variant != 0) return;
     const uint32_t na = min(n_pairs, (uint32_t)BB_HALF), nb = min(n_singles, (uint32_t)BB_HALF), n = na + nb;
+    // Cost-based hand-over (r04).  The search certifies the arg-max by scoring every surviving block against all N points; on a
+    // flat vote landscape (radial noise of several voxels) the survivors of the fine levels outgrow the rasteriser's work, which
+    // is one interval evaluation per (point, column inside the shell's disc) ~ N * pi * r^2 whatever the noise.  Measured on the
+    // bench cloud (N = 15.5k, radii 50 ... 94 voxels; tools/vote_sweep.py): 1.25 ps per (block, point) against 8 ps per (point,
+    // column), and the 2-voxel level sees about twice the 4-voxel level's survivors -- so once MORE than 3.7 r_max^2 four-voxel
+    // candidates survive (33k on that cloud), finishing the search costs more than voting the whole grid: the search gives up
+    // here (the fallback every search exit takes: k_vote decides; identical result by construction).  Both costs are
+    // proportional to N; the grid edge does not enter (false positives on a background plane widen the grid, not the shells).
+    if (edge == 4 && (double)n > 3.7 * H.rmax * H.rmax) {
+        if (threadIdx.x == 0) {
+            hdr->bb_overflow = 1;
+            hdr->bb_handover = 1;
+        }
+        return;
+    }
     unsigned long long best = 0;
     __shared__ int s_box[6];
     if (threadIdx.x < 6) s_box[threadIdx.x] = (threadIdx.x & 1) ? -1 : 0x7fffffff;

@@ -27,9 +27,11 @@ def build_parser():
     p.add_argument('--dtype', type=str, default='f16x3', choices=['f16x3', 'fp32', 'bf16', 'fp16'],
                    help="engine arithmetic: f16x3 (default; fp16 hi/lo pairs, 3 MFMAs per product) and fp32 reproduce the reference's "
                         "fp32 forward to 1e-4; bf16 / fp16 are throughput modes outside that tolerance")
-    p.add_argument('--frames_per_step', type=int, default=8,
-                   help="frames of a class that travel through the device pipeline together (LINEMOD loop with checkpoints); "
-                        "results do not depend on it")
+    p.add_argument('--frames_per_step', type=int, default=53,
+                   help="frames of a class that travel through the device pipeline together (LINEMOD loop with checkpoints; default: "
+                        "bench.py's batch); results do not depend on it")
+    p.add_argument('--eval_threads', type=int, default=16,
+                   help="host threads (one HIP stream each) for the per-frame Horn / ADD(-S) / ICP evaluation of a batch")
     return p
 
 

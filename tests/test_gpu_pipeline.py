@@ -167,7 +167,7 @@ def test_keypoints_under_false_positives_and_noise_equal_the_oracle(golden_dir, 
     cases = [dict(noise_dm=0.02, outlier_frac=0.0, seg_false_pos=0.1), dict(noise_dm=0.05, outlier_frac=0.2, seg_false_pos=0.1)]
     fr = [frames.synthetic_frame(300 + i, **cases[i]) for i in range(2)]
     B, G, H, W = 2, 3, 480, 640
-    pipe = FramePipeline(_state_dicts(golden_dir), H, W, dtype="bf16", frames_per_step=B)   # (only the voting half is used)
+    pipe = FramePipeline(_state_dicts(golden_dir), H, W, frames_per_step=B)   # (only the voting half is used)
     pipe.seg.copy_(torch.from_numpy(np.stack([np.stack([f["seg"] for f in fr])] * G))[:, :, None].cuda())
     pipe.radial.copy_(torch.from_numpy(np.stack([np.stack([f["radial"][k] for f in fr]) for k in range(G)]))[:, :, None].cuda())
     depth = torch.from_numpy(np.stack([f["depth"] for f in fr]).view(np.int16)).cuda()
@@ -184,3 +184,31 @@ def test_keypoints_under_false_positives_and_noise_equal_the_oracle(golden_dir, 
             ref, _, info, _ = oracle.accumulator_3d(xyz, rl, sparse=True, return_all=True)
             assert np.array_equal(kp[b, k], ref[0]), (b, k)
             assert r.dim == info.dim and r.n_points == len(xyz)
+
+
+def test_flat_vote_landscape_is_handed_to_the_rasteriser_and_equals_the_oracle(golden_dir, oracle):
+    """Four voxels of radial noise flatten the vote landscape until certifying its arg-max by branch and bound costs more than
+    voting the whole grid: the search hands such an item to the LDS rasteriser once more than 0.6 D^2 four-voxel candidates
+    survive (d_bb_restart, r04).  Same keypoints as the oracle either way; a benign frame in the same batch stays with the search."""
+    from rcvpose_amd.pipeline import FramePipeline
+
+    fr = [frames.synthetic_frame(310, noise_dm=0.2), frames.synthetic_frame(311)]
+    B, G, H, W = 2, 3, 480, 640
+    pipe = FramePipeline(_state_dicts(golden_dir), H, W, frames_per_step=B)   # (only the voting half is used)
+    pipe.seg.copy_(torch.from_numpy(np.stack([np.stack([f["seg"] for f in fr])] * G))[:, :, None].cuda())
+    pipe.radial.copy_(torch.from_numpy(np.stack([np.stack([f["radial"][k] for f in fr]) for k in range(G)]))[:, :, None].cuda())
+    depth = torch.from_numpy(np.stack([f["depth"] for f in fr]).view(np.int16)).cuda()
+    rmax = torch.tensor(np.stack([f["max_radii_dm"] for f in fr]), dtype=torch.float64, device="cuda")
+    pipe.vote(depth, rmax)
+    kp, res = pipe.read_results()
+    hdr = pipe.ws[:, :512].cpu().numpy().view(np.int32)
+    done = [[int(hdr[b * G + k, 116 // 4]) for k in range(G)] for b in range(B)]   # AccHeader::bb_done
+    print("decided by the search (1) / by the rasteriser (0):", done)
+    assert sum(done[0]) < G and sum(done[1]) == G
+    for b in range(B):
+        for k in range(G):
+            r = res[b * G + k]
+            xyz, rl = oracle.seam(fr[b]["seg"], fr[b]["radial"][k], fr[b]["depth"], fr[b]["max_radii_dm"][k])
+            ref, _, info, peak = oracle.accumulator_3d(xyz, rl, sparse=True, return_all=True)
+            assert r.status == 0 and np.array_equal(kp[b, k], ref[0]), (b, k)
+            assert (r.dim, r.peak_votes) == (info.dim, peak)

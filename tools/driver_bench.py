@@ -23,7 +23,7 @@ import torch
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--frames", type=int, default=64)
-    ap.add_argument("--frames_per_step", type=int, default=16)
+    ap.add_argument("--frames_per_step", type=int, default=53)
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "driver_bench.json"))
     args = ap.parse_args()
     import test_gpu_driver as T  # the synthetic LINEMOD layout of the driver tests
