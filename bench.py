@@ -477,7 +477,8 @@ def main(argv=None):
         # HBM bytes of the conv family: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the FCN of this mode
         # (gfx950 correction applied), committed under profiles/ with the batch they were taken at -- NOT counters of this run
         traffic, traffic_src = None, None
-        for name, modes in (("r03_conv_hbm_traffic_%s.json" % args.dtype, (args.dtype,)), ("r02_conv_hbm_traffic.json", ("bf16", "fp16"))):
+        for name, modes in (("r04_conv_hbm_traffic_%s.json" % args.dtype, (args.dtype,)), ("r03_conv_hbm_traffic_%s.json" % args.dtype, (args.dtype,)),
+                            ("r02_conv_hbm_traffic.json", ("bf16", "fp16"))):
             tpath = os.path.join(ROOT, "profiles", name)
             if os.path.exists(tpath) and args.dtype in modes:
                 tj = json.load(open(tpath))["conv_family"]
@@ -508,13 +509,13 @@ def main(argv=None):
             "equivalent_votes_note": "sum of 5.44 r^2 shell voxels per point / stage time: the votes a rasteriser would cast; the timed "
                                      "engine (exact branch-and-bound peak search) never casts them",
         }
-        vp = next((q for q in (os.path.join(ROOT, "profiles", n) for n in ("r03_vote_pmc.json", "r02_vote_pmc.json")) if os.path.exists(q)), None)
-        if vp:  # separate rocprofv3 --pmc passes of the voting stage at 72 frames (tools/collect_profiles.sh)
+        vp = next((q for q in (os.path.join(ROOT, "profiles", n) for n in ("r04_vote_pmc.json", "r03_vote_pmc.json", "r02_vote_pmc.json")) if os.path.exists(q)), None)
+        if vp:  # separate rocprofv3 --pmc passes of the voting stage (tools/collect_profiles.sh; r04: at the bench batch)
             pj = json.load(open(vp))
             roof_vote["pmc"] = {"source": "profiles/%s: " % os.path.basename(vp) + pj["source"], "definitions": pj["definitions"],
                                 "kernels": {k: {q: v[q] for q in ("ms_per_batch", "valu_issue_frac", "hbm_bytes_per_batch") if q in v}
                                             for k, v in pj["kernels"].items() if v["ms_per_batch"] >= 0.1}}
-            if B == 72:
+            if B == int(pj.get("frames_per_batch", 72)):
                 roof_vote["traffic"] = pj["hbm_bytes_per_batch_sum"]
                 roof_vote["traffic_note"] = ("HBM-side bytes per step of all voting kernels (FETCH_SIZE / WRITE_SIZE passes, Infinity-Cache hits "
                                              "included): the point lists are re-streamed by every pass of every search level out of L2 / "
@@ -580,10 +581,10 @@ def main(argv=None):
         line["precision_meets_tolerance"] = bool(line["precision"]["radial_map_rel_err_vs_fp32_engine"] <= MAP_TOLERANCE and
                                                  line["precision"]["seg_map_rel_err_vs_fp32_engine"] <= MAP_TOLERANCE)
         ok = ok and line["precision_meets_tolerance"] and line["precision"]["range_flags_of_timed_engine"] == 0
-        sweep = os.path.join(ROOT, "profiles", "r03_vote_sweep.json")
+        sweep = next((q for q in (os.path.join(ROOT, "profiles", n) for n in ("r04_vote_sweep.json", "r03_vote_sweep.json")) if os.path.exists(q)), "")
         if os.path.exists(sweep):  # data dependence of the peak search (tools/vote_sweep.py), a committed measurement, not this run
             sj = json.load(open(sweep))
-            roof_vote["sensitivity"] = {"source": "profiles/r03_vote_sweep.json (%s)" % sj.get("command", ""), "benign_ms_per_216_items": sj.get("benign_ms"),
+            roof_vote["sensitivity"] = {"source": "profiles/%s (%s)" % (os.path.basename(sweep), sj.get("command", "")), "benign_ms_per_216_items": sj.get("benign_ms"),
                                         "worst_ms_per_216_items": sj.get("worst_ms"), "worst_case": sj.get("worst_case"),
                                         "fallback_rate_worst": sj.get("worst_fallback_rate")}
         if not args.no_extras and world == 1:

@@ -503,6 +503,10 @@ def estimate_6d_pose_lm(opts, return_details=False):
         if opts.using_ckpts and todo:  # the engine (BN folding, weight packing, upload) is built once per class, before the frame loop
             H, W = read_depth(rootPath + 'data/depth' + str(int(todo[0][1])) + '.dpt').shape
             n_step = max(1, min(int(getattr(opts, 'frames_per_step', DEFAULT_FRAMES_PER_STEP)), len(todo)))
+            # equal batches: the device pipeline runs whole batches, so 128 frames travel as 43 + 43 + 42, not as 53 + 53 + 22 with
+            # 31 padded frames of wasted work
+            n_batches = (len(todo) + n_step - 1) // n_step
+            n_step = (len(todo) + n_batches - 1) // n_batches
             pipe = FramePipeline(sds, H, W, dtype=getattr(opts, 'dtype', 'f16x3'), frames_per_step=n_step)
             pipe.set_stage_timing(True)
         t_loop = _time.perf_counter()

@@ -2,7 +2,7 @@
 # Runs ON THE GPU BOX (through gpurun): the rocprofv3 passes behind profiles/r03* (r02: the same passes with the bf16 engine at 72 frames).  Kernel trace / stats and each PMC
 # counter set are separate runs (never --pmc together with the sys/hip trace domains); the program follows `--` directly.
 #   tools/collect_profiles.sh <tag>          -> gpurun_out/<tag>/...
-TAG=${1:-r03}
+TAG=${1:-r04}
 DT=${2:-f16x3}     # FCN arithmetic of the traffic / matrix-core passes (bench.py's default)
 FB=${3:-53}
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
@@ -21,9 +21,9 @@ done
 run mfma --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/mfma -- python3 $ROOT/tools/fcn_bench.py --dtype $DT --batch $FB --iters 1
 run mfma2 --kernel-trace --pmc SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_INSTS_MFMA SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_LDS SQ_WAIT_INST_LDS --output-format csv -d $OUT/mfma2 -- python3 $ROOT/tools/fcn_bench.py --dtype $DT --batch $FB --iters 1
 # 4. VALU occupancy of the voting kernels at the bench batch
-run valu --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/valu -- python3 $ROOT/tools/vote_batch_bench.py --frames 72 --iters 2
-run vote_fetch --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/vote_fetch -- python3 $ROOT/tools/vote_batch_bench.py --frames 72 --iters 2
-run vote_write --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/vote_write -- python3 $ROOT/tools/vote_batch_bench.py --frames 72 --iters 2
+run valu --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/valu -- python3 $ROOT/tools/vote_batch_bench.py --frames $FB --iters 2
+run vote_fetch --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/vote_fetch -- python3 $ROOT/tools/vote_batch_bench.py --frames $FB --iters 2
+run vote_write --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/vote_write -- python3 $ROOT/tools/vote_batch_bench.py --frames $FB --iters 2
 # keep only the CSVs (the merged-back directory is capped at 64 MiB)
 find $OUT -name "*.csv" -size +20M -delete
 find $OUT -type f ! -name "*.csv" ! -name "*.log" -delete

@@ -31,6 +31,9 @@ def short(n):
     mm = re.search(r'k_convI(\w+?)Li(\d+)ELi(\d+)', n)
     if mm:
         return 'k_conv<%s,%s,%s>' % ("16-bit" if ("16b" in mm.group(1) or "DF16" in mm.group(1)) else "f32", mm.group(2), mm.group(3))
+    mc2 = re.search(r'k_chain2_x3<(\d+)>', n) or re.search(r'k_chain2_x3ILi(\d+)', n)
+    if mc2:
+        return 'k_chain2_x3<%s>' % mc2.group(1)
     mc = re.search(r'k_chain_x3<(\d+)>', n) or re.search(r'k_chain_x3ILi(\d+)', n)
     if mc:
         return 'k_chain_x3<%s>' % mc.group(1)
@@ -144,10 +147,10 @@ if v is not None:
     tot_ms = sum(e["ms_per_batch"] for e in rows.values())
     tot_bytes = sum(e.get("hbm_bytes_per_batch", 0.0) for e in rows.values())
     json.dump({"source": "rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE, and the "
-                         "FETCH_SIZE / WRITE_SIZE passes -- python3 tools/vote_batch_bench.py --frames 72 --iters 2 (seam + voting of 216 (frame, keypoint) items)",
+                         "FETCH_SIZE / WRITE_SIZE passes -- python3 tools/vote_batch_bench.py --frames %d --iters 2 (seam + voting of %d (frame, keypoint) items)" % (FB, 3 * FB),
                "definitions": "valu_issue_frac = 4 * SQ_INSTS_VALU / (GRBM_GUI_ACTIVE/8 * 1024 SIMDs): a wave64 VALU instruction holds its SIMD's 16 lanes for 4 cycles, "
                               "so this is lane-instructions / (256 CU x 4 SIMD x 16 lanes/clk x cycles)",
-               "tool_output": log_tail("valu"), "kernel_ms_per_batch_sum": tot_ms, "hbm_bytes_per_batch_sum": tot_bytes,
+               "tool_output": log_tail("valu"), "frames_per_batch": FB, "kernel_ms_per_batch_sum": tot_ms, "hbm_bytes_per_batch_sum": tot_bytes,
                "dominant_kernel": max(rows, key=lambda k: rows[k]["ms_per_batch"]), "kernels": rows},
               open(os.path.join(OUT, TAG + "_vote_pmc.json"), "w"), indent=1)
 print("wrote", [f for f in sorted(os.listdir(OUT)) if f.startswith(TAG)])
