@@ -775,6 +775,9 @@ __global__ __launch_bounds__(512) void k_conv_dma(const ConvParams p)
 // is what keeps a frame's maps independent of the batch it travels in.  No split-K: a different summation order would
 // break exactly that.
 // ---------------------------------------------------------------------------------------------
+#ifndef RCV_LAT_AHEAD
+#define RCV_LAT_AHEAD 1  // fragment reads one K step ahead of the MFMAs (0: the r02 form, bit-identical)
+#endif
 constexpr int LAT_BM = 64, LAT_BN = 64, LAT_STAGES = 8;
 constexpr int LAT_STAGE_BYTES = (LAT_BM + LAT_BN) * 128;
 
@@ -877,12 +880,35 @@ __global__ __launch_bounds__(512) void k_conv_lat(const ConvParams p)
         for (int j = 0; j < NT; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int r16 = lane & 15, kq = lane >> 4;
     const int ch0 = ((0 * 4 + kq) ^ ((r16 >> 1) & 7)) << 4, ch1 = ((1 * 4 + kq) ^ ((r16 >> 1) & 7)) << 4;
+    // this wave's fragments of one K step (A rows wm*32 .. +31, B rows wn*32 .. +31; two 32-wide K halves each)
+    bf16x8 af[2][2][MT], bfr[2][2][NT];  // [register set][K half][tile]
+    auto read_frags = [&](int set, int st) {
+        const unsigned char *Ab = smem + st * LAT_STAGE_BYTES + (wm * 32 + r16) * 128;
+        const unsigned char *Bb = smem + st * LAT_STAGE_BYTES + BM * 128 + (wn * 32 + r16) * 128;
 #pragma unroll
-    for (int s_ = 0; s_ < NS - 1; s_++) RCV_LAT_ISSUE(s_);
-    int stage = 0;
-    for (int kt = 0; kt < nk; kt++) {
-        // steps issued after step kt: min(NS - 2, nk - 1 - kt), two pieces each (wave-uniform)
-        const int younger = min(NS - 2, nk - 1 - kt);
+        for (int i = 0; i < MT; i++) { af[set][0][i] = *(const bf16x8 *)(Ab + i * 16 * 128 + ch0); af[set][1][i] = *(const bf16x8 *)(Ab + i * 16 * 128 + ch1); }
+#pragma unroll
+        for (int j = 0; j < NT; j++) { bfr[set][0][j] = *(const bf16x8 *)(Bb + j * 16 * 128 + ch0); bfr[set][1][j] = *(const bf16x8 *)(Bb + j * 16 * 128 + ch1); }
+    };
+    auto multiply = [&](int set) {
+        if constexpr (kX3) {  // [32 hi | 32 lo] K rows: hi*hi, hi*lo, lo*hi
+#pragma unroll
+            for (int t = 0; t < 3; t++)
+#pragma unroll
+                for (int i = 0; i < MT; i++)
+#pragma unroll
+                    for (int j = 0; j < NT; j++) acc[i][j] = RCV_MFMA16(af[set][t == 2 ? 1 : 0][i], bfr[set][t == 1 ? 1 : 0][j], acc[i][j], 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < 2; kk++)
+#pragma unroll
+                for (int i = 0; i < MT; i++)
+#pragma unroll
+                    for (int j = 0; j < NT; j++) acc[i][j] = RCV_MFMA16(af[set][kk][i], bfr[set][kk][j], acc[i][j], 0, 0, 0);
+        }
+    };
+    // counted wait: `younger` K steps (two pieces each, wave-uniform) were issued after the one needed now
+    auto wait_steps = [&](int younger) {
         if (younger >= 6) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
         else if (younger == 5) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
         else if (younger == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
@@ -890,36 +916,54 @@ __global__ __launch_bounds__(512) void k_conv_lat(const ConvParams p)
         else if (younger == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else if (younger == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        static_assert(NS == 8, "the counted waits above are written for 8 stages");
+    };
+    static_assert(NS == 8, "the counted waits are written for 8 stages");
+#if RCV_LAT_AHEAD
+    // r04: the fragment reads run ONE STEP AHEAD of the MFMAs.  A step used to be barrier -> DMA issue -> eight fragment reads ->
+    // their LDS latency -> the MFMAs, a dependent chain of ~750 cycles walked 36 ... 864 times by a launch with few tiles.  Now the
+    // barrier of step kt certifies step kt + 1 (all eight stages are issued up front and the counted wait looks one step further),
+    // the multiplying waves request the fragments of step kt + 1 into a second register set and multiply step kt's, which they
+    // have held since the previous step: the LDS round trip leaves the chain.  The stage of step kt is free as soon as that
+    // barrier is passed (its fragments are in registers) and takes step kt + 8.  Same products in the same order.
+#pragma unroll
+    for (int s_ = 0; s_ < NS; s_++) RCV_LAT_ISSUE(s_);
+    wait_steps(min(NS - 1, nk - 1));
+    __builtin_amdgcn_s_barrier();
+    if (mma) read_frags(0, 0);
+    int stage = 0;
+    for (int kt = 0; kt < nk; kt += 2) {
+#pragma unroll
+        for (int par = 0; par < 2; par++) {  // (two steps per trip: the register set of a step is a compile-time index)
+            const int k_ = kt + par;
+            if (k_ < nk) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's reads of stage `stage` are complete: it may be refilled
+                if (k_ + 1 < nk) wait_steps(min(NS - 2, nk - 2 - k_));  // step k_ + 1 has landed (this wave's pieces)
+                __builtin_amdgcn_s_barrier();                        // ... and everybody's; everybody holds step k_ in registers
+                const int nxt = stage + 1 == NS ? 0 : stage + 1;
+                if (mma && k_ + 1 < nk) read_frags(par ^ 1, nxt);
+                RCV_LAT_ISSUE(stage);
+                if (mma) multiply(par);
+                stage = nxt;
+            }
+        }
+    }
+#else
+#pragma unroll
+    for (int s_ = 0; s_ < NS - 1; s_++) RCV_LAT_ISSUE(s_);
+    int stage = 0;
+    for (int kt = 0; kt < nk; kt++) {
+        // steps issued after step kt: min(NS - 2, nk - 1 - kt), two pieces each (wave-uniform)
+        wait_steps(min(NS - 2, nk - 1 - kt));
         __builtin_amdgcn_s_barrier();  // step kt has landed for every wave; every wave is done reading step kt - 1
         const int free_ = stage == 0 ? NS - 1 : stage - 1;  // the stage step kt - 1 was read from
         RCV_LAT_ISSUE(free_);
         if (mma) {
-            const unsigned char *Ab = smem + stage * LAT_STAGE_BYTES + (wm * 32 + r16) * 128;
-            const unsigned char *Bb = smem + stage * LAT_STAGE_BYTES + BM * 128 + (wn * 32 + r16) * 128;
-            bf16x8 af[2][MT], bfr[2][NT];
-#pragma unroll
-            for (int i = 0; i < MT; i++) { af[0][i] = *(const bf16x8 *)(Ab + i * 16 * 128 + ch0); af[1][i] = *(const bf16x8 *)(Ab + i * 16 * 128 + ch1); }
-#pragma unroll
-            for (int j = 0; j < NT; j++) { bfr[0][j] = *(const bf16x8 *)(Bb + j * 16 * 128 + ch0); bfr[1][j] = *(const bf16x8 *)(Bb + j * 16 * 128 + ch1); }
-            if constexpr (kX3) {  // [32 hi | 32 lo] K rows: hi*hi, hi*lo, lo*hi
-#pragma unroll
-                for (int t = 0; t < 3; t++)
-#pragma unroll
-                    for (int i = 0; i < MT; i++)
-#pragma unroll
-                        for (int j = 0; j < NT; j++) acc[i][j] = RCV_MFMA16(af[t == 2 ? 1 : 0][i], bfr[t == 1 ? 1 : 0][j], acc[i][j], 0, 0, 0);
-            } else {
-#pragma unroll
-                for (int kk = 0; kk < 2; kk++)
-#pragma unroll
-                    for (int i = 0; i < MT; i++)
-#pragma unroll
-                        for (int j = 0; j < NT; j++) acc[i][j] = RCV_MFMA16(af[kk][i], bfr[kk][j], acc[i][j], 0, 0, 0);
-            }
+            read_frags(0, stage);
+            multiply(0);
         }
         stage = stage + 1 == NS ? 0 : stage + 1;
     }
+#endif
 #undef RCV_LAT_ISSUE
     // epilogue: fp32 tile through LDS, 16-byte vectors of contiguous channels (bias + residual + ReLU fused)
     T *dst = (T *)p.dst + (long long)g * p.dst_gs;
