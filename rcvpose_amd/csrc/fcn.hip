@@ -776,7 +776,7 @@ __global__ __launch_bounds__(512) void k_conv_dma(const ConvParams p)
 // break exactly that.
 // ---------------------------------------------------------------------------------------------
 #ifndef RCV_LAT_AHEAD
-#define RCV_LAT_AHEAD 1  // fragment reads one K step ahead of the MFMAs (0: the r02 form, bit-identical)
+#define RCV_LAT_AHEAD 0  // 1: fragment reads one K step ahead of the MFMAs (bit-identical; measured r04: 4.41 vs 4.30 ms per batch-1 f16x3 forward -- slower, off)
 #endif
 constexpr int LAT_BM = 64, LAT_BN = 64, LAT_STAGES = 8;
 constexpr int LAT_STAGE_BYTES = (LAT_BM + LAT_BN) * 128;
@@ -919,7 +919,7 @@ __global__ __launch_bounds__(512) void k_conv_lat(const ConvParams p)
     };
     static_assert(NS == 8, "the counted waits are written for 8 stages");
 #if RCV_LAT_AHEAD
-    // r04: the fragment reads run ONE STEP AHEAD of the MFMAs.  A step used to be barrier -> DMA issue -> eight fragment reads ->
+    // r04 experiment (off): the fragment reads run ONE STEP AHEAD of the MFMAs.  A step is barrier -> DMA issue -> eight fragment reads ->
     // their LDS latency -> the MFMAs, a dependent chain of ~750 cycles walked 36 ... 864 times by a launch with few tiles.  Now the
     // barrier of step kt certifies step kt + 1 (all eight stages are issued up front and the counted wait looks one step further),
     // the multiplying waves request the fragments of step kt + 1 into a second register set and multiply step kt's, which they
