@@ -90,12 +90,20 @@ template <typename T> __device__ __forceinline__ long long nhwc_off(long long m,
     if constexpr (is_x3<T>()) return m * (2LL * C) + x3_off(n);
     else return m * C + n;
 }
-// v -> (hi, lo); magnitudes beyond the half range saturate (65504 + 65504) instead of turning into inf - inf
+// v -> (hi, lo); magnitudes beyond the half range saturate (65504 + 65504) instead of turning into inf - inf.  r04: the
+// saturation is the hardware's -- every kernel of the split engine sets MODE.FP16_OVFL (RCV_X3_MODE), under which a float -> half
+// conversion that overflows returns +-65504 instead of an infinity (tools/probe/ovfl_probe.hip: v_cvt_f16_f32 and
+// v_cvt_pk_f16_f32 alike; a true infinity stays one) -- so the two v_med3_f32 per element that used to clamp by hand are gone
+// (16 of the 36 VALU instructions of a split of eight).  Same values for every finite input.
+#if defined(RCV_FCN_X3)
+#define RCV_X3_MODE() __builtin_amdgcn_s_setreg(((1 - 1) << 11) | (23 << 6) | 1, 1)  /* hwreg(HW_REG_MODE, 23, 1) = 1: FP16_OVFL */
+#else
+#define RCV_X3_MODE()
+#endif
 __device__ __forceinline__ void x3_split(float v, H16 &hi, H16 &lo)
 {
-    const float h = __builtin_amdgcn_fmed3f(v, -65504.f, 65504.f);
-    hi = (H16)h;
-    lo = (H16)__builtin_amdgcn_fmed3f(v - (float)hi, -65504.f, 65504.f);
+    hi = (H16)v;
+    lo = (H16)(v - (float)hi);
 }
 // eight consecutive channels as two 16-byte vectors.  Written on pairs: gfx950 converts two floats to packed halves in one
 // instruction (v_cvt_pk_f16_f32) and subtracts / adds two floats in one (v_pk_add_f32) -- 36 VALU instructions per eight
@@ -109,11 +117,10 @@ __device__ __forceinline__ void x3_split8(const float *v, uint4 &hi, uint4 &lo)
     unsigned *wh = (unsigned *)&hi, *wl = (unsigned *)&lo;
 #pragma unroll
     for (int e = 0; e < 4; e++) {
-        const f32x2 c = {__builtin_amdgcn_fmed3f(v[2 * e], -65504.f, 65504.f), __builtin_amdgcn_fmed3f(v[2 * e + 1], -65504.f, 65504.f)};
-        const x3_h2 h = __builtin_convertvector(c, x3_h2);
-        const f32x2 r = (f32x2){v[2 * e], v[2 * e + 1]} - __builtin_convertvector(h, f32x2);
-        const f32x2 rc = {__builtin_amdgcn_fmed3f(r[0], -65504.f, 65504.f), __builtin_amdgcn_fmed3f(r[1], -65504.f, 65504.f)};
-        const x3_h2 l = __builtin_convertvector(rc, x3_h2);
+        const f32x2 c = {v[2 * e], v[2 * e + 1]};
+        const x3_h2 h = __builtin_convertvector(c, x3_h2);  // (saturating: RCV_X3_MODE)
+        const f32x2 r = c - __builtin_convertvector(h, f32x2);
+        const x3_h2 l = __builtin_convertvector(r, x3_h2);
         wh[e] = __builtin_bit_cast(unsigned, h);
         wl[e] = __builtin_bit_cast(unsigned, l);
     }
@@ -203,6 +210,7 @@ __device__ __forceinline__ void tile_of_block(int n_tiles, int &mt, int &nt)
 template <typename T, int BM, int BN>
 __global__ __launch_bounds__(256) void k_conv(const ConvParams p)
 {
+    RCV_X3_MODE();
     constexpr int KE = Traits<T>::KE, EPV = Traits<T>::EPV;
     constexpr int AR = BM / 32, BR = BN / 32;  // 16-byte rows each thread stages per tile
     constexpr int MT = BM / 32, NT = BN / 32;  // 16x16 MFMA tiles per wave (waves are 2 x 2)
@@ -458,6 +466,7 @@ constexpr int DMA_STAGE_BYTES = (DMA_BM + DMA_BN) * 128;
 
 __global__ __launch_bounds__(512) void k_conv_dma(const ConvParams p)
 {
+    RCV_X3_MODE();
     using T = H16;
     constexpr int KE = 64, EPV = 8, BM = DMA_BM, BN = DMA_BN;
     constexpr int MT = 4, NT = 4;
@@ -790,6 +799,7 @@ __device__ __forceinline__ void lat_dma16(const void *base, int num_bytes, unsig
 
 __global__ __launch_bounds__(512) void k_conv_lat(const ConvParams p)
 {
+    RCV_X3_MODE();
     using T = H16;
     constexpr int KE = 64, EPV = 8, BM = LAT_BM, BN = LAT_BN, NS = LAT_STAGES;
     constexpr int MT = 2, NT = 2;
@@ -1089,6 +1099,7 @@ __device__ __forceinline__ void halo_dma16(const void *base, int num_bytes, unsi
 template <int BN, int MT>
 __global__ __launch_bounds__(512) void k_conv_halo(const HaloParams p)
 {
+    RCV_X3_MODE();
     using T = H16;
     constexpr int EPV = 8, NT = BN / 32, RW = 16 * MT;   // 8 waves = 4 x 2 of RW pixels x BN / 2 channels (tile: 4 * RW rows)
     constexpr int BPW = BN / 64;                             // weight pieces per wave and K step
@@ -1521,6 +1532,7 @@ constexpr int STEM_LDS = STEM_NH * (STEM_MAXG * 64 * STEM_PITCH + 3 * STEM_IH * 
 __global__ __launch_bounds__(256, (kX3 ? 1 : 2)) void k_stem_mfma(const float *x, const H16 *w, const float *bias, H16 *dst, int H, int W,
                                                       int Ho, int Wo, int groups, long long w_gs, int bias_gs, long long dst_gs, unsigned *range)
 {
+    RCV_X3_MODE();
     using T = H16;
     float rmax = 0.f;  // range guard
     constexpr int NH = STEM_NH;
@@ -1843,6 +1855,7 @@ __device__ __forceinline__ void blk_dma16(const void *base, int num_bytes, unsig
 template <int CMID, bool CHAIN, bool STAG = false>
 __global__ __launch_bounds__(512, (CMID == 64 ? 4 : 2)) void k_conv_block(const BlockParams p)
 {
+    RCV_X3_MODE();
     static_assert(!STAG || (CHAIN && CMID == 256), "the staggered schedule is written for the chained 256-wide block");
     using T = H16;
     constexpr int KE = 64, EPV = 8, BM = BLK_BM, KS = 3, PAD = 1;
@@ -2528,6 +2541,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void k_stem(const float *x, const T *w, const float *bias, T *dst, int B, int H, int W,
                                               int Ho, int Wo, long long w_gs, int bias_gs, long long dst_gs, unsigned *range)
 {
+    RCV_X3_MODE();
     float rmax = 0.f;  // range guard (half-precision engines)
     constexpr int TP = 16, IN = TP * 2 + 5;  // 37 x 37 input patch per channel
     __shared__ float s_in[3][IN][IN + 1];
@@ -2601,6 +2615,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void k_maxpool(const T *src, T *dst, int C, int Hin, int Win, int Hout, int Wout,
                                                  long long total_vec, long long src_gs, long long dst_gs)
 {
+    RCV_X3_MODE();
     constexpr int EPV = Traits<T>::EPV;
     const int g = blockIdx.y;
     const int cv = C / EPV;
@@ -2652,6 +2667,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void k_upsample2(const T *src, T *dst, int C, int Hin, int Win, long long total_vec,
                                                    long long src_gs, long long dst_gs)
 {
+    RCV_X3_MODE();
     // One thread = one source cell (a, b) (a in [-1, Hin-1], b in [-1, Win-1]) and one 16-byte channel chunk: the up to
     // four destination pixels rows {2a+1, 2a+2} x columns {2b+1, 2b+2} all interpolate between source rows (a, a+1) and
     // columns (b, b+1) (clamped at the borders, where the weight of the clamped neighbour is zero or both neighbours are
@@ -2726,6 +2742,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void k_head(const T *src, const T *w, const float *bias, float *seg, float *radial, int C,
                                               long long npix, long long src_gs, long long w_gs, int bias_gs, int rad_f16)
 {
+    RCV_X3_MODE();
     constexpr int EPV = Traits<T>::EPV;
     const int g = blockIdx.y;
     const T *wg = w + (long long)g * w_gs;
@@ -2765,6 +2782,7 @@ __global__ __launch_bounds__(256) void k_head(const T *src, const T *w, const fl
 
 __global__ __launch_bounds__(256) void k_preprocess(const uint8_t *rgb, float *x, int HW, long long total)
 {
+    RCV_X3_MODE();
     // img/255, -mean, /std in float64, then .float()  (reference AccumulatorSpace.py:143-151)
     const double mean[3] = {0.485, 0.456, 0.406}, sd[3] = {0.229, 0.224, 0.225};
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
@@ -2809,6 +2827,7 @@ __global__ __launch_bounds__(256, 2) void k_tail(const H16 *src, const H16 *w7, 
                                                  float *seg, float *radial, int B, int Hin, int Win, long long src_gs, long long w7_gs,
                                                  int b7_gs, long long w8_gs, int b8_gs, int rad_f16, unsigned *range)
 {
+    RCV_X3_MODE();
     using T = H16;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char *sU = smem;                                        // [340][TAIL_UP] upsampled patch ...
@@ -3019,6 +3038,7 @@ constexpr int CH_LDS = CH_RING * CH_SLOT + 8 * 16 * CH_XP + CH_BIAS;
 template <int CMID>
 __global__ __launch_bounds__(512) void k_chain_x3(const BlockParams p)
 {
+    RCV_X3_MODE();
     using T = H16;
     constexpr int COUT = 4 * CMID, NC = COUT / 128, KE = CMID / 32, KR = 4;  // 128-channel chunks; K slices per chunk: expand, reduce
     constexpr int NTR = CMID / 16;                                            // 16-channel tiles of the reduce's output
@@ -3284,6 +3304,9 @@ constexpr int c2_slot(int cmid) { return cmid * 128 > 16384 ? cmid * 128 : 16384
 #ifndef RCV_C2_DIST
 #define RCV_C2_DIST 2  // steps between the issue of a step's weights and their use (ring slots = RCV_C2_DIST + 1)
 #endif
+#ifndef RCV_C2_DIAG
+#define RCV_C2_DIAG 0  // timing diagnostics with WRONG outputs: 1 = residual loads / block-output stores always hit the same line (no HBM traffic), 2 = weights always of the first chunk (L2-hot), 3 = no weight DMA after the first half chunk, 4 = 1 + 3
+#endif
 #ifndef RCV_C2_DEPHASE
 #define RCV_C2_DEPHASE 0  // cycles per phase unit of the start-up delay (blockIdx.x % 6 units): spreads the workgroups' store / load bursts
 #endif
@@ -3305,6 +3328,7 @@ __device__ __forceinline__ void lds_arrive4(f32x4 &a, f32x4 &b, f32x4 &c, f32x4 
 template <int CMID>
 __global__ __launch_bounds__(512) void k_chain2_x3(const BlockParams p)
 {
+    RCV_X3_MODE();
     using T = H16;
     constexpr int COUT = 4 * CMID, HC = COUT / 64, KE = CMID / 32;  // half chunks of 64 output channels; K slices of the expand
     constexpr int ES = KE / 2, SPC = ES + 2;                        // expand steps (two K slices each) + two reduce steps per half chunk
@@ -3347,14 +3371,14 @@ __global__ __launch_bounds__(512) void k_chain2_x3(const BlockParams p)
 #pragma unroll
             for (int c = 0; c < PE; c++) {
                 const int pid = wave * PE + c, ks = pid >> 3, row = (pid & 7) * 8 + lrow;
-                const int off = ((h * 64 + row) * (2 * CMID) + (2 * q + ks) * 64 + ((lpos ^ c2_key(row)) << 3)) * 2;
+                const int off = (((RCV_C2_DIAG == 2 ? 0 : h) * 64 + row) * (2 * CMID) + (2 * q + ks) * 64 + ((lpos ^ c2_key(row)) << 3)) * 2;
                 blk_dma16(w2, w2_bytes, sl + pid * 1024, off);
             }
         } else {       // [CMID out channels][32 ch] of w3 [CMID][COUT / 32][64 halves], K slice h*2 + t
 #pragma unroll
             for (int c = 0; c < PR; c++) {
                 const int pid = wave * PR + c, row = pid * 8 + lrow;
-                const int off = (row * (2 * COUT) + (h * 2 + (q - ES)) * 64 + ((lpos ^ c2_key(row)) << 3)) * 2;
+                const int off = (row * (2 * COUT) + ((RCV_C2_DIAG == 2 ? 0 : h) * 2 + (q - ES)) * 64 + ((lpos ^ c2_key(row)) << 3)) * 2;
                 blk_dma16(w3, w3_bytes, sl + pid * 1024, off);
             }
         }
@@ -3434,17 +3458,16 @@ __global__ __launch_bounds__(512) void k_chain2_x3(const BlockParams p)
         case 6: rmax = rng_see<8>(rmax, ev); break;
         case 7: case 8: case 9: case 10: {  // split of elements 2(k-7), 2(k-7) + 1 (x3_split8's operations)
             const int e = k - 7;
-            const f32x2 c = {__builtin_amdgcn_fmed3f(ev[2 * e], -65504.f, 65504.f), __builtin_amdgcn_fmed3f(ev[2 * e + 1], -65504.f, 65504.f)};
+            const f32x2 c = {ev[2 * e], ev[2 * e + 1]};
             const x3_h2 hh = __builtin_convertvector(c, x3_h2);
-            const f32x2 r = (f32x2){ev[2 * e], ev[2 * e + 1]} - __builtin_convertvector(hh, f32x2);
-            const f32x2 rc = {__builtin_amdgcn_fmed3f(r[0], -65504.f, 65504.f), __builtin_amdgcn_fmed3f(r[1], -65504.f, 65504.f)};
-            const x3_h2 ll = __builtin_convertvector(rc, x3_h2);
+            const f32x2 r = c - __builtin_convertvector(hh, f32x2);
+            const x3_h2 ll = __builtin_convertvector(r, x3_h2);
             wh_[e] = __builtin_bit_cast(unsigned, hh);
             wl_[e] = __builtin_bit_cast(unsigned, ll);
             break;
         }
         default: {  // 11: the block output (full 128-byte lines per pixel over the wave's two stores)
-            T *op = dst + mrow * (2 * COUT) + (h * 2 + t) * 64 + kq * 8;
+            T *op = dst + mrow * (2 * COUT) + ((RCV_C2_DIAG == 1 || RCV_C2_DIAG == 4 ? 0 : h) * 2 + t) * 64 + kq * 8;
             *(uint4 *)op = eoh;
             *(uint4 *)(op + 32) = eol;
             break;
@@ -3493,11 +3516,11 @@ __global__ __launch_bounds__(512) void k_chain2_x3(const BlockParams p)
             __builtin_amdgcn_sched_barrier(0);
             {
                 const int q2 = (q + C2_DIST) % SPC, h2 = h + (q + C2_DIST) / SPC;
-                if (h2 < HC) issue(h2, q2, slot + C2_DIST >= C2_RING ? slot + C2_DIST - C2_RING : slot + C2_DIST);
+                if (h2 < HC && !((RCV_C2_DIAG == 3 || RCV_C2_DIAG == 4) && h2 > 0)) issue(h2, q2, slot + C2_DIST >= C2_RING ? slot + C2_DIST - C2_RING : slot + C2_DIST);
                 if (q == 0) {  // this half chunk's residual: channels kq*8 .. +7 of the slices h*2 + t (hi, lo)
 #pragma unroll
                     for (int t2 = 0; t2 < 2; t2++) {
-                        const T *rp = res + mrow * (2 * COUT) + (h * 2 + t2) * 64 + kq * 8;
+                        const T *rp = res + mrow * (2 * COUT) + ((RCV_C2_DIAG == 1 || RCV_C2_DIAG == 4 ? 0 : h) * 2 + t2) * 64 + kq * 8;  // (diag 1: one hot line)
                         rres[t2][0] = *(const uint4 *)rp;
                         rres[t2][1] = *(const uint4 *)(rp + 32);
                     }
@@ -3603,7 +3626,7 @@ __global__ __launch_bounds__(512) void k_chain2_x3(const BlockParams p)
         *(uint4 *)op = oh;
         *(uint4 *)(op + 32) = ol;
     }
-    rng_flush(p.range, rmax);
+    if constexpr (RCV_C2_DIAG == 0) rng_flush(p.range, rmax);  // (the diagnostic builds compute garbage on purpose)
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -3641,6 +3664,7 @@ __global__ __launch_bounds__(256, 2) void k_tail_x3(const H16 *src, const H16 *w
                                                  float *seg, float *radial, int B, int Hin, int Win, long long src_gs, long long w7_gs,
                                                  int b7_gs, long long w8_gs, int b8_gs, int rad_f16, unsigned *range)
 {
+    RCV_X3_MODE();
     using T = H16;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char *sU = smem;                                        // [6 x 34][TX_UP] upsampled patch ...
@@ -3852,6 +3876,7 @@ __global__ __launch_bounds__(256, 2) void k_tail_x3(const H16 *src, const H16 *w
 template <typename T>
 __global__ void k_slot_to_f32(const T *src, float *dst, long long n)
 {
+    RCV_X3_MODE();
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
         if constexpr (is_x3<T>()) {  // every tensor has a multiple of 32 channels: logical element i -> its group of 32
             const long long o = ((i >> 5) << 6) + (i & 31);

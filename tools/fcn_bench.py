@@ -32,6 +32,7 @@ def main():
     ap.add_argument("--opt", action="append", default=[], help="engine option as key=value (repeatable)")
     ap.add_argument("--graph", action="store_true", help="also time the forward replayed as one HIP graph")
     ap.add_argument("--all", action="store_true", help="print every op, not the per-shape summary")
+    ap.add_argument("--ignore-range", action="store_true", help="clear the engine's range flag after every forward (diagnostic builds that compute garbage on purpose)")
     args = ap.parse_args()
     shapes = json.load(open(os.path.join(ROOT, "tests", "golden", "fcn_state_dict_keys.json")))
     sds = [{k: torch.from_numpy(v) for k, v in synthetic_weights.make_state_dict_numpy(shapes, seed=s).items()}
@@ -46,6 +47,8 @@ def main():
     x = torch.randn(args.batch, 3, 480, 640, device="cuda")
     for _ in range(2):
         eng.forward(x)
+        if args.ignore_range:
+            eng.range_status(clear=True)
     eng.set_profiling(True)
     acc = np.zeros(len(eng.ops))
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -54,6 +57,8 @@ def main():
     for _ in range(args.iters):
         eng.forward(x)
         acc += np.array(eng.get_op_times())
+        if args.ignore_range:
+            eng.range_status(clear=True)
     e1.record()
     torch.cuda.synchronize()
     acc /= args.iters
