@@ -3300,7 +3300,11 @@ __global__ __launch_bounds__(512) void k_chain_x3(const BlockParams p)
 //     order BEFORE the MFMAs of reduce step t and free of LDS round trips, so the scheduler interleaves it with those MFMAs
 //     instead of both waves of a SIMD doing VALU work while the matrix pipe idles; slice 0's sits in the last expand step.
 // ---------------------------------------------------------------------------------------------
-constexpr int c2_slot(int cmid) { return cmid * 128 > 16384 ? cmid * 128 : 16384; }       // ring slot: the larger of the two step images
+#ifndef RCV_C2_SE
+#define RCV_C2_SE 2  // K slices of the expand per step (2: 24 MFMAs per wave behind a barrier; 4: 48, two barriers less per half chunk)
+#endif
+constexpr int c2_se(int cmid) { return RCV_C2_SE < cmid / 32 ? RCV_C2_SE : cmid / 32; }      // K slices of the expand per step
+constexpr int c2_slot(int cmid) { return cmid * 128 > c2_se(cmid) * 8192 ? cmid * 128 : c2_se(cmid) * 8192; }  // ring slot: the larger of the two step images
 #ifndef RCV_C2_DIST
 #define RCV_C2_DIST 2  // steps between the issue of a step's weights and their use (ring slots = RCV_C2_DIST + 1)
 #endif
@@ -3331,9 +3335,10 @@ __global__ __launch_bounds__(512) void k_chain2_x3(const BlockParams p)
     RCV_X3_MODE();
     using T = H16;
     constexpr int COUT = 4 * CMID, HC = COUT / 64, KE = CMID / 32;  // half chunks of 64 output channels; K slices of the expand
-    constexpr int ES = KE / 2, SPC = ES + 2;                        // expand steps (two K slices each) + two reduce steps per half chunk
+    constexpr int SE = c2_se(CMID);                                 // K slices of the expand per step
+    constexpr int ES = KE / SE, SPC = ES + 2;                       // expand steps + two reduce steps per half chunk
     constexpr int NTR = CMID / 16;                                  // 16-channel tiles of the reduce's output
-    constexpr int PE = 2, PR = CMID / 64;                           // DMA pieces (8 rows x 128 B) per wave: expand step, reduce step
+    constexpr int PE = SE, PR = CMID / 64;                          // DMA pieces (8 rows x 128 B) per wave: expand step, reduce step
     constexpr int SLOT = c2_slot(CMID);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -3367,11 +3372,11 @@ __global__ __launch_bounds__(512) void k_chain2_x3(const BlockParams p)
     // ---- weights of step (half chunk h, position q) into ring slot `slot`: lane -> (row of the piece, 16-byte column)
     auto issue = [&](int h, int q, int slot) {
         unsigned char *sl = smem + slot * SLOT;
-        if (q < ES) {  // [2 K slices][64 out channels h*64 ..][32 ch (hi | lo)] of w2 [COUT][KE][64 halves]
+        if (q < ES) {  // [SE K slices][64 out channels h*64 ..][32 ch (hi | lo)] of w2 [COUT][KE][64 halves]
 #pragma unroll
             for (int c = 0; c < PE; c++) {
                 const int pid = wave * PE + c, ks = pid >> 3, row = (pid & 7) * 8 + lrow;
-                const int off = (((RCV_C2_DIAG == 2 ? 0 : h) * 64 + row) * (2 * CMID) + (2 * q + ks) * 64 + ((lpos ^ c2_key(row)) << 3)) * 2;
+                const int off = (((RCV_C2_DIAG == 2 ? 0 : h) * 64 + row) * (2 * CMID) + (SE * q + ks) * 64 + ((lpos ^ c2_key(row)) << 3)) * 2;
                 blk_dma16(w2, w2_bytes, sl + pid * 1024, off);
             }
         } else {       // [CMID out channels][32 ch] of w3 [CMID][COUT / 32][64 halves], K slice h*2 + t
@@ -3540,23 +3545,26 @@ __global__ __launch_bounds__(512) void k_chain2_x3(const BlockParams p)
 #pragma unroll
                     for (int j = 0; j < 4; j++) accE[j] = f32x4{0.f, 0.f, 0.f, 0.f};
                 }
-                auto off = [](int i) { return ((i >> 1) & 1) * 8192 + (i >> 2) * 4096 + (i & 1) * 512; };
+                constexpr int NTE = 4 * SE;  // tiles of the step: [tile pair][K slice][tile of the pair]
+                auto off = [&](int i) { return ((i >> 1) % SE) * 8192 + (i / (2 * SE)) * 4096 + (i & 1) * 512; };
                 if (q == ES - 1) ep_request(h, 0);
                 __builtin_amdgcn_sched_barrier(0);  // (the requests stay older than every fragment read of the step)
                 rd(0, off(0));
                 rd(1, off(1));
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int i = 0; i < 8; i++) {
-                    if (i + 2 < 8) rd((i + 2) % 3, off(i + 2));
-                    const int ks = (i >> 1) & 1;
-                    f32x4 &a = accE[(i >> 2) * 2 + (i & 1)];
-                    a = RCV_MFMA16(fwh[i % 3], aE[2 * q + ks][0], a, 0, 0, 0);
-                    a = RCV_MFMA16(fwl[i % 3], aE[2 * q + ks][0], a, 0, 0, 0);
-                    a = RCV_MFMA16(fwh[i % 3], aE[2 * q + ks][1], a, 0, 0, 0);
-                    if (q == ES - 1 && i >= 4) {
+                for (int i = 0; i < NTE; i++) {
+                    if (i + 2 < NTE) rd((i + 2) % 3, off(i + 2));
+                    const int ks = (i >> 1) % SE;
+                    f32x4 &a = accE[(i / (2 * SE)) * 2 + (i & 1)];
+                    a = RCV_MFMA16(fwh[i % 3], aE[SE * q + ks][0], a, 0, 0, 0);
+                    a = RCV_MFMA16(fwl[i % 3], aE[SE * q + ks][0], a, 0, 0, 0);
+                    a = RCV_MFMA16(fwh[i % 3], aE[SE * q + ks][1], a, 0, 0, 0);
+                    if (q == ES - 1 && i >= NTE / 2) {  // slice 0 is final: its epilogue rides on the second tile pair's MFMAs
+                        constexpr int PPT = (EP_N + NTE / 2 - 1) / (NTE / 2);
 #pragma unroll
-                        for (int k = 0; k < 3; k++) ep_piece(h, 0, (i - 4) * 3 + k);
+                        for (int k = 0; k < PPT; k++)
+                            if ((i - NTE / 2) * PPT + k < EP_N) ep_piece(h, 0, (i - NTE / 2) * PPT + k);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
