@@ -576,6 +576,8 @@ def estimate_6d_pose_lm(opts, return_details=False):
                         submit(ci + 1)
                     loaded, _rgb, depth_dev, seg_b, rad_b, done = inflight.pop(ci)
                     done.synchronize()                         # one result copy per batch
+                    # half-precision engines: a stored activation beyond 65504 makes the maps of that forward invalid -- loud, not clipped
+                    pipe.engine.range_status(clear=True, raise_on_flag=True)
                     torch.cuda.current_stream().wait_event(done)
                     raw = host_res[ci & 1].numpy()
                     res = [_hip.AccResult.from_buffer_copy(raw[i].tobytes()) for i in range(raw.shape[0])]
