@@ -354,7 +354,8 @@ int rcv_fcn_set_profiling(rcv_fcn *h, int enable);
  * key 9 (default 1, bf16): latency kernel (k_conv_lat: 64 x 64 tiles, eight LDS-DMA stages in flight) for launches with few output
  * tiles -- one or a few frames; 0: k_conv, bit-identical output.
  * key 10 (default 1, RCV_F16X3): the fused 1x1 expand + next 1x1 reduce kernel in its round-4 form (k_chain2_x3: no LDS
- * transposition, half chunks, epilogue between the MFMAs); 0: k_chain_x3, bit-identical output. */
+ * transposition, half chunks, epilogue between the MFMAs); 0: k_chain_x3; 2: k_chain3_x3 for the 256-wide block (four waves of 32
+ * pixels, one per SIMD: half the LDS fragment traffic, measured 4 % slower); bit-identical output in every form. */
 int rcv_fcn_set_option(rcv_fcn *h, int key, int value);
 int rcv_fcn_get_profile(rcv_fcn *h, double *conv_ms, double *other_ms, double *conv_flop);
 /* Per-op device times (ms) of the last profiled forward; ms_out has room for n_ops doubles. */

@@ -3638,6 +3638,307 @@ __global__ __launch_bounds__(512) void k_chain2_x3(const BlockParams p)
 }
 
 // ---------------------------------------------------------------------------------------------
+// k_chain3_x3<CMID> (split precision, r04 experiment): k_chain2_x3's two layers with FOUR waves per workgroup, one per SIMD, each
+// owning 32 pixels (two 16-pixel sub-tiles) and the whole register file (512 per lane).  Why: with every memory stream removed
+// k_chain2_x3<256> still takes 530 of its 686 us (RCV_C2_DIAG) -- each of its eight waves re-reads every weight fragment for 16
+// pixels (two ds_read_b128 per three MFMAs: two thirds of the LDS array's time), and a ~76-instruction VALU epilogue per slice finds
+// one free issue slot per MFMA between two waves that issue MFMAs in lockstep.  Here a fragment pair feeds SIX MFMAs (both
+// sub-tiles), so the LDS traffic halves, and the lone wave of a SIMD has twelve vector slots per tile for the epilogue pieces and the
+// DMA pieces, which are dealt out between the tiles instead of bunched at the step's top.  Same decomposition otherwise (weights
+// through a three-slot LDS ring two steps ahead, half chunks of 64 output channels, weight rows chosen so that a lane's accumulators
+// are eight consecutive channels), same MFMA sequence per output element: bit-identical to k_chain2_x3 / k_chain_x3 / the plain kernels.
+// ---------------------------------------------------------------------------------------------
+template <int CMID>
+__global__ __launch_bounds__(256) void k_chain3_x3(const BlockParams p)
+{
+    RCV_X3_MODE();
+    using T = H16;
+    constexpr int COUT = 4 * CMID, HC = COUT / 64, KE = CMID / 32;
+    constexpr int SE = 2, ES = KE / SE, SPC = ES + 2;   // two K slices per expand step; expand steps + two reduce steps per half chunk
+    constexpr int NTR = CMID / 16;
+    constexpr int PE = 16 / 4, PR = (CMID / 8) / 4;     // DMA pieces (8 rows x 128 B) per wave: expand step (16 KB), reduce step
+    constexpr int SLOT = CMID * 128 > 16384 ? CMID * 128 : 16384;
+    constexpr int NS = 2;                               // 16-pixel sub-tiles per wave
+    static_assert(CMID == 256, "register plan written for the 256-wide block");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r16 = lane & 15, kq = lane >> 4, lrow = lane >> 3, lpos = lane & 7;
+    const int g = blockIdx.z;
+    const int m0 = blockIdx.x * CH_BM;
+    const T *src = (const T *)p.src + (long long)g * p.src_gs;
+    const T *res = (const T *)p.res + (long long)g * p.res_gs;
+    T *dst = (T *)p.dst + (long long)g * p.dst_gs;
+    T *dst3 = (T *)p.dst3 + (long long)g * p.dst3_gs;
+    const char *w2 = (const char *)((const T *)p.w2 + (long long)g * p.w2_gs);
+    const char *w3 = (const char *)((const T *)p.w3 + (long long)g * p.w3_gs);
+    const float *b2 = p.b2 + (long long)g * p.b2_gs, *b3 = p.b3 + (long long)g * p.b3_gs;
+    const int w2_bytes = COUT * CMID * 4, w3_bytes = CMID * COUT * 4;
+    float *sB2 = (float *)(smem + 3 * SLOT), *sB3 = sB2 + 2 * COUT;
+    for (int i = tid; i < 2 * COUT; i += 256) sB2[i] = b2[i];
+    for (int i = tid; i < 2 * CMID; i += 256) sB3[i] = b3[i];
+    const unsigned aB2 = (unsigned)(3 * SLOT) + kq * 32, aB3 = (unsigned)(3 * SLOT + 2 * COUT * 4) + kq * 32;
+
+    long long mrow[NS];
+#pragma unroll
+    for (int s_ = 0; s_ < NS; s_++) {
+        const int m = m0 + wave * 32 + s_ * 16 + r16;
+        mrow[s_] = m < p.M ? m : p.M - 1;  // (rows beyond M recompute and re-store row M - 1: equal VM operation counts)
+    }
+
+    // ---- piece c of this wave's share of the weights of step (half chunk h, position q) into ring slot `slot`
+    auto issue_piece = [&](int h, int q, int slot, int c) {
+        unsigned char *sl = smem + slot * SLOT;
+        if (q < ES) {
+            const int pid = wave * PE + c, ks = pid >> 3, row = (pid & 7) * 8 + lrow;
+            const int off = ((h * 64 + row) * (2 * CMID) + (SE * q + ks) * 64 + ((lpos ^ c2_key(row)) << 3)) * 2;
+            blk_dma16(w2, w2_bytes, sl + pid * 1024, off);
+        } else {
+            const int pid = wave * PR + c, row = pid * 8 + lrow;
+            const int off = (row * (2 * COUT) + (h * 2 + (q - ES)) * 64 + ((lpos ^ c2_key(row)) << 3)) * 2;
+            blk_dma16(w3, w3_bytes, sl + pid * 1024, off);
+        }
+    };
+    auto pieces_for = [&](int q2) { return q2 < ES ? PE : PR; };
+    // besides the pieces: the half chunk's residual vectors (2 slices x (hi, lo) x 2 sub-tiles) at its first step; the stores of
+    // slice 0 (2 x 2 sub-tiles) in the last expand step and of slice 1 in reduce step 0
+    auto extra_at = [&](int q_) { return (q_ == 0 ? 4 * NS : 0) + (q_ == ES - 1 || q_ == ES ? 2 * NS : 0); };
+
+    bf16x8 aE[NS][KE][2];
+#pragma unroll
+    for (int s_ = 0; s_ < NS; s_++) {
+        const T *sp = src + mrow[s_] * (2 * CMID) + kq * 8;
+#pragma unroll
+        for (int k_ = 0; k_ < KE; k_++) {
+            aE[s_][k_][0] = *(const bf16x8 *)(sp + k_ * 64);
+            aE[s_][k_][1] = *(const bf16x8 *)(sp + k_ * 64 + 32);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 2; k++)
+#pragma unroll
+        for (int c = 0; c < PE; c++) issue_piece(0, k, k, c);  // (steps 0 and 1 are expand steps: ES >= 2)
+    static_assert(ES >= 2, "the prologue issues two expand steps");
+    f32x4 accR[NS][NTR];
+#pragma unroll
+    for (int s_ = 0; s_ < NS; s_++)
+#pragma unroll
+        for (int j = 0; j < NTR; j++) accR[s_][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 accE[NS][4];
+    uint4 rres[NS][2][2];
+    bf16x8 ah[NS], al[NS];
+    float rmax = 0.f;
+    const int fkey = ((r16 >> 1) & 1) | ((r16 >> 2) << 1);
+    const unsigned frow = (unsigned)(((r16 >> 2) * 8 + (r16 & 3)) * 128);
+    const unsigned fhi = frow + ((kq ^ fkey) << 4), flo = frow + (((4 + kq) ^ fkey) << 4);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    // epilogue of slice t of half chunk h for sub-tile s_, in EP_N pieces (k_chain2_x3's, element for element)
+    constexpr int EP_N = 12;
+    float ev[8], erv[8];
+    f32x4 ebi0, ebi1, esc0, esc1;
+    uint4 eoh, eol;
+    auto ep_request = [&](int h, int t) {
+        const unsigned a = aB2 + (unsigned)(h * 64 + t * 32) * 4;
+        lds_req128(a, ebi0); lds_req128(a + 16, ebi1); lds_req128(a + COUT * 4, esc0); lds_req128(a + COUT * 4 + 16, esc1);
+    };
+    auto ep_piece = [&](int h, int t, int s_, int k) {
+        unsigned *wh_ = (unsigned *)&eoh, *wl_ = (unsigned *)&eol;
+        const unsigned *rh = (const unsigned *)&rres[s_][t][0], *rl = (const unsigned *)&rres[s_][t][1];
+        switch (k) {
+        case 0:
+            if (s_ == 0) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(ebi0), "+v"(ebi1), "+v"(esc0), "+v"(esc1));
+#pragma unroll
+            for (int e = 0; e < 4; e++) ev[e] = __fmaf_rn(accE[s_][2 * t][e], esc0[e], ebi0[e]);
+            break;
+        case 1:
+#pragma unroll
+            for (int e = 0; e < 4; e++) ev[4 + e] = __fmaf_rn(accE[s_][2 * t + 1][e], esc1[e], ebi1[e]);
+            break;
+        case 2: case 3: {
+            const int b = (k - 2) * 2;
+#pragma unroll
+            for (int e = 0; e < 2; e++) {
+                const f32x2 s2 = __builtin_convertvector(__builtin_bit_cast(x3_h2, rh[b + e]), f32x2) + __builtin_convertvector(__builtin_bit_cast(x3_h2, rl[b + e]), f32x2);
+                erv[2 * (b + e)] = s2[0];
+                erv[2 * (b + e) + 1] = s2[1];
+            }
+            break;
+        }
+        case 4: case 5: {
+            const int b = (k - 4) * 4;
+#pragma unroll
+            for (int e = 0; e < 4; e++) ev[b + e] = fmaxf(ev[b + e] + erv[b + e], 0.f);
+            break;
+        }
+        case 6: rmax = rng_see<8>(rmax, ev); break;
+        case 7: case 8: case 9: case 10: {
+            const int e = k - 7;
+            const f32x2 c = {ev[2 * e], ev[2 * e + 1]};
+            const x3_h2 hh = __builtin_convertvector(c, x3_h2);
+            const f32x2 r = c - __builtin_convertvector(hh, f32x2);
+            const x3_h2 ll = __builtin_convertvector(r, x3_h2);
+            wh_[e] = __builtin_bit_cast(unsigned, hh);
+            wl_[e] = __builtin_bit_cast(unsigned, ll);
+            break;
+        }
+        default: {
+            T *op = dst + mrow[s_] * (2 * COUT) + (h * 2 + t) * 64 + kq * 8;
+            *(uint4 *)op = eoh;
+            *(uint4 *)(op + 32) = eol;
+            break;
+        }
+        }
+    };
+
+    bf16x8 fwh[3], fwl[3];
+    int slot = 0;
+    for (int h = 0; h < HC; h++) {
+        const bool last = h == HC - 1;
+#pragma unroll
+        for (int q = 0; q < SPC; q++) {
+            if (h > 0 || q >= 1) {
+                if (h > 0 || q >= 2) {
+                    // this step's weights were the LAST vector-memory operations of the step before last (every tile body ends with
+                    // its DMA pieces, the last piece goes out at the last tile): younger are exactly the operations of the previous
+                    // step -- its loads / stores and the pieces it dealt out for the next step (if there is one)
+                    const bool exists = h * SPC + q + 1 < HC * SPC;
+                    blk_vmwait((exists ? pieces_for((q + 1) % SPC) : 0) + extra_at((q + 2 * SPC - 1) % SPC));
+                }
+                __builtin_amdgcn_s_barrier();
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // the step two ahead, whose pieces are dealt out between this step's tiles
+            const int q2 = (q + 2) % SPC, h2 = h + (q + 2) / SPC;
+            const int slot2 = slot + 2 >= 3 ? slot + 2 - 3 : slot + 2;
+            const int np2 = h2 < HC ? pieces_for(q2) : 0;
+            if (q == 0) {
+#pragma unroll
+                for (int s_ = 0; s_ < NS; s_++)
+#pragma unroll
+                    for (int t2 = 0; t2 < 2; t2++) {
+                        const T *rp = res + mrow[s_] * (2 * COUT) + (h * 2 + t2) * 64 + kq * 8;
+                        rres[s_][t2][0] = *(const uint4 *)rp;
+                        rres[s_][t2][1] = *(const uint4 *)(rp + 32);
+                    }
+            }
+            const unsigned sbase = (unsigned)(slot * SLOT);
+            const unsigned char *slh = smem + sbase + fhi, *sll = smem + sbase + flo;
+            auto rd = [&](int buf, int o) {
+                fwh[buf] = *(const bf16x8 *)(slh + o);
+                fwl[buf] = *(const bf16x8 *)(sll + o);
+            };
+            if (q < ES) {
+                if (q == 0) {
+#pragma unroll
+                    for (int s_ = 0; s_ < NS; s_++)
+#pragma unroll
+                        for (int j = 0; j < 4; j++) accE[s_][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+                constexpr int NTE = 4 * SE;
+                auto off = [&](int i) { return ((i >> 1) % SE) * 8192 + (i / (2 * SE)) * 4096 + (i & 1) * 512; };
+                if (q == ES - 1) ep_request(h, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                rd(0, off(0));
+                rd(1, off(1));
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < NTE; i++) {
+                    if (i + 2 < NTE) rd((i + 2) % 3, off(i + 2));
+                    const int ks = (i >> 1) % SE, ti = (i / (2 * SE)) * 2 + (i & 1);
+#pragma unroll
+                    for (int s_ = 0; s_ < NS; s_++) {
+                        f32x4 &a = accE[s_][ti];
+                        a = RCV_MFMA16(fwh[i % 3], aE[s_][SE * q + ks][0], a, 0, 0, 0);
+                        a = RCV_MFMA16(fwl[i % 3], aE[s_][SE * q + ks][0], a, 0, 0, 0);
+                        a = RCV_MFMA16(fwh[i % 3], aE[s_][SE * q + ks][1], a, 0, 0, 0);
+                    }
+                    if (q == ES - 1 && i >= NTE / 2) {  // slice 0 is final: both sub-tiles' epilogues over the second tile pair
+                        constexpr int PPT = (2 * EP_N + NTE / 2 - 1) / (NTE / 2);
+#pragma unroll
+                        for (int k = 0; k < PPT; k++) {
+                            const int pc = (i - NTE / 2) * PPT + k;
+                            if (pc < 2 * EP_N) {
+                                ep_piece(h, 0, pc / EP_N, pc % EP_N);
+                                if (pc % EP_N == EP_N - 1) { ah[pc / EP_N] = *(const bf16x8 *)&eoh; al[pc / EP_N] = *(const bf16x8 *)&eol; }
+                            }
+                        }
+                    }
+                    // the step-after-next's pieces, dealt evenly over the tiles; the tile body ends with them (see the counted wait)
+#pragma unroll
+                    for (int c = 0; c < PR; c++)
+                        if (c >= i * np2 / NTE && c < (i + 1) * np2 / NTE) issue_piece(h2, q2, slot2, c);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else {
+                const int t = q - ES;
+                auto off = [](int j) { return (j >> 1) * 4096 + (j & 1) * 512; };
+                if (t == 0) ep_request(h, 1);
+                __builtin_amdgcn_sched_barrier(0);
+                rd(0, off(0));
+                rd(1, off(1));
+                __builtin_amdgcn_sched_barrier(0);
+                bf16x8 nh[NS], nl[NS];
+#pragma unroll
+                for (int j = 0; j < NTR; j++) {
+                    if (j + 2 < NTR) rd((j + 2) % 3, off(j + 2));
+#pragma unroll
+                    for (int s_ = 0; s_ < NS; s_++) {
+                        accR[s_][j] = RCV_MFMA16(fwh[j % 3], ah[s_], accR[s_][j], 0, 0, 0);
+                        accR[s_][j] = RCV_MFMA16(fwl[j % 3], ah[s_], accR[s_][j], 0, 0, 0);
+                        accR[s_][j] = RCV_MFMA16(fwh[j % 3], al[s_], accR[s_][j], 0, 0, 0);
+                    }
+                    if (t == 0) {  // slice 1's epilogues (both sub-tiles) over the tiles from the second on
+                        constexpr int PPT = (2 * EP_N + NTR - 2) / (NTR - 1);
+#pragma unroll
+                        for (int k = 0; k < PPT; k++) {
+                            const int pc = (j - 1) * PPT + k;
+                            if (j >= 1 && pc < 2 * EP_N) {
+                                ep_piece(h, 1, pc / EP_N, pc % EP_N);
+                                if (pc % EP_N == EP_N - 1) { nh[pc / EP_N] = *(const bf16x8 *)&eoh; nl[pc / EP_N] = *(const bf16x8 *)&eol; }
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int c = 0; c < PR; c++)
+                        if (c >= j * np2 / NTR && c < (j + 1) * np2 / NTR) issue_piece(h2, q2, slot2, c);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (t == 0) {
+#pragma unroll
+                    for (int s_ = 0; s_ < NS; s_++) { ah[s_] = nh[s_]; al[s_] = nl[s_]; }
+                }
+            }
+            slot = slot + 1 == 3 ? 0 : slot + 1;
+        }
+    }
+    // ---- the reduce's epilogue
+#pragma unroll
+    for (int t = 0; t < NTR / 2; t++) {
+        f32x4 bi0, bi1, sc0, sc1;
+        const unsigned a = aB3 + (unsigned)(t * 32) * 4;
+        lds_req128(a, bi0); lds_req128(a + 16, bi1); lds_req128(a + CMID * 4, sc0); lds_req128(a + CMID * 4 + 16, sc1);
+        lds_arrive4(bi0, bi1, sc0, sc1);
+#pragma unroll
+        for (int s_ = 0; s_ < NS; s_++) {
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                v[e] = fmaxf(__fmaf_rn(accR[s_][2 * t][e], sc0[e], bi0[e]), 0.f);
+                v[4 + e] = fmaxf(__fmaf_rn(accR[s_][2 * t + 1][e], sc1[e], bi1[e]), 0.f);
+            }
+            rmax = rng_see<8>(rmax, v);
+            uint4 oh, ol;
+            x3_split8(v, oh, ol);
+            T *op = dst3 + mrow[s_] * (2 * CMID) + t * 64 + kq * 8;
+            *(uint4 *)op = oh;
+            *(uint4 *)(op + 32) = ol;
+        }
+    }
+    rng_flush(p.range, rmax);
+}
+
+// ---------------------------------------------------------------------------------------------
 // k_tail_x3 (split precision): the same three layers -- 2x bilinear upsampling of the 64-channel map, conv7 (3x3, 64 -> 32,
 // ReLU) and the 1x1 head -- for the RCV_F16X3 engine.  Unfused they move 17 GB per 72 (frame, network) items through HBM
 // (the 480x640x64 upsampled map alone is 79 MB per item in hi / lo storage); fused only the 240x320x64 source is read.
@@ -3921,7 +4222,7 @@ struct rcv_fcn {
     bool use_dma = true;  // LDS-DMA conv kernel for the shapes it covers (bf16, Cout % 128 == 0, enough tiles)
     bool radial_f16 = false;  // the radial plane leaves the head as float16 (BASELINE.json stress configuration)
     bool use_lat = true;      // latency kernel (k_conv_lat) for launches with few tiles (small batches)
-    bool use_chain2 = true;   // split engine: k_chain2_x3 (r04) instead of k_chain_x3
+    int use_chain2 = 1;       // split engine: 1 = k_chain2_x3 (r04), 0 = k_chain_x3, 2 = k_chain3_x3 for the 256-wide block
     // range guard of the half-precision engines: one sticky flag word on the device (kernels OR bits into it), mirrored into
     // pinned host memory by a 4-byte copy at the end of every forward
     unsigned *range_dev = nullptr;
@@ -4195,6 +4496,7 @@ int register_kernel_attributes()
     RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_chain2_x3<64>, hipFuncAttributeMaxDynamicSharedMemorySize, c2_lds(64)));
     RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_chain2_x3<128>, hipFuncAttributeMaxDynamicSharedMemorySize, c2_lds(128)));
     RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_chain2_x3<256>, hipFuncAttributeMaxDynamicSharedMemorySize, c2_lds(256)));
+    RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_chain3_x3<256>, hipFuncAttributeMaxDynamicSharedMemorySize, c2_lds(256)));
     RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_conv_block<64, false>, hipFuncAttributeMaxDynamicSharedMemorySize, blk_lds(64)));
     RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_conv_block<64, true>, hipFuncAttributeMaxDynamicSharedMemorySize, blk_lds(64)));
     RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_conv_block<128, false>, hipFuncAttributeMaxDynamicSharedMemorySize, blk_lds(128)));
@@ -4308,7 +4610,9 @@ int forward_impl(rcv_fcn *h, const float *x, int B, float *seg, float *radial, c
                     q.range = h->range_dev;
                     if (h->profiling) RCV_HIP_CHECK(hipEventRecord(h->events[2 * i], st));  // time booked on the expand
                     const dim3 grid((unsigned)((M + CH_BM - 1) / CH_BM), 1, h->groups);
-                    if (h->use_chain2) {  // (option 10: the r04 form; 0: k_chain_x3, bit-identical output)
+                    if (h->use_chain2 == 2 && cmid == 256) {  // (option 10 = 2: four waves x 32 pixels, one wave per SIMD)
+                        hipLaunchKernelGGL((k_chain3_x3<256>), grid, dim3(256), c2_lds(256), st, q);
+                    } else if (h->use_chain2) {  // (option 10: the r04 form; 0: k_chain_x3, bit-identical output)
                         if (cmid == 256) hipLaunchKernelGGL((k_chain2_x3<256>), grid, dim3(512), c2_lds(256), st, q);
                         else if (cmid == 128) hipLaunchKernelGGL((k_chain2_x3<128>), grid, dim3(512), c2_lds(128), st, q);
                         else hipLaunchKernelGGL((k_chain2_x3<64>), grid, dim3(512), c2_lds(64), st, q);
@@ -4576,7 +4880,7 @@ int rcv_fcn_set_option(rcv_fcn *h, int key, int value)
     if (key == 7) { h->use_halo = value; h->attrs_set = false; return RCV_OK; }
     if (key == 8) { h->radial_f16 = value != 0; return RCV_OK; }
     if (key == 9) { h->use_lat = value != 0; return RCV_OK; }
-    if (key == 10) { h->use_chain2 = value != 0; return RCV_OK; }
+    if (key == 10) { h->use_chain2 = value; return RCV_OK; }
     return RCV_E_INVALID;
 }
 

@@ -96,9 +96,10 @@ def test_x3_kernel_variants_identical(shapes):
         eng = FcnEngine(sds, H, W, dtype="f16x3")
         x = torch.from_numpy(fcn_weights.make_input(31, (B, 3, H, W))).cuda()
         seg_a, rad_a = [t.clone() for t in eng.forward(x)]
-        eng.set_option(10, 0)  # the chain kernel in its round-3 form (k_chain_x3 instead of k_chain2_x3)
-        seg_c, rad_c = [t.clone() for t in eng.forward(x)]
-        assert torch.equal(seg_a, seg_c) and torch.equal(rad_a, rad_c), (H, W, B)
+        for form in (2, 0):  # the chain kernel as k_chain3_x3 (one wave per SIMD, 256-wide block) and in its round-3 form (k_chain_x3)
+            eng.set_option(10, form)
+            seg_c, rad_c = [t.clone() for t in eng.forward(x)]
+            assert torch.equal(seg_a, seg_c) and torch.equal(rad_a, rad_c), (H, W, B, form)
         for key in (1, 3, 4, 5, 6, 7, 9):
             eng.set_option(key, 0)
         seg_b, rad_b = eng.forward(x)
