@@ -212,3 +212,26 @@ def test_flat_vote_landscape_is_handed_to_the_rasteriser_and_equals_the_oracle(g
             ref, _, info, peak = oracle.accumulator_3d(xyz, rl, sparse=True, return_all=True)
             assert r.status == 0 and np.array_equal(kp[b, k], ref[0]), (b, k)
             assert (r.dim, r.peak_votes) == (info.dim, peak)
+
+
+def test_pipeline_reports_a_forward_that_left_the_half_range(golden_dir):
+    """The batched pipeline stays asynchronous, so an activation beyond the half range (a checkpoint whose stem weights are
+    3e5 times too large here) surfaces where the results are read: FramePipeline.read_results raises (RCV_E_RANGE) instead of
+    handing out keypoints voted on clipped maps; the same frames through the fp32 engine pass."""
+    from rcvpose_amd import _hip
+    from rcvpose_amd.pipeline import FramePipeline
+
+    H, W = 64, 96
+    sds = _state_dicts(golden_dir, 1)
+    bad = dict(sds[0])
+    bad["conv1.weight"] = bad["conv1.weight"] * 3.0e5
+    rng = np.random.default_rng(5)
+    rgb = torch.from_numpy(rng.integers(0, 256, size=(1, H, W, 3), dtype=np.uint8)).cuda()
+    depth = torch.from_numpy((800 + rng.integers(0, 40, size=(1, H, W))).astype(np.uint16).view(np.int16)).cuda()
+    pipe = FramePipeline([bad], H, W, frames_per_step=1)           # default arithmetic: f16x3
+    pipe.process(rgb, depth, [50.0])
+    with pytest.raises(_hip.HalfRangeError):
+        pipe.read_results()
+    ok = FramePipeline([bad], H, W, dtype="fp32", frames_per_step=1)
+    ok.process(rgb, depth, [50.0])
+    ok.read_results()                                               # fp32 has the reference's range: no flag
