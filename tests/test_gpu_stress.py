@@ -56,7 +56,7 @@ def test_configs4_eight_frames_fp16_radial_one_millimetre_against_oracle(oracle,
             r = res[b * G + k]
             assert r.status == 0 and r.dim > 800 and 47500 <= r.n_points <= 52500, (b, k, r.status, r.dim, r.n_points)
             assert np.abs(kpts[b, k] - fr[b]["keypoints_m"][k] * 1000).max() <= 5.0      # 1 mm voxels: within 5 voxels of the truth
-    for b, k in ((0, 0), (4, 1), (7, 2)):
+    for b, k in ((0, 0), (7, 2)):  # (two of the 24 items against the 1 mm oracle: ~35 s each on the box's host cores)
         xyz, rl = oracle.seam(fr[b]["seg"], rad16[k, b].astype(np.float32), fr[b]["depth"], rmax[b, k], K=fr[b]["K"])
         r = res[b * G + k]
         assert (r.n_points, r.n_radii) == (len(xyz), len(rl))
