@@ -1293,33 +1293,33 @@ __device__ __forceinline__ void d_bb_wide(AccHeader *hdr, const float *F, size_t
                 const float q[3] = {sb[0][li], sb[1][li], sb[2][li]};
                 const float tlo = sb[3][li], thi = sb[4][li];
                 const f32x2 thi2 = {thi, thi}, tlo2 = {tlo, tlo};
-                // dmin^2 / dmax^2 of both halves of one axis of parent u as float2 (v_pk_add_f32 / v_pk_mul_f32);
-                // max(e1^2, e2^2) = max(|e1|, |e2|)^2 exactly (the |.| are free source modifiers): one multiply less
-#define RCV_BBW_AXIS(u, a, mn, mx)                                                                                          \
+                // dmin / dmax of both halves of one axis of parent u as float2 (v_pk_add_f32); max(e1^2, e2^2) = max(|e1|, |e2|)^2
+                // exactly (the |.| are free source modifiers).  r04: the squares are not formed on their own any more -- every sum
+                // they enter is one v_pk_fma_f32 (dmin * dmin + rest, rest - dmax * dmax): 16 multiplies less per four parents and
+                // point, and one rounding less per term, so the thresholds' float32 slack covers the sums as before
+#define RCV_BBW_AXIS(u, a, dn, dx)                                                                                          \
     {                                                                                                                       \
         const f32x2 qq = {q[a], q[a]};                                                                                      \
         const f32x2 e1 = lo2[u][a] - qq, e2 = qq - hi2[u][a];                                                               \
-        const f32x2 dmin = {fmaxf(fmaxf(e1.x, e2.x), 0.f), fmaxf(fmaxf(e1.y, e2.y), 0.f)};                                  \
-        const f32x2 dmax = {fmaxf(fabsf(e1.x), fabsf(e2.x)), fmaxf(fabsf(e1.y), fabsf(e2.y))};                              \
-        mn = dmin * dmin;                                                                                                   \
-        mx = dmax * dmax;                                                                                                   \
+        dn = f32x2{fmaxf(fmaxf(e1.x, e2.x), 0.f), fmaxf(fmaxf(e1.y, e2.y), 0.f)};                                           \
+        dx = f32x2{fmaxf(fabsf(e1.x), fabsf(e2.x)), fmaxf(fabsf(e1.y), fabsf(e2.y))};                                       \
     }
+#define RCV_SQ_ADD(d, c) __builtin_elementwise_fma((d), (d), (c))      /* d * d + c */
+#define RCV_SUB_SQ(c, d) __builtin_elementwise_fma(-(d), (d), (c))     /* c - d * d */
                 if constexpr (VOX) {
                     // last level: the children are single voxels (lo == hi), the box distances collapse to the distance
                     // to the voxel centre: d2 per child, 36 instead of 54 instructions per (parent, point)
 #pragma unroll
                     for (int u = 0; u < BBW_NP; u++) {
-                        f32x2 sq[3];
+                        f32x2 t[3];
 #pragma unroll
-                        for (int a = 0; a < 3; a++) {
-                            const f32x2 t = lo2[u][a] - f32x2{q[a], q[a]};
-                            sq[a] = t * t;
-                        }
-                        const f32x2 xy[2] = {f32x2{sq[0].x, sq[0].x} + sq[1], f32x2{sq[0].y, sq[0].y} + sq[1]};
+                        for (int a = 0; a < 3; a++) t[a] = lo2[u][a] - f32x2{q[a], q[a]};
+                        const f32x2 sq0 = t[0] * t[0];
+                        const f32x2 xy[2] = {RCV_SQ_ADD(t[1], (f32x2{sq0.x, sq0.x})), RCV_SQ_ADD(t[1], (f32x2{sq0.y, sq0.y}))};
 #pragma unroll
                         for (int c = 0; c < 4; c++) {
                             const float v = (c & 1) ? xy[c >> 1].y : xy[c >> 1].x;
-                            const f32x2 d2 = f32x2{v, v} + sq[2];
+                            const f32x2 d2 = RCV_SQ_ADD(t[2], (f32x2{v, v}));
                             const f32x2 below = d2 - thi2;  // negative <=> d2 < thi
                             const f32x2 reach = tlo2 - d2;  // negative <=> d2 > tlo
                             RCV_BBW_TAIL(u, c, below, reach);
@@ -1331,21 +1331,21 @@ __device__ __forceinline__ void d_bb_wide(AccHeader *hdr, const float *F, size_t
 #pragma unroll
                     for (int pr = 0; pr < BBW_NP / 2; pr++) {
                         const int uA = 2 * pr;
-                        f32x2 mny, mxy, mnz, mxz;
-                        RCV_BBW_AXIS(uA, 1, mny, mxy);
-                        RCV_BBW_AXIS(uA, 2, mnz, mxz);
-                        const f32x2 zb = mnz - thi2, zr = tlo2 - mxz;
-                        const f32x2 byz[2] = {f32x2{mny.x, mny.x} + zb, f32x2{mny.y, mny.y} + zb};
-                        const f32x2 ryz[2] = {zr - f32x2{mxy.x, mxy.x}, zr - f32x2{mxy.y, mxy.y}};
+                        f32x2 dny, dxy, dnz, dxz;
+                        RCV_BBW_AXIS(uA, 1, dny, dxy);
+                        RCV_BBW_AXIS(uA, 2, dnz, dxz);
+                        const f32x2 zb = RCV_SQ_ADD(dnz, -thi2), zr = RCV_SUB_SQ(tlo2, dxz);
+                        const f32x2 byz[2] = {RCV_SQ_ADD((f32x2{dny.x, dny.x}), zb), RCV_SQ_ADD((f32x2{dny.y, dny.y}), zb)};
+                        const f32x2 ryz[2] = {RCV_SUB_SQ(zr, (f32x2{dxy.x, dxy.x})), RCV_SUB_SQ(zr, (f32x2{dxy.y, dxy.y}))};
 #pragma unroll
                         for (int u = uA; u <= uA + 1; u++) {
-                            f32x2 mnx, mxx;
-                            RCV_BBW_AXIS(u, 0, mnx, mxx);
+                            f32x2 dnx, dxx;
+                            RCV_BBW_AXIS(u, 0, dnx, dxx);
 #pragma unroll
                             for (int c = 0; c < 4; c++) {  // c = hx * 2 + hy
-                                const float mn = (c >> 1) ? mnx.y : mnx.x, mx = (c >> 1) ? mxx.y : mxx.x;
-                                const f32x2 below = f32x2{mn, mn} + byz[c & 1];
-                                const f32x2 reach = ryz[c & 1] - f32x2{mx, mx};
+                                const float dn = (c >> 1) ? dnx.y : dnx.x, dx = (c >> 1) ? dxx.y : dxx.x;
+                                const f32x2 below = RCV_SQ_ADD((f32x2{dn, dn}), byz[c & 1]);
+                                const f32x2 reach = RCV_SUB_SQ(ryz[c & 1], (f32x2{dx, dx}));
                                 RCV_BBW_TAIL(u, c, below, reach);
                             }
                         }
@@ -1353,14 +1353,15 @@ __device__ __forceinline__ void d_bb_wide(AccHeader *hdr, const float *F, size_t
                 } else {
 #pragma unroll
                     for (int u = 0; u < BBW_NP; u++) {
-                        f32x2 mn2[3], mx2[3];
+                        f32x2 dn2[3], dx2[3];
 #pragma unroll
-                        for (int a = 0; a < 3; a++) RCV_BBW_AXIS(u, a, mn2[a], mx2[a]);
+                        for (int a = 0; a < 3; a++) RCV_BBW_AXIS(u, a, dn2[a], dx2[a]);
                         // the xy partial sums are shared by the two z halves, the thresholds are folded into the z terms
-                        const f32x2 mnxy[2] = {f32x2{mn2[0].x, mn2[0].x} + mn2[1], f32x2{mn2[0].y, mn2[0].y} + mn2[1]};
-                        const f32x2 mxxy[2] = {f32x2{mx2[0].x, mx2[0].x} + mx2[1], f32x2{mx2[0].y, mx2[0].y} + mx2[1]};
-                        const f32x2 zb = mn2[2] - thi2;
-                        const f32x2 zr = tlo2 - mx2[2];
+                        const f32x2 mn0 = dn2[0] * dn2[0], mx0 = dx2[0] * dx2[0];
+                        const f32x2 mnxy[2] = {RCV_SQ_ADD(dn2[1], (f32x2{mn0.x, mn0.x})), RCV_SQ_ADD(dn2[1], (f32x2{mn0.y, mn0.y}))};
+                        const f32x2 mxxy[2] = {RCV_SQ_ADD(dx2[1], (f32x2{mx0.x, mx0.x})), RCV_SQ_ADD(dx2[1], (f32x2{mx0.y, mx0.y}))};
+                        const f32x2 zb = RCV_SQ_ADD(dn2[2], -thi2);
+                        const f32x2 zr = RCV_SUB_SQ(tlo2, dx2[2]);
 #pragma unroll
                         for (int c = 0; c < 4; c++) {
                             const float mn = (c & 1) ? mnxy[c >> 1].y : mnxy[c >> 1].x;
@@ -1372,6 +1373,8 @@ __device__ __forceinline__ void d_bb_wide(AccHeader *hdr, const float *F, size_t
                     }
                 }
 #undef RCV_BBW_AXIS
+#undef RCV_SQ_ADD
+#undef RCV_SUB_SQ
             }
             if ((ch & (32 / PT - 1)) == 32 / PT - 1) {
 #pragma unroll
