@@ -1728,12 +1728,12 @@ __device__ __forceinline__ void d_bb_restart(AccHeader *hdr, const BBEntry *list
     // Cost-based hand-over (r04).  The search certifies the arg-max by scoring every surviving block against all N points; on a
     // flat vote landscape (radial noise of several voxels) the survivors of the fine levels outgrow the rasteriser's work, which
     // is one interval evaluation per (point, column inside the shell's disc) ~ N * pi * r^2 whatever the noise.  Measured on the
-    // bench cloud (N = 15.5k, radii 50 ... 94 voxels; tools/vote_sweep.py): 1.25 ps per (block, point) against 8 ps per (point,
-    // column), and the 2-voxel level sees about twice the 4-voxel level's survivors -- so once MORE than 3.7 r_max^2 four-voxel
-    // candidates survive (33k on that cloud), finishing the search costs more than voting the whole grid: the search gives up
+    // bench cloud (N = 15.5k, radii 50 ... 94 voxels; tools/vote_sweep.py): 1.1 ps per (block, point) against 8 ps per (point,
+    // column), and the 2-voxel level sees about twice the 4-voxel level's survivors -- so once MORE than 4.2 r_max^2 four-voxel
+    // candidates survive (37k on that cloud), finishing the search costs more than voting the whole grid: the search gives up
     // here (the fallback every search exit takes: k_vote decides; identical result by construction).  Both costs are
     // proportional to N; the grid edge does not enter (false positives on a background plane widen the grid, not the shells).
-    if (edge == 4 && (double)n > 3.7 * H.rmax * H.rmax) {
+    if (edge == 4 && (double)n > 4.2 * H.rmax * H.rmax) {
         if (threadIdx.x == 0) {
             hdr->bb_overflow = 1;
             hdr->bb_handover = 1;
