@@ -112,30 +112,69 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // (-DRCV_X3_SCALAR_HELPERS: the element-by-element forms, for an A-B check of the outputs' hash -- tools/fcn_hash.py)
 typedef _Float16 x3_h2 __attribute__((ext_vector_type(2)));
 #if defined(RCV_FCN_X3) && !defined(RCV_X3_SCALAR_HELPERS)
+// Two elements at a time.  r04: the conversions half -> float never stand alone -- v_fma_mix_f32 reads a half (either half of a
+// register, op_sel) as an operand of a float FMA, so `(float)hi + (float)lo` is fma(hi, 1, lo) and `v - (float)hi` is fma(hi, -1, v),
+// one instruction per element and one rounding like the convert-then-add forms: identical results over 10^9 operand pairs incl.
+// subnormal halves (tools/probe/mix_probe.hip).  A split of eight: 16 VALU instructions instead of 20 (36 at the start of r04), a join: 8 (12).
+// Where it pays is where instruction SLOTS are scarce (the chain kernels' epilogue pieces between MFMAs: -5 % on k_chain2_x3<256>);
+// a loop that is bound by vector THROUGHPUT loses (k_tail_x3's patch build: 6.1 -> 7.4 ms -- the mixed FMA issues slower than a
+// conversion), so MIX is a per-call-site choice and the stand-alone split / join of eight keep the conversions.
+template <bool MIX = false>
+__device__ __forceinline__ f32x2 x3_join2(unsigned wh, unsigned wl)  // (float)hi + (float)lo of the two elements of a register pair
+{
+    if constexpr (MIX) {
+        f32x2 r;
+        asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "=v"(r.x) : "v"(wh), "v"(wl));
+        asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,1] op_sel_hi:[1,0,1]" : "=v"(r.y) : "v"(wh), "v"(wl));
+        return r;
+    } else
+        return __builtin_convertvector(__builtin_bit_cast(x3_h2, wh), f32x2) + __builtin_convertvector(__builtin_bit_cast(x3_h2, wl), f32x2);
+}
+template <bool MIX = false>
+__device__ __forceinline__ void x3_split2(float v0, float v1, unsigned &wh, unsigned &wl)  // two values -> packed hi halves, packed lo halves
+{
+    const f32x2 c = {v0, v1};
+    const x3_h2 h = __builtin_convertvector(c, x3_h2);  // (saturating: RCV_X3_MODE)
+    wh = __builtin_bit_cast(unsigned, h);
+    f32x2 r;
+    if constexpr (MIX) {
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r.x) : "v"(wh), "v"(v0));
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r.y) : "v"(wh), "v"(v1));
+    } else
+        r = c - __builtin_convertvector(h, f32x2);
+    wl = __builtin_bit_cast(unsigned, __builtin_convertvector(r, x3_h2));
+}
 __device__ __forceinline__ void x3_split8(const float *v, uint4 &hi, uint4 &lo)
 {
     unsigned *wh = (unsigned *)&hi, *wl = (unsigned *)&lo;
 #pragma unroll
-    for (int e = 0; e < 4; e++) {
-        const f32x2 c = {v[2 * e], v[2 * e + 1]};
-        const x3_h2 h = __builtin_convertvector(c, x3_h2);  // (saturating: RCV_X3_MODE)
-        const f32x2 r = c - __builtin_convertvector(h, f32x2);
-        const x3_h2 l = __builtin_convertvector(r, x3_h2);
-        wh[e] = __builtin_bit_cast(unsigned, h);
-        wl[e] = __builtin_bit_cast(unsigned, l);
-    }
+    for (int e = 0; e < 4; e++) x3_split2(v[2 * e], v[2 * e + 1], wh[e], wl[e]);
 }
 __device__ __forceinline__ void x3_join8(const uint4 &hi, const uint4 &lo, float *v)
 {
     const unsigned *wh = (const unsigned *)&hi, *wl = (const unsigned *)&lo;
 #pragma unroll
     for (int e = 0; e < 4; e++) {
-        const f32x2 s = __builtin_convertvector(__builtin_bit_cast(x3_h2, wh[e]), f32x2) + __builtin_convertvector(__builtin_bit_cast(x3_h2, wl[e]), f32x2);
+        const f32x2 s = x3_join2(wh[e], wl[e]);
         v[2 * e] = s[0];
         v[2 * e + 1] = s[1];
     }
 }
 #else
+// (the other translation units never run these; the chain kernels' templates are compiled there all the same)
+template <bool MIX = false>
+__device__ __forceinline__ f32x2 x3_join2(unsigned wh, unsigned wl)
+{
+    return __builtin_convertvector(__builtin_bit_cast(x3_h2, wh), f32x2) + __builtin_convertvector(__builtin_bit_cast(x3_h2, wl), f32x2);
+}
+template <bool MIX = false>
+__device__ __forceinline__ void x3_split2(float v0, float v1, unsigned &wh, unsigned &wl)
+{
+    const f32x2 c = {v0, v1};
+    const x3_h2 h = __builtin_convertvector(c, x3_h2);
+    wh = __builtin_bit_cast(unsigned, h);
+    wl = __builtin_bit_cast(unsigned, __builtin_convertvector(c - __builtin_convertvector(h, f32x2), x3_h2));
+}
 __device__ __forceinline__ void x3_split8(const float *v, uint4 &hi, uint4 &lo)
 {
     H16 *ph = (H16 *)&hi, *pl = (H16 *)&lo;
@@ -3448,7 +3487,7 @@ __global__ __launch_bounds__(512) void k_chain2_x3(const BlockParams p)
             const int b = (k - 2) * 2;
 #pragma unroll
             for (int e = 0; e < 2; e++) {
-                const f32x2 s2 = __builtin_convertvector(__builtin_bit_cast(x3_h2, rh[b + e]), f32x2) + __builtin_convertvector(__builtin_bit_cast(x3_h2, rl[b + e]), f32x2);
+                const f32x2 s2 = x3_join2<true>(rh[b + e], rl[b + e]);
                 erv[2 * (b + e)] = s2[0];
                 erv[2 * (b + e) + 1] = s2[1];
             }
@@ -3463,12 +3502,7 @@ __global__ __launch_bounds__(512) void k_chain2_x3(const BlockParams p)
         case 6: rmax = rng_see<8>(rmax, ev); break;
         case 7: case 8: case 9: case 10: {  // split of elements 2(k-7), 2(k-7) + 1 (x3_split8's operations)
             const int e = k - 7;
-            const f32x2 c = {ev[2 * e], ev[2 * e + 1]};
-            const x3_h2 hh = __builtin_convertvector(c, x3_h2);
-            const f32x2 r = c - __builtin_convertvector(hh, f32x2);
-            const x3_h2 ll = __builtin_convertvector(r, x3_h2);
-            wh_[e] = __builtin_bit_cast(unsigned, hh);
-            wl_[e] = __builtin_bit_cast(unsigned, ll);
+            x3_split2<true>(ev[2 * e], ev[2 * e + 1], wh_[e], wl_[e]);
             break;
         }
         default: {  // 11: the block output (full 128-byte lines per pixel over the wave's two stores)
@@ -3759,7 +3793,7 @@ __global__ __launch_bounds__(256) void k_chain3_x3(const BlockParams p)
             const int b = (k - 2) * 2;
 #pragma unroll
             for (int e = 0; e < 2; e++) {
-                const f32x2 s2 = __builtin_convertvector(__builtin_bit_cast(x3_h2, rh[b + e]), f32x2) + __builtin_convertvector(__builtin_bit_cast(x3_h2, rl[b + e]), f32x2);
+                const f32x2 s2 = x3_join2<true>(rh[b + e], rl[b + e]);
                 erv[2 * (b + e)] = s2[0];
                 erv[2 * (b + e) + 1] = s2[1];
             }
@@ -3774,12 +3808,7 @@ __global__ __launch_bounds__(256) void k_chain3_x3(const BlockParams p)
         case 6: rmax = rng_see<8>(rmax, ev); break;
         case 7: case 8: case 9: case 10: {
             const int e = k - 7;
-            const f32x2 c = {ev[2 * e], ev[2 * e + 1]};
-            const x3_h2 hh = __builtin_convertvector(c, x3_h2);
-            const f32x2 r = c - __builtin_convertvector(hh, f32x2);
-            const x3_h2 ll = __builtin_convertvector(r, x3_h2);
-            wh_[e] = __builtin_bit_cast(unsigned, hh);
-            wl_[e] = __builtin_bit_cast(unsigned, ll);
+            x3_split2<true>(ev[2 * e], ev[2 * e + 1], wh_[e], wl_[e]);
             break;
         }
         default: {
