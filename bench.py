@@ -542,7 +542,7 @@ def main(argv=None):
                          "frac_of_mode_ceiling": achieved / peak * (3 if args.dtype == "f16x3" else 1),
                          "kernel": "implicit-GEMM convolution family of the %s engine (k_conv_halo, k_conv_dma, k_conv<..>, %s), %d convolutions per "
                                    "forward, algorithmic 265.568 GFLOP per network forward" %
-                                   (args.dtype, {"f16x3": "k_chain_x3, k_tail_x3", "fp32": "k_head"}.get(args.dtype, "k_conv_block, k_tail"),
+                                   (args.dtype, {"f16x3": "k_chain2_x3, k_tail_x3", "fp32": "k_head"}.get(args.dtype, "k_conv_block, k_tail"),
                                     sum(1 for o in pipe.engine.ops if o["kind"] == 3)),
                          "fcn_conv_ms_per_step": prof["conv_ms"], "fcn_other_ms_per_step": prof["other_ms"]},
             "roofline_vote": roof_vote,
