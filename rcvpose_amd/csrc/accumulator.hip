@@ -58,7 +58,7 @@ constexpr int SEAM_PIX_PER_BLOCK = 1024;
 constexpr int SEAM_MAX_BLOCKS = 4096;
 constexpr int VOTE_THREADS = 1024;
 constexpr int VOTE_WAVES = VOTE_THREADS / 64;
-constexpr int CELL_BYTES = 60 * 1024;  // LDS bytes of vote counters per tile
+constexpr int CELL_BYTES = 120 * 1024;  // LDS bytes of vote counters per tile (32-bit; the 1024-thread workgroup owns its CU)
 constexpr int MAX_DIM = 1600;          // flat index must fit 32 bits
 constexpr int NPY_BUFSIZE = 8192;      // numpy ufunc buffer (elements): chunking of add.reduce
 constexpr int PW_BLOCK = 128;          // numpy pairwise-sum leaf size
@@ -70,9 +70,9 @@ struct alignas(16) AccHeader {
     double unit;
     int32_t n, m;
     int32_t zb, dim;
-    int32_t TI, TJ, TK, TKp;  // tile footprint, k-extent, padded (even) cells per column
+    int32_t TI, TJ, TK, TKp;  // tile footprint, k-extent, padded (even) cells per column (32-bit counters)
     int32_t nti, ntj, ntk, ntiles;
-    int32_t wide;     // 1: 32-bit counters (n >= 65536), 0: packed 16-bit
+    int32_t wide_;    // (r01-r03: packed 16-bit counters below 65536 points; all counters are 32-bit since r04)
     int32_t nparts;   // every tile's point list is split over this many workgroups (load balance)
     int32_t status;
     uint32_t tile_counter;
@@ -527,9 +527,8 @@ __device__ __forceinline__ bool finish_header(AccHeader &H, long long dim, int n
     if (dim > MAX_DIM) { H.status = RCV_E_TOO_LARGE; H.dim = (int)min(dim, 2000000000ll); return false; }
     const int D = (int)dim;
     H.dim = D;
-    H.wide = n >= 65536;
-    const int cell_bytes = H.wide ? 4 : 2;
-    const int cells = CELL_BYTES / cell_bytes;
+    H.wide_ = 0;
+    const int cells = CELL_BYTES / 4;
     // tile: TJ = 16 (or D if smaller) columns across j; TI rows; full k extent when it fits
     int TJ = D < 16 ? D : 16, TI, TK = D, TKp = (D + 1) & ~1;
     if ((long long)TJ * TKp > cells) {  // a single row of columns does not fit: split k
@@ -636,7 +635,7 @@ __device__ __forceinline__ int tile_from_order(int order, const AccHeader &H)
 }
 
 // ---------------------------------------------------------------------------------------------
-// vote: one workgroup per tile, counters in LDS, arg-max straight from LDS
+// vote: one workgroup per tile, 32-bit counters in LDS, arg-max straight from LDS
 //
 // Per (point, column) the shell crosses the column in at most two k-intervals whose end points are
 // z -/+ sqrt(T_hi - sxy) and z -/+ sqrt(T_lo - sxy).  The end points are evaluated in fp32 relative to
@@ -645,26 +644,21 @@ __device__ __forceinline__ int tile_from_order(int order, const AccHeader &H)
 // ~1e-12), so those votes are cast without any per-voxel arithmetic.  An integer within eps of an end
 // point (probability ~1e-3 per column) is decided by the exact float64 predicate T_lo <= d2 < T_hi.
 // The resulting counts are therefore identical to the reference's float64 loop.
+//
+// r04: the kernel issues VALU instructions on 0.76 of all SIMD cycles, so its time is its instruction count
+// (110 per (point, column) before).  Now ~45: a column inside the rim band (T_lo <= sxy: one interval) is
+// treated as two intervals that meet at z (inner root 0) -- the integer nearest z, if within eps, goes through
+// the exact predicate like any other end point -- so there is one code path; the four end points are two
+// packed fp32 additions; the "too close to an integer" tests are two packed subtractions and one maximum of
+// absolute values; counters are 32-bit (the 1024-thread workgroup owns its CU, 120 of the 160 KB of LDS), so a
+// vote is one shift-add and one ds_add_u32, and the second voxel of an interval is the same address with an
+// immediate offset.
 // ---------------------------------------------------------------------------------------------
-template <bool WIDE>
-__device__ __forceinline__ uint32_t cell_read(const uint32_t *cells, int cell)
-{
-    if (WIDE) return cells[cell];
-    return (cells[cell >> 1] >> ((cell & 1) * 16)) & 0xFFFFu;
-}
-
-template <bool WIDE>
-__device__ __forceinline__ void cell_vote(uint32_t *cells, int cell)
-{
-    if (WIDE) atomicAdd(&cells[cell], 1u);
-    else atomicAdd(&cells[cell >> 1], 1u << ((cell & 1) * 16));
-}
-
 constexpr int NONE_K = -0x40000000;
+typedef float vote_f2 __attribute__((ext_vector_type(2)));
 
 // tile arg-max (first maximum in C order) + tie count + optional copy of the tile to the HBM grid.
 // Waves walk columns, lanes walk k.  Must be called by all VOTE_THREADS threads after a barrier.
-template <bool WIDE>
 __device__ __forceinline__ void tile_epilogue(const uint32_t *cells, uint64_t *wred, int *wredi, const AccHeader &H, int tile,
                                               uint32_t *grid_out, uint64_t *tile_best, uint32_t *tile_ties)
 {
@@ -680,7 +674,7 @@ __device__ __forceinline__ void tile_epilogue(const uint32_t *cells, uint64_t *w
         if (i >= i1 || j >= j1) continue;
         const uint32_t fbase = ((uint32_t)i * (uint32_t)D + (uint32_t)j) * (uint32_t)D + (uint32_t)k0;
         for (int kk = lane; kk < k1 - k0; kk += 64) {
-            const uint32_t v = cell_read<WIDE>(cells, col * TKp + kk);
+            const uint32_t v = cells[col * TKp + kk];
             const uint64_t key = ((uint64_t)v << 32) | (uint64_t)(0xFFFFFFFFu - (fbase + kk));
             best = key > best ? key : best;
             if (grid_out) grid_out[fbase + kk] = v;
@@ -696,7 +690,7 @@ __device__ __forceinline__ void tile_epilogue(const uint32_t *cells, uint64_t *w
     for (int col = wv; col < ncols; col += VOTE_WAVES) {
         const int il = col / TJ, jl = col - il * TJ;
         if (i0 + il >= i1 || j0 + jl >= j1) continue;
-        for (int kk = lane; kk < k1 - k0; kk += 64) ties += cell_read<WIDE>(cells, col * TKp + kk) == vmax;
+        for (int kk = lane; kk < k1 - k0; kk += 64) ties += cells[col * TKp + kk] == vmax;
     }
     ties = wave_sum_i32(ties);
     if (lane == 0) wredi[wv] = ties;
@@ -709,85 +703,93 @@ __device__ __forceinline__ void tile_epilogue(const uint32_t *cells, uint64_t *w
     }
 }
 
-// one (point, column): the votes of the shell of `point` along column (ci, cj) of the tile
-template <bool WIDE>
-__device__ __forceinline__ void vote_column(uint32_t *cells, double ci, double cj, int cbase, double px, double py,
-                                            double pz, double tlo, double thi, int zi, float zfr, float eps, int rlo,
-                                            int rhi)
-{
-    const double dx = ci - px, dy = cj - py;
-    const double sxy = dx * dx + dy * dy;  // (i-x)**2 + (j-y)**2, reference order (:337)
-    const double a = thi - sxy;
-    if (!(a > 0.0)) return;
-    const double b = tlo - sxy;
-    const bool two = b > 0.0;
-    const float zh = __builtin_amdgcn_sqrtf((float)a);
-    const float zl = two ? __builtin_amdgcn_sqrtf((float)b) : 0.f;
-    // Interval end points relative to floor(z): lower interval [e1, e2], upper [e3, e4] (one interval
-    // [e1, e4] when the column lies in the rim band, T_lo <= sxy).  Sure votes are the integers at least
-    // eps inside: [ceil(e_lo + eps), floor(e_hi - eps)].  An integer within eps of an end point shows up as
-    // a rounded value that moved by almost a full unit: ceil(t) - t > 1 - 2 eps  (resp. t - floor(t)).
-    const float lim = 1.f - 2.f * eps;
-    const float t1 = (zfr - zh) + eps, t4 = (zfr + zh) - eps;
-    const float c1 = ceilf(t1), f4 = floorf(t4);
-    bool unc = (c1 - t1 > lim) | (t4 - f4 > lim);
-    int s1a = (int)c1, s1b = (int)f4, s2a = 1, s2b = 0;
-    float f2 = 0.f, c3 = 0.f;
-    if (two) {
-        const float t2 = (zfr - zl) - eps, t3 = (zfr + zl) + eps;
-        f2 = floorf(t2);
-        c3 = ceilf(t3);
-        unc |= (t2 - f2 > lim) | (c3 - t3 > lim);
-        s1b = (int)f2; s2a = (int)c3; s2b = (int)f4;
-    }
-    s1a = max(s1a, rlo); s1b = min(s1b, rhi);
-    s2a = max(s2a, rlo); s2b = min(s2b, rhi);
-    const int n1 = s1b - s1a + 1, n2 = s2b - s2a + 1;
-    const int cb = cbase + zi;
-    // cap columns cross the shell in 1-2 voxels per interval: those are voted inline, the rest in a loop
-    if (n1 > 0) cell_vote<WIDE>(cells, cb + s1a);
-    if (n1 > 1) cell_vote<WIDE>(cells, cb + s1a + 1);
-    if (n2 > 0) cell_vote<WIDE>(cells, cb + s2a);
-    if (n2 > 1) cell_vote<WIDE>(cells, cb + s2a + 1);
-    for (int r = s1a + 2; r <= s1b; r++) cell_vote<WIDE>(cells, cb + r);
-    for (int r = s2a + 2; r <= s2b; r++) cell_vote<WIDE>(cells, cb + r);
-    if (unc) {  // some integer is too close to an end point: decide those with the exact float64 predicate
-        // candidates: the integer just outside each sure range (at most one per end point, eps < 0.5)
-        int u1 = (int)c1 - 1, u4 = (int)f4 + 1, u2 = NONE_K, u3 = NONE_K;
-        if (!(c1 - t1 > lim)) u1 = NONE_K;
-        if (!(t4 - f4 > lim)) u4 = NONE_K;
-        if (two) {
-            const float t2 = (zfr - zl) - eps, t3 = (zfr + zl) + eps;
-            if (t2 - f2 > lim) u2 = (int)f2 + 1;
-            if (c3 - t3 > lim) u3 = (int)c3 - 1;
-        }
-        if (u2 == u1) u2 = NONE_K;
-        if (u3 == u2 || u3 == u1) u3 = NONE_K;
-        if (u4 == u3 || u4 == u2 || u4 == u1) u4 = NONE_K;
-        const int us[4] = {u1, u2, u3, u4};
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const int r = us[q];
-            if (r == NONE_K || r < rlo || r > rhi) continue;
-            const double dz = (double)(zi + r) - pz;
-            const double d2 = sxy + dz * dz;  // ... + (k-z)**2
-            if (d2 >= tlo && d2 < thi) cell_vote<WIDE>(cells, cb + r);
-        }
-    }
-}
-
 __device__ __forceinline__ double readlane_f64(double v, int l)
 {
     const long long b = __double_as_longlong(v);
     const int lo = __builtin_amdgcn_readlane((int)b, l), hi = __builtin_amdgcn_readlane((int)(b >> 32), l);
     return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
+__device__ __forceinline__ float readlane_f32(float v, int l)
+{
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
+}
+
+// one point against one tile, wave-uniform
+struct VotePoint {
+    double x, y, tlo, thi;  // voxel coordinates of the point (fast_for's frame), its shell thresholds
+    float zpe, zme, lim;    // frac(z) + eps, frac(z) - eps, 1 - 2 eps
+    int zi;                 // floor(z)
+    int rlo, rhi;           // the tile's k-range relative to floor(z)
+};
+
+// one (point, column): the votes of the shell of the point along column (ci, cj) of the tile; `cbyte` = byte offset of the
+// column's cell k = 0 in the LDS image (may be negative: k0 > 0), `zsrc` / `L`: where the exact path finds the point's z
+__device__ __forceinline__ void vote_column(unsigned char *cells, double ci, double cj, int cbyte, const VotePoint &q, double zsrc,
+                                            int L)
+{
+    const double dx = ci - q.x, dy = cj - q.y;
+    const double sxy = dx * dx + dy * dy;  // (i-x)**2 + (j-y)**2, reference order (:337)
+    const double a = q.thi - sxy;
+    if (!(a > 0.0)) return;
+    const double b = q.tlo - sxy;  // <= 0 in the rim band: inner root 0, the two intervals meet at z
+    const float zh = __builtin_amdgcn_sqrtf((float)a);
+    const float zl = __builtin_amdgcn_sqrtf(fmaxf((float)b, 0.f));
+    // End points relative to floor(z), moved inwards by eps: lower interval [tA.x, tA.y], upper [tB.y, tB.x].  Sure votes are
+    // the integers ceil(low) .. floor(high).  An integer within eps of an end point shows up as a rounded value that moved by
+    // almost a full unit: |round(t) - t| > 1 - 2 eps.
+    const vote_f2 zz = {zh, zl};
+    const vote_f2 tA = vote_f2{q.zpe, q.zme} - zz;
+    const vote_f2 tB = vote_f2{q.zme, q.zpe} + zz;
+    const vote_f2 rA = {ceilf(tA.x), floorf(tA.y)};
+    const vote_f2 rB = {floorf(tB.x), ceilf(tB.y)};
+    const vote_f2 dA = rA - tA, dB = rB - tB;
+    const bool unc = fmaxf(fmaxf(fabsf(dA.x), fabsf(dA.y)), fmaxf(fabsf(dB.x), fabsf(dB.y))) > q.lim;
+    const int a0 = max((int)rA.x, q.rlo), a1 = min((int)rA.y, q.rhi);
+    const int b0 = max((int)rB.y, q.rlo), b1 = min((int)rB.x, q.rhi);
+    unsigned char *col = cells + (cbyte + q.zi * 4);
+    const int na = a1 - a0, nb = b1 - b0;  // votes of the interval - 1
+    // cap columns cross the shell in 1-2 voxels per interval: those are voted inline, the rest in a loop
+    if (na >= 0) {
+        uint32_t *c = (uint32_t *)(col + a0 * 4);
+        atomicAdd(c, 1u);
+        if (na >= 1) atomicAdd(c + 1, 1u);
+    }
+    if (nb >= 0) {
+        uint32_t *c = (uint32_t *)(col + b0 * 4);
+        atomicAdd(c, 1u);
+        if (nb >= 1) atomicAdd(c + 1, 1u);
+    }
+    if (max(na, nb) >= 2) {
+        for (int r = a0 + 2; r <= a1; r++) atomicAdd((uint32_t *)(col + r * 4), 1u);
+        for (int r = b0 + 2; r <= b1; r++) atomicAdd((uint32_t *)(col + r * 4), 1u);
+    }
+    if (unc) {  // some integer is too close to an end point: decide those with the exact float64 predicate
+        // candidates: the integer just outside each sure range (at most one per end point, eps < 0.5)
+        int u1 = fabsf(dA.x) > q.lim ? (int)rA.x - 1 : NONE_K;
+        int u2 = fabsf(dA.y) > q.lim ? (int)rA.y + 1 : NONE_K;
+        int u3 = fabsf(dB.y) > q.lim ? (int)rB.y - 1 : NONE_K;
+        int u4 = fabsf(dB.x) > q.lim ? (int)rB.x + 1 : NONE_K;
+        if (u2 == u1) u2 = NONE_K;
+        if (u3 == u2 || u3 == u1) u3 = NONE_K;
+        if (u4 == u3 || u4 == u2 || u4 == u1) u4 = NONE_K;
+        const double pz = readlane_f64(zsrc, L);
+        const int us[4] = {u1, u2, u3, u4};
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            const int r = us[t];
+            if (r == NONE_K || r < q.rlo || r > q.rhi) continue;
+            if ((r >= a0 && r <= a1) || (r >= b0 && r <= b1)) continue;  // already a sure vote (cannot happen in exact arithmetic)
+            const double dz = (double)(q.zi + r) - pz;
+            const double d2 = sxy + dz * dz;  // ... + (k-z)**2
+            if (d2 >= q.tlo && d2 < q.thi) atomicAdd((uint32_t *)(col + r * 4), 1u);
+        }
+    }
+}
 
 // The waves of a workgroup are independent between the two barriers that frame a tile: wave w takes the
 // 64-point batches w, w+16, ... of the point list, culls them against the tile footprint (one point per
 // lane, loads of the next batch already in flight) and rasterises the survivors one after the other, the
 // point broadcast to the wave with v_readlane, the lanes spread over the tile's (<= 128) columns.
-template <bool WIDE>
 __device__ __forceinline__ void d_vote(AccHeader *hdr, const double *P, int cap, unsigned char *replicas,
                                                        uint64_t *tile_best, uint32_t *tile_ties, uint32_t *grid_out,
                                                        unsigned long long grid_cells)
@@ -799,12 +801,11 @@ __device__ __forceinline__ void d_vote(AccHeader *hdr, const double *P, int cap,
     int *s_tile_p = (int *)(smem + CELL_BYTES + 12 * VOTE_WAVES);
 
     const AccHeader H = *hdr;
-    if (H.status != RCV_OK || (int)H.wide != (int)WIDE || H.bb_done) return;
+    if (H.status != RCV_OK || H.bb_done) return;
     const int D = H.dim, n = H.n, TI = H.TI, TJ = H.TJ, TK = H.TK, TKp = H.TKp;
     const int lane = lane_id(), wv = wave_id(), tid = threadIdx.x;
     const int ncols = TI * TJ;  // <= 128: two 64-column passes per point
-    const int ncells = ncols * TKp;
-    const int nwords = WIDE ? ncells : ncells / 2;
+    const int nwords = ncols * TKp;
     const bool flush = grid_out != nullptr && (unsigned long long)D * D * D <= grid_cells;
     const double *Px = P, *Py = P + (size_t)cap, *Pz = P + 2 * (size_t)cap, *Plo = P + 3 * (size_t)cap,
                  *Phi = P + 4 * (size_t)cap;
@@ -822,11 +823,11 @@ __device__ __forceinline__ void d_vote(AccHeader *hdr, const double *P, int cap,
         const int tk = tile % H.ntk, tj = (tile / H.ntk) % H.ntj, ti = tile / (H.ntk * H.ntj);
         const int i0 = ti * TI, j0 = tj * TJ, k0 = tk * TK;
         const int i1 = min(i0 + TI, D), j1 = min(j0 + TJ, D), k1 = min(k0 + TK, D);
-        for (int w = tid; w < nwords; w += VOTE_THREADS) cells[w] = 0u;
+        for (int w = tid; w < (nwords + 3) / 4; w += VOTE_THREADS) ((uint4 *)cells)[w] = uint4{0u, 0u, 0u, 0u};
 
         // this lane's two columns
         double ci[2], cj[2];
-        int cbase[2];
+        int cbyte[2];
         bool cvalid[2];
 #pragma unroll
         for (int p = 0; p < 2; p++) {
@@ -835,7 +836,7 @@ __device__ __forceinline__ void d_vote(AccHeader *hdr, const double *P, int cap,
             cvalid[p] = col < ncols && i0 + il < i1 && j0 + jl < j1;
             ci[p] = (double)(i0 + il);
             cj[p] = (double)(j0 + jl);
-            cbase[p] = col * TKp - k0;
+            cbyte[p] = (col * TKp - k0) * 4;
         }
         const double fi0 = (double)i0, fi1 = (double)(i1 - 1), fj0 = (double)j0, fj1 = (double)(j1 - 1);
         const double fk0 = (double)k0, fk1 = (double)(k1 - 1);
@@ -865,20 +866,20 @@ __device__ __forceinline__ void d_vote(AccHeader *hdr, const double *P, int cap,
             const int zi = (int)zf;
             const float zfr = (float)(z - zf);
             const float eps = 2.0e-6f * ((float)rr + 8.f);
+            const float zpe = zfr + eps, zme = zfr - eps, lim = 1.f - 2.f * eps;
             uint64_t mask = __ballot(keep);
             while (mask) {
                 const int L = __ffsll((unsigned long long)mask) - 1;
                 mask &= mask - 1;
-                const double sx = readlane_f64(x, L), sy = readlane_f64(y, L), sz = readlane_f64(z, L);
-                const double slo = readlane_f64(tlo, L), shi = readlane_f64(thi, L);
-                const int szi = __builtin_amdgcn_readlane(zi, L);
-                const float szfr = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(zfr), L));
-                const float seps = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(eps), L));
-                const int rlo = k0 - szi, rhi = k1 - 1 - szi;  // tile k-range relative to floor(z)
+                VotePoint q;
+                q.x = readlane_f64(x, L); q.y = readlane_f64(y, L);
+                q.tlo = readlane_f64(tlo, L); q.thi = readlane_f64(thi, L);
+                q.zpe = readlane_f32(zpe, L); q.zme = readlane_f32(zme, L); q.lim = readlane_f32(lim, L);
+                q.zi = __builtin_amdgcn_readlane(zi, L);
+                q.rlo = k0 - q.zi; q.rhi = k1 - 1 - q.zi;  // tile k-range relative to floor(z)
 #pragma unroll
                 for (int p = 0; p < 2; p++)
-                    if (cvalid[p])
-                        vote_column<WIDE>(cells, ci[p], cj[p], cbase[p], sx, sy, sz, slo, shi, szi, szfr, seps, rlo, rhi);
+                    if (cvalid[p]) vote_column(smem, ci[p], cj[p], cbyte[p], q, z, L);
             }
         }
         __syncthreads();
@@ -889,14 +890,13 @@ __device__ __forceinline__ void d_vote(AccHeader *hdr, const double *P, int cap,
             const uint4 *src = (const uint4 *)cells;
             for (int w = tid; w < (nwords + 3) / 4; w += VOTE_THREADS) dst[w] = src[w];
         } else {
-            tile_epilogue<WIDE>(cells, wred, wredi, H, tile, flush ? grid_out : nullptr, tile_best, tile_ties);
+            tile_epilogue(cells, wred, wredi, H, tile, flush ? grid_out : nullptr, tile_best, tile_ties);
         }
         __syncthreads();
     }
 }
 
 // sums the nparts LDS images of every tile and takes its arg-max (only launched work when nparts > 1)
-template <bool WIDE>
 __device__ __forceinline__ void d_merge(const AccHeader *hdr, const unsigned char *replicas,
                                                         uint64_t *tile_best, uint32_t *tile_ties, uint32_t *grid_out,
                                                         unsigned long long grid_cells)
@@ -906,9 +906,8 @@ __device__ __forceinline__ void d_merge(const AccHeader *hdr, const unsigned cha
     uint64_t *wred = (uint64_t *)(smem + CELL_BYTES);
     int *wredi = (int *)(smem + CELL_BYTES + 8 * VOTE_WAVES);
     const AccHeader H = *hdr;
-    if (H.status != RCV_OK || (int)H.wide != (int)WIDE || H.nparts <= 1 || H.bb_done) return;
-    const int ncells = H.TI * H.TJ * H.TKp;
-    const int nvec = ((WIDE ? ncells : ncells / 2) + 3) / 4;
+    if (H.status != RCV_OK || H.nparts <= 1 || H.bb_done) return;
+    const int nvec = (H.TI * H.TJ * H.TKp + 3) / 4;
     const bool flush = grid_out != nullptr && (unsigned long long)H.dim * H.dim * H.dim <= grid_cells;
     for (int tile = blockIdx.x; tile < H.ntiles; tile += gridDim.x) {
         const uint4 *src = (const uint4 *)(replicas + (size_t)tile * H.nparts * CELL_BYTES);
@@ -916,12 +915,12 @@ __device__ __forceinline__ void d_merge(const AccHeader *hdr, const unsigned cha
             uint4 acc = src[w];
             for (int q = 1; q < H.nparts; q++) {
                 const uint4 v = src[(size_t)q * (CELL_BYTES / 16) + w];
-                acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;  // packed 16-bit halves never carry (n < 65536)
+                acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
             }
             ((uint4 *)cells)[w] = acc;
         }
         __syncthreads();
-        tile_epilogue<WIDE>(cells, wred, wredi, H, tile, flush ? grid_out : nullptr, tile_best, tile_ties);
+        tile_epilogue(cells, wred, wredi, H, tile, flush ? grid_out : nullptr, tile_best, tile_ties);
         __syncthreads();
     }
 }
@@ -2294,20 +2293,18 @@ __global__ __launch_bounds__(1024) void k_bb_final(SP<rcv_acc_result> out, SP<un
     BBEntry *la = (BBEntry *)(w + L.bb_lists), *lb = la + BB_CAP;
     d_bb_final((AccHeader *)(w + L.header), ((BB_LEVELS & 1) ? lb : la) + BB_HALF, out.get());
 }
-template <bool WIDE>
 __global__ __launch_bounds__(VOTE_THREADS) void k_vote(int cap, SP<uint32_t> grid, unsigned long long grid_cells,
                                                        SP<unsigned char> ws, Layout L)
 {
     unsigned char *w = ws.get();
-    d_vote<WIDE>((AccHeader *)(w + L.header), (const double *)(w + L.P), cap, w + L.replicas, (uint64_t *)(w + L.tile_best),
+    d_vote((AccHeader *)(w + L.header), (const double *)(w + L.P), cap, w + L.replicas, (uint64_t *)(w + L.tile_best),
                  (uint32_t *)(w + L.tile_ties), grid.get(), grid_cells);
 }
-template <bool WIDE>
 __global__ __launch_bounds__(VOTE_THREADS) void k_merge(SP<uint32_t> grid, unsigned long long grid_cells, SP<unsigned char> ws,
                                                         Layout L)
 {
     unsigned char *w = ws.get();
-    d_merge<WIDE>((const AccHeader *)(w + L.header), w + L.replicas, (uint64_t *)(w + L.tile_best), (uint32_t *)(w + L.tile_ties),
+    d_merge((const AccHeader *)(w + L.header), w + L.replicas, (uint64_t *)(w + L.tile_best), (uint32_t *)(w + L.tile_ties),
                   grid.get(), grid_cells);
 }
 __global__ __launch_bounds__(256) void k_final(int grid_given, unsigned long long grid_cells, SP<rcv_acc_result> out,
@@ -2673,21 +2670,12 @@ static int run_engines(int cap, int bb_enable, SP<rcv_acc_result> sres, SP<uint3
         RCV_LAUNCH_CHECK();
     }
     const int vote_blocks = n_items >= 4 ? 128 : 512 / n_items;  // work items are handed out by a per-item counter
-    const bool maybe_wide = cap >= 65536;
-    hipLaunchKernelGGL(k_vote<false>, grid3(vote_blocks), dim3(VOTE_THREADS), VOTE_LDS_BYTES, st, cap, sgrid,
+    hipLaunchKernelGGL(k_vote, grid3(vote_blocks), dim3(VOTE_THREADS), VOTE_LDS_BYTES, st, cap, sgrid,
                        (unsigned long long)grid_cells, sws, L);
     RCV_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_merge<false>, grid3(vote_blocks), dim3(VOTE_THREADS), VOTE_LDS_BYTES, st, sgrid,
+    hipLaunchKernelGGL(k_merge, grid3(vote_blocks), dim3(VOTE_THREADS), VOTE_LDS_BYTES, st, sgrid,
                        (unsigned long long)grid_cells, sws, L);
     RCV_LAUNCH_CHECK();
-    if (maybe_wide) {
-        hipLaunchKernelGGL(k_vote<true>, grid3(vote_blocks), dim3(VOTE_THREADS), VOTE_LDS_BYTES, st, cap, sgrid,
-                           (unsigned long long)grid_cells, sws, L);
-        RCV_LAUNCH_CHECK();
-        hipLaunchKernelGGL(k_merge<true>, grid3(vote_blocks), dim3(VOTE_THREADS), VOTE_LDS_BYTES, st, sgrid,
-                           (unsigned long long)grid_cells, sws, L);
-        RCV_LAUNCH_CHECK();
-    }
     hipLaunchKernelGGL(k_final, items, dim3(256), 0, st, grid_given ? 1 : 0, (unsigned long long)grid_cells, sres, sws, L);
     RCV_LAUNCH_CHECK();
     return RCV_OK;
@@ -2710,10 +2698,8 @@ static int accumulate_batch(rcv_strided xyz, rcv_strided radial, int radial_is_f
     const long long replica_slots = (long long)((ws_bytes - L.replicas) / CELL_BYTES);
     hipStream_t st = (hipStream_t)stream;
     if (!g_vote_attr_set) {
-        RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_vote<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)VOTE_LDS_BYTES));
-        RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_vote<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)VOTE_LDS_BYTES));
-        RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_merge<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)VOTE_LDS_BYTES));
-        RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_merge<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)VOTE_LDS_BYTES));
+        RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_vote, hipFuncAttributeMaxDynamicSharedMemorySize, (int)VOTE_LDS_BYTES));
+        RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_merge, hipFuncAttributeMaxDynamicSharedMemorySize, (int)VOTE_LDS_BYTES));
         g_vote_attr_set = true;
     }
     const SP<unsigned char> sws{(unsigned char *)ws.ptr, ws.stride_frame, ws.stride_kp};
@@ -2856,10 +2842,8 @@ int rcv_accumulate_3d_no_depth(const double *xyz_m_dev, const void *radial_dm_de
     const long long replica_slots = (long long)((ws_bytes - L.replicas) / CELL_BYTES);
     hipStream_t st = (hipStream_t)stream;
     if (!g_vote_attr_set) {
-        RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_vote<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)VOTE_LDS_BYTES));
-        RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_vote<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)VOTE_LDS_BYTES));
-        RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_merge<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)VOTE_LDS_BYTES));
-        RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_merge<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)VOTE_LDS_BYTES));
+        RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_vote, hipFuncAttributeMaxDynamicSharedMemorySize, (int)VOTE_LDS_BYTES));
+        RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_merge, hipFuncAttributeMaxDynamicSharedMemorySize, (int)VOTE_LDS_BYTES));
         g_vote_attr_set = true;
     }
     unsigned char *w = (unsigned char *)ws;

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """The voting stage alone on a batch of synthetic frames (seam + Accumulator_3D for frames x 3 keypoints in one batched launch
 sequence), as bench.py runs it -- used under rocprofv3 for the PMC passes of the k_bb_* kernels.
-    python tools/vote_batch_bench.py [--frames 72] [--iters 3]"""
+    python tools/vote_batch_bench.py [--frames 72] [--iters 3] [--engine auto|full]"""
 import argparse
 import json
 import os
@@ -18,11 +18,12 @@ from rcvpose_amd.pipeline import FramePipeline
 ap = argparse.ArgumentParser()
 ap.add_argument("--frames", type=int, default=72)
 ap.add_argument("--iters", type=int, default=3)
+ap.add_argument("--engine", default="auto", help="'full': the LDS rasteriser decides every item")
 args = ap.parse_args()
 B = args.frames
 shapes = json.load(open(os.path.join(ROOT, "tests", "golden", "fcn_state_dict_keys.json")))
 sds = [{k: torch.from_numpy(v) for k, v in synthetic_weights.make_state_dict_numpy(shapes, seed=s).items()} for s in range(3)]
-pipe = FramePipeline(sds, 480, 640, dtype="bf16", frames_per_step=B)
+pipe = FramePipeline(sds, 480, 640, dtype="bf16", frames_per_step=B, engine=args.engine)
 fr = [synthetic.synthetic_frame(i) for i in range(min(B, 12))]
 fr = [fr[i % len(fr)] for i in range(B)]
 rmax = torch.tensor(np.stack([f["max_radii_dm"] for f in fr]), dtype=torch.float64, device="cuda")
