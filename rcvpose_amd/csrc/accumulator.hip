@@ -530,11 +530,11 @@ __device__ __forceinline__ bool finish_header(AccHeader &H, long long dim, int n
     H.wide_ = 0;
     const int cells = CELL_BYTES / 4;
     // tile: TJ = 16 (or D if smaller) columns across j; TI rows; full k extent when it fits
-    int TJ = D < 16 ? D : 16, TI, TK = D, TKp = (D + 1) & ~1;
+    int TJ = D < 16 ? D : 16, TI, TK = D, TKp = D | 1;  // odd stride: the lanes' columns fall into different LDS banks
     if ((long long)TJ * TKp > cells) {  // a single row of columns does not fit: split k
         TI = 1;
         TJ = D < 64 ? D : 64;
-        TKp = (cells / TJ) & ~1;
+        TKp = (cells / TJ - 1) | 1;  // odd, <= cells / TJ
         TK = TKp;
     } else {
         TI = cells / (TJ * TKp);
@@ -652,7 +652,10 @@ __device__ __forceinline__ int tile_from_order(int order, const AccHeader &H)
 // packed fp32 additions; the "too close to an integer" tests are two packed subtractions and one maximum of
 // absolute values; counters are 32-bit (the 1024-thread workgroup owns its CU, 120 of the 160 KB of LDS), so a
 // vote is one shift-add and one ds_add_u32, and the second voxel of an interval is the same address with an
-// immediate offset.
+// immediate offset.  Columns are an odd number of cells apart (the lanes of a wave vote at similar k in 64 different
+// columns: with the even stride 60 % of the LDS cycles were bank conflicts) and the waves of a workgroup take the
+// 64-point batches of a tile from a counter instead of a fixed round-robin (survivors per batch vary: the static deal
+// left the slowest wave 10 % over the mean).  Together: 1.30 -> 0.78 ms per 15.5k-point / D = 229 item.
 // ---------------------------------------------------------------------------------------------
 constexpr int NONE_K = -0x40000000;
 typedef float vote_f2 __attribute__((ext_vector_type(2)));
@@ -808,11 +811,12 @@ __device__ __forceinline__ void d_vote(AccHeader *hdr, const double *P, int cap,
     uint64_t *wred = (uint64_t *)(smem + CELL_BYTES);                    // [VOTE_WAVES]
     int *wredi = (int *)(smem + CELL_BYTES + 8 * VOTE_WAVES);            // [VOTE_WAVES]
     int *s_tile_p = (int *)(smem + CELL_BYTES + 12 * VOTE_WAVES);
+    int *s_next = s_tile_p + 1;  // next 64-point batch of the tile (the waves take batches as they finish: survivors per batch vary)
 
     const AccHeader H = *hdr;
     if (H.status != RCV_OK || H.bb_done) return;
     const int D = H.dim, n = H.n, TI = H.TI, TJ = H.TJ, TK = H.TK, TKp = H.TKp;
-    const int lane = lane_id(), wv = wave_id(), tid = threadIdx.x;
+    const int lane = lane_id(), tid = threadIdx.x;
     const int ncols = TI * TJ;  // <= 128: two 64-column passes per point
     const int nwords = ncols * TKp;
     const bool flush = grid_out != nullptr && (unsigned long long)D * D * D <= grid_cells;
@@ -822,7 +826,10 @@ __device__ __forceinline__ void d_vote(AccHeader *hdr, const double *P, int cap,
 
     for (;;) {
         // tiles are handed out through one counter, heaviest (central) first
-        if (tid == 0) *s_tile_p = (int)atomicAdd(&hdr->tile_counter, 1u);
+        if (tid == 0) {
+            *s_tile_p = (int)atomicAdd(&hdr->tile_counter, 1u);
+            *s_next = 0;
+        }
         __syncthreads();
         const int torder = *s_tile_p;
         __syncthreads();
@@ -852,19 +859,26 @@ __device__ __forceinline__ void d_vote(AccHeader *hdr, const double *P, int cap,
         const double fk0 = (double)k0, fk1 = (double)(k1 - 1);
         __syncthreads();
 
-        // software pipeline: raw loads of the next batch are issued before the current one is rasterised
+        // software pipeline: raw loads of the next batch are issued before the current one is rasterised; batch q of this part
+        // is batch part + nparts * q of the list, q from the tile's counter
         double nx = 0, ny = 0, nz = 0, nlo = 0, nhi = 0;
-        const int bstride = VOTE_WAVES * H.nparts;
+        auto grab = [&]() {
+            int q = 0;
+            if (lane == 0) q = atomicAdd(s_next, 1);
+            return part + H.nparts * __builtin_amdgcn_readfirstlane(q);
+        };
+        int batch = grab();
         {
-            const int p = (part + H.nparts * wv) * 64 + lane;
+            const int p = batch * 64 + lane;
             if (p < n) { nx = Px[p]; ny = Py[p]; nz = Pz[p]; nlo = Plo[p]; nhi = Phi[p]; }
         }
-        for (int batch = part + H.nparts * wv; batch < nbatch; batch += bstride) {
+        while (batch < nbatch) {
             // fast_for sees xyz_mm - mean - zero_boundary (AccumulatorSpace.py:384-386,397)
             const double x = (nx - H.mean[0]) - H.shift, y = (ny - H.mean[1]) - H.shift, z = (nz - H.mean[2]) - H.shift;
             const double tlo = nlo, thi = nhi;
+            batch = grab();
             {
-                const int p = (batch + bstride) * 64 + lane;
+                const int p = batch * 64 + lane;
                 nhi = 0;
                 if (p < n) { nx = Px[p]; ny = Py[p]; nz = Pz[p]; nlo = Plo[p]; nhi = Phi[p]; }
             }
@@ -1744,12 +1758,13 @@ __device__ __forceinline__ void d_bb_restart(AccHeader *hdr, const BBEntry *list
     // Cost-based hand-over (r04).  The search certifies the arg-max by scoring every surviving block against all N points; on a
     // flat vote landscape (radial noise of several voxels) the survivors of the fine levels outgrow the rasteriser's work, which
     // is one interval evaluation per (point, column inside the shell's disc) ~ N * pi * r^2 whatever the noise.  Measured on the
-    // bench cloud (N = 15.5k, radii 50 ... 94 voxels; tools/vote_sweep.py): 1.1 ps per (block, point) against 8 ps per (point,
-    // column), and the 2-voxel level sees about twice the 4-voxel level's survivors -- so once MORE than 4.2 r_max^2 four-voxel
-    // candidates survive (37k on that cloud), finishing the search costs more than voting the whole grid: the search gives up
+    // bench cloud (N = 15.5k, radii 50 ... 94 voxels; tools/vote_sweep.py): 1.1 ps per (block, point) against 4.8 ps per (point,
+    // column) (8 before the rasteriser's r04 rework), and the 2-voxel level sees about twice the 4-voxel level's survivors -- so
+    // once MORE than 2.5 r_max^2 four-voxel candidates survive (22k on that cloud), finishing the search costs more than voting
+    // the whole grid: the search gives up
     // here (the fallback every search exit takes: k_vote decides; identical result by construction).  Both costs are
     // proportional to N; the grid edge does not enter (false positives on a background plane widen the grid, not the shells).
-    if (edge == 4 && (double)n > 4.2 * H.rmax * H.rmax) {
+    if (edge == 4 && (double)n > 2.5 * H.rmax * H.rmax) {
         if (threadIdx.x == 0) {
             hdr->bb_overflow = 1;
             hdr->bb_handover = 1;
