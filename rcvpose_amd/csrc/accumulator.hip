@@ -728,9 +728,8 @@ struct VotePoint {
 // one (point, column): the votes of the shell of the point along column (ci, cj) of the tile; `ey` = T_hi - (cj - y)^2 (shared by
 // the columns of a lane that lie in one grid row), `cbyte` = byte offset of the column's cell k = 0 in the LDS image (may be
 // negative: k0 > 0), `zsrc` / `lsrc` / `L`: where the exact path finds the point's z and T_lo.  The end points only have to be
-// good to ~1e-6, so a = T_hi - sxy is two fused multiply-adds here; the exact path forms sxy in the reference's order.  The early
-// return matters: a third of all (point, 64-column half tile) pairs lie outside the disc as a whole and skip the rest wave-wide
-// (a straight-line version that interleaved the lane's two columns measured 1.28 instead of 0.93 ms per item).
+// good to ~1e-6, so a = T_hi - sxy is two fused multiply-adds here; the exact path forms sxy in the reference's order.  (A straight-line
+// version that computed the lane's two columns as interleaved chains before any vote measured 1.28 instead of 0.93 ms per item.)
 __device__ __forceinline__ void vote_column(unsigned char *cells, double ci, double cj, double ey, int cbyte, const VotePoint &q,
                                             double zsrc, double lsrc, int L)
 {
@@ -774,26 +773,29 @@ __device__ __forceinline__ void vote_column(unsigned char *cells, double ci, dou
         }
     }
     if (unc) {  // some integer is too close to an end point: decide those with the exact float64 predicate
-        // candidates: the integer just outside each sure range (at most one per end point, eps < 0.5)
-        int u1 = fabsf(dA.x) > q.lim ? (int)rA.x - 1 : NONE_K;
-        int u2 = fabsf(dA.y) > q.lim ? (int)rA.y + 1 : NONE_K;
-        int u3 = fabsf(dB.y) > q.lim ? (int)rB.y - 1 : NONE_K;
-        int u4 = fabsf(dB.x) > q.lim ? (int)rB.x + 1 : NONE_K;
-        if (u2 == u1) u2 = NONE_K;
-        if (u3 == u2 || u3 == u1) u3 = NONE_K;
-        if (u4 == u3 || u4 == u2 || u4 == u1) u4 = NONE_K;
+        // candidates: the integer just outside each sure range (at most one per end point, eps < 0.5).  Typically ONE lane of the
+        // wave has ONE such end point: every candidate's block starts with the wave-wide question whether anybody has it.
         const double pz = readlane_f64(zsrc, L), tlo = readlane_f64(lsrc, L);
         const double dy = cj - q.y;
         const double sxy = dx * dx + dy * dy;  // (i-x)**2 + (j-y)**2, reference order (:337)
-        const int us[4] = {u1, u2, u3, u4};
+        const float moved[4] = {fabsf(dA.x), fabsf(dA.y), fabsf(dB.y), fabsf(dB.x)};
+        const float edge[4] = {rA.x, rA.y, rB.y, rB.x};
+        int seen[4] = {NONE_K, NONE_K, NONE_K, NONE_K};
 #pragma unroll
         for (int t = 0; t < 4; t++) {
-            const int r = us[t];
-            if (r == NONE_K || r < q.rlo || r > q.rhi) continue;
-            if ((r >= a0 && r <= a1) || (r >= b0 && r <= b1)) continue;  // already a sure vote (cannot happen in exact arithmetic)
-            const double dz = (double)(q.zi + r) - pz;
-            const double d2 = sxy + dz * dz;  // ... + (k-z)**2
-            if (d2 >= tlo && d2 < q.thi) atomicAdd((uint32_t *)(col + r * 4), 1u);
+            const bool flagged = moved[t] > q.lim;
+            if (!__builtin_amdgcn_ballot_w64(flagged)) continue;
+            const int r = flagged ? (int)edge[t] + ((t & 1) ? 1 : -1) : NONE_K;  // below a lower end / above an upper end
+            seen[t] = r;
+            bool go = r != NONE_K && r >= q.rlo && r <= q.rhi;
+#pragma unroll
+            for (int e = 0; e < t; e++) go = go && r != seen[e];  // two end points within eps of the same integer
+            go = go && !((r >= a0 && r <= a1) || (r >= b0 && r <= b1));  // already a sure vote (cannot happen in exact arithmetic)
+            if (go) {
+                const double dz = (double)(q.zi + r) - pz;
+                const double d2 = sxy + dz * dz;  // ... + (k-z)**2
+                if (d2 >= tlo && d2 < q.thi) atomicAdd((uint32_t *)(col + r * 4), 1u);
+            }
         }
     }
 }
