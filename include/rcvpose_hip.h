@@ -75,7 +75,7 @@ typedef struct rcv_acc_result {
 /* Bytes of workspace for rcv_seam_compact / rcv_accumulate_3d for clouds of up to max_points points (and radii).
  * rcv_acc_workspace_bytes_min is what every call needs (~45 MB at 640x480); rcv_acc_workspace_bytes adds the replica area
  * with which the LDS rasteriser splits a tile's point list over up to 8 workgroups (load balance of a SINGLE item;
- * ~125 MB more).  The calls take whatever lies between the two and size the split from it: batched callers, whose
+ * ~250 MB more).  The calls take whatever lies between the two and size the split from it: batched callers, whose
  * items already fill the chip, allocate the minimum per item. */
 size_t rcv_acc_workspace_bytes(int max_points);
 size_t rcv_acc_workspace_bytes_min(int max_points);
