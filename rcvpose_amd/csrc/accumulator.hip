@@ -8,8 +8,8 @@
 //     peak search (k_bb_*): box upper bounds in float32 over a point list streamed through LDS by LDS-DMA, exact
 //     float64 counts for the probe / hill-climb lower bound and for the few surviving voxels.
 //   * the general engine (and the one that materialises the grid) never needs the vote grid in HBM either: the
-//     grid is cut into column tiles (TI x TJ x TK voxels) that fit the 160 KB LDS of a CU as packed 16-bit
-//     counters; one 1024-thread workgroup owns a tile, culls the point list against the tile footprint, and
+//     grid is cut into column tiles (TI x TJ x TK voxels) that fit the 160 KB LDS of a CU as 32-bit counters
+//     (120 KB per tile); one 1024-thread workgroup owns a tile, culls the point list against the tile footprint, and
 //     rasterises, per (point, column), only the few voxels of the spherical shell that cross that column.
 //     Votes are LDS atomics; no global atomics exist anywhere on the path.
 //   * the arg-max is taken per tile straight out of LDS with a wavefront reduction on the packed key
