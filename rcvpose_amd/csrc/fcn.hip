@@ -1172,12 +1172,15 @@ __global__ __launch_bounds__(512) void k_conv_halo(const HaloParams p)
         const int pr = (k * 8 + wave) * 8 + lrow;
         const int py = (int)(((float)pr + 0.5f) * rP), px = pr - py * pitch;
         const int y = y0 - 1 + py, x = x0 - 1 + px;
-        lin[k] = (pr < prows && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W) ? (img * p.H + y) * p.W + x : -1;
+        // The patch is swizzled with chunk ^= key(patch position), key = (px + tw * py) & 7, kept in bits 28..30 of lin[k] (a pixel
+        // index is < 2^24: 32-bit byte offsets).  The taps read the patch rows of 16 CONSECUTIVE PIXELS of the rectangle from any
+        // start; along the rectangle's pixel order this key counts on across the end of a rectangle row, where the patch row
+        // jumps by the two halo columns -- with the r02/r03 key (patch row & 7, continuous only inside a row) every 16-pixel tile
+        // that wraps (three of four in the 15 x 20 rectangles of layer 3) read with 2-way bank conflicts: rocprofv3 counted
+        // SQ_LDS_BANK_CONFLICT at 0.9 of SQ_ACTIVE_INST_LDS in k_conv_halo<128,5> and zero in the other kernels (r04).
+        const int key = (px + p.tw * py) & 7;
+        lin[k] = (pr < prows && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W) ? ((img * p.H + y) * p.W + x) | (key << 28) : -1;
     }
-    // The patch is swizzled with chunk ^= row & 7 (= lrow here), not with the tiles' (row >> 1) & 7: the taps read 16 consecutive
-    // patch rows from ANY start row, and under ds_read_b128's lane grouping this key is conflict-free for every start (the
-    // tiles' key is only for starts that are multiples of 4: 2-way conflicts on 12 of 16 offsets)
-    const int pchunk16 = (lpos ^ lrow) << 4;
     int b_off[BPW];
 #pragma unroll
     for (int c = 0; c < BPW; c++) {
@@ -1207,7 +1210,9 @@ __global__ __launch_bounds__(512) void k_conv_halo(const HaloParams p)
         const bool first_ = cgp_ < p.C0, live_ = (sl_) < nsl;                                                  \
         const int Cs_ = first_ ? p.C0 : p.C1;                                                                  \
         const char *ab_ = (const char *)(first_ ? src0 : src1) + (long long)(first_ ? cgp_ : cgp_ - p.C0) * 2; \
-        const int off_ = (live_ && lin[k] >= 0) ? lin[k] * (Cs_ * 2) + pchunk16 : OOB;                         \
+        int lk_ = lin[k];                                                                                      \
+        asm volatile("" : "+v"(lk_)); /* unpack here, every time: hoisted out of the K loop the two halves cost 7 registers and spill */ \
+        const int off_ = (live_ && lk_ >= 0) ? (lk_ & 0x0FFFFFFF) * (Cs_ * 2) + ((lpos ^ (lk_ >> 28)) << 4) : OOB; \
         halo_dma16(ab_, first_ ? a_bytes0 : a_bytes1, sP + ((sl_) & 1) * HALO_PATCH + ((k) * 8 + wave) * 1024, off_); \
     }
 // weight piece c of K step (slice sl_, tap t_) into ring stage st_; steps beyond the last one: zeros
@@ -1237,10 +1242,8 @@ __global__ __launch_bounds__(512) void k_conv_halo(const HaloParams p)
         const unsigned char *Bb = sB + stage * (BN * 128) + (wn * (BN / 2) + r16) * 128;                       \
         const int st2 = stage + 2 >= 3 ? stage + 2 - 3 : stage + 2;                                            \
         int ao_[MT];                                                                                           \
-        _Pragma("unroll") for (int i = 0; i < MT; i++) {                                                       \
-            const int prow_ = pr0[i] + shift_;                                                                 \
-            ao_[i] = prow_ * 128 + ((kq ^ (prow_ & 7)) << 4);                                                  \
-        }                                                                                                      \
+        const int kx_ = (kq ^ ((r16 + ((TAP) / 3) * p.tw + (TAP) % 3) & 7)) << 4;                              \
+        _Pragma("unroll") for (int i = 0; i < MT; i++) ao_[i] = (pr0[i] + shift_) * 128 + kx_;                 \
         bf16x8 af[MT], bfr[NT];                                                                                \
         _Pragma("unroll") for (int i = 0; i < MT; i++) af[i] = *(const bf16x8 *)(Pb + ao_[i]);                 \
         _Pragma("unroll") for (int j = 0; j < NT; j++) bfr[j] = *(const bf16x8 *)(Bb + j * 16 * 128 + ch0);    \
@@ -1286,8 +1289,7 @@ __global__ __launch_bounds__(512) void k_conv_halo(const HaloParams p)
         const int st2 = stage + 2 >= 3 ? stage + 2 - 3 : stage + 2;                                            \
         bf16x8 af[2][MT], bfr[2][NT];                                                                          \
         _Pragma("unroll") for (int i = 0; i < MT; i++) {                                                       \
-            const int prow_ = pr0[i] + shift_;                                                                 \
-            const int ao_ = prow_ * 128 + ((kq ^ (prow_ & 7)) << 4);                                           \
+            const int ao_ = (pr0[i] + shift_) * 128 + ((kq ^ ((r16 + ((TAP) / 3) * p.tw + (TAP) % 3) & 7)) << 4); \
             af[0][i] = *(const bf16x8 *)(Pb + ao_);                                                            \
             af[1][i] = *(const bf16x8 *)(Pb + (ao_ ^ 64));                                                     \
         }                                                                                                      \
@@ -1329,10 +1331,8 @@ __global__ __launch_bounds__(512) void k_conv_halo(const HaloParams p)
         const unsigned char *Bb = sB + stage * (BN * 128) + (wn * (BN / 2) + r16) * 128;                       \
         const int st2 = stage + 2 >= 3 ? stage + 2 - 3 : stage + 2;                                            \
         int ao_[MT];                                                                                           \
-        _Pragma("unroll") for (int i = 0; i < MT; i++) {                                                       \
-            const int prow_ = pr0[i] + shift_;                                                                 \
-            ao_[i] = prow_ * 128 + ((kq ^ (prow_ & 7)) << 4);                                                  \
-        }                                                                                                      \
+        const int kx_ = (kq ^ ((r16 + ((TAP) / 3) * p.tw + (TAP) % 3) & 7)) << 4;                              \
+        _Pragma("unroll") for (int i = 0; i < MT; i++) ao_[i] = (pr0[i] + shift_) * 128 + kx_;                 \
         bf16x8 ah[MT], al[MT], bh[NT], bl[NT];                                                                 \
         _Pragma("unroll") for (int i = 0; i < MT; i++) ah[i] = *(const bf16x8 *)(Pb + ao_[i]);                 \
         _Pragma("unroll") for (int j = 0; j < NT; j++) bh[j] = *(const bf16x8 *)(Bb + j * 16 * 128 + ch0);     \
@@ -1386,8 +1386,7 @@ __global__ __launch_bounds__(512) void k_conv_halo(const HaloParams p)
         const int st2 = stage + 2 >= 3 ? stage + 2 - 3 : stage + 2;                                            \
         bf16x8 af[2][MT], bfr[2][NT];                                                                          \
         _Pragma("unroll") for (int i = 0; i < MT; i++) {                                                       \
-            const int prow_ = pr0[i] + shift_;                                                                 \
-            const int ao_ = prow_ * 128 + ((kq ^ (prow_ & 7)) << 4);                                           \
+            const int ao_ = (pr0[i] + shift_) * 128 + ((kq ^ ((r16 + ((TAP) / 3) * p.tw + (TAP) % 3) & 7)) << 4); \
             af[0][i] = *(const bf16x8 *)(Pb + ao_);                                                            \
             af[1][i] = *(const bf16x8 *)(Pb + (ao_ ^ 64));                                                     \
         }                                                                                                      \
