@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--frames", type=int, default=64)
     ap.add_argument("--frames_per_step", type=int, default=53)
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "driver_bench.json"))
+    ap.add_argument("--sweep", default="", help="comma-separated frames_per_step values: only the batched main.py runs, one per value")
     args = ap.parse_args()
     import test_gpu_driver as T  # the synthetic LINEMOD layout of the driver tests
     from rcvpose_amd import AccumulatorSpace as A
@@ -37,6 +38,14 @@ def main():
         cls, _ = T._write_dataset(root, n_frames=args.frames)
         T._write_lm_checkpoints(root, cls, os.path.join(ROOT, "tests", "golden"), (3.0, 3.5, 4.0))
         out = {"frames": args.frames, "frames_per_step": args.frames_per_step}
+        if args.sweep:
+            for n in [int(v) for v in args.sweep.split(",")]:
+                res = rcv_main(["--mode", "test", "--root_dataset", root, "--model_dir", root, "--using_ckpts", "true", "--frames_per_step", str(n)])
+                out["sweep_%d" % n] = {"frames_per_s": args.frames / res[cls]["frame_loop_s"], "net_time_ms": res[cls]["net_time_ms"],
+                                       "acc_time_ms": res[cls]["acc_time_ms"]}
+            json.dump(out, open(args.out, "w"), indent=1)
+            print(json.dumps(out))
+            return
         for n in (args.frames_per_step, 1):
             t0 = time.perf_counter()
             res = rcv_main(["--mode", "test", "--root_dataset", root, "--model_dir", root, "--using_ckpts", "true",
