@@ -1615,7 +1615,11 @@ __device__ __forceinline__ void d_bb_climb(AccHeader *hdr, const double *Q, cons
     // 0 before round 1)
     const bool from_seed = round == 0;
     if (from_seed && H.seed == 0) return;
-    const unsigned long long frozen = from_seed ? 0ull : H.climb_key[(round - 1) & 1];
+    // (the two slots are read through the pointer: indexing the header COPY with a run-time subscript keeps the whole 400-byte
+    // struct in scratch memory -- every thread of every workgroup loaded and stored it, 19 us per launch even for the rounds that
+    // return at once; r04)
+    const int prev = (round - 1) & 1;
+    const unsigned long long frozen = from_seed ? 0ull : hdr->climb_key[prev];
     if (!from_seed && frozen == 0) return;
     const int D = H.dim, n = H.n;
     const unsigned long long flat = from_seed ? H.seed - 1 : (frozen & 0xFFFFFFFFull);
@@ -1623,7 +1627,7 @@ __device__ __forceinline__ void d_bb_climb(AccHeader *hdr, const double *Q, cons
     if (!from_seed && threadIdx.x == 0) atomicMax(&hdr->climb_key[round & 1], frozen);
     // converged: the best voxel is the one the previous round was centred on -- its whole neighbourhood has been counted
     // and nothing in it was better.  (Every workgroup of the round computes the same centre; the first one records it.)
-    if (round > 0 && H.climb_center[(round - 1) & 1] == flat + 1) {
+    if (round > 0 && hdr->climb_center[prev] == flat + 1) {
         if (blockIdx.x == 0 && threadIdx.x == 0) hdr->climb_center[round & 1] = flat + 1;
         return;
     }
