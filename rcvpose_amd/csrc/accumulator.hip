@@ -51,6 +51,7 @@ constexpr int BB_LEVELS = 6;
 #ifndef RCV_BB_CLIMB_ROUNDS
 #define RCV_BB_CLIMB_ROUNDS 12
 #endif
+constexpr int BB_SEED_THREADS = 1024;  // k_bb_seed: one workgroup per item
 constexpr int BB_BEAM = RCV_BB_BEAM;   // blocks per level followed by the greedy probe that seeds the lower bound
 constexpr int PREP_BLOCKS = 128;
 constexpr int PREP_THREADS = 256;
@@ -1477,7 +1478,10 @@ __device__ __forceinline__ void d_bb_wide(AccHeader *hdr, const float *F, size_t
 __device__ __forceinline__ void d_bb_seed(AccHeader *hdr, const double *Q, const double *P, const int32_t *ri, int cap)
 {
     constexpr int NS = 15;  // upper triangle of A^T A (10) + A^T b (4), rows a_p = (-2x, -2y, -2z, 1), b_p = r^2 - |q|^2; + the row count
-    __shared__ double part[NS][256];
+    // 1024 threads (r04; 256 before): the passes are chains of dependent loads, and one wave per SIMD hid none of their latency
+    // (465 us per launch with the chip idle around it); sums per wave by shuffles, the 16 wave sums added in a fixed order
+    constexpr int NT = BB_SEED_THREADS, NW = NT / 64;
+    __shared__ double part[NS][NW];
     __shared__ double tot[NS];
     __shared__ double s_c[3];   // the current estimate (relative to the grid centre)
     __shared__ int s_have;      // an estimate exists
@@ -1502,9 +1506,9 @@ __device__ __forceinline__ void d_bb_seed(AccHeader *hdr, const double *Q, const
         if (trim && !s_have) break;
         const double cx = s_c[0], cy = s_c[1], cz = s_c[2];
         if (trim) {
-            for (int t = threadIdx.x; t < 512; t += 256) s_hist[t] = 0;
+            for (int t = threadIdx.x; t < 512; t += NT) s_hist[t] = 0;
             __syncthreads();
-            for (int p = threadIdx.x; p < n; p += 256) {
+            for (int p = threadIdx.x; p < n; p += NT) {
                 if (!(Phi[p] > 0.0)) continue;
                 const double dx = cx - (Q[p] - t0), dy = cy - (Q[(size_t)cap + p] - t0), dz = cz - (Q[2 * (size_t)cap + p] - t0);
                 const double res = fabs(sqrt((dx * dx + dy * dy) + dz * dz) - (double)ri[p]);
@@ -1525,7 +1529,7 @@ __device__ __forceinline__ void d_bb_seed(AccHeader *hdr, const double *Q, const
 #pragma unroll
         for (int k = 0; k < NS; k++) sm[k] = 0.0;
 #pragma unroll 2
-        for (int p = threadIdx.x; p < n; p += 256) {
+        for (int p = threadIdx.x; p < n; p += NT) {
             if (!(Phi[p] > 0.0)) continue;  // never votes
             const double x = Q[p] - t0, y = Q[(size_t)cap + p] - t0, z = Q[2 * (size_t)cap + p] - t0, r = (double)ri[p];
             if (trim) {
@@ -1544,11 +1548,15 @@ __device__ __forceinline__ void d_bb_seed(AccHeader *hdr, const double *Q, const
             sm[14] += 1.0;
         }
 #pragma unroll
-        for (int k = 0; k < NS; k++) part[k][threadIdx.x] = sm[k];
+        for (int k = 0; k < NS; k++) {
+            double v = sm[k];
+            for (int m = 32; m; m >>= 1) v += shfl_xor_f64(v, m);
+            if (lane_id() == 0) part[k][wave_id()] = v;
+        }
         __syncthreads();
         if (threadIdx.x < NS) {
             double acc = 0.0;
-            for (int t = 0; t < 256; t++) acc += part[threadIdx.x][t];
+            for (int t = 0; t < NW; t++) acc += part[threadIdx.x][t];
             tot[threadIdx.x] = acc;
         }
         __syncthreads();
@@ -2255,7 +2263,7 @@ __global__ __launch_bounds__(BBW_THREADS) void k_bb_wide(int cap, int level, SP<
                                             &hdr->bb_count[level + 1], &hdr->bs_count[level + 1], BB_HALF, BB_HALF, level);
     }
 }
-__global__ __launch_bounds__(256) void k_bb_seed(int cap, SP<unsigned char> ws, Layout L)
+__global__ __launch_bounds__(BB_SEED_THREADS) void k_bb_seed(int cap, SP<unsigned char> ws, Layout L)
 {
     unsigned char *w = ws.get();
     d_bb_seed((AccHeader *)(w + L.header), (const double *)(w + L.Q), (const double *)(w + L.P), (const int32_t *)(w + L.ri), cap);
@@ -2628,7 +2636,7 @@ static int run_engines(int cap, int bb_enable, SP<rcv_acc_result> sres, SP<uint3
         RCV_LAUNCH_CHECK();
         // a least-squares estimate of the keypoint's voxel, one round of exact counts around it, and the decision whether the
         // greedy probe is still needed (r02; see d_bb_seed / k_bb_gate)
-        hipLaunchKernelGGL(k_bb_seed, grid3(1), dim3(256), 0, st, cap, sws, L);
+        hipLaunchKernelGGL(k_bb_seed, grid3(1), dim3(BB_SEED_THREADS), 0, st, cap, sws, L);
         RCV_LAUNCH_CHECK();
         hipLaunchKernelGGL(k_bb_climb, grid3(BB_CLIMB_W), dim3(256), 0, st, cap, 0, sws, L);
         RCV_LAUNCH_CHECK();
