@@ -70,5 +70,34 @@ def main():
         print("weights seed %d, %dx%d:" % (seed, H, W), {k: "radial %.2e seg %.2e" % v for k, v in res.items()})
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and "--stages" not in sys.argv:
     main()
+
+
+def stage_limited():
+    """19-bit storage only where a 3-byte stream could be built: the block outputs inside layers 1 and 2 (consumed by the chain kernels'
+    VALU epilogues); everything else stays at 22 bits.  python tools/probe/storage_bits_probe.py --stages"""
+    shapes = json.load(open(os.path.join(ROOT, "tests", "golden", "fcn_state_dict_keys.json")))
+    torch.set_num_threads(8)
+    orig_conv = fcn_torch._conv16
+
+    def conv16(sd, x, conv, bn, bias, stride=1, padding=0, relu=True, res=None):
+        y = orig_conv(sd, x, conv, bn, bias, stride=stride, padding=padding, relu=relu, res=res)
+        if conv.endswith("conv3") and (conv.startswith("block1") or conv.startswith("block2")):
+            y = split19(y)
+        return y
+
+    for seed in (0, 1, 2):
+        sd = {k: torch.from_numpy(v) for k, v in synthetic_weights.make_state_dict_numpy(shapes, seed=seed).items()}
+        x = torch.randn((1, 3, 64, 96), generator=torch.Generator().manual_seed(100 + seed))
+        seg0, rad0 = fcn_torch.forward(sd, x)
+        fcn_torch._r16 = split22
+        fcn_torch._conv16 = conv16
+        seg, rad = fcn_torch.forward_bf16(sd, x)
+        fcn_torch._conv16 = orig_conv
+        print("weights seed %d: block outputs of layers 1-2 at 19 bits, the rest at 22: radial %.2e seg %.2e" % (
+            seed, float((rad - rad0).abs().max() / rad0.abs().max()), float((seg - seg0).abs().max() / seg0.abs().max())))
+
+
+if __name__ == "__main__" and "--stages" in sys.argv:
+    stage_limited()
