@@ -47,6 +47,11 @@ const char *rcv_strerror(int status);
 int rcv_version(void);
 /* Text of the last failing HIP call in this process (for RCV_E_HIP). */
 const char *rcv_last_hip_error(void);
+/* Measurement aid (bench.py; no reference counterpart): runs a bare v_mfma_f32_16x16x32_f16 loop on every SIMD of the device for
+ * about `seconds` and returns the dense fp16 TFLOP/s it reached and (optional) the in-kernel shader clock in MHz
+ * (s_memtime / s_memrealtime, median over workgroups) -- the matrix rate THIS device holds under load, which differs by
+ * several per cent between MI355X devices.  Synchronises `stream`. */
+int rcv_mfma_calibrate(double seconds, double *tflops_out, double *clock_mhz_out, void *stream);
 /* Builds the per-device constant tables (shell thresholds).  Called lazily by the entry points;
  * call it once up front to keep the first timed call clean. */
 int rcv_init(void);
@@ -291,6 +296,8 @@ typedef struct rcv_op {
     int32_t relu;
     int64_t w_off;           /* element offset of this op's weights [G][cout][k][k][c0+c1] in the weight blob */
     int64_t b_off;           /* element offset of this op's fp32 bias [G][cout] in the bias blob */
+    int64_t wq_off;          /* RCV_F16X3: element offset of a second copy of this op's weights in the q6 row layout (engine
+                              * option 11, below), or 0 = none */
 } rcv_op;
 
 typedef struct rcv_fcn rcv_fcn; /* opaque engine handle */
@@ -335,6 +342,10 @@ int rcv_fcn_range_status(rcv_fcn *h, unsigned *flags_out, int clear, void *strea
 /* Test hook: copy activation slot `slot` of group g (as stored: NHWC, engine dtype) to out_dev as fp32. */
 int rcv_fcn_debug_slot(rcv_fcn *h, const void *ws, int B, int g, int slot, float *out_dev, void *stream);
 
+/* Test hook (RCV_F16X3, engine option 11): rewrite n_rows 128-byte rows [32 hi halves | 32 lo halves] in place into q6 rows
+ * [32 hi halves | 4 x (16 e2m3 codes, scale in byte 12)] -- the kernel the executor runs on the source of a q6 op. */
+int rcv_fcn_debug_q6_pack(void *rows_dev, long long n_rows, void *stream);
+
 /* Name and average device time (ms, HIP events on `stream`) of the slowest op kind in the last
  * profiled forward; used by bench.py for the roofline line.  Enable with rcv_fcn_set_profiling. */
 int rcv_fcn_set_profiling(rcv_fcn *h, int enable);
@@ -355,7 +366,16 @@ int rcv_fcn_set_profiling(rcv_fcn *h, int enable);
  * tiles -- one or a few frames; 0: k_conv, bit-identical output.
  * key 10 (default 1, RCV_F16X3): the fused 1x1 expand + next 1x1 reduce kernel in its round-4 form (k_chain2_x3: no LDS
  * transposition, half chunks, epilogue between the MFMAs); 0: k_chain_x3; 2: k_chain3_x3 for the 256-wide block (four waves of 32
- * pixels, one per SIMD: half the LDS fragment traffic, measured 4 % slower); bit-identical output in every form. */
+ * pixels, one per SIMD: half the LDS fragment traffic, measured 4 % slower); bit-identical output in every form.
+ * key 11 (default 1, RCV_F16X3): fp6 cross terms.  For a 3x3 / stride-1 op whose rcv_op::wq_off names a q6 copy of its weights
+ * (and whose source tensor feeds no other op) the two cross terms hi*lo + lo*hi of the split product run as ONE block-scaled
+ * v_mfma_scale_f32_16x16x128_f8f6f4 on e2m3 operands instead of two half-precision MFMAs (hi*hi stays fp16): the source is
+ * rewritten in place (k_q6_pack) into rows [32 hi halves | 4 x (16 e2m3 codes in 12 bytes, e8m0 block scale in byte 12, 3 zero
+ * bytes)] for the blocks hi[0:16], hi[16:32], lo[0:16], lo[16:32] of each 32-channel group; the q6 weight rows are
+ * [32 hi halves | lo[0:16], lo[16:32], hi[0:16], hi[16:32]] with the scale in byte 14 of each 16-byte chunk; block scale
+ * 2^(floor(log2 max|block|) - 2), codes rounded to nearest even, saturating at 7.5.  rcvpose_amd/fcn_engine.py requests it for
+ * the 3x3 convolutions of layer 3 only (measured map error 1-2e-5 instead of 0.4-0.8e-5; every 3x3 layer: 6-7e-5,
+ * tools/probe/fp8_cross_probe.py).  0: three half-precision MFMAs everywhere (the bit-identical family of kernels). */
 int rcv_fcn_set_option(rcv_fcn *h, int key, int value);
 int rcv_fcn_get_profile(rcv_fcn *h, double *conv_ms, double *other_ms, double *conv_flop);
 /* Per-op device times (ms) of the last profiled forward; ms_out has room for n_ops doubles. */

@@ -80,6 +80,7 @@ class Op(ctypes.Structure):
         ("relu", ctypes.c_int32),
         ("w_off", ctypes.c_int64),
         ("b_off", ctypes.c_int64),
+        ("wq_off", ctypes.c_int64),
     ]
 
 
@@ -92,6 +93,7 @@ SYMBOLS = {
     "rcv_version": (_i, []),
     "rcv_last_hip_error": (ctypes.c_char_p, []),
     "rcv_init": (_i, []),
+    "rcv_mfma_calibrate": (_i, [_d, ctypes.POINTER(_d), ctypes.POINTER(_d), _vp]),
     "rcv_acc_workspace_bytes": (_sz, [_i]),
     "rcv_seam_compact": (_i, [_vp, _vp, _vp, _i, _i, ctypes.POINTER(_d), _f, _d, _i, _vp, _vp, _vp, _i, _vp, _sz, _vp]),
     "rcv_acc_workspace_bytes_min": (_sz, [_i]),
@@ -112,6 +114,7 @@ SYMBOLS = {
     "rcv_fcn_forward": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _sz, _vp]),
     "rcv_fcn_range_status": (_i, [_vp, ctypes.POINTER(ctypes.c_uint), _i, _vp]),
     "rcv_fcn_debug_slot": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
+    "rcv_fcn_debug_q6_pack": (_i, [_vp, ctypes.c_longlong, _vp]),
     "rcv_fcn_set_profiling": (_i, [_vp, _i]),
     "rcv_fcn_set_option": (_i, [_vp, _i, _i]),
     "rcv_fcn_get_profile": (_i, [_vp, ctypes.POINTER(_d), ctypes.POINTER(_d), ctypes.POINTER(_d)]),

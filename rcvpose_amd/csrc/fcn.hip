@@ -216,6 +216,25 @@ __device__ __forceinline__ void rng_flush(unsigned *flag, float m)
     }
 }
 
+// ---- q6: the fp6 (e2m3) side band of the split-precision engine (r05).  A 128-byte row of a q6 tensor keeps the 32 hi halves of
+// its channel group and, in place of the 32 lo halves, four 16-byte chunks = the blocks of v_mfma_scale_f32_16x16x128_f8f6f4:
+// 16 e2m3 codes (12 bytes, element j in bits [6j, 6j + 6)) of hi[0:16], hi[16:32], lo[0:16], lo[16:32] and the block's e8m0
+// scale in byte 12 (activations) / byte 14 (weights).  Block scale = 2^(floor(log2 max|block|) - 2): the largest element lands
+// in e2m3's top binade [4, 8) (7.75 and above saturate at 7.5); conversion = v_cvt_scalef32_pk32_fp6_f16 (round to nearest
+// even, saturating; tools/probe/fp6_mfma_probe.hip).
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x6 __attribute__((ext_vector_type(6)));
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x32 __attribute__((ext_vector_type(32)));
+__device__ __forceinline__ f32x4 q6_mfma(i32x8 a, i32x8 b, f32x4 c, int scale_a, int scale_b)
+{
+#if defined(RCV_FCN_X3)
+    // cbsz = blgp = 2: both operands e2m3; the A scale is byte 0 of its register, the B scale byte 2
+    return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c, 2, 2, 0, scale_a, 2, scale_b);
+#else
+    return c;
+#endif
+}
 struct ConvParams {
     const void *src0, *src1, *res, *w;
     void *dst;
@@ -227,6 +246,7 @@ struct ConvParams {
     int KS, stride, pad, relu;
     int M, K;  // GEMM sizes per group
     unsigned *range;  // the engine's sticky range-flag word (half-precision engines), or null
+    int q6;           // split engine: src0 and w are in the q6 row layout, the cross terms run in fp6 (engine option 11)
 };
 
 // Tile order.  Blocks are numbered so that the N tiles of one M tile are neighbours (they share the gathered
@@ -342,10 +362,21 @@ __global__ __launch_bounds__(256) void k_conv(const ConvParams p)
             _Pragma("unroll") for (int j = 0; j < NT; j++) { bh[j] = *(const bf16x8 *)(Bb + j * 16 * 128 + chh); bl[j] = *(const bf16x8 *)(Bb + j * 16 * 128 + chl); } \
             _Pragma("unroll") for (int i = 0; i < MT; i++)                                                   \
                 _Pragma("unroll") for (int j = 0; j < NT; j++) acc[i][j] = RCV_MFMA16(ah[i], bh[j], acc[i][j], 0, 0, 0); \
-            _Pragma("unroll") for (int i = 0; i < MT; i++)                                                   \
-                _Pragma("unroll") for (int j = 0; j < NT; j++) acc[i][j] = RCV_MFMA16(ah[i], bl[j], acc[i][j], 0, 0, 0); \
-            _Pragma("unroll") for (int i = 0; i < MT; i++)                                                   \
-                _Pragma("unroll") for (int j = 0; j < NT; j++) acc[i][j] = RCV_MFMA16(al[i], bh[j], acc[i][j], 0, 0, 0); \
+            if (p.q6) {  /* q6 rows: the second halves are fp6 blocks -- one scaled MFMA for hi*lo + lo*hi (see k_conv_halo) */ \
+                _Pragma("unroll") for (int j = 0; j < NT; j++) {                                             \
+                    const i32x4 bq_ = __builtin_bit_cast(i32x4, bl[j]);                                      \
+                    const i32x8 b8_ = {bq_[0], bq_[1], bq_[2], bq_[3], 0, 0, 0, 0};                          \
+                    _Pragma("unroll") for (int i = 0; i < MT; i++) {                                         \
+                        const i32x4 aq_ = __builtin_bit_cast(i32x4, al[i]);                                  \
+                        acc[i][j] = q6_mfma(__builtin_shufflevector(aq_, aq_, 0, 1, 2, 3, -1, -1, -1, -1), b8_, acc[i][j], aq_[3], bq_[3]); \
+                    }                                                                                        \
+                }                                                                                            \
+            } else {                                                                                         \
+                _Pragma("unroll") for (int i = 0; i < MT; i++)                                               \
+                    _Pragma("unroll") for (int j = 0; j < NT; j++) acc[i][j] = RCV_MFMA16(ah[i], bl[j], acc[i][j], 0, 0, 0); \
+                _Pragma("unroll") for (int i = 0; i < MT; i++)                                               \
+                    _Pragma("unroll") for (int j = 0; j < NT; j++) acc[i][j] = RCV_MFMA16(al[i], bh[j], acc[i][j], 0, 0, 0); \
+            }                                                                                                \
         } else if constexpr (sizeof(T) == 2) {                                                               \
             _Pragma("unroll") for (int kk = 0; kk < 2; kk++) {                                               \
                 bf16x8 af[MT], bfr[NT];                                                                      \
@@ -1110,6 +1141,64 @@ __device__ unsigned g_chain_stamps[2][64];  // k_chain_x3<256>, chunk 3: four st
 #else
 #define RCV_HSTAMP(idx)
 #endif
+// 16 halves (two registers quads: this lane's chunk and its neighbour's) -> 12 bytes of codes + the scale byte
+__device__ __forceinline__ i32x4 q6_block(const uint4 &lo8, const uint4 &hi8, int scale_byte_pos)
+{
+#if defined(RCV_FCN_X3)
+    const unsigned w[8] = {lo8.x, lo8.y, lo8.z, lo8.w, hi8.x, hi8.y, hi8.z, hi8.w};
+    unsigned m = 0u;  // max |.| of the 16 halves as a bit pattern (|half| orders like an unsigned integer)
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+        const unsigned a = w[e] & 0x7fff7fffu;
+        m = max(m, max(a & 0xffffu, a >> 16));
+    }
+    const float amax = (float)__builtin_bit_cast(_Float16, (unsigned short)m);
+    const int ex = max((int)(__float_as_uint(amax) >> 23), 3) - 2;  // e8m0 byte of the block scale (an all-zero block: 2^-126)
+    f16x32 v;
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+        const x3_h2 h = __builtin_bit_cast(x3_h2, w[e]);
+        v[2 * e] = h[0];
+        v[2 * e + 1] = h[1];
+    }
+#pragma unroll
+    for (int e = 16; e < 32; e++) v[e] = (_Float16)0.f;
+    const i32x6 c = __builtin_amdgcn_cvt_scalef32_pk32_fp6_f16(v, __uint_as_float((unsigned)ex << 23));
+    return i32x4{c[0], c[1], c[2], ex << (8 * scale_byte_pos)};
+#else
+    return i32x4{0, 0, 0, 0};
+#endif
+}
+// In place: [32 hi | 32 lo] rows -> q6 rows.  A wave takes 64 rows (8 KB) per pass: lane = (row in a group of 8, chunk), eight
+// coalesced 1 KB loads, all of them before the first store (the lo chunks are overwritten); the even lane of a pair converts
+// the pair's 16 channels and stores one 16-byte chunk.
+__global__ __launch_bounds__(256) void k_q6_pack(H16 *t, long long n_rows)
+{
+    const int lane = threadIdx.x & 63;
+    const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = (long long)gridDim.x * 4;
+    for (long long r0 = wave * 64; r0 < n_rows; r0 += n_waves * 64) {
+        uint4 v[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const long long row = r0 + k * 8 + (lane >> 3);
+            v[k] = row < n_rows ? *(const uint4 *)((const char *)t + row * 128 + (lane & 7) * 16) : uint4{0u, 0u, 0u, 0u};
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            uint4 nb;  // the neighbouring chunk (lane ^ 1)
+            nb.x = (unsigned)__builtin_amdgcn_mov_dpp((int)v[k].x, 0xb1, 0xf, 0xf, true);  // quad_perm [1,0,3,2]
+            nb.y = (unsigned)__builtin_amdgcn_mov_dpp((int)v[k].y, 0xb1, 0xf, 0xf, true);
+            nb.z = (unsigned)__builtin_amdgcn_mov_dpp((int)v[k].z, 0xb1, 0xf, 0xf, true);
+            nb.w = (unsigned)__builtin_amdgcn_mov_dpp((int)v[k].w, 0xb1, 0xf, 0xf, true);
+            const long long row = r0 + k * 8 + (lane >> 3);
+            if ((lane & 1) == 0 && row < n_rows) {
+                const i32x4 q = q6_block(v[k], nb, 0);
+                *(i32x4 *)((char *)t + row * 128 + 64 + ((lane & 7) >> 1) * 16) = q;
+            }
+        }
+    }
+}
 struct HaloParams {
     const void *src0, *src1, *w;
     void *dst;
@@ -1135,7 +1224,7 @@ __device__ __forceinline__ void halo_dma16(const void *base, int num_bytes, unsi
     __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void *)lds_wave_base, 16, voffset, 0, 0, 0);
 }
 
-template <int BN, int MT>
+template <int BN, int MT, bool Q6 = false>
 __global__ __launch_bounds__(512) void k_conv_halo(const HaloParams p)
 {
     RCV_X3_MODE();
@@ -1376,6 +1465,58 @@ __global__ __launch_bounds__(512) void k_conv_halo(const HaloParams p)
         RCV_HSTAMP_X(TAP, 8);                                                                                  \
         stage = stage + 1 == 3 ? 0 : stage + 1;                                                                \
     }
+// Split precision with the cross terms in fp6 (Q6, r05; engine option 11).  The source tensor and the weights are in the q6 row
+// layout (k_q6_pack, include/rcvpose_hip.h): [32 hi halves | 4 x (16 e2m3 codes, block scale)] per 32 channels, so the second
+// half of every patch / weight row is read with the very same ds_read_b128 as a lo fragment was -- chunk 4 + kq is block kq of
+// v_mfma_scale_f32_16x16x128_f8f6f4 (A: a_hi6[0:16], a_hi6[16:32], a_lo6[0:16], a_lo6[16:32]; B: w_lo6, w_lo6, w_hi6, w_hi6), whose
+// elements 16 .. 31 are zero on the B side (registers 3 .. 5: the scale byte sits where the A side has zeros, and the other way
+// round; registers 4 .. 5 of the A operand may hold anything: e2m3 has no NaN).  One scaled instruction (17.7 cycles, measured:
+// tools/probe/fp6_mfma_probe.hip) replaces the two half-precision MFMAs hi*lo + lo*hi (2 x 17.3): 40 instead of 60 per step,
+// 20 (hi*hi) in the first MFMA phase, 20 (cross) in the second.  NOT bit-identical to the three-MFMA form: tolerance-tested.
+#define RCV_HALO_STEP_X3Q(TAP)                                                                                 \
+    {                                                                                                          \
+        constexpr int T2_ = ((TAP) + 2) % 9, S2_ = ((TAP) + 2) / 9;                                            \
+        const int shift_ = ((TAP) / 3 - 1) * pitch + ((TAP) % 3 - 1);                                          \
+        const unsigned char *Pb = sP + (sl & 1) * HALO_PATCH;                                                  \
+        const unsigned char *Bb = sB + stage * (BN * 128) + (wn * (BN / 2) + r16) * 128;                       \
+        const int st2 = stage + 2 >= 3 ? stage + 2 - 3 : stage + 2;                                            \
+        int ao_[MT];                                                                                           \
+        const int kx_ = (kq ^ ((r16 + ((TAP) / 3) * p.tw + (TAP) % 3) & 7)) << 4;                              \
+        _Pragma("unroll") for (int i = 0; i < MT; i++) ao_[i] = (pr0[i] + shift_) * 128 + kx_;                 \
+        bf16x8 ah[MT], bh[NT];                                                                                 \
+        i32x4 aq[MT], bq[NT];                                                                                  \
+        _Pragma("unroll") for (int i = 0; i < MT; i++) ah[i] = *(const bf16x8 *)(Pb + ao_[i]);                 \
+        _Pragma("unroll") for (int j = 0; j < NT; j++) bh[j] = *(const bf16x8 *)(Bb + j * 16 * 128 + ch0);     \
+        RCV_HALO_B(sl + S2_, T2_, st2, 0);                                                                     \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                     \
+        __builtin_amdgcn_s_barrier();                                                                          \
+        __builtin_amdgcn_s_setprio(1);                                                                         \
+        _Pragma("unroll") for (int i = 0; i < MT; i++)                                                         \
+            _Pragma("unroll") for (int j = 0; j < NT; j++) acc[i][j] = RCV_MFMA16(ah[i], bh[j], acc[i][j], 0, 0, 0); \
+        __builtin_amdgcn_s_setprio(0);                                                                         \
+        __builtin_amdgcn_s_barrier();                                                                          \
+        _Pragma("unroll") for (int i = 0; i < MT; i++) aq[i] = *(const i32x4 *)(Pb + (ao_[i] ^ 64));           \
+        _Pragma("unroll") for (int j = 0; j < NT; j++) bq[j] = *(const i32x4 *)(Bb + j * 16 * 128 + ch1);      \
+        if constexpr (BPW == 2) RCV_HALO_B(sl + S2_, T2_, st2, 1);                                             \
+        if constexpr ((TAP) < HALO_PPW) {                                                                      \
+            RCV_HALO_PATCH(sl + 1, TAP);                                                                       \
+            if constexpr (BPW == 2) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");                \
+            else asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");                                   \
+        } else {                                                                                               \
+            if constexpr (BPW == 2) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");                \
+            else asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");                                   \
+        }                                                                                                      \
+        __builtin_amdgcn_s_barrier();                                                                          \
+        __builtin_amdgcn_s_setprio(1);                                                                         \
+        _Pragma("unroll") for (int j = 0; j < NT; j++) {                                                       \
+            const i32x8 b8_ = {bq[j][0], bq[j][1], bq[j][2], bq[j][3], 0, 0, 0, 0};                             \
+            _Pragma("unroll") for (int i = 0; i < MT; i++)                                                     \
+                acc[i][j] = q6_mfma(__builtin_shufflevector(aq[i], aq[i], 0, 1, 2, 3, -1, -1, -1, -1), b8_, acc[i][j], aq[i][3], bq[j][3]); \
+        }                                                                                                      \
+        __builtin_amdgcn_s_setprio(0);                                                                         \
+        __builtin_amdgcn_s_barrier();                                                                          \
+        stage = stage + 1 == 3 ? 0 : stage + 1;                                                                \
+    }
 // BN = 64, split precision: one load phase, 24 MFMAs
 #define RCV_HALO_STEP2_X3(TAP)                                                                                 \
     {                                                                                                          \
@@ -1438,7 +1579,14 @@ __global__ __launch_bounds__(512) void k_conv_halo(const HaloParams p)
 #ifndef RCV_X3_HALO_TWO_PHASE
 #define RCV_X3_HALO_TWO_PHASE 0  // (r03 A-B on one box: 83.9 vs 83.8 ms per 36-frame forward -- the barrier count is not what the kernel waits for)
 #endif
-    if constexpr (BPW == 2 && kX3 && (!RCV_X3_HALO_TWO_PHASE || MT == 5)) {  // (the 320-row tile would spill in the two-phase form)
+    if constexpr (Q6) {
+        static_assert(!Q6 || BPW == 2, "the fp6 cross-term form exists for the 128-channel tile (of the split engine: q6_mfma)");
+        for (int sl = 0; sl < nsl; sl++) {
+            RCV_HALO_STEP_X3Q(0); RCV_HALO_STEP_X3Q(1); RCV_HALO_STEP_X3Q(2);
+            RCV_HALO_STEP_X3Q(3); RCV_HALO_STEP_X3Q(4); RCV_HALO_STEP_X3Q(5);
+            RCV_HALO_STEP_X3Q(6); RCV_HALO_STEP_X3Q(7); RCV_HALO_STEP_X3Q(8);
+        }
+    } else if constexpr (BPW == 2 && kX3 && (!RCV_X3_HALO_TWO_PHASE || MT == 5)) {  // (the 320-row tile would spill in the two-phase form)
         for (int sl = 0; sl < nsl; sl++) {
 #ifdef RCV_HALO_STAMPS
             stamp_on = stamp_blk && sl == 2;
@@ -1475,6 +1623,7 @@ __global__ __launch_bounds__(512) void k_conv_halo(const HaloParams p)
 #undef RCV_HALO_STEP
 #undef RCV_HALO_STEP2
 #undef RCV_HALO_STEP_X3
+#undef RCV_HALO_STEP_X3Q
 #undef RCV_HALO_STEP2_X3
 #undef RCV_HALO_B
 #undef RCV_HALO_PATCH
@@ -1855,6 +2004,7 @@ struct BlockParams {
     long long w3_gs, dst3_gs;
     int b3_gs;
     unsigned *range;  // sticky range-flag word (ConvParams::range)
+    int q6_dst3;      // k_chain2_x3: dst3 feeds a q6 op only (engine option 11) -- write q6 rows instead of [hi | lo] rows
 };
 constexpr int BLK_BM = 128;
 constexpr int BLK_RING = 3, BLK_SLOT = 128 * 128;  // expand-weight ring: 16 KB slots (128 out channels x 64 K)
@@ -3665,7 +3815,27 @@ __global__ __launch_bounds__(512) void k_chain2_x3(const BlockParams p)
         x3_split8(v, oh, ol);
         T *op = dst3 + mrow * (2 * CMID) + t * 64 + kq * 8;
         *(uint4 *)op = oh;
-        *(uint4 *)(op + 32) = ol;
+        if (p.q6_dst3) {
+            // q6 row (k_q6_pack's result, written here): the lanes kq, kq ^ 1 of a pixel hold channels 0 .. 7 and 8 .. 15 of a 16-channel
+            // block.  v_permlane16_swap(oh, ol) leaves, in the even rows of lanes, (hi of the pair's first lane, hi of its second) and in
+            // the odd rows (lo of the first, lo of the second): every lane holds one whole block -- even kq the hi block, odd kq the lo
+            // block of channels (kq >> 1) * 16 .. + 15 -- converts it and stores chunk 4 + (kq >> 1) + 2 * (kq & 1).
+            uint4 b0, b1;
+#if defined(RCV_FCN_X3)
+#define RCV_SWAP16(c)                                                                          \
+    {                                                                                          \
+        const auto r_ = __builtin_amdgcn_permlane16_swap(oh.c, ol.c, false, false);            \
+        b0.c = r_[0];                                                                          \
+        b1.c = r_[1];                                                                          \
+    }
+            RCV_SWAP16(x) RCV_SWAP16(y) RCV_SWAP16(z) RCV_SWAP16(w)
+#undef RCV_SWAP16
+#else
+            b0 = oh; b1 = ol;
+#endif
+            *(i32x4 *)(op + 32 + ((kq >> 1) + 2 * (kq & 1) - kq) * 8) = q6_block(b0, b1, 0);
+        } else
+            *(uint4 *)(op + 32) = ol;
     }
     if constexpr (RCV_C2_DIAG == 0) rng_flush(p.range, rmax);  // (the diagnostic builds compute garbage on purpose)
 }
@@ -4232,6 +4402,7 @@ using namespace rcv;
 // ---------------------------------------------------------------------------------------------
 struct rcv_fcn {
     std::vector<rcv_op> ops;
+    std::vector<char> q6_ok;  // per op: its source tensor has no other reader before it is overwritten (k_q6_pack may rewrite it in place)
     std::vector<int64_t> slot_elems;
     int groups = 1;
     int dtype = RCV_BF16;
@@ -4251,6 +4422,7 @@ struct rcv_fcn {
     bool radial_f16 = false;  // the radial plane leaves the head as float16 (BASELINE.json stress configuration)
     bool use_lat = true;      // latency kernel (k_conv_lat) for launches with few tiles (small batches)
     int use_chain2 = 1;       // split engine: 1 = k_chain2_x3 (r04), 0 = k_chain_x3, 2 = k_chain3_x3 for the 256-wide block
+    int use_q6 = 1;           // split engine: fp6 cross terms (k_conv_halo<.., true>) for the ops whose weights come with a q6 copy (rcv_op::wq_off)
     // range guard of the half-precision engines: one sticky flag word on the device (kernels OR bits into it), mirrored into
     // pinned host memory by a 4-byte copy at the end of every forward
     unsigned *range_dev = nullptr;
@@ -4331,6 +4503,7 @@ int launch_conv_halo(const ConvParams &p, int B, int groups, int mode, hipStream
     HaloParams q;
     memset(&q, 0, sizeof(q));
     const int bn = p.Cout % 128 == 0 ? 128 : 64;
+    if (p.q6 && (bn != 128 || p.src1 || !kX3)) return RCV_E_UNSUPPORTED;
     if (!halo_tile(p.Hout, p.Wout, mode, bn, (long long)B * groups * (p.Cout / bn), q.th, q.tw)) return RCV_E_UNSUPPORTED;
     q.src0 = p.src0; q.src1 = p.src1; q.w = p.w; q.dst = p.dst; q.bias = p.bias;
     q.src0_gs = p.src0_gs; q.src1_gs = p.src1_gs; q.dst_gs = p.dst_gs; q.w_gs = p.w_gs; q.bias_gs = p.bias_gs;
@@ -4338,6 +4511,12 @@ int launch_conv_halo(const ConvParams &p, int B, int groups, int mode, hipStream
     q.tiles_y = (q.H + q.th - 1) / q.th; q.tiles_x = (q.W + q.tw - 1) / q.tw;
     q.range = p.range;
     dim3 grid(p.Cout / bn, (unsigned)(B * q.tiles_y * q.tiles_x), groups);
+    if (p.q6) {  // fp6 cross terms (option 11): source and weights in the q6 row layout
+        if (q.th * q.tw > 256) hipLaunchKernelGGL((k_conv_halo<128, 5, true>), grid, dim3(512), halo_lds(128), st, q);
+        else hipLaunchKernelGGL((k_conv_halo<128, 4, true>), grid, dim3(512), halo_lds(128), st, q);
+        RCV_LAUNCH_CHECK();
+        return RCV_OK;
+    }
     if (q.th * q.tw > 256) {
         if (bn == 128) hipLaunchKernelGGL((k_conv_halo<128, 5>), grid, dim3(512), halo_lds(128), st, q);
         else hipLaunchKernelGGL((k_conv_halo<64, 6>), grid, dim3(512), halo_lds(64), st, q);
@@ -4384,9 +4563,17 @@ int launch_conv(const ConvParams &p, int groups, hipStream_t st, bool set_attr, 
     return small ? launch_conv_variant<T, 64, 32>(p, groups, st, set_attr) : launch_conv_variant<T, 128, 32>(p, groups, st, set_attr);
 }
 
+// fp6 cross terms (engine option 11) apply to op i: it comes with a q6 copy of its weights and its source feeds nothing else
+bool q6_active(const rcv_fcn *h, size_t i)
+{
+    const rcv_op &op = h->ops[i];
+    return kX3 && h->dtype == RCV_F16X3 && h->use_q6 && op.kind == RCV_OP_CONV && op.wq_off > 0 && op.src1 < 0 && op.res < 0 &&
+           op.cout % 128 == 0 && op.c0 % 32 == 0 && h->q6_ok[i];
+}
+
 template <typename T>
 int run_op(rcv_fcn *h, const rcv_op &op, const float *x, int B, float *seg, float *radial, char *ws,
-           const std::vector<size_t> &off, hipStream_t st)
+           const std::vector<size_t> &off, hipStream_t st, bool src_is_q6 = false)
 {
     const int G = h->groups;
     constexpr int ES = is_x3<T>() ? 2 : 1;  // elements of T per logical element (split storage: hi and lo halves)
@@ -4460,6 +4647,20 @@ int run_op(rcv_fcn *h, const rcv_op &op, const float *x, int B, float *seg, floa
         p.w_gs = (long long)op.cout * p.K;
         p.bias_gs = op.cout * ES;  // (split: [bias | scale] per group)
         p.range = h->range_dev;
+        if constexpr (is_x3<T>()) {
+            // fp6 cross terms (option 11) for an op that comes with a q6 copy of its weights: its source tensor is rewritten in place
+            // into the q6 row layout (nothing else reads it: q6_ok), whichever kernel then runs the op -- a frame's maps do not
+            // depend on the batch it travels in
+            if (q6_active(h, &op - h->ops.data())) {
+                if (!src_is_q6) {  // (the fused producer k_chain2_x3 writes q6 rows itself)
+                    const long long n_rows = (long long)G * B * op.hin * op.win * (op.c0 / 32);
+                    hipLaunchKernelGGL(k_q6_pack, dim3((unsigned)std::min<long long>((n_rows + 255) / 256, 256 * 8)), dim3(256), 0, st, (H16 *)p.src0, n_rows);
+                    RCV_LAUNCH_CHECK();
+                }
+                p.w = (const T *)h->weights + op.wq_off;
+                p.q6 = 1;
+            }
+        }
         // the LDS-DMA kernels address a tensor through a buffer descriptor with 32-bit byte offsets: only below 2 GiB per group
         auto fits32 = [&](int s) { return s < 0 || (long long)h->slot_elems[s] * B * (long long)sizeof(T) * ES < 0x7fffffffLL; };
         const bool dma_ok = h->use_dma && fits32(op.src0) && fits32(op.src1) && fits32(op.res) && fits32(op.dst);
@@ -4472,7 +4673,8 @@ int run_op(rcv_fcn *h, const rcv_op &op, const float *x, int B, float *seg, floa
                 (long long)B * ((op.hout + th - 1) / th) * ((op.wout + tw - 1) / tw) * (p.Cout / hbn) * G >= 192)
                 return launch_conv_halo(p, B, G, h->use_halo, st);
         }
-        return launch_conv<T>(p, G, st, !h->attrs_set, dma_ok, h->use_lat);
+        // (q6 ops outside the halo kernel's reach: the plain kernel, same arithmetic -- the DMA / latency kernels have no q6 form)
+        return launch_conv<T>(p, G, st, !h->attrs_set, dma_ok && !p.q6, h->use_lat && !p.q6);
     }
     default: return RCV_E_UNSUPPORTED;
     }
@@ -4510,6 +4712,8 @@ int register_kernel_attributes()
     RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_conv_halo<128, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, halo_lds(128)));
     RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_conv_halo<64, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, halo_lds(64)));
     RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_conv_halo<64, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, halo_lds(64)));
+    RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_conv_halo<128, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, halo_lds(128)));
+    RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_conv_halo<128, 5, true>, hipFuncAttributeMaxDynamicSharedMemorySize, halo_lds(128)));
     RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_stem_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, STEM_LDS));
     RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_tail, hipFuncAttributeMaxDynamicSharedMemorySize, TAIL_LDS));
     RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_tail_x3, hipFuncAttributeMaxDynamicSharedMemorySize, TX_LDS));
@@ -4547,6 +4751,7 @@ int forward_impl(rcv_fcn *h, const float *x, int B, float *seg, float *radial, c
         h->events.resize(2 * h->ops.size());
         for (auto &e : h->events) RCV_HIP_CHECK(hipEventCreate(&e));
     }
+    std::vector<char> src_q6(h->ops.size() + 3, 0);  // per op: its source was written as q6 rows by its (fused) producer
     for (size_t i = 0; i < h->ops.size(); i++) {
         if constexpr (sizeof(T) == 2) {
             // 3x3 (-> 256 channels, ReLU) followed by the 1x1 expand to 1024 channels with residual and ReLU: the second
@@ -4636,6 +4841,11 @@ int forward_impl(rcv_fcn *h, const float *x, int B, float *seg, float *radial, c
                     q.b2_gs = 2 * a.cout; q.b3_gs = 2 * b.cout;
                     q.M = (int)M;
                     q.range = h->range_dev;
+                    // the reduce's output feeds the next block's 3x3: where that runs with fp6 cross terms, k_chain2_x3 writes q6 rows
+                    if (h->use_chain2 == 1 && i + 2 < h->ops.size() && h->ops[i + 2].src0 == b.dst && q6_active(h, i + 2)) {
+                        q.q6_dst3 = 1;
+                        src_q6[i + 2] = 1;
+                    }
                     if (h->profiling) RCV_HIP_CHECK(hipEventRecord(h->events[2 * i], st));  // time booked on the expand
                     const dim3 grid((unsigned)((M + CH_BM - 1) / CH_BM), 1, h->groups);
                     if (h->use_chain2 == 2 && cmid == 256) {  // (option 10 = 2: four waves x 32 pixels, one wave per SIMD)
@@ -4693,7 +4903,7 @@ int forward_impl(rcv_fcn *h, const float *x, int B, float *seg, float *radial, c
             }
         }
         if (h->profiling) RCV_HIP_CHECK(hipEventRecord(h->events[2 * i], st));
-        int rc = run_op<T>(h, h->ops[i], x, B, seg, radial, ws, off, st);
+        int rc = run_op<T>(h, h->ops[i], x, B, seg, radial, ws, off, st, src_q6[i] != 0);
         if (rc != RCV_OK) return rc;
         if (h->profiling) RCV_HIP_CHECK(hipEventRecord(h->events[2 * i + 1], st));
     }
@@ -4725,6 +4935,14 @@ int RCV_TU_SUFFIX(fcn_debug_slot)(const void *src, float *out_dev, long long n, 
     RCV_LAUNCH_CHECK();
     return RCV_OK;
 }
+#if defined(RCV_FCN_X3)
+int fcn_q6_pack_x3(void *rows, long long n_rows, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_q6_pack, dim3((unsigned)std::min<long long>((n_rows + 255) / 256, 256 * 8)), dim3(256), 0, st, (H16 *)rows, n_rows);
+    RCV_LAUNCH_CHECK();
+    return RCV_OK;
+}
+#endif
 #if defined(RCV_HALO_STAMPS) && defined(RCV_FCN_X3)
 }  // namespace rcv
 extern "C" int rcv_debug_halo_stamps(unsigned *out32)
@@ -4748,6 +4966,7 @@ int fcn_debug_slot_f16(const void *src, float *out_dev, long long n, hipStream_t
 int fcn_forward_x3(rcv_fcn *h, const float *x, int B, float *seg, float *radial, char *ws, hipStream_t st);
 int fcn_register_x3();
 int fcn_debug_slot_x3(const void *src, float *out_dev, long long n, hipStream_t st);
+int fcn_q6_pack_x3(void *rows, long long n_rows, hipStream_t st);
 #endif
 }  // namespace rcv
 
@@ -4806,6 +5025,23 @@ int rcv_fcn_create(const rcv_op *ops, int n_ops, int n_slots, const int64_t *slo
         *h->range_host = 0u;
     }
     h->ops.assign(ops, ops + n_ops);
+    // q6 (option 11): k_q6_pack rewrites an op's source slot in place, which is only sound while nothing else reads that slot
+    // between its producer and its next writer
+    h->q6_ok.assign(n_ops, 0);
+    for (int i = 0; i < n_ops; i++) {
+        const rcv_op &o = ops[i];
+        if (o.kind != RCV_OP_CONV || o.wq_off <= 0 || o.src0 < 0 || o.src1 >= 0) continue;
+        bool ok = true;
+        for (int j = i - 1; j >= 0 && ok; j--) {  // back to the producer: no reader in between
+            if (ops[j].dst == o.src0) break;
+            ok = ops[j].src0 != o.src0 && ops[j].src1 != o.src0 && ops[j].res != o.src0;
+        }
+        for (int j = i + 1; j < n_ops && ok; j++) {  // forward to the next writer: no reader either
+            if (ops[j].src0 == o.src0 || ops[j].src1 == o.src0 || ops[j].res == o.src0) ok = false;
+            if (ops[j].dst == o.src0) break;
+        }
+        h->q6_ok[i] = ok ? 1 : 0;
+    }
     h->slot_elems.assign(slot_elems, slot_elems + n_slots);
     h->groups = groups;
     h->dtype = dtype;
@@ -4888,6 +5124,12 @@ int rcv_fcn_debug_slot(rcv_fcn *h, const void *ws, int B, int g, int slot, float
     return RCV_OK;
 }
 
+int rcv_fcn_debug_q6_pack(void *rows_dev, long long n_rows, void *stream)
+{
+    if (!rows_dev || n_rows <= 0) return RCV_E_INVALID;
+    return rcv::fcn_q6_pack_x3(rows_dev, n_rows, (hipStream_t)stream);
+}
+
 #ifdef RCV_BLK_STAMPS
 extern "C" int rcv_debug_blk_stamps(unsigned *out160)
 {
@@ -4909,6 +5151,7 @@ int rcv_fcn_set_option(rcv_fcn *h, int key, int value)
     if (key == 8) { h->radial_f16 = value != 0; return RCV_OK; }
     if (key == 9) { h->use_lat = value != 0; return RCV_OK; }
     if (key == 10) { h->use_chain2 = value; return RCV_OK; }
+    if (key == 11) { h->use_q6 = value; return RCV_OK; }
     return RCV_E_INVALID;
 }
 

@@ -37,7 +37,7 @@ def test_struct_layouts_match_header():
     from rcvpose_amd import _hip
 
     assert ctypes.sizeof(_hip.AccResult) == 96      # 7 doubles + 10 int32
-    assert ctypes.sizeof(_hip.Op) == 16 * 4 + 2 * 8
+    assert ctypes.sizeof(_hip.Op) == 16 * 4 + 3 * 8
     assert ctypes.sizeof(_hip.IcpResult) == 16 * 8 + 2 * 8 + 4 * 4  # rcv_icp_result
     assert _hip.AccResult.status.offset == 92
 
