@@ -327,7 +327,10 @@ def pack_split_q6(w):
     return rows.reshape(-1).view(torch.float16)
 
 
-def q6_wanted(spec, op):
+Q6_DEFAULT = r"block[234]\.\d+\.conv2"
+
+
+def q6_wanted(spec, op, pattern=Q6_DEFAULT):
     """The ops that get a q6 copy of their weights (fp6 cross terms, engine option 11): the 3x3 / stride-1 convolutions of the
     bottleneck blocks of layers 2-4 (blockN.M.conv2 with >= 128 channels: 44 launches, 20 ms of a 110 ms forward at the bench
     batch).  Their rounding noise enters the residual trunk through the following 1x1 and is diluted there: measured map error with
@@ -336,10 +339,10 @@ def q6_wanted(spec, op):
     import re
 
     return (op["kind"] == _hip.OP_CONV and op["ksize"] == 3 and op["stride"] == 1 and op["src1"] < 0 and op["c0"] % 32 == 0 and
-            op["cout"] % 128 == 0 and re.fullmatch(r"block[234]\.\d+\.conv2", spec["conv"]) is not None)
+            op["cout"] % 128 == 0 and re.fullmatch(pattern, spec["conv"]) is not None)
 
 
-def pack_weights(state_dicts, builder, ops, dtype, q6=True):
+def pack_weights(state_dicts, builder, ops, dtype, q6=False):
     """-> (weights tensor [engine dtype], bias tensor fp32, ops with w_off / b_off / wq_off filled)."""
     import torch
 
@@ -353,7 +356,7 @@ def pack_weights(state_dicts, builder, ops, dtype, q6=True):
             op["w_off"], op["b_off"] = 0, 0
             continue
         ws, bs, wq = [], [], []
-        want_q6 = q6 and dtype == _hip.RCV_F16X3 and q6_wanted(spec, op)
+        want_q6 = bool(q6) and dtype == _hip.RCV_F16X3 and q6_wanted(spec, op, Q6_DEFAULT if q6 is True else q6)
         for sd in sds:
             w, b = fold_conv_bn(sd, spec, op["cout"])
             wmax = float(w.abs().max()) if w.numel() else 0.0
@@ -407,9 +410,12 @@ class FcnEngine:
     instruction), "f16x3" (the FAST parity mode: half-precision hi / lo pairs, three MFMAs per product -- maps within 1e-4 of
     the reference like fp32), "bf16" (the throughput mode BASELINE.json names) or "fp16" (IEEE half: the same kernels and
     speed as bf16 with 11 instead of 8 significand bits).
+    q6 (f16x3 only; default off): True or a regex over convolution names -- those stride-1 3x3 convolutions run the cross terms of
+    the split product as one block-scaled fp6 matrix instruction (engine option 11, q6_wanted): -18 % on those launches, -3 % on
+    the forward, for 2-3x the map error (worst network of the bench 3.4e-5 -> 7.8e-5 of the 1e-4 tolerance: r05 measurement).
     """
 
-    def __init__(self, state_dicts, H, W, dtype="bf16", device="cuda", reuse_slots=True, arch="dense", q6=True):
+    def __init__(self, state_dicts, H, W, dtype="bf16", device="cuda", reuse_slots=True, arch="dense", q6=False):
         import torch
 
         self.lib = _hip.lib()

@@ -16,10 +16,11 @@ from . import _hip, fcn_engine
 
 class FramePipeline:
     def __init__(self, state_dicts, H=480, W=640, dtype="f16x3", frames_per_step=1, K=A.linemod_K, acc_unit=A.ACC_UNIT_MM,
-                 device="cuda", overlap=False, radial_f16=False, engine="auto"):
+                 device="cuda", overlap=False, radial_f16=False, engine="auto", q6=False):
         """acc_unit: voxel edge in mm (the reference hard-codes 5, AccumulatorSpace.py:374).  radial_f16: the FCN head
         writes the radial maps as float16 and the seam reads them as such (the stress configuration of BASELINE.json).
-        engine: 'auto' / 'full', the arg-max engine of rcv_accumulate_3d (identical results)."""
+        engine: 'auto' / 'full', the arg-max engine of rcv_accumulate_3d (identical results).  q6: FcnEngine's q6 (fp6 cross
+        terms in the stride-1 3x3 convolutions of layers 2-4; default off)."""
         import torch
 
         assert len(state_dicts) >= 1
@@ -33,7 +34,7 @@ class FramePipeline:
         self.vote_engine = _hip.VOTE_ENGINES[engine]
         self.seg_threshold = float(A.SEG_THRESHOLD)  # reference :603 (LINEMOD); the LM-O driver uses >= 0.5 (:836)
         self.device = device
-        self.engine = fcn_engine.FcnEngine(state_dicts, H, W, dtype=dtype, device=device)
+        self.engine = fcn_engine.FcnEngine(state_dicts, H, W, dtype=dtype, device=device, q6=q6)
         self.engine.workspace(self.B)
         if self.radial_f16:
             self.engine.set_option(8, 1)

@@ -17,7 +17,7 @@ from oracle import q6_ref
 pytestmark = pytest.mark.gpu
 
 REL = 1e-4         # north star
-REL_GUARD = 6e-5   # regression guard for the q6 engine (measured 1-3e-5; the three-MFMA engine: 0.4-0.8e-5)
+REL_GUARD = 9e-5   # regression guard for the q6 engine (measured 2-8e-5 by network; the three-MFMA engine: 0.4-3.4e-5)
 
 
 @pytest.fixture(scope="module")
@@ -143,7 +143,7 @@ def test_q6_engine_stages_and_output_vs_golden(shapes, golden_dir):
 
     g = np.load(os.path.join(golden_dir, "fcn1_64x96.npz"))
     x = torch.from_numpy(fcn_weights.make_input(int(g["input_seed"]), (1, 3, 64, 96))).cuda()
-    eng = FcnEngine([_sd(shapes)], 64, 96, dtype="f16x3", reuse_slots=False)
+    eng = FcnEngine([_sd(shapes)], 64, 96, dtype="f16x3", reuse_slots=False, q6=True)
     assert sum(1 for o in eng.ops if o["wq_off"]) == 44
     for key in (3, 4):
         eng.set_option(key, 0)
@@ -175,7 +175,7 @@ def test_q6_engine_full_size_whole_maps_and_batch_independence(shapes, golden_di
     g = np.load(os.path.join(golden_dir, "fcn2_480x640_samples.npz"))
     x1 = torch.from_numpy(fcn_weights.make_input(int(g["input_seed"]), (1, 3, 480, 640))).cuda()
     x = torch.cat([x1, torch.from_numpy(fcn_weights.make_input(17, (7, 3, 480, 640))).cuda()])
-    eng = FcnEngine(sds, 480, 640, dtype="f16x3")
+    eng = FcnEngine(sds, 480, 640, dtype="f16x3", q6=True)
     seg, rad = [t.clone() for t in eng.forward(x)]
     pix = g["pix"]
     err_r = np.abs(rad[0, 0].cpu().numpy().reshape(-1)[pix] - g["radial"]).max() / float(g["radial_absmax"])

@@ -35,7 +35,7 @@ def test_x3_stages_and_output_vs_golden(shapes, golden_dir):
 
     g = np.load(os.path.join(golden_dir, "fcn1_64x96.npz"))
     x = torch.from_numpy(fcn_weights.make_input(int(g["input_seed"]), (1, 3, 64, 96))).cuda()
-    eng = FcnEngine([_sd(shapes)], 64, 96, dtype="f16x3", reuse_slots=False, q6=False)
+    eng = FcnEngine([_sd(shapes)], 64, 96, dtype="f16x3", reuse_slots=False)
     for key in (3, 4):  # the fused kernels never write the tensors between their layers: every stage through its own kernel
         eng.set_option(key, 0)
     seg, rad = eng.forward(x)
@@ -61,7 +61,7 @@ def test_x3_full_size_vs_golden_samples(shapes, golden_dir):
 
     g = np.load(os.path.join(golden_dir, "fcn2_480x640_samples.npz"))
     x = torch.from_numpy(fcn_weights.make_input(int(g["input_seed"]), (1, 3, 480, 640))).cuda()
-    seg, rad = FcnEngine([_sd(shapes), _sd(shapes, 1), _sd(shapes, 2)], 480, 640, dtype="f16x3", q6=False).forward(x)
+    seg, rad = FcnEngine([_sd(shapes), _sd(shapes, 1), _sd(shapes, 2)], 480, 640, dtype="f16x3").forward(x)
     pix = g["pix"]
     err_r = np.abs(rad[0].cpu().numpy().reshape(-1)[pix] - g["radial"]).max() / float(g["radial_absmax"])
     err_s = np.abs(seg[0].cpu().numpy().reshape(-1)[pix] - g["seg"]).max() / float(g["seg_absmax"])
@@ -75,7 +75,7 @@ def test_x3_against_fp32_engine_whole_maps(shapes):
 
     sds = [_sd(shapes, s) for s in range(3)]
     x = torch.from_numpy(fcn_weights.make_input(17, (4, 3, 480, 640))).cuda()
-    seg_a, rad_a = FcnEngine(sds, 480, 640, dtype="f16x3", q6=False).forward(x)
+    seg_a, rad_a = FcnEngine(sds, 480, 640, dtype="f16x3").forward(x)
     seg_b, rad_b = FcnEngine(sds, 480, 640, dtype="fp32").forward(x)
     for g in range(3):
         er = float((rad_a[g] - rad_b[g]).abs().max() / rad_b[g].abs().max())
@@ -93,7 +93,7 @@ def test_x3_kernel_variants_identical(shapes):
     # 7 frames: the smallest batch at which every fused kernel is active at 480x640 -- k_chain_x3<256> needs 192 tiles of 128
     # pixels (7 x 1200 px x 3 networks = 197, the last tile of each network partial: 80 of 128 rows)
     for (H, W, B) in ((480, 640, 7), (480, 640, 1), (96, 160, 3)):
-        eng = FcnEngine(sds, H, W, dtype="f16x3", q6=False)
+        eng = FcnEngine(sds, H, W, dtype="f16x3")
         x = torch.from_numpy(fcn_weights.make_input(31, (B, 3, H, W))).cuda()
         seg_a, rad_a = [t.clone() for t in eng.forward(x)]
         for form in (2, 0):  # the chain kernel as k_chain3_x3 (one wave per SIMD, 256-wide block) and in its round-3 form (k_chain_x3)
@@ -115,7 +115,7 @@ def test_x3_mfma_stem_against_direct_stem(shapes):
     x = torch.from_numpy(fcn_weights.make_input(5, (2, 3, 64, 96))).cuda()
     outs = []
     for mfma in (1, 0):
-        eng = FcnEngine([_sd(shapes), _sd(shapes, 1)], 64, 96, dtype="f16x3", reuse_slots=False, q6=False)
+        eng = FcnEngine([_sd(shapes), _sd(shapes, 1)], 64, 96, dtype="f16x3", reuse_slots=False)
         eng.set_option(2, mfma)
         seg, rad = eng.forward(x)
         outs.append((eng.debug_stage(2, 1, "bn1").cpu().numpy(), rad.cpu().numpy()))
@@ -130,9 +130,9 @@ def test_x3_groups_and_batch(shapes):
 
     sds = [_sd(shapes, s) for s in range(3)]
     x = torch.from_numpy(fcn_weights.make_input(23, (3, 3, 64, 96))).cuda()
-    seg3, rad3 = FcnEngine(sds, 64, 96, dtype="f16x3", q6=False).forward(x)
+    seg3, rad3 = FcnEngine(sds, 64, 96, dtype="f16x3").forward(x)
     for g in range(3):
-        seg1, rad1 = FcnEngine([sds[g]], 64, 96, dtype="f16x3", q6=False).forward(x[1:2])
+        seg1, rad1 = FcnEngine([sds[g]], 64, 96, dtype="f16x3").forward(x[1:2])
         assert torch.equal(rad1[0, 0], rad3[g, 1]) and torch.equal(seg1[0, 0], seg3[g, 1])
 
 
@@ -143,7 +143,7 @@ def test_half_precision_range_is_guarded(shapes):
 
     sd = _sd(shapes)
     x = torch.from_numpy(fcn_weights.make_input(3, (1, 3, 64, 96))).cuda() * 3.0e5   # activations far beyond 65504
-    seg, rad = FcnEngine([sd], 64, 96, dtype="f16x3", q6=False).forward(x)
+    seg, rad = FcnEngine([sd], 64, 96, dtype="f16x3").forward(x)
     assert bool(torch.isfinite(seg).all()) and bool(torch.isfinite(rad).all())
     # (a ReLU turns NaN into 0, so an overflow inside the network does not always reach the maps; what does reach them is refused)
     bad = dict(sd)
@@ -168,7 +168,7 @@ def test_range_guard_reports_clamped_activations(shapes):
 
     sd = _sd(shapes)
     x = torch.from_numpy(fcn_weights.make_input(3, (1, 3, 64, 96))).cuda()
-    eng = FcnEngine([sd], 64, 96, dtype="f16x3", q6=False)
+    eng = FcnEngine([sd], 64, 96, dtype="f16x3")
     seg0, rad0 = eng.forward(x)
     assert eng.range_status(clear=False) == 0                       # an ordinary image: nothing left the range
     eng.forward(x * 3.0e5)                                          # activations far beyond 65504
@@ -215,7 +215,7 @@ def test_x3_accuracy_with_large_activations(shapes):
 
     sd = _sd(shapes)
     x = torch.from_numpy(fcn_weights.make_input(3, (1, 3, 64, 96))).cuda()
-    eng = FcnEngine([sd], 64, 96, dtype="f16x3", q6=False)
+    eng = FcnEngine([sd], 64, 96, dtype="f16x3")
     s, last_ok = 1.0, None
     while s < 1e9:
         eng.forward(x * s)

@@ -67,7 +67,7 @@ def test_q6_weight_rows_and_program_flags(golden_dir):
     sd = {k: torch.from_numpy(v) for k, v in fcn_weights.make_state_dict_numpy(shapes, seed=0).items()}
     b = fcn_engine.build_program(64, 96)
     ops, _ = fcn_engine.assign_slots(b)
-    w, bias, ops = fcn_engine.pack_weights([sd], b, ops, _hip.RCV_F16X3)
+    w, bias, ops = fcn_engine.pack_weights([sd], b, ops, _hip.RCV_F16X3, q6=True)
     flagged = [(o, sp) for o, sp in zip(ops, b.wspecs) if o.get("wq_off", 0)]
     assert len(flagged) == 44 and all(sp["conv"][:7] in ("block2.", "block3.", "block4.") and sp["conv"].endswith(".conv2") for _, sp in flagged)
     w_off = fcn_engine.pack_weights([sd], b, [dict(o) for o in ops], _hip.RCV_F16X3, q6=False)[0]
