@@ -30,6 +30,7 @@ def main():
     ap.add_argument("--no-dma", action="store_true", help="disable the LDS-DMA conv kernel")
     ap.add_argument("--off", type=int, action="append", default=[], help="engine option key to switch off (repeatable)")
     ap.add_argument("--opt", action="append", default=[], help="engine option as key=value (repeatable)")
+    ap.add_argument("--q6", action="store_true", help="f16x3: build the engine with fp6 cross terms in the stride-1 3x3 convolutions of layers 2-4 (A-B: --opt 11=0)")
     ap.add_argument("--graph", action="store_true", help="also time the forward replayed as one HIP graph")
     ap.add_argument("--all", action="store_true", help="print every op, not the per-shape summary")
     ap.add_argument("--ignore-range", action="store_true", help="clear the engine's range flag after every forward (diagnostic builds that compute garbage on purpose)")
@@ -37,7 +38,7 @@ def main():
     shapes = json.load(open(os.path.join(ROOT, "tests", "golden", "fcn_state_dict_keys.json")))
     sds = [{k: torch.from_numpy(v) for k, v in synthetic_weights.make_state_dict_numpy(shapes, seed=s).items()}
            for s in range(args.groups)]
-    eng = FcnEngine(sds, 480, 640, dtype=args.dtype)
+    eng = FcnEngine(sds, 480, 640, dtype=args.dtype, q6=args.q6)
     if args.no_dma:
         eng.set_option(1, 0)
     for key in args.off:
