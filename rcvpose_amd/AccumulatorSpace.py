@@ -534,7 +534,7 @@ def estimate_6d_pose_lm(opts, return_details=False):
             kpts_model = keypoints[1:4, :] * 1000
             import threading
 
-            n_eval = max(1, int(getattr(opts, 'eval_threads', min(16, os.cpu_count() or 8))))
+            n_eval = max(1, int(getattr(opts, 'eval_threads', 16)))  # (main.py's default)
             tls = threading.local()
 
             def worker_stream():

@@ -40,6 +40,14 @@ constexpr int BB_CAP = 1 << 19;         // candidate blocks per level of the bra
 constexpr int BB_HALF = BB_CAP / 2;     // a level's list is two regions: [0, BB_HALF) x-sibling pairs, [BB_HALF, BB_CAP) single blocks
 constexpr int BB_ROOT = 64;            // edge (voxels) of the root blocks; 6 halvings down to single voxels
 constexpr int BB_LEVELS = 6;
+// cost model of the two arg-max engines (measured on the bench cloud, N = 15.5k, radii 50 ... 94 voxels: tools/vote_sweep.py,
+// profiles/r04_rasteriser_pmc.json): what the hand-over rules of k_bb_gate (r05) and d_bb_restart (r04) are derived from
+constexpr double BB_PS_PER_BLOCK_POINT = 1.1, RAST_PS_PER_POINT_COLUMN = 4.8, BB_BLOCKS_TIMES_F2 = 500.0, RAST_DISC_FILL = 0.6;
+constexpr double BB_FLAT_F_RMAX = 7.8;  // sqrt(BB_BLOCKS_TIMES_F2 * BB_PS_PER_BLOCK_POINT / (RAST_PS_PER_POINT_COLUMN * pi * RAST_DISC_FILL))
+static_assert(BB_FLAT_F_RMAX * BB_FLAT_F_RMAX * RAST_PS_PER_POINT_COLUMN * 3.14159265 * RAST_DISC_FILL > 0.97 * BB_BLOCKS_TIMES_F2 * BB_PS_PER_BLOCK_POINT &&
+              BB_FLAT_F_RMAX * BB_FLAT_F_RMAX * RAST_PS_PER_POINT_COLUMN * 3.14159265 * RAST_DISC_FILL < 1.03 * BB_BLOCKS_TIMES_F2 * BB_PS_PER_BLOCK_POINT,
+              "BB_FLAT_F_RMAX follows from the four measured constants");
+constexpr double BB_HANDOVER_R2 = 2.5;  // d_bb_restart gives up above BB_HANDOVER_R2 * r_max^2 four-voxel candidates (derivation there)
 // Probe width and hill-climb length only steer how close the lower bound gets to the peak before the wide levels run
 // (any exact count is a valid bound).  Measured on the bench workload (72 frames x 3 keypoints, seam + voting, ms):
 // beam/rounds 8/8 26.1, 4/8 27.3, 2/8 83.6, 8/4 32.1, 8/12 25.7, 8/16 26.3, 4/12 24.8, 4/16 25.3, 3/16 25.4, 4/24 26.5.
@@ -90,12 +98,12 @@ struct alignas(16) AccHeader {
     // RGB-only variant (rcv_accumulate_3d_no_depth): the points in P are final voxel coordinates (mean = shift = 0 above)
     // and the result is formed the reference's other way (AccumulatorSpace.py:468-477)
     int32_t variant;         // 0: Accumulator_3D, 1: Accumulator_3D_no_depth
-    int32_t pad_;
+    int32_t gate_best;       // diagnostics (tools/vote_sweep.py): bb_best when k_bb_gate(2) took the flat-landscape decision
     double nd_mean[3];       // x/y/z_mean_mm of :440-442
     unsigned long long climb_center[2];  // 1 + flat index of the voxel the hill-climb round (parity) was centred on; 0: none
     unsigned long long seed;             // 1 + flat index of the least-squares estimate of the keypoint's voxel (k_bb_seed); 0: none
     int32_t probe_skip;                  // the round of exact counts around the seed already found a strong peak: no greedy probe
-    int32_t bb_handover;                 // the search gave up on cost (d_bb_restart): the rasteriser decides (diagnostics)
+    int32_t bb_handover;                 // the search gave up on cost: 1 = d_bb_restart (survivor count), 2 = k_bb_gate(2) (flat landscape predicted); the rasteriser decides
     // best key (votes << 32 | flat index) as of the END of hill-climb round r, in slot r & 1: round r + 1 centres on it.  Round r
     // only writes slot r & 1 and only reads the other one, so every workgroup of a round sees the same, frozen centre (r03;
     // before, each workgroup took the live bb_best_key at its own start and a late one could centre on a voxel found by its
@@ -590,7 +598,8 @@ __device__ __forceinline__ void d_setup(const PrepPartial *partials, const doubl
     __syncthreads();
     if (t != 0) return;
 
-    AccHeader H;
+    __shared__ AccHeader sH;  // (thread 0's working copy: in LDS -- as a local it lived in scratch memory, 416 bytes per thread until r05)
+    AccHeader &H = sH;
     memset(&H, 0, sizeof(H));
     H.n = n; H.m = m; H.unit = unit;
     if (n <= 0 || m <= 0) {
@@ -1487,6 +1496,7 @@ __device__ __forceinline__ void d_bb_seed(AccHeader *hdr, const double *Q, const
     __shared__ int s_have;      // an estimate exists
     __shared__ int s_hist[512]; // |residual| of the points against the current estimate, 1-voxel bins
     __shared__ double s_tau;
+    __shared__ double M[4][5], sol[4];  // thread 0's elimination: pivoting indexes rows at run time -- in LDS, not in scratch memory (176 bytes per thread until r05)
     const AccHeader H = *hdr;
     if (H.status != RCV_OK || !H.bb_enabled) return;
     if (threadIdx.x == 0) { hdr->seed = 0; s_have = 0; }
@@ -1562,7 +1572,6 @@ __device__ __forceinline__ void d_bb_seed(AccHeader *hdr, const double *Q, const
         __syncthreads();
         if (threadIdx.x == 0) {
             bool ok = !trim || (tot[14] >= 16.0 && tot[14] * 16.0 >= (double)n);
-            double M[4][5];
             {
                 int k = 0;
                 for (int u = 0; u < 4; u++)
@@ -1581,7 +1590,6 @@ __device__ __forceinline__ void d_bb_seed(AccHeader *hdr, const double *Q, const
                 }
             }
             if (ok) {
-                double sol[4];
                 for (int c = 3; c >= 0; c--) {
                     double v = M[c][4];
                     for (int u = c + 1; u < 4; u++) v -= M[c][u] * sol[u];
@@ -1617,7 +1625,7 @@ __device__ __forceinline__ void d_bb_climb(AccHeader *hdr, const double *Q, cons
     constexpr int W = BB_CLIMB_W, NV = W * W;
     __shared__ int red[4][NV];
     const AccHeader H = *hdr;
-    if (H.status != RCV_OK || !H.bb_enabled) return;
+    if (H.status != RCV_OK || !H.bb_enabled || H.bb_overflow) return;  // (handed over to the rasteriser: nothing left to bound)
     // the round's centre: round 0 looks around the least-squares estimate; round r > 0 around the best voxel as of the end of
     // round r - 1 (climb_key[(r - 1) & 1], which no workgroup of THIS round writes: k_bb_gate folds the probe's finds into slot
     // 0 before round 1)
@@ -1701,7 +1709,7 @@ __device__ __forceinline__ void d_bb_line(AccHeader *hdr, const double *Q, const
     constexpr int NV = 25;
     __shared__ int red[4][NV];
     const AccHeader H = *hdr;
-    if (H.status != RCV_OK || !H.bb_enabled || H.variant != 0) return;
+    if (H.status != RCV_OK || !H.bb_enabled || H.bb_overflow || H.variant != 0) return;
     // mode 0: through the least-squares seed, when its round found no strong peak; mode 1: through the restart voxel (k_bb_restart)
     if (mode == 0 ? (H.seed == 0 || H.probe_skip) : H.restart == 0) return;
     const int D = H.dim, n = H.n;
@@ -1715,12 +1723,10 @@ __device__ __forceinline__ void d_bb_line(AccHeader *hdr, const double *Q, const
     if (!(nrm >= 1.0)) return;
     u0 /= nrm; u1 /= nrm; u2 /= nrm;
     double vi[NV], vj[NV], vk[NV];
-    bool inside[NV];
 #pragma unroll
     for (int v = 0; v < NV; v++) {
         const double t = (double)((int)blockIdx.x * NV + v - 62);
         vi[v] = rint(s0 + t * u0); vj[v] = rint(s1 + t * u1); vk[v] = rint(s2 + t * u2);
-        inside[v] = vi[v] >= 0.0 && vj[v] >= 0.0 && vk[v] >= 0.0 && vi[v] < (double)D && vj[v] < (double)D && vk[v] < (double)D;
     }
     const double *Qx = Q, *Qy = Q + (size_t)cap, *Qz = Q + 2 * (size_t)cap;
     const double *Plo = P + 3 * (size_t)cap, *Phi = P + 4 * (size_t)cap;
@@ -1746,13 +1752,19 @@ __device__ __forceinline__ void d_bb_line(AccHeader *hdr, const double *Q, const
         if (lane_id() == 0) red[wave_id()][v] = c;
     }
     __syncthreads();
-    if (threadIdx.x < NV && inside[threadIdx.x]) {
+    if (threadIdx.x < NV) {
+        // (position v = threadIdx.x recomputed: a run-time subscript into vi / vj / vk / inside would put the four arrays into scratch
+        // memory -- 656 bytes per thread until r05)
         const int v = threadIdx.x;
-        const int c = red[0][v] + red[1][v] + red[2][v] + red[3][v];
-        const unsigned long long key = ((unsigned long long)c << 32) | (((unsigned long long)vi[v] * D + (unsigned long long)vj[v]) * D + (unsigned long long)vk[v]);
-        atomicMax(&hdr->bb_best, c);
-        atomicMax(&hdr->bb_best_key, key);
-        atomicMax(&hdr->climb_key[slot], key);
+        const double t = (double)((int)blockIdx.x * NV + v - 62);
+        const double wi = rint(s0 + t * u0), wj = rint(s1 + t * u1), wk = rint(s2 + t * u2);
+        if (wi >= 0.0 && wj >= 0.0 && wk >= 0.0 && wi < (double)D && wj < (double)D && wk < (double)D) {
+            const int c = red[0][v] + red[1][v] + red[2][v] + red[3][v];
+            const unsigned long long key = ((unsigned long long)c << 32) | (((unsigned long long)wi * D + (unsigned long long)wj) * D + (unsigned long long)wk);
+            atomicMax(&hdr->bb_best, c);
+            atomicMax(&hdr->bb_best_key, key);
+            atomicMax(&hdr->climb_key[slot], key);
+        }
     }
 }
 
@@ -1778,7 +1790,7 @@ __device__ __forceinline__ void d_bb_restart(AccHeader *hdr, const BBEntry *list
     // the whole grid: the search gives up
     // here (the fallback every search exit takes: k_vote decides; identical result by construction).  Both costs are
     // proportional to N; the grid edge does not enter (false positives on a background plane widen the grid, not the shells).
-    if (edge == 4 && (double)n > 2.5 * H.rmax * H.rmax) {
+    if (edge == 4 && (double)n > BB_HANDOVER_R2 * H.rmax * H.rmax) {
         if (threadIdx.x == 0) {
             hdr->bb_overflow = 1;
             hdr->bb_handover = 1;
@@ -2271,12 +2283,33 @@ __global__ __launch_bounds__(BB_SEED_THREADS) void k_bb_seed(int cap, SP<unsigne
 // After the round around the seed: a voxel that an eighth of all points vote for is the peak's neighbourhood for every purpose
 // of the search (its count is the lower bound the wide levels prune with) -- the greedy probe, which exists to find such a
 // voxel, is skipped.  Otherwise (no seed, outliers, several weak maxima) the probe runs as before.
+//
+// Flat-landscape decision (r05; mode 2, launched behind the second start of the lower bound -- d_bb_restart + line search + two climb
+// rounds on the 8-voxel candidates -- and before the wide level that scores their children, the first expensive one).  What the
+// fine levels cost is set by how sharply the peak stands out: with f = (best exact count) / N the search scores about 500 / f^2
+// blocks against all N points (sweep, 216 items on the bench cloud: f = 0.33 -> 4.6 k blocks, 0.16 -> 16 k, 0.086 -> 60 k; radial
+// noise of sigma_v voxels gives f ~ 0.43 / (sqrt(2 pi) sigma_v)), at BB_PS_PER_BLOCK_POINT each, while the rasteriser evaluates one
+// interval per (point, column inside the shell's disc) ~ N pi 0.6 r_max^2 at RAST_PS_PER_POINT_COLUMN, whatever the noise.  N
+// cancels: the search is the dearer engine when 500 / f^2 * 1.1 > 4.8 pi 0.6 r_max^2, i.e. f r_max < 7.8; then it stops here and
+// k_vote decides (identical result by construction).  Why not earlier: before the restart the lower bound can sit on a side
+// lobe -- with 10 % false-positive pixels two thirds of the items reach k_bb_gate(1) at f ~ 0.04 and end at f = 0.29; deciding
+// there sent them to the rasteriser (33 -> 136 ms per 216 items, profiles/r05_vote_sweep_gate1.json).  d_bb_restart's survivor
+// count (BB_HANDOVER_R2 r_max^2 four-voxel candidates, from the same constants) stays as the second line.
 __global__ void k_bb_gate(int mode, SP<unsigned char> ws, Layout L)
 {
     AccHeader *hdr = (AccHeader *)(ws.get() + L.header);
     if (threadIdx.x == 0) {
         if (mode == 0) hdr->probe_skip = (hdr->seed != 0 && (long long)hdr->bb_best * 8 >= (long long)hdr->n) ? 1 : 0;
-        else if (hdr->bb_best_key > hdr->climb_key[0]) hdr->climb_key[0] = hdr->bb_best_key;  // mode 1, before round 1: the probe's best
+        else if (mode == 1) {  // before round 1: the probe's best
+            if (hdr->bb_best_key > hdr->climb_key[0]) hdr->climb_key[0] = hdr->bb_best_key;
+        } else {               // mode 2: the flat-landscape decision (above)
+            hdr->gate_best = hdr->bb_best;
+            if (hdr->status == RCV_OK && hdr->bb_enabled && hdr->variant == 0 && !hdr->bb_overflow &&
+                (double)hdr->bb_best * hdr->rmax < BB_FLAT_F_RMAX * (double)hdr->n) {
+                hdr->bb_overflow = 1;  // (every later kernel of the search skips its work; k_bb_final leaves the item to k_vote)
+                hdr->bb_handover = 2;
+            }
+        }
     }
 }
 __global__ __launch_bounds__(256) void k_bb_climb(int cap, int round, SP<unsigned char> ws, Layout L)
@@ -2525,7 +2558,8 @@ __global__ __launch_bounds__(1024) void k_nd_setup(int Z, int N, int m, int cap,
     for (int q = 1; q < 16; q++) { mn = fmin(mn, s_mn[q]); mx = fmax(mx, s_mx[q]); }
     double rmax = -INF;
     for (int b = 0; b < PREP_BLOCKS; b++) rmax = fmax(rmax, partials[b].rmax);
-    AccHeader H;
+    __shared__ AccHeader sH;  // (in LDS, not in scratch memory: d_setup)
+    AccHeader &H = sH;
     memset(&H, 0, sizeof(H));
     H.variant = 1;
     H.n = (int)n; H.m = m; H.unit = 5.0;
@@ -2693,6 +2727,10 @@ static int run_engines(int cap, int bb_enable, SP<rcv_acc_result> sres, SP<uint3
                     RCV_LAUNCH_CHECK();
                 }
                 extra_round += 2;
+                if (level == 3) {  // the lower bound is as good as it gets: flat landscape -> the rasteriser (k_bb_gate, mode 2)
+                    hipLaunchKernelGGL(k_bb_gate, items, dim3(64), 0, st, 2, sws, L);
+                    RCV_LAUNCH_CHECK();
+                }
             }
             // every level list is two regions, x-sibling pairs and single blocks, each with its own launch; the level before
             // the voxel level and the voxel level itself write single entries only

@@ -4380,6 +4380,9 @@ __global__ __launch_bounds__(256, 2) void k_tail_x3(const H16 *src, const H16 *w
     rng_flush(range, rmax);
 }
 
+// rcv_fcn_range_status: flag[1] = flag[0], atomically cleared on request
+__global__ void k_range_fetch(unsigned *flag, int clear) { flag[1] = clear ? atomicExch(flag, 0u) : atomicOr(flag, 0u); }
+
 template <typename T>
 __global__ void k_slot_to_f32(const T *src, float *dst, long long n)
 {
@@ -5091,12 +5094,14 @@ int rcv_fcn_range_status(rcv_fcn *h, unsigned *flags_out, int clear, void *strea
     if (!h) return RCV_E_INVALID;
     unsigned f = 0u;
     if (h->range_dev) {
+        // read -- and, if asked, clear -- in ONE atomic exchange on the device: a forward of the next batch may be running on another
+        // stream, and an atomicOr of its kernels landing between a separate read and a memset would be lost (r05; the word's second
+        // slot receives the value)
+        hipLaunchKernelGGL(k_range_fetch, dim3(1), dim3(1), 0, (hipStream_t)stream, h->range_dev, clear);
+        RCV_LAUNCH_CHECK();
         RCV_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
-        RCV_HIP_CHECK(hipMemcpy(&f, h->range_dev, sizeof(unsigned), hipMemcpyDeviceToHost));
-        if (clear) {
-            RCV_HIP_CHECK(hipMemset(h->range_dev, 0, sizeof(unsigned)));
-            *h->range_host = 0u;
-        } else *h->range_host = f;
+        RCV_HIP_CHECK(hipMemcpy(&f, h->range_dev + 1, sizeof(unsigned), hipMemcpyDeviceToHost));
+        *h->range_host = clear ? 0u : f;
     }
     if (flags_out) *flags_out = f;
     return f ? RCV_E_RANGE : RCV_OK;

@@ -20,6 +20,8 @@
 
 #include <vector>
 
+#include <mutex>
+
 #include "common.hpp"
 
 namespace rcv {
@@ -500,14 +502,16 @@ int rcv_icp_point_to_point(const double *src_dev, int n_src, const double *tgt_d
         const size_t o_sorted = o_max + 256, o_sidx = o_sorted + align_up(sizeof(double) * 3 * (size_t)n_tgt, 256);
         const size_t g_total = o_sidx + align_up(sizeof(int) * (size_t)n_tgt, 256);
         {   // the stream's pool keeps what it has handed out once (default: everything goes back to the OS at each synchronise)
-            static bool pool_set = false;
-            hipMemPool_t pool;
-            int dev = 0;
-            if (!pool_set && hipGetDevice(&dev) == hipSuccess && hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess) {
-                uint64_t keep = 1ull << 30;
-                (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
-                pool_set = true;
-            }
+            // (once per process, whatever the number of host threads calling in: std::call_once)
+            static std::once_flag pool_once;
+            std::call_once(pool_once, [] {
+                hipMemPool_t pool;
+                int dev = 0;
+                if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess) {
+                    uint64_t keep = 1ull << 30;
+                    (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
+                }
+            });
         }
         if (hipMallocAsync((void **)&gmem, g_total, st) != hipSuccess) {
             (void)hipGetLastError();  // no room next to the caller's allocator: the exhaustive scan needs no extra memory

@@ -139,6 +139,10 @@ class FramePipeline:
         raw = self.results.cpu().numpy()
         self.finish()
         self.engine.range_status(clear=True, raise_on_flag=True)
+        # the range guard sees magnitudes, not NaNs (v_max drops them, and so does the next ReLU): the maps the votes were cast on are
+        # checked themselves -- one reduction over the current output planes per call
+        if not (bool(self.torch.isfinite(self.seg).all()) and bool(self.torch.isfinite(self.radial).all())):
+            raise FloatingPointError("non-finite FCN output in %s mode (NaN weights or input?)" % self.engine.dtype_name)
         res = [_hip.AccResult.from_buffer_copy(raw[i].tobytes()) for i in range(raw.shape[0])]
         kpts = np.array([[r.center_mm[0], r.center_mm[1], r.center_mm[2]] for r in res]).reshape(self.B, self.G, 3)
         return kpts, res

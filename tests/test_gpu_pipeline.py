@@ -188,8 +188,11 @@ def test_keypoints_under_false_positives_and_noise_equal_the_oracle(golden_dir, 
 
 def test_flat_vote_landscape_is_handed_to_the_rasteriser_and_equals_the_oracle(golden_dir, oracle):
     """Four voxels of radial noise flatten the vote landscape until certifying its arg-max by branch and bound costs more than
-    voting the whole grid: the search hands such an item to the LDS rasteriser once more than 0.6 D^2 four-voxel candidates
-    survive (d_bb_restart, r04).  Same keypoints as the oracle either way; a benign frame in the same batch stays with the search."""
+    voting the whole grid.  The search hands such an item to the LDS rasteriser: as soon as its lower bound says so (k_bb_gate(2)
+    behind the restart on the 8-voxel candidates, r05: best exact count / N times r_max below BB_FLAT_F_RMAX = 7.8 --
+    AccHeader::bb_handover 2) or, failing that prediction,
+    once more than BB_HANDOVER_R2 = 2.5 r_max^2 four-voxel candidates survive (d_bb_restart, r04 -- bb_handover 1).  Same keypoints
+    as the oracle either way; a benign frame in the same batch stays with the search."""
     from rcvpose_amd.pipeline import FramePipeline
 
     fr = [frames.synthetic_frame(310, noise_dm=0.2), frames.synthetic_frame(311)]
@@ -203,8 +206,10 @@ def test_flat_vote_landscape_is_handed_to_the_rasteriser_and_equals_the_oracle(g
     kp, res = pipe.read_results()
     hdr = pipe.ws[:, :512].cpu().numpy().view(np.int32)
     done = [[int(hdr[b * G + k, 116 // 4]) for k in range(G)] for b in range(B)]   # AccHeader::bb_done
-    print("decided by the search (1) / by the rasteriser (0):", done)
-    assert sum(done[0]) < G and sum(done[1]) == G
+    hand = [[int(hdr[b * G + k, 324 // 4]) for k in range(G)] for b in range(B)]   # AccHeader::bb_handover
+    print("decided by the search (1) / by the rasteriser (0):", done, "hand-over kind:", hand)
+    assert sum(done[0]) == 0 and all(h in (1, 2) for h in hand[0]) and 2 in hand[0]   # (peak / N ~ 0.05, r_max ~ 94: f r_max ~ 4.5)
+    assert sum(done[1]) == G and not any(hand[1])
     for b in range(B):
         for k in range(G):
             r = res[b * G + k]

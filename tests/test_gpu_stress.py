@@ -56,7 +56,19 @@ def test_configs4_eight_frames_fp16_radial_one_millimetre_against_oracle(oracle,
             r = res[b * G + k]
             assert r.status == 0 and r.dim > 800 and 47500 <= r.n_points <= 52500, (b, k, r.status, r.dim, r.n_points)
             assert np.abs(kpts[b, k] - fr[b]["keypoints_m"][k] * 1000).max() <= 5.0      # 1 mm voxels: within 5 voxels of the truth
-    for b, k in ((0, 0), (7, 2)):  # (two of the 24 items against the 1 mm oracle: ~35 s each on the box's host cores)
+    # both arg-max engines on all 24 items (r05): the LDS rasteriser alone (engine 'full', ~170 ms per item at 1 mm) must return the
+    # search's (peak, ties, first index, centre) bit for bit
+    del pipe
+    torch.cuda.empty_cache()
+    pipe_r = FramePipeline(sds, H, W, frames_per_step=B, K=_K(fr[0]), acc_unit=1.0, radial_f16=True, engine="full")
+    pipe_r.process(rgb, depth, torch.from_numpy(rmax).cuda(), inject=(seg, torch.from_numpy(rad16)[:, :, None].contiguous().cuda()))
+    kpts_r, res_r = pipe_r.read_results()
+    assert np.array_equal(kpts_r, kpts)
+    for a, c in zip(res, res_r):
+        assert (a.status, a.dim, a.n_points, a.peak_votes, a.n_ties, tuple(a.first_idx[:])) == (c.status, c.dim, c.n_points, c.peak_votes, c.n_ties, tuple(c.first_idx[:]))
+    del pipe_r
+    torch.cuda.empty_cache()
+    for b, k in ((0, 0), (7, 2), (3, 1), (5, 0)):  # (four of the 24 items against the 1 mm oracle: ~35 s each on the box's host cores)
         xyz, rl = oracle.seam(fr[b]["seg"], rad16[k, b].astype(np.float32), fr[b]["depth"], rmax[b, k], K=fr[b]["K"])
         r = res[b * G + k]
         assert (r.n_points, r.n_radii) == (len(xyz), len(rl))

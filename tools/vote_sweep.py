@@ -36,11 +36,13 @@ def main():
     ap.add_argument("--iters", type=int, default=3)
     ap.add_argument("--oracle-items", type=int, default=2)
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "vote_sweep.json"))
+    ap.add_argument("--raster-too", action="store_true", help="also time every case with the rasteriser as the only engine (engine 'full')")
     args = ap.parse_args()
     B, G = args.frames, 3
     shapes = json.load(open(os.path.join(ROOT, "tests", "golden", "fcn_state_dict_keys.json")))
     sds = [{k: torch.from_numpy(v) for k, v in synthetic_weights.make_state_dict_numpy(shapes, seed=s).items()} for s in range(G)]
     pipe = FramePipeline(sds, 480, 640, dtype="bf16", frames_per_step=B)  # (only its voting half is used)
+    engine_auto, engine_full = _hip.VOTE_ENGINES["auto"], _hip.VOTE_ENGINES["full"]
     from oracle import cpu_oracle
 
     cases = []
@@ -77,7 +79,26 @@ def main():
             xyz, rl = cpu_oracle.seam(f["seg"], f["radial"][k], f["depth"], f["max_radii_dm"][k])
             ref = cpu_oracle.accumulator_3d(xyz, rl, sparse=True)
             same = same and bool(np.array_equal(kp[it, k], ref[0]))
+        hand = [int(hdr[i, 324 // 4]) for i in range(B * G)]            # AccHeader::bb_handover
+        gate_f = [hdr[i, 268 // 4] / max(1, res[i].n_points) for i in range(B * G)]   # AccHeader::gate_best / n
+        rmx = pipe.ws[:, 24:32].cpu().numpy().view(np.float64)[:, 0]      # AccHeader::rmax
+        ms_r = None
+        if args.raster_too:
+            pipe.vote_engine = engine_full
+            pipe.vote(depth, rmax)
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(args.iters):
+                pipe.vote(depth, rmax)
+            e1.record()
+            torch.cuda.synchronize()
+            ms_r = e0.elapsed_time(e1) / args.iters
+            kp_r, _ = pipe.read_results()
+            same = same and bool(np.array_equal(kp_r, kp))
+            pipe.vote_engine = engine_auto
         row = {"sigma_dm": sigma, "outlier_frac": outl, "seg_false_pos": fp, "ms_per_%d_items" % (B * G): ms,
+               "ms_rasteriser_only": ms_r, "handed_over_at_gate": hand.count(2), "handed_over_at_restart": hand.count(1),
+               "lower_bound_over_points_at_gate": float(np.mean(gate_f)), "f_times_rmax_at_gate": float(np.mean(np.array(gate_f) * rmx)),
                "items_decided_by_rasteriser": fallback, "items_with_list_overflow": overflow,
                "mean_points": float(np.mean([r.n_points for r in res])), "mean_dim": float(np.mean([r.dim for r in res])),
                "peak_votes_over_points": float(np.mean([r.peak_votes / max(1, r.n_points) for r in res])),
