@@ -237,8 +237,10 @@ def extras(sds, frames, H, W, dtype, B_timed, kp_timed):
     # configs[1]: one DenseFCNResNet152, bf16, batch 1, 640x480, forward only.  The forward's ~175 launches are replayed as one HIP
     # graph (FcnEngine.capture): launched one by one from Python they take the same device time when the host keeps up
     # (2.41 ms both ways) and 50 % more on a box whose host does not -- the eager figure is kept beside it.
-    def batch1(mode):
+    def batch1(mode, split_k=False):
         eng = FcnEngine(sds[:1], H, W, dtype=mode)
+        if split_k:
+            eng.set_option(12, 1)  # opt-in latency option: split-K in the few-tile launches (another summation order: tolerance, not bits)
         x = torch.randn((1, 3, H, W), device="cuda")
         for _ in range(5):
             eng.forward(x)
@@ -272,6 +274,9 @@ def extras(sds, frames, H, W, dtype, B_timed, kp_timed):
     ms, eager, _ = batch1("f16x3")
     out["batch1_f16x3_forward_ms"] = ms
     out["batch1_f16x3_forward_ms_launched_from_python"] = eager
+    # ... and both with the opt-in latency option (engine option 12: deterministic split-K; maps within tolerance, not bit-identical)
+    out["configs1_batch1_bf16_forward_ms_split_k_option"] = batch1("bf16", True)[0]
+    out["batch1_f16x3_forward_ms_split_k_option"] = batch1("f16x3", True)[0]
     # the other arithmetic modes, whole path (same frames, ideal maps injected)
     for mode, bb, steps in (("bf16", 72, 4), ("fp16", 72, 4), ("fp32", 24, 2), ("f16x3", 36, 3)):
         if mode == dtype:

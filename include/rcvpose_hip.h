@@ -375,7 +375,13 @@ int rcv_fcn_set_profiling(rcv_fcn *h, int enable);
  * [32 hi halves | lo[0:16], lo[16:32], hi[0:16], hi[16:32]] with the scale in byte 14 of each 16-byte chunk; block scale
  * 2^(floor(log2 max|block|) - 2), codes rounded to nearest even, saturating at 7.5.  rcvpose_amd/fcn_engine.py requests it for
  * the 3x3 convolutions of layer 3 only (measured map error 1-2e-5 instead of 0.4-0.8e-5; every 3x3 layer: 6-7e-5,
- * tools/probe/fp8_cross_probe.py).  0: three half-precision MFMAs everywhere (the bit-identical family of kernels). */
+ * tools/probe/fp8_cross_probe.py).  0: three half-precision MFMAs everywhere (the bit-identical family of kernels).
+ * key 12 (default 0, 16-bit and split engines): latency option for one or a few frames in flight (the reference calls the model
+ * frame by frame, AccumulatorSpace.py:596).  Launches of k_conv_lat with far fewer tiles than the chip has CUs deal their K steps
+ * over S workgroups per tile (S depends on the layer's shape only) and a second kernel adds the S partial sums in a fixed order
+ * and applies the epilogue: run-to-run identical results, within the engine's tolerance of -- but not bit-identical to -- the
+ * unsplit kernels, so a frame's maps then depend on the batch size it travels in.  Switching it on allocates a 48 MB buffer
+ * owned by the handle. */
 int rcv_fcn_set_option(rcv_fcn *h, int key, int value);
 int rcv_fcn_get_profile(rcv_fcn *h, double *conv_ms, double *other_ms, double *conv_flop);
 /* Per-op device times (ms) of the last profiled forward; ms_out has room for n_ops doubles. */

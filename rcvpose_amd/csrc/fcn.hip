@@ -247,6 +247,8 @@ struct ConvParams {
     int M, K;  // GEMM sizes per group
     unsigned *range;  // the engine's sticky range-flag word (half-precision engines), or null
     int q6;           // split engine: src0 and w are in the q6 row layout, the cross terms run in fp6 (engine option 11)
+    int splits;       // k_conv_lat (engine option 12): the K steps are dealt over `splits` workgroups per output tile (blockIdx.z = group * splits + split),
+    float *partial;   // ... which leave their raw fp32 sums in partial[group][split][M][Cout] for k_splitk_finish; 0 / null: off
 };
 
 // Tile order.  Blocks are numbered so that the N tiles of one M tile are neighbours (they share the gathered
@@ -882,12 +884,15 @@ __global__ __launch_bounds__(512) void k_conv_lat(const ConvParams p)
     const int wm = (wave >> 1) & 1, wn = wave & 1;
     int mt_, nt_;
     tile_of_block(p.Cout / BN, mt_, nt_);
-    const int g = blockIdx.z, m0 = mt_ * BM, n0 = nt_ * BN;
+    // split-K (engine option 12, one or a few frames in flight): blockIdx.z = group * splits + split; this workgroup walks K steps
+    // [kt0, kt1) of the same (slice-major, taps inside) order and leaves raw sums for k_splitk_finish
+    const int nsplit = p.splits > 1 ? p.splits : 1;
+    const int g = blockIdx.z / nsplit, ksp = blockIdx.z - g * nsplit, m0 = mt_ * BM, n0 = nt_ * BN;
     const int Ctot = p.C0 + p.C1;
     const T *src0 = (const T *)p.src0 + (long long)g * p.src0_gs;
     const T *src1 = p.src1 ? (const T *)p.src1 + (long long)g * p.src1_gs : nullptr;
     const T *wg = (const T *)p.w + (long long)g * p.w_gs;
-    const T *res = p.res ? (const T *)p.res + (long long)g * p.res_gs : nullptr;
+    const T *res = (p.res && nsplit == 1) ? (const T *)p.res + (long long)g * p.res_gs : nullptr;
     // residual tile: 64 rows x 8 chunks of 16 B = 512 chunks, one per thread, requested up front
     uint4 rres = make_uint4(0u, 0u, 0u, 0u), rres_lo = make_uint4(0u, 0u, 0u, 0u);
     if (res) {
@@ -928,8 +933,11 @@ __global__ __launch_bounds__(512) void k_conv_lat(const ConvParams p)
     const int n_img = __builtin_amdgcn_readfirstlane(p.M / HWo);
     const int a_bytes0 = (int)((long long)p.C0 * p.Hin * p.Win * n_img * 2), a_bytes1 = (int)((long long)p.C1 * p.Hin * p.Win * n_img * 2);
     const int b_bytes = BN * p.K * 2;
-    const int nk = p.K / KE;
-    int tap_r = 0, tap_s = 0, cg = 0, issued = 0;
+    const int nk_all = p.K / KE;
+    const int kt0 = (int)((long long)nk_all * ksp / nsplit), kt1 = (int)((long long)nk_all * (ksp + 1) / nsplit);
+    const int nk = kt1 - kt0;  // K steps of this workgroup
+    const int taps = p.KS * p.KS, tap0 = kt0 % taps;
+    int tap_r = tap0 / p.KS, tap_s = tap0 - (tap0 / p.KS) * p.KS, cg = (kt0 / taps) * KE, issued = 0;
 
 // the two pieces of the next K step (if there is one) into stage `st_`
 #define RCV_LAT_ISSUE(st_)                                                                                     \
@@ -1051,6 +1059,25 @@ __global__ __launch_bounds__(512) void k_conv_lat(const ConvParams p)
     constexpr int SROW = BN + 4;
     float *stg = (float *)smem;
     __syncthreads();
+    if (nsplit > 1) {  // raw sums -> partial[g][split][m][n]; bias, scale, residual, ReLU and the store happen in k_splitk_finish
+        if (mma) {
+#pragma unroll
+            for (int j = 0; j < NT; j++)
+#pragma unroll
+                for (int i = 0; i < MT; i++)
+#pragma unroll
+                    for (int e = 0; e < 4; e++) stg[(wm * 32 + i * 16 + kq * 4 + e) * SROW + wn * 32 + j * 16 + r16] = acc[i][j][e];
+        }
+        __syncthreads();
+        const int row = tid >> 3, cc = tid & 7, m = m0 + row;
+        if (m < p.M) {
+            float *pp = p.partial + (((long long)g * nsplit + ksp) * p.M + m) * p.Cout + n0 + cc * EPV;
+            const float4 *sp4 = (const float4 *)(stg + row * SROW + cc * EPV);
+            *(float4 *)pp = sp4[0];
+            *(float4 *)(pp + 4) = sp4[1];
+        }
+        return;
+    }
     if (mma) {
 #pragma unroll
         for (int j = 0; j < NT; j++) {
@@ -1108,6 +1135,65 @@ __global__ __launch_bounds__(512) void k_conv_lat(const ConvParams p)
                 *(uint4 *)op_ = outv;
             }
         }
+    }
+    rng_flush(p.range, rmax);
+}
+
+// k_splitk_finish (engine option 12): the `splits` partial sums of k_conv_lat are added in split order (a fixed order: results are
+// run-to-run identical, though not the bits of the unsplit kernel) and go through k_conv_lat's epilogue -- scale / bias, residual,
+// ReLU, range guard, store.  One thread per (row, eight channels).
+__global__ __launch_bounds__(256) void k_splitk_finish(const ConvParams p)
+{
+    RCV_X3_MODE();
+    using T = H16;
+    constexpr int EPV = 8;
+    const int g = blockIdx.y, cpr = p.Cout / EPV;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)p.M * cpr) return;
+    const int m = (int)(idx / cpr), n = (int)(idx - (long long)m * cpr) * EPV;
+    float v[EPV];
+#pragma unroll
+    for (int q = 0; q < EPV; q++) v[q] = 0.f;
+    for (int s_ = 0; s_ < p.splits; s_++) {
+        const float *pp = p.partial + (((long long)g * p.splits + s_) * p.M + m) * p.Cout + n;
+        const float4 a = *(const float4 *)pp, b = *(const float4 *)(pp + 4);
+        v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w; v[4] += b.x; v[5] += b.y; v[6] += b.z; v[7] += b.w;
+    }
+    const float *bias = p.bias + (long long)g * p.bias_gs;
+#pragma unroll
+    for (int q = 0; q < EPV; q++) v[q] = kX3 ? __fmaf_rn(v[q], bias[p.Cout + n + q], bias[n + q]) : v[q] + bias[n + q];
+    if (p.res) {
+        const T *rp = (const T *)p.res + (long long)g * p.res_gs + nhwc_off<T>(m, p.Cout, n);
+        const uint4 rh = *(const uint4 *)rp;
+        if constexpr (kX3) {
+            const uint4 rl = *(const uint4 *)(rp + 32);
+            float rv[8];
+            x3_join8(rh, rl, rv);
+#pragma unroll
+            for (int q = 0; q < EPV; q++) v[q] += rv[q];
+        } else {
+            const T *r8 = (const T *)&rh;
+#pragma unroll
+            for (int q = 0; q < EPV; q++) v[q] += to_f32(r8[q]);
+        }
+    }
+    if (p.relu) {
+#pragma unroll
+        for (int q = 0; q < EPV; q++) v[q] = fmaxf(v[q], 0.f);
+    }
+    float rmax = rng_see<EPV>(0.f, v);
+    T *op_ = (T *)p.dst + (long long)g * p.dst_gs + nhwc_off<T>(m, p.Cout, n);
+    if constexpr (kX3) {
+        uint4 oh, ol;
+        x3_split8(v, oh, ol);
+        *(uint4 *)op_ = oh;
+        *(uint4 *)(op_ + 32) = ol;
+    } else {
+        uint4 outv;
+        T *o8 = (T *)&outv;
+#pragma unroll
+        for (int q = 0; q < EPV; q++) o8[q] = from_f32<T>(v[q]);
+        *(uint4 *)op_ = outv;
     }
     rng_flush(p.range, rmax);
 }
@@ -4425,6 +4511,9 @@ struct rcv_fcn {
     bool radial_f16 = false;  // the radial plane leaves the head as float16 (BASELINE.json stress configuration)
     bool use_lat = true;      // latency kernel (k_conv_lat) for launches with few tiles (small batches)
     int use_chain2 = 1;       // split engine: 1 = k_chain2_x3 (r04), 0 = k_chain_x3, 2 = k_chain3_x3 for the 256-wide block
+    int use_splitk = 0;       // latency option (12): split-K in k_conv_lat + k_splitk_finish for launches with few tiles (one or a few frames)
+    float *splitk_ws = nullptr;  // ... its partial sums (allocated when the option is switched on, never on the hot path)
+    size_t splitk_bytes = 0;
     int use_q6 = 1;           // split engine: fp6 cross terms (k_conv_halo<.., true>) for the ops whose weights come with a q6 copy (rcv_op::wq_off)
     // range guard of the half-precision engines: one sticky flag word on the device (kernels OR bits into it), mirrored into
     // pinned host memory by a 4-byte copy at the end of every forward
@@ -4529,16 +4618,37 @@ int launch_conv_halo(const ConvParams &p, int B, int groups, int mode, hipStream
     return RCV_OK;
 }
 
-int launch_conv_lat(const ConvParams &p, int groups, hipStream_t st)
+int launch_conv_lat(const ConvParams &p, int groups, hipStream_t st, float *splitk_ws = nullptr, size_t splitk_bytes = 0)
 {
-    dim3 grid(p.Cout / LAT_BN, (p.M + LAT_BM - 1) / LAT_BM, groups);
-    hipLaunchKernelGGL(k_conv_lat, grid, dim3(512), LAT_STAGES * LAT_STAGE_BYTES, st, p);
+    // Split-K (engine option 12, opt-in): with one or a few frames in flight a launch has far fewer tiles than the chip has CUs and
+    // its time is its chain of dependent K steps (~0.37 us each).  The steps are dealt over S workgroups per tile -- S from the layer
+    // alone (tiles, steps), never from timing -- that leave raw fp32 sums; k_splitk_finish adds them in split order and applies the
+    // epilogue.  Worth a second launch (~4.5 us) only where it removes more than ~16 steps from the chain.
+    const long long tiles = (long long)(p.Cout / LAT_BN) * ((p.M + LAT_BM - 1) / LAT_BM) * groups;
+    const int nk = p.K / 64;
+    int S = 1;
+    if (splitk_ws && tiles > 0) {
+        S = (int)std::min<long long>(256 / tiles, nk / 8);   // fill the chip once; at least 8 steps per split
+        if (S < 2 || nk - nk / S < 16) S = 1;
+        while (S > 1 && (size_t)groups * S * p.M * p.Cout * sizeof(float) > splitk_bytes) S--;
+    }
+    ConvParams q = p;
+    q.splits = S > 1 ? S : 0;
+    q.partial = S > 1 ? splitk_ws : nullptr;
+    dim3 grid(p.Cout / LAT_BN, (p.M + LAT_BM - 1) / LAT_BM, groups * (S > 1 ? S : 1));
+    hipLaunchKernelGGL(k_conv_lat, grid, dim3(512), LAT_STAGES * LAT_STAGE_BYTES, st, q);
     RCV_LAUNCH_CHECK();
+    if (S > 1) {
+        const long long n = (long long)p.M * (p.Cout / 8);
+        hipLaunchKernelGGL(k_splitk_finish, dim3((unsigned)((n + 255) / 256), groups), dim3(256), 0, st, q);
+        RCV_LAUNCH_CHECK();
+    }
     return RCV_OK;
 }
 
 template <typename T>
-int launch_conv(const ConvParams &p, int groups, hipStream_t st, bool set_attr, bool allow_dma, bool allow_lat = false)
+int launch_conv(const ConvParams &p, int groups, hipStream_t st, bool set_attr, bool allow_dma, bool allow_lat = false, float *splitk_ws = nullptr,
+                size_t splitk_bytes = 0)
 {
     constexpr int KE = Traits<T>::KE;
     if (p.C0 % KE || p.C1 % KE || p.Cout % 32 || p.K % KE) return RCV_E_UNSUPPORTED;
@@ -4546,7 +4656,7 @@ int launch_conv(const ConvParams &p, int groups, hipStream_t st, bool set_attr, 
     // (measured at batch 1: it pays from K = 1024 on; short-K layers keep k_conv, whose tiles are cheaper to set up)
     if (sizeof(T) == 2 && allow_lat && allow_dma && p.Cout % LAT_BN == 0 && p.K >= 1024 * (kX3 ? 2 : 1) &&
         (long long)((p.M + 127) / 128) * ((p.Cout + 127) / 128) * groups <= 128)
-        return launch_conv_lat(p, groups, st);
+        return launch_conv_lat(p, groups, st, splitk_ws, splitk_bytes);
     if (sizeof(T) == 2 && allow_dma && p.Cout % DMA_BN == 0 &&
         (long long)((p.M + DMA_BM - 1) / DMA_BM) * (p.Cout / DMA_BN) * groups >= 192)
         return launch_conv_dma(p, groups, st, set_attr);
@@ -4677,7 +4787,7 @@ int run_op(rcv_fcn *h, const rcv_op &op, const float *x, int B, float *seg, floa
                 return launch_conv_halo(p, B, G, h->use_halo, st);
         }
         // (q6 ops outside the halo kernel's reach: the plain kernel, same arithmetic -- the DMA / latency kernels have no q6 form)
-        return launch_conv<T>(p, G, st, !h->attrs_set, dma_ok && !p.q6, h->use_lat && !p.q6);
+        return launch_conv<T>(p, G, st, !h->attrs_set, dma_ok && !p.q6, h->use_lat && !p.q6, h->use_splitk ? h->splitk_ws : nullptr, h->splitk_bytes);
     }
     default: return RCV_E_UNSUPPORTED;
     }
@@ -5060,6 +5170,7 @@ void rcv_fcn_destroy(rcv_fcn *h)
     for (auto e : h->events) (void)hipEventDestroy(e);
     if (h->range_dev) (void)hipFree(h->range_dev);
     if (h->range_host) (void)hipHostFree((void *)h->range_host);
+    if (h->splitk_ws) (void)hipFree(h->splitk_ws);
     delete h;
 }
 
@@ -5157,6 +5268,15 @@ int rcv_fcn_set_option(rcv_fcn *h, int key, int value)
     if (key == 9) { h->use_lat = value != 0; return RCV_OK; }
     if (key == 10) { h->use_chain2 = value; return RCV_OK; }
     if (key == 11) { h->use_q6 = value; return RCV_OK; }
+    if (key == 12) {
+        if (value && !h->splitk_ws) {
+            const size_t bytes = (size_t)48 << 20;  // the largest split launch of the FCN programs at up to 3 networks x 1 frame needs 11 MB
+            RCV_HIP_CHECK(hipMalloc((void **)&h->splitk_ws, bytes));
+            h->splitk_bytes = bytes;
+        }
+        h->use_splitk = value != 0;
+        return RCV_OK;
+    }
     return RCV_E_INVALID;
 }
 

@@ -281,3 +281,33 @@ def test_x3_engine_refuses_channel_counts_it_cannot_store():
     arr[0].cout = 64
     assert L.rcv_fcn_create(arr, 1, 2, slots, 1, _hip.RCV_F16X3, _hip.ptr(w), _hip.ptr(b), ctypes.byref(h)) == _hip.RCV_OK
     L.rcv_fcn_destroy(h)
+
+
+def test_latency_option_split_k_within_tolerance_and_repeatable(shapes, golden_dir):
+    """Engine option 12 (opt-in, one frame in flight -- the reference's call pattern, AccumulatorSpace.py:596): k_conv_lat deals the
+    K steps of launches with few tiles over several workgroups and k_splitk_finish adds the partial sums in a fixed order.  Not
+    the bits of the unsplit kernels (another summation order), so: the golden forward within tolerance, run-to-run identical
+    maps, and close to the default path."""
+    from rcvpose_amd.fcn_engine import FcnEngine
+
+    g = np.load(os.path.join(golden_dir, "fcn2_480x640_samples.npz"))
+    x = torch.from_numpy(fcn_weights.make_input(int(g["input_seed"]), (1, 3, 480, 640))).cuda()
+    pix = g["pix"]
+    for dtype, tol in (("f16x3", REL_TIGHT), ("bf16", 6e-2)):
+        eng = FcnEngine([_sd(shapes)], 480, 640, dtype=dtype)
+        seg0, rad0 = [t.clone() for t in eng.forward(x)]
+        eng.set_option(12, 1)
+        seg1, rad1 = [t.clone() for t in eng.forward(x)]
+        seg2, rad2 = eng.forward(x)
+        assert torch.equal(seg1, seg2) and torch.equal(rad1, rad2)          # deterministic
+        assert not torch.equal(rad0, rad1)                                  # ... and really another summation order
+        err_r = np.abs(rad1[0].cpu().numpy().reshape(-1)[pix] - g["radial"]).max() / float(g["radial_absmax"])
+        err_s = np.abs(seg1[0].cpu().numpy().reshape(-1)[pix] - g["seg"]).max() / float(g["seg_absmax"])
+        d = float((rad1 - rad0).abs().max() / rad0.abs().max())
+        print("%s, split-K latency option at batch 1: radial %.2e seg %.2e vs golden; %.2e from the default path" % (dtype, err_r, err_s, d))
+        assert err_r <= tol and err_s <= tol
+        if dtype == "f16x3":
+            assert d <= 1e-5 and eng.range_status() == 0
+        eng.set_option(12, 0)
+        seg3, rad3 = eng.forward(x)
+        assert torch.equal(rad3, rad0) and torch.equal(seg3, seg0)
