@@ -505,9 +505,20 @@ def estimate_6d_pose_lm(opts, return_details=False):
             n_step = max(1, min(int(getattr(opts, 'frames_per_step', DEFAULT_FRAMES_PER_STEP)), len(todo)))
             # equal batches: the device pipeline runs whole batches, so 128 frames travel as 43 + 43 + 42, not as 53 + 53 + 22 with
             # 31 padded frames of wasted work
-            n_batches = (len(todo) + n_step - 1) // n_step
-            n_step = (len(todo) + n_batches - 1) // n_batches
-            pipe = FramePipeline(sds, H, W, dtype=getattr(opts, 'dtype', 'f16x3'), frames_per_step=n_step)
+            # (the default of 53 is tuned for one MI355X with 288 GB: on a smaller or shared device the workspaces of a batch may not
+            # fit -- halve the batch until they do; results do not depend on it)
+            while True:
+                n_batches = (len(todo) + n_step - 1) // n_step
+                n_step = (len(todo) + n_batches - 1) // n_batches
+                try:
+                    pipe = FramePipeline(sds, H, W, dtype=getattr(opts, 'dtype', 'f16x3'), frames_per_step=n_step)
+                    break
+                except _torch().cuda.OutOfMemoryError:
+                    if n_step == 1:
+                        raise
+                    _torch().cuda.empty_cache()
+                    n_step = max(1, n_step // 2)
+                    print('frames_per_step reduced to %d (device memory)' % n_step)
             pipe.set_stage_timing(True)
         t_loop = _time.perf_counter()
         if opts.using_ckpts and todo:
