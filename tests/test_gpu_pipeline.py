@@ -240,3 +240,37 @@ def test_pipeline_reports_a_forward_that_left_the_half_range(golden_dir):
     ok = FramePipeline([bad], H, W, dtype="fp32", frames_per_step=1)
     ok.process(rgb, depth, [50.0])
     ok.read_results()                                               # fp32 has the reference's range: no flag
+
+
+def test_read_results_refuses_non_finite_maps(golden_dir):
+    """The range guard sees magnitudes, not NaNs (v_max and the next ReLU drop them): FramePipeline.read_results checks the maps the
+    votes were cast on.  A NaN written into the radial plane after the forward surfaces as FloatingPointError."""
+    from rcvpose_amd.pipeline import FramePipeline
+
+    H, W = 64, 96
+    pipe = FramePipeline(_state_dicts(golden_dir, 1), H, W, frames_per_step=1)
+    rng = np.random.default_rng(2)
+    rgb = torch.from_numpy(rng.integers(0, 256, size=(1, H, W, 3), dtype=np.uint8)).cuda()
+    depth = torch.from_numpy((800 + rng.integers(0, 40, size=(1, H, W))).astype(np.uint16).view(np.int16)).cuda()
+    seg = torch.full((1, 1, 1, H, W), 1.0, device="cuda")
+    rad = torch.full((1, 1, 1, H, W), 0.5, device="cuda")
+    pipe.process(rgb, depth, [1.0], inject=(seg, rad))
+    pipe.read_results()                       # finite maps: fine
+    rad[0, 0, 0, 3, 5] = float("nan")
+    pipe.process(rgb, depth, [1.0], inject=(seg, rad))
+    with pytest.raises(FloatingPointError):
+        pipe.read_results()
+
+
+def test_mfma_calibration_returns_a_plausible_rate():
+    """rcv_mfma_calibrate (bench.py's yardstick for the box): a bare fp16 MFMA loop on every SIMD -- between a third of and the
+    whole dense peak, at a shader clock the chip can hold."""
+    import ctypes
+
+    from rcvpose_amd import _hip
+
+    tf, mhz = ctypes.c_double(), ctypes.c_double()
+    _hip.check(_hip.lib().rcv_mfma_calibrate(0.05, ctypes.byref(tf), ctypes.byref(mhz), _hip.current_stream()), "rcv_mfma_calibrate")
+    print("bare MFMA loop: %.0f TFLOP/s at %.0f MHz" % (tf.value, mhz.value))
+    assert 800.0 < tf.value < 2600.0 and 1000.0 < mhz.value < 2600.0
+    assert _hip.lib().rcv_mfma_calibrate(0.0, ctypes.byref(tf), None, None) == _hip.RCV_E_INVALID
