@@ -1603,6 +1603,52 @@ __global__ __launch_bounds__(512) void k_conv_halo(const HaloParams p)
         __builtin_amdgcn_s_barrier();                                                                          \
         stage = stage + 1 == 3 ? 0 : stage + 1;                                                                \
     }
+// The q6 step with ONE load phase and ONE MFMA phase (two barriers per step, as RCV_HALO_STEP2_X3; -DRCV_Q6_TWO_PHASE=1).  Why it
+// exists: with 40 instead of 60 MFMAs per step the four-phase form is bound by its load phases (~425 cycles each: nine fragment
+// reads, the DMA issue, the counted waits) against 320 cycles of MFMAs -- rocprofv3 counted the matrix cores 0.59 busy in it
+// (profiles/r05_q6_pmc.txt; the three-MFMA kernel: 0.85) -- which is why q6 buys -18.5 % and not -33 %.  Why it is off: see
+// RCV_Q6_TWO_PHASE.  Same products in the same order per output element (hh, then the scaled cross instruction): identical results.
+#define RCV_HALO_STEP2_X3Q(TAP)                                                                                \
+    {                                                                                                          \
+        constexpr int T2_ = ((TAP) + 2) % 9, S2_ = ((TAP) + 2) / 9;                                            \
+        const int shift_ = ((TAP) / 3 - 1) * pitch + ((TAP) % 3 - 1);                                          \
+        const unsigned char *Pb = sP + (sl & 1) * HALO_PATCH;                                                  \
+        const unsigned char *Bb = sB + stage * (BN * 128) + (wn * (BN / 2) + r16) * 128;                       \
+        const int st2 = stage + 2 >= 3 ? stage + 2 - 3 : stage + 2;                                            \
+        bf16x8 ah[MT], bh[NT];                                                                                 \
+        i32x4 aq[MT], bq[NT];                                                                                  \
+        _Pragma("unroll") for (int i = 0; i < MT; i++) {                                                       \
+            const int ao_ = (pr0[i] + shift_) * 128 + ((kq ^ ((r16 + ((TAP) / 3) * p.tw + (TAP) % 3) & 7)) << 4); \
+            ah[i] = *(const bf16x8 *)(Pb + ao_);                                                               \
+            aq[i] = *(const i32x4 *)(Pb + (ao_ ^ 64));                                                         \
+        }                                                                                                      \
+        _Pragma("unroll") for (int j = 0; j < NT; j++) {                                                       \
+            bh[j] = *(const bf16x8 *)(Bb + j * 16 * 128 + ch0);                                                \
+            bq[j] = *(const i32x4 *)(Bb + j * 16 * 128 + ch1);                                                 \
+        }                                                                                                      \
+        RCV_HALO_B(sl + S2_, T2_, st2, 0);                                                                     \
+        if constexpr (BPW == 2) RCV_HALO_B(sl + S2_, T2_, st2, 1);                                             \
+        if constexpr ((TAP) < HALO_PPW) {                                                                      \
+            RCV_HALO_PATCH(sl + 1, TAP);                                                                       \
+            if constexpr (BPW == 2) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");                \
+            else asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");                                   \
+        } else {                                                                                               \
+            if constexpr (BPW == 2) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");                \
+            else asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");                                   \
+        }                                                                                                      \
+        __builtin_amdgcn_s_barrier();                                                                          \
+        __builtin_amdgcn_s_setprio(1);                                                                         \
+        _Pragma("unroll") for (int i = 0; i < MT; i++)                                                         \
+            _Pragma("unroll") for (int j = 0; j < NT; j++) acc[i][j] = RCV_MFMA16(ah[i], bh[j], acc[i][j], 0, 0, 0); \
+        _Pragma("unroll") for (int j = 0; j < NT; j++) {                                                       \
+            const i32x8 b8_ = {bq[j][0], bq[j][1], bq[j][2], bq[j][3], 0, 0, 0, 0};                             \
+            _Pragma("unroll") for (int i = 0; i < MT; i++)                                                     \
+                acc[i][j] = q6_mfma(__builtin_shufflevector(aq[i], aq[i], 0, 1, 2, 3, -1, -1, -1, -1), b8_, acc[i][j], aq[i][3], bq[j][3]); \
+        }                                                                                                      \
+        __builtin_amdgcn_s_setprio(0);                                                                         \
+        __builtin_amdgcn_s_barrier();                                                                          \
+        stage = stage + 1 == 3 ? 0 : stage + 1;                                                                \
+    }
 // BN = 64, split precision: one load phase, 24 MFMAs
 #define RCV_HALO_STEP2_X3(TAP)                                                                                 \
     {                                                                                                          \
@@ -1667,10 +1713,19 @@ __global__ __launch_bounds__(512) void k_conv_halo(const HaloParams p)
 #endif
     if constexpr (Q6) {
         static_assert(!Q6 || BPW == 2, "the fp6 cross-term form exists for the 128-channel tile (of the split engine: q6_mfma)");
+#ifndef RCV_Q6_TWO_PHASE
+#define RCV_Q6_TWO_PHASE 0  // 1: one load phase + one MFMA phase per step (below).  Measured r05: 17.9 ms per 35 layer-3 launches against 12.3 in the four-phase form -- its 72 fragment registers beside the 6-wide operand tuples spill 22 registers, the reloads sit in the K loop and every scratch load joins the vmcnt queue of the DMA pieces
+#endif
         for (int sl = 0; sl < nsl; sl++) {
+#if RCV_Q6_TWO_PHASE
+            RCV_HALO_STEP2_X3Q(0); RCV_HALO_STEP2_X3Q(1); RCV_HALO_STEP2_X3Q(2);
+            RCV_HALO_STEP2_X3Q(3); RCV_HALO_STEP2_X3Q(4); RCV_HALO_STEP2_X3Q(5);
+            RCV_HALO_STEP2_X3Q(6); RCV_HALO_STEP2_X3Q(7); RCV_HALO_STEP2_X3Q(8);
+#else
             RCV_HALO_STEP_X3Q(0); RCV_HALO_STEP_X3Q(1); RCV_HALO_STEP_X3Q(2);
             RCV_HALO_STEP_X3Q(3); RCV_HALO_STEP_X3Q(4); RCV_HALO_STEP_X3Q(5);
             RCV_HALO_STEP_X3Q(6); RCV_HALO_STEP_X3Q(7); RCV_HALO_STEP_X3Q(8);
+#endif
         }
     } else if constexpr (BPW == 2 && kX3 && (!RCV_X3_HALO_TWO_PHASE || MT == 5)) {  // (the 320-row tile would spill in the two-phase form)
         for (int sl = 0; sl < nsl; sl++) {
@@ -1710,6 +1765,7 @@ __global__ __launch_bounds__(512) void k_conv_halo(const HaloParams p)
 #undef RCV_HALO_STEP2
 #undef RCV_HALO_STEP_X3
 #undef RCV_HALO_STEP_X3Q
+#undef RCV_HALO_STEP2_X3Q
 #undef RCV_HALO_STEP2_X3
 #undef RCV_HALO_B
 #undef RCV_HALO_PATCH
