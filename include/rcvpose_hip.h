@@ -381,7 +381,15 @@ int rcv_fcn_set_profiling(rcv_fcn *h, int enable);
  * over S workgroups per tile (S depends on the layer's shape only) and a second kernel adds the S partial sums in a fixed order
  * and applies the epilogue: run-to-run identical results, within the engine's tolerance of -- but not bit-identical to -- the
  * unsplit kernels, so a frame's maps then depend on the batch size it travels in.  Switching it on allocates a 48 MB buffer
- * owned by the handle. */
+ * owned by the handle.
+ * key 13 (default 0 -- a measured experiment: 6.5 ms against k_tail_x3's 6.1; RCV_F16X3): the tail (x2 bilinear upsampling ->
+ * conv7 3x3 -> head; reference models/fcnresnet.py:177-191) as ONE
+ * 3x3 convolution on the low-resolution tensor: both maps are linear, so conv7 on the upsampled image equals a convolution with 4 x 32
+ * parity-stacked output channels whose weights the host composes (rcv_op::wq_off of the conv7 op: [G][128][3][3][cin] behind the first
+ * copy, its [bias x 4 | scale] records behind the first copy's; rcvpose_amd/fcn_engine.py::compose_upsample_conv3).  k_conv_halo reads
+ * the low-resolution tensor with replicate padding and applies ReLU + the head in its epilogue; the outermost ring of output pixels
+ * (where the upsampling's clamp and the convolution's zero padding meet) is recomputed by k_tail_ring.  Same function, another
+ * summation: within ~2e-6 of k_tail_x3 (0: that kernel), not its bits. */
 int rcv_fcn_set_option(rcv_fcn *h, int key, int value);
 int rcv_fcn_get_profile(rcv_fcn *h, double *conv_ms, double *other_ms, double *conv_flop);
 /* Per-op device times (ms) of the last profiled forward; ms_out has room for n_ops doubles. */

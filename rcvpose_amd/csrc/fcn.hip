@@ -1294,6 +1294,12 @@ struct HaloParams {
     int C0, C1, Cout, H, W, n_img, relu, K;
     int th, tw, tiles_y, tiles_x;
     unsigned *range;  // sticky range-flag word (ConvParams::range)
+    // parity-composed tail (template parameter TAILC, engine option 13): the head's weights / [bias | scale] record and the output planes
+    const void *w8;
+    const float *b8;
+    long long w8_gs;
+    int b8_gs, rad_f16;
+    float *seg, *radial;
 };
 // patch pieces (8 rows x 128 B) per wave and slice, one per tap 0 .. PPW - 1.  BN = 128: 7 -> 448 patch rows, a 320-pixel rectangle
 // with its halo (10 x 42); BN = 64 (half the weight stages): 8 -> 512 rows, a 384-pixel rectangle (14 x 34)
@@ -1310,7 +1316,7 @@ __device__ __forceinline__ void halo_dma16(const void *base, int num_bytes, unsi
     __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void *)lds_wave_base, 16, voffset, 0, 0, 0);
 }
 
-template <int BN, int MT, bool Q6 = false>
+template <int BN, int MT, bool Q6 = false, bool TAILC = false>
 __global__ __launch_bounds__(512) void k_conv_halo(const HaloParams p)
 {
     RCV_X3_MODE();
@@ -1354,7 +1360,11 @@ __global__ __launch_bounds__(512) void k_conv_halo(const HaloParams p)
         // that wraps (three of four in the 15 x 20 rectangles of layer 3) read with 2-way bank conflicts: rocprofv3 counted
         // SQ_LDS_BANK_CONFLICT at 0.9 of SQ_ACTIVE_INST_LDS in k_conv_halo<128,5> and zero in the other kernels (r04).
         const int key = (px + p.tw * py) & 7;
-        lin[k] = (pr < prows && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W) ? ((img * p.H + y) * p.W + x) | (key << 28) : -1;
+        if constexpr (TAILC) {  // the composed tail reads the low-resolution tensor with REPLICATE padding (the upsampling's clamp)
+            const int yc = min(max(y, 0), p.H - 1), xc = min(max(x, 0), p.W - 1);
+            lin[k] = pr < prows ? ((img * p.H + yc) * p.W + xc) | (key << 28) : -1;
+        } else
+            lin[k] = (pr < prows && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W) ? ((img * p.H + y) * p.W + x) | (key << 28) : -1;
     }
     int b_off[BPW];
 #pragma unroll
@@ -1794,6 +1804,49 @@ __global__ __launch_bounds__(512) void k_conv_halo(const HaloParams p)
             }
         }
         __syncthreads();
+        if constexpr (TAILC) {
+            // The 128 staged values of a low-resolution pixel are conv7's 32 channels at its four high-resolution pixels (2y + py,
+            // 2x + px), channel (2 py + px) * 32 + c.  Task = (py, row, px), consecutive lanes = consecutive (row, px): a wave's two
+            // stores (seg, radial) are 256 contiguous bytes of one output row each.  ReLU and the head's two FMA chains over the 32
+            // channels in fp32 (the activation is not rounded to a stored pair here: it is never stored).
+            static_assert(!TAILC || BN == 128, "four parities x 32 channels");
+            float hw0[32], hw1[32];
+            {
+                const H16 *w8 = (const H16 *)p.w8 + (long long)g * p.w8_gs;
+#pragma unroll
+                for (int c = 0; c < 32; c++) {
+                    hw0[c] = (float)w8[c] + (float)w8[64 + c];
+                    hw1[c] = (float)w8[32 + c] + (float)w8[96 + c];
+                }
+            }
+            const float hb0 = p.b8[(long long)g * p.b8_gs], hb1 = p.b8[(long long)g * p.b8_gs + 1];
+            const float hs0 = p.b8[(long long)g * p.b8_gs + 2], hs1 = p.b8[(long long)g * p.b8_gs + 3];
+            const int Ho = 2 * p.H, Wo = 2 * p.W;
+            for (int t = tid; t < 2 * (2 * RW) * 2; t += 512) {
+                const int ppx = t & 1, lr = (t >> 1) % (2 * RW), ppy = (t >> 1) / (2 * RW);
+                const int r = half * 2 * RW + lr;
+                const int py = (int)(((float)r + 0.5f) * rT), px = r - py * p.tw;
+                const int y = y0 + py, x = x0 + px;
+                if (r >= npx || y >= p.H || x >= p.W) continue;
+                const float4 *sp4 = (const float4 *)(stg + lr * SROW + (ppy * 2 + ppx) * 32);
+                float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+                for (int c4 = 0; c4 < 8; c4++) {
+                    const float4 t4 = sp4[c4];
+                    const float v0 = fmaxf(t4.x, 0.f), v1 = fmaxf(t4.y, 0.f), v2 = fmaxf(t4.z, 0.f), v3 = fmaxf(t4.w, 0.f);
+                    rmax = fmaxf(fmaxf(rmax, fmaxf(v0, v1)), fmaxf(v2, v3));
+                    a0 = fmaf(v0, hw0[c4 * 4], a0); a1 = fmaf(v0, hw1[c4 * 4], a1);
+                    a0 = fmaf(v1, hw0[c4 * 4 + 1], a0); a1 = fmaf(v1, hw1[c4 * 4 + 1], a1);
+                    a0 = fmaf(v2, hw0[c4 * 4 + 2], a0); a1 = fmaf(v2, hw1[c4 * 4 + 2], a1);
+                    a0 = fmaf(v3, hw0[c4 * 4 + 3], a0); a1 = fmaf(v3, hw1[c4 * 4 + 3], a1);
+                }
+                const long long o = ((long long)(g * p.n_img + img) * Ho + (2 * y + ppy)) * Wo + (2 * x + ppx);
+                p.seg[o] = __fmaf_rn(a0, hs0, hb0);
+                const float o1 = __fmaf_rn(a1, hs1, hb1);
+                if (p.rad_f16) ((_Float16 *)p.radial)[o] = (_Float16)o1;
+                else p.radial[o] = o1;
+            }
+        } else
 #pragma unroll
         for (int pass = 0; pass < (2 * RW + RPR - 1) / RPR; pass++) {
             const int lr = pass * RPR + tid / CPR, cc = tid % CPR;  // row within the half, 16-byte chunk
@@ -1830,6 +1883,99 @@ __global__ __launch_bounds__(512) void k_conv_halo(const HaloParams p)
         if (half == 0) __syncthreads();
     }
     rng_flush(p.range, rmax);
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_tail_ring (engine option 13): the outermost ring of high-resolution pixels of the parity-composed tail, recomputed directly.
+// There the upsampling clamps and conv7 pads with zeros, which the composed low-resolution convolution (replicate padding) cannot
+// express: rows 0 and Ho - 1, columns 0 and Wo - 1 -- 0.7 % of the pixels.  A workgroup keeps conv7's weights as fp32 in LDS and walks
+// 64 ring pixels four at a time: thread = (pixel, channel) builds the 3 x 3 x 64 upsampled patches (zero outside the image), thread =
+// (pixel, tap parity, output channel) multiplies, then the tap sums, scale / bias, ReLU and the head.  fp32 VALU arithmetic.
+// ---------------------------------------------------------------------------------------------
+constexpr int RING_PX = 64;                                  // ring pixels per workgroup
+constexpr int RING_LDS = (9 * 64 * 33 + 4 * 9 * 64 + 4 * 32 * 9) * 4;  // conv7 weights [tap][ci][co + pad], four patches, partial sums
+__global__ __launch_bounds__(256) void k_tail_ring(const H16 *src, const H16 *w7, const float *b7, const H16 *w8, const float *b8, float *seg,
+                                                    float *radial, int B, int Hin, int Win, long long src_gs, long long w7_gs, int b7_gs,
+                                                    long long w8_gs, int b8_gs, int rad_f16)
+{
+    using T = H16;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float *sw = (float *)smem;               // [9 * 64][33]: conv7 weights as fp32 (hi + lo), row = tap * 64 + ci, column = co
+    float *su = sw + 9 * 64 * 33;            // [4 pixels][9 * 64]: upsampled patches (zero outside the image)
+    float *sp = su + 4 * 9 * 64;             // [4 pixels][32 co][9 taps]: partial sums
+    const int Ho = 2 * Hin, Wo = 2 * Win, ring = 2 * Wo + 2 * (Ho - 2);
+    const int g = blockIdx.z, img = blockIdx.y, tid = threadIdx.x;
+    {   // weights [co][tap][2 groups][32 hi | 32 lo] -> fp32 [tap * 64 + ci][co]
+        const T *w = w7 + (long long)g * w7_gs;
+        for (int e = tid; e < 32 * 9 * 64; e += 256) {
+            const int ci = e & 63, t = (e >> 6) % 9, co = e / 576;
+            const T *q = w + ((long long)co * 9 + t) * 128 + ((ci >> 5) << 6) + (ci & 31);
+            sw[(t * 64 + ci) * 33 + co] = (float)q[0] + (float)q[32];
+        }
+    }
+    const T *z = src + (long long)g * src_gs + (long long)img * Hin * Win * 128;  // 64 channels = two groups of [32 hi | 32 lo]
+    const float *bb = b7 + (long long)g * b7_gs;
+    const int pix = tid >> 6, c = tid & 63, coff = ((c >> 5) << 6) + (c & 31);   // patch build: thread = (pixel of four, channel)
+    const int co = tid & 31, tp = (tid >> 5) & 1, pq = tid >> 6;                 // multiply: thread = (pixel of four, tap parity, channel)
+    for (int p0 = blockIdx.x * RING_PX; p0 < min(ring, (int)(blockIdx.x + 1) * RING_PX); p0 += 4) {
+        __syncthreads();
+        {
+            const int idx = min(p0 + pix, ring - 1);
+            int Y, X;
+            if (idx < Wo) { Y = 0; X = idx; }
+            else if (idx < 2 * Wo) { Y = Ho - 1; X = idx - Wo; }
+            else { const int k = idx - 2 * Wo; Y = 1 + (k >> 1); X = (k & 1) ? Wo - 1 : 0; }
+            for (int t = 0; t < 9; t++) {
+                const int yy = Y + t / 3 - 1, xx = X + t % 3 - 1;
+                float u = 0.f;
+                if (yy >= 0 && yy < Ho && xx >= 0 && xx < Wo) {
+                    // align_corners = False: source coordinate (p + 0.5) / 2 - 0.5, clamped at 0 (PyTorch's area_pixel_compute_source_index)
+                    const float fy = fmaxf((yy + 0.5f) * 0.5f - 0.5f, 0.f), fx = fmaxf((xx + 0.5f) * 0.5f - 0.5f, 0.f);
+                    const int y0 = (int)fy, x0 = (int)fx, y1 = min(y0 + 1, Hin - 1), x1 = min(x0 + 1, Win - 1);
+                    const float ly = fy - (float)y0, lx = fx - (float)x0;
+                    auto at = [&](int yq, int xq) {
+                        const T *q = z + ((long long)yq * Win + xq) * 128 + coff;
+                        return (float)q[0] + (float)q[32];
+                    };
+                    u = (1.f - ly) * ((1.f - lx) * at(y0, x0) + lx * at(y0, x1)) + ly * ((1.f - lx) * at(y1, x0) + lx * at(y1, x1));
+                }
+                su[pix * 576 + t * 64 + c] = u;
+            }
+        }
+        __syncthreads();
+        {   // taps of this thread's parity (0: 0, 2, 4, 6, 8; 1: 1, 3, 5, 7), 64 channels each
+            const float *up = su + pq * 576;
+            for (int t = tp; t < 9; t += 2) {
+                float a = 0.f;
+#pragma unroll 16
+                for (int ci = 0; ci < 64; ci++) a = fmaf(up[t * 64 + ci], sw[(t * 64 + ci) * 33 + co], a);
+                sp[(pq * 32 + co) * 9 + t] = a;
+            }
+        }
+        __syncthreads();
+        if (tid < 128) {  // thread = (pixel, channel): the nine tap sums in order, scale / bias, ReLU -> su (reused: 32 floats per pixel)
+            const int q4 = tid >> 5, ch = tid & 31;
+            float a = 0.f;
+            for (int t = 0; t < 9; t++) a += sp[(q4 * 32 + ch) * 9 + t];
+            sp[(q4 * 32 + ch) * 9] = fmaxf(__fmaf_rn(a, bb[32 + ch], bb[ch]), 0.f);
+        }
+        __syncthreads();
+        if (tid < 8 && p0 + (tid >> 1) < min(ring, (int)(blockIdx.x + 1) * RING_PX)) {
+            const int q4 = tid >> 1, oc = tid & 1, idx = p0 + q4;
+            int Y, X;
+            if (idx < Wo) { Y = 0; X = idx; }
+            else if (idx < 2 * Wo) { Y = Ho - 1; X = idx - Wo; }
+            else { const int k = idx - 2 * Wo; Y = 1 + (k >> 1); X = (k & 1) ? Wo - 1 : 0; }
+            const T *h8 = w8 + (long long)g * w8_gs + oc * 32;
+            float a = 0.f;
+            for (int ci = 0; ci < 32; ci++) a = fmaf(sp[(q4 * 32 + ci) * 9], (float)h8[ci] + (float)h8[64 + ci], a);
+            const float outv = __fmaf_rn(a, b8[(long long)g * b8_gs + 2 + oc], b8[(long long)g * b8_gs + oc]);
+            const long long o = ((long long)(g * B + img) * Ho + Y) * Wo + X;
+            if (oc == 0) seg[o] = outv;
+            else if (rad_f16) ((_Float16 *)radial)[o] = (_Float16)outv;
+            else radial[o] = outv;
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -4567,6 +4713,8 @@ struct rcv_fcn {
     bool radial_f16 = false;  // the radial plane leaves the head as float16 (BASELINE.json stress configuration)
     bool use_lat = true;      // latency kernel (k_conv_lat) for launches with few tiles (small batches)
     int use_chain2 = 1;       // split engine: 1 = k_chain2_x3 (r04), 0 = k_chain_x3, 2 = k_chain3_x3 for the 256-wide block
+    int use_tailc = 0;        // split engine (13, measured experiment, off): (upsampling, conv7, head) as one parity-composed 3x3 on the low-resolution
+                              // tensor (+ k_tail_ring): 4.5 + 2.0 ms per forward of 53 x 3 against k_tail_x3's 6.1 (r05)
     int use_splitk = 0;       // latency option (12): split-K in k_conv_lat + k_splitk_finish for launches with few tiles (one or a few frames)
     float *splitk_ws = nullptr;  // ... its partial sums (allocated when the option is switched on, never on the hot path)
     size_t splitk_bytes = 0;
@@ -4883,6 +5031,9 @@ int register_kernel_attributes()
     RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_conv_halo<64, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, halo_lds(64)));
     RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_conv_halo<128, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, halo_lds(128)));
     RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_conv_halo<128, 5, true>, hipFuncAttributeMaxDynamicSharedMemorySize, halo_lds(128)));
+    RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_tail_ring, hipFuncAttributeMaxDynamicSharedMemorySize, RING_LDS));
+    RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_conv_halo<128, 4, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, halo_lds(128)));
+    RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_conv_halo<128, 5, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, halo_lds(128)));
     RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_stem_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, STEM_LDS));
     RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_tail, hipFuncAttributeMaxDynamicSharedMemorySize, TAIL_LDS));
     RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_tail_x3, hipFuncAttributeMaxDynamicSharedMemorySize, TX_LDS));
@@ -5050,7 +5201,38 @@ int forward_impl(rcv_fcn *h, const float *x, int B, float *seg, float *radial, c
                         RCV_HIP_CHECK(hipEventRecord(h->events[2 * i + 2], st));
                     }
                     dim3 grid((u.hout + TAIL_TH - 1) / TAIL_TH, B, h->groups);
-                    if constexpr (kX3)
+                    int tth = 0, ttw = 0;
+                    const bool tailc = kX3 && h->use_tailc && c.wq_off > 0 && u.c0 == 64 && h->use_halo &&
+                                       (long long)h->slot_elems[u.src0] * B * 4 < 0x7fffffffLL &&
+                                       halo_tile(u.hin, u.win, h->use_halo, 128, (long long)B * h->groups, tth, ttw) &&
+                                       (long long)B * ((u.hin + tth - 1) / tth) * ((u.win + ttw - 1) / ttw) * h->groups >= 192;
+                    if (tailc) {
+                        // (r05, option 13) conv7 on the x2 upsampling == a 3x3 convolution on the LOW-resolution tensor with 4 x 32
+                        // parity-stacked output channels (fcn_engine.compose_upsample_conv3): the halo kernel with replicate padding
+                        // and the head in its epilogue; the outermost ring of output pixels, where clamp and zero padding differ
+                        // from that, is recomputed by k_tail_ring.  No upsampled tensor, no VALU patch build.
+                        HaloParams q;
+                        memset(&q, 0, sizeof(q));
+                        q.th = tth; q.tw = ttw;
+                        q.src0 = ws + off[u.src0]; q.src0_gs = (long long)h->slot_elems[u.src0] * B * 2;
+                        q.w = (const H16 *)h->weights + c.wq_off; q.w_gs = (long long)128 * 9 * 128;
+                        q.bias = h->bias + c.b_off + (long long)h->groups * 64; q.bias_gs = 256;
+                        q.C0 = 128; q.C1 = 0; q.Cout = 128; q.H = u.hin; q.W = u.win; q.n_img = B; q.relu = 1; q.K = 9 * 128;
+                        q.tiles_y = (q.H + q.th - 1) / q.th; q.tiles_x = (q.W + q.tw - 1) / q.tw;
+                        q.range = h->range_dev;
+                        q.w8 = (const H16 *)h->weights + d.w_off; q.w8_gs = 128; q.b8 = h->bias + d.b_off; q.b8_gs = 4;
+                        q.seg = seg; q.radial = radial; q.rad_f16 = h->radial_f16 ? 1 : 0;
+                        const dim3 hgrid(1, (unsigned)(B * q.tiles_y * q.tiles_x), h->groups);
+                        if (q.th * q.tw > 256) hipLaunchKernelGGL((k_conv_halo<128, 5, false, true>), hgrid, dim3(512), halo_lds(128), st, q);
+                        else hipLaunchKernelGGL((k_conv_halo<128, 4, false, true>), hgrid, dim3(512), halo_lds(128), st, q);
+                        RCV_LAUNCH_CHECK();
+                        const int ring = 2 * (2 * u.win) + 2 * (2 * u.hin - 2);
+                        hipLaunchKernelGGL(k_tail_ring, dim3((ring + RING_PX - 1) / RING_PX, B, h->groups), dim3(256), RING_LDS, st, (const H16 *)(ws + off[u.src0]),
+                                           (const H16 *)h->weights + c.w_off, h->bias + c.b_off, (const H16 *)h->weights + d.w_off,
+                                           h->bias + d.b_off, seg, radial, B, u.hin, u.win, (long long)h->slot_elems[u.src0] * B * 2,
+                                           (long long)32 * 576 * 2, 64, (long long)128, 4, h->radial_f16 ? 1 : 0);
+                        RCV_LAUNCH_CHECK();
+                    } else if constexpr (kX3)
                         hipLaunchKernelGGL(k_tail_x3, dim3((u.hout + TX_TH - 1) / TX_TH, B, h->groups), dim3(256), TX_LDS, st, (const H16 *)(ws + off[u.src0]),
                                            (const H16 *)h->weights + c.w_off, h->bias + c.b_off, (const H16 *)h->weights + d.w_off,
                                            h->bias + d.b_off, seg, radial, B, u.hin, u.win, (long long)h->slot_elems[u.src0] * B * 2,
@@ -5324,6 +5506,7 @@ int rcv_fcn_set_option(rcv_fcn *h, int key, int value)
     if (key == 9) { h->use_lat = value != 0; return RCV_OK; }
     if (key == 10) { h->use_chain2 = value; return RCV_OK; }
     if (key == 11) { h->use_q6 = value; return RCV_OK; }
+    if (key == 13) { h->use_tailc = value; return RCV_OK; }
     if (key == 12) {
         if (value && !h->splitk_ws) {
             const size_t bytes = (size_t)48 << 20;  // the largest split launch of the FCN programs at up to 3 networks x 1 frame needs 11 MB

@@ -342,6 +342,41 @@ def q6_wanted(spec, op, pattern=Q6_DEFAULT):
             op["cout"] % 128 == 0 and re.fullmatch(pattern, spec["conv"]) is not None)
 
 
+# bilinear x2 (align_corners=False) seen from the 3x3 convolution that follows it: the high-resolution tap t - 1 (t = 0, 1, 2) of output
+# row 2i + p reads low-resolution rows i - 1, i, i + 1 with these weights (row p, then t, then k).  out[2i] = .25 in[i-1] + .75 in[i],
+# out[2i+1] = .75 in[i] + .25 in[i+1] (reference models/fcnresnet.py:93,177: nn.Upsample(scale_factor=2, mode='bilinear'))
+UP2_TAPS = (((0.75, 0.25, 0.0), (0.25, 0.75, 0.0), (0.0, 0.75, 0.25)),
+            ((0.25, 0.75, 0.0), (0.0, 0.75, 0.25), (0.0, 0.25, 0.75)))
+
+
+def compose_upsample_conv3(w):
+    """BN-folded float64 weights [cout, 3, 3, cin] of a 3x3 / pad-1 convolution that reads a x2 bilinear upsampling -> the weights
+    [4 * cout, 3, 3, cin] of the equivalent 3x3 convolution on the LOW-resolution tensor whose output channel (2 py + px) * cout + co
+    is channel co of the high-resolution pixel (2 i + py, 2 j + px) -- both maps are linear, the composition is exact.  (Away from
+    the image border: the upsampling clamps there and the convolution pads with zeros, so the outermost ring of high-resolution
+    pixels is recomputed separately: k_tail_ring.)"""
+    import torch
+
+    cout = w.shape[0]
+    C = torch.tensor(UP2_TAPS, dtype=torch.float64)                      # [parity, t, k]
+    # Wc[py, px, co, a, b, ci] = sum_{r, s} w[co, r, s, ci] C[py, r, a] C[px, s, b]
+    wc = torch.einsum("orsc,pra,qsb->pqoabc", w.to(torch.float64), C, C)
+    return wc.reshape(4 * cout, 3, 3, w.shape[3]).contiguous()
+
+
+def tail_composed_wanted(builder, i):
+    """Op i is the conv7 of a (x2 upsampling -> 3x3 convolution to 32 channels -> head) tail: the executor can run the three as ONE
+    3x3 convolution on the low-resolution tensor with 4 x 32 parity-stacked output channels + the head in its epilogue (engine
+    option 13), given the composed weights as the op's second copy."""
+    ops = builder.ops
+    if i < 1 or i + 1 >= len(ops):
+        return False
+    u, c, d = ops[i - 1], ops[i], ops[i + 1]
+    return (u["kind"] == _hip.OP_UPSAMPLE2 and c["kind"] == _hip.OP_CONV and d["kind"] == _hip.OP_HEAD and c["src0"] == u["dst"] and
+            c["src1"] < 0 and c["res"] < 0 and c["ksize"] == 3 and c["stride"] == 1 and c["pad"] == 1 and c["cout"] == 32 and
+            c["c0"] % 32 == 0 and d["src0"] == c["dst"] and d["c0"] == 32 and d["cout"] == 2 and c["relu"] == 1)
+
+
 def pack_weights(state_dicts, builder, ops, dtype, q6=False):
     """-> (weights tensor [engine dtype], bias tensor fp32, ops with w_off / b_off / wq_off filled)."""
     import torch
@@ -350,13 +385,14 @@ def pack_weights(state_dicts, builder, ops, dtype, q6=False):
     tdt = {_hip.RCV_F32: torch.float32, _hip.RCV_BF16: torch.bfloat16, _hip.RCV_F16: torch.float16,
            _hip.RCV_F16X3: torch.float16}[dtype]
     wparts, bparts, woff, boff = [], [], 0, 0
-    for op, spec in zip(ops, builder.wspecs):
+    for idx, (op, spec) in enumerate(zip(ops, builder.wspecs)):
         op["wq_off"] = 0
         if spec is None:
             op["w_off"], op["b_off"] = 0, 0
             continue
-        ws, bs, wq = [], [], []
+        ws, bs, wq, bq = [], [], [], []
         want_q6 = bool(q6) and dtype == _hip.RCV_F16X3 and q6_wanted(spec, op, Q6_DEFAULT if q6 is True else q6)
+        want_tailc = dtype == _hip.RCV_F16X3 and tail_composed_wanted(builder, idx)
         for sd in sds:
             w, b = fold_conv_bn(sd, spec, op["cout"])
             wmax = float(w.abs().max()) if w.numel() else 0.0
@@ -368,11 +404,15 @@ def pack_weights(state_dicts, builder, ops, dtype, q6=False):
                 bs.append(torch.cat([b.to(torch.float32), scale]))
                 if want_q6:
                     wq.append(pack_split_q6(w))
+                if want_tailc:  # the parity-composed weights [4 * cout][3][3][cin] and their [bias x 4 | scale] record
+                    flat_c, scale_c = pack_split(compose_upsample_conv3(w), op["kind"])
+                    wq.append(flat_c)
+                    bq.append(torch.cat([b.to(torch.float32).repeat(4), scale_c]))
             else:
                 ws.append(w.reshape(-1))
                 bs.append(b)
         wcat = torch.cat(ws).to(tdt)
-        bcat = torch.cat(bs).to(torch.float32)
+        bcat = torch.cat(bs + bq).to(torch.float32)  # (second-copy records of all networks BEHIND the first-copy records: strides unchanged)
         op["w_off"], op["b_off"] = woff, boff
         pad = (-wcat.numel()) % 64  # keep every op's weights 128-byte aligned for 16-byte vector loads
         if pad:
@@ -384,9 +424,9 @@ def pack_weights(state_dicts, builder, ops, dtype, q6=False):
         bparts.append(bcat)
         woff += wcat.numel()
         boff += bcat.numel()
-        if wq:  # the q6 copy of all groups, same strides as the first copy
+        if wq:  # the second copy of all groups (q6 rows: same strides as the first copy; parity-composed tail: four times the rows)
             qcat = torch.cat(wq)
-            assert qcat.numel() + pad == wcat.numel() and qcat.numel() % 64 == 0
+            assert qcat.numel() % 64 == 0 and (want_tailc or qcat.numel() + pad == wcat.numel())
             op["wq_off"] = woff
             wparts.append(qcat)
             woff += qcat.numel()

@@ -311,3 +311,39 @@ def test_latency_option_split_k_within_tolerance_and_repeatable(shapes, golden_d
         eng.set_option(12, 0)
         seg3, rad3 = eng.forward(x)
         assert torch.equal(rad3, rad0) and torch.equal(seg3, seg0)
+
+
+def test_x3_composed_tail_against_the_three_kernel_tail(shapes):
+    """Engine option 13 (a measured experiment, off by default): upsampling + conv7 + head as one parity-composed 3x3 convolution on
+    the low-resolution tensor (+ k_tail_ring for the outermost ring of pixels) against k_tail_x3 (the default) and against the three
+    separate kernels (option 3 = 0): the same function with another summation order -- whole maps within 5e-6, every border pixel
+    included; the float16 radial plane (option 8) likewise."""
+    from rcvpose_amd.fcn_engine import FcnEngine
+
+    sds = [_sd(shapes, s) for s in range(3)]
+    for (H, W, B) in ((480, 640, 2), (96, 160, 5)):
+        eng = FcnEngine(sds, H, W, dtype="f16x3")
+        assert any(o["wq_off"] for o in eng.ops if o["cout"] == 32)
+        x = torch.from_numpy(fcn_weights.make_input(41, (B, 3, H, W))).cuda()
+        eng.set_option(13, 1)
+        seg_a, rad_a = [t.clone() for t in eng.forward(x)]
+        eng.set_option(13, 0)
+        seg_b, rad_b = [t.clone() for t in eng.forward(x)]
+        eng.set_option(3, 0)
+        seg_c, rad_c = [t.clone() for t in eng.forward(x)]
+        assert torch.equal(seg_b, seg_c) and torch.equal(rad_b, rad_c)      # (the bit-identical family)
+        for g in range(3):
+            er = float((rad_a[g] - rad_b[g]).abs().max() / rad_b[g].abs().max())
+            es = float((seg_a[g] - seg_b[g]).abs().max() / seg_b[g].abs().max())
+            ring = torch.ones_like(rad_b[g], dtype=torch.bool)
+            ring[..., 1:-1, 1:-1] = False
+            err_ring = float((rad_a[g] - rad_b[g])[ring].abs().max() / rad_b[g].abs().max())
+            print("%dx%d network %d: composed tail vs k_tail_x3: radial %.2e (ring %.2e) seg %.2e" % (H, W, g, er, err_ring, es))
+            assert er <= 5e-6 and es <= 5e-6
+        assert not torch.equal(rad_a, rad_b)
+        eng.set_option(3, 1)
+        eng.set_option(13, 1)
+        eng.set_option(8, 1)
+        seg_h, rad_h = eng.forward(x)
+        assert rad_h.dtype == torch.float16 and torch.equal(rad_h, rad_a.to(torch.float16)) and torch.equal(seg_h, seg_a)
+        assert eng.range_status() == 0

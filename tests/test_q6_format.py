@@ -68,10 +68,10 @@ def test_q6_weight_rows_and_program_flags(golden_dir):
     b = fcn_engine.build_program(64, 96)
     ops, _ = fcn_engine.assign_slots(b)
     w, bias, ops = fcn_engine.pack_weights([sd], b, ops, _hip.RCV_F16X3, q6=True)
-    flagged = [(o, sp) for o, sp in zip(ops, b.wspecs) if o.get("wq_off", 0)]
+    flagged = [(o, sp) for o, sp in zip(ops, b.wspecs) if o.get("wq_off", 0) and o["cout"] % 128 == 0]   # (conv7's second copy is the composed tail's)
     assert len(flagged) == 44 and all(sp["conv"][:7] in ("block2.", "block3.", "block4.") and sp["conv"].endswith(".conv2") for _, sp in flagged)
     w_off = fcn_engine.pack_weights([sd], b, [dict(o) for o in ops], _hip.RCV_F16X3, q6=False)[0]
-    assert w.numel() == w_off.numel() + (7 * 128 * 128 + 35 * 256 * 256 + 2 * 512 * 512) * 9 * 2
+    assert w.numel() == w_off.numel() + (7 * 128 * 128 + 35 * 256 * 256 + 2 * 512 * 512) * 9 * 2   # (both carry the composed tail copy)
     o, sp = [f for f in flagged if f[1]["conv"].startswith("block3.")][0]
     n = 256 * 9 * 256 * 2
     first = w[o["w_off"]:o["w_off"] + n].view(torch.uint8).numpy().reshape(256, 9, 8, 128)
@@ -86,3 +86,23 @@ def test_q6_weight_rows_and_program_flags(golden_dir):
         np.testing.assert_array_equal(c, ce)
         np.testing.assert_array_equal(s, se)
         assert not q[..., 64 + 16 * k + 12].any() and not q[..., 64 + 16 * k + 13].any() and not q[..., 64 + 16 * k + 15].any()
+
+
+def test_composed_tail_weights_equal_upsampling_followed_by_the_convolution():
+    """fcn_engine.compose_upsample_conv3 (engine option 13): a 3x3 convolution on the x2 bilinear upsampling (reference
+    models/fcnresnet.py:177-183) == the composed 3x3 convolution on the replicate-padded low-resolution tensor, parity by parity,
+    everywhere but on the outermost ring of output pixels (which k_tail_ring recomputes)."""
+    import torch.nn.functional as F
+
+    torch.manual_seed(0)
+    w = torch.randn(6, 3, 3, 8, dtype=torch.float64)
+    z = torch.randn(2, 8, 7, 9, dtype=torch.float64)
+    ref = F.conv2d(F.interpolate(z, scale_factor=2, mode="bilinear", align_corners=False), w.permute(0, 3, 1, 2), padding=1)
+    wc = fcn_engine.compose_upsample_conv3(w)
+    low = F.conv2d(F.pad(z, (1, 1, 1, 1), mode="replicate"), wc.permute(0, 3, 1, 2))
+    out = low.reshape(2, 2, 2, 6, 7, 9).permute(0, 3, 4, 1, 5, 2).reshape(2, 6, 14, 18)
+    assert float((out - ref)[:, :, 1:-1, 1:-1].abs().max()) < 1e-12
+    assert float((out - ref).abs().max()) > 1e-3       # ... the ring really differs
+    b = fcn_engine.build_program(64, 96)
+    assert [i for i in range(len(b.ops)) if fcn_engine.tail_composed_wanted(b, i)] == [len(b.ops) - 2]
+    assert not any(fcn_engine.tail_composed_wanted(fcn_engine.build_program_res(64, 96), i) for i in range(10))
