@@ -648,7 +648,8 @@ def main(argv=None):
         line["precision"] = measured_precision(pipe, sds, H, W)
         line["precision_meets_tolerance"] = bool(line["precision"]["radial_map_rel_err_vs_fp32_engine"] <= MAP_TOLERANCE and
                                                  line["precision"]["seg_map_rel_err_vs_fp32_engine"] <= MAP_TOLERANCE)
-        ok = ok and line["precision_meets_tolerance"] and line["precision"]["range_flags_of_timed_engine"] == 0
+        line["precision_gate_applies"] = args.dtype in PARITY_DTYPES  # (bf16 / fp16 are throughput modes outside the tolerance: reported, not gated)
+        ok = ok and (line["precision_meets_tolerance"] or args.dtype not in PARITY_DTYPES) and line["precision"]["range_flags_of_timed_engine"] == 0
         sweep = next((q for q in (os.path.join(ROOT, "profiles", n) for n in ("r05_vote_sweep.json", "r04_vote_sweep.json", "r03_vote_sweep.json")) if os.path.exists(q)), "")
         if os.path.exists(sweep):  # data dependence of the peak search (tools/vote_sweep.py), a committed measurement, not this run
             sj = json.load(open(sweep))
