@@ -459,7 +459,6 @@ def main(argv=None):
     for s in range(args.warmup):
         step_fn(s)
     fence()
-    cal = [calibrate()]
     pipe.engine.set_profiling(True)   # HIP events around every FCN op, on the launch stream
     # EXACTLY `steps` steps are timed, bracketed by barrier + synchronize, max over ranks -- and that region is run REGIONS times
     # back to back: `value` is the median region, the others are reported (a 3 % kernel gain must not drown in run-to-run spread)
@@ -483,7 +482,9 @@ def main(argv=None):
         regions.append(dict(seconds=float(tmax.item()), prof=pipe.engine.get_profile(), stages=pipe.stage_times(), mfma_bound_ms=mfma_ms))
         pipe.set_stage_timing(False)
     pipe.engine.set_profiling(False)
-    cal.append(calibrate())
+    # (r06: both samples AFTER the regions -- three quarters of a second of full-chip MFMA load right in front of region 0 would
+    # pre-heat the device the regions are then timed on)
+    cal = [calibrate(), calibrate()]
     order = sorted(range(REGIONS), key=lambda i: regions[i]["seconds"])
     med = regions[order[REGIONS // 2]]
     dt, prof, stages, mfma_bound_ms = med["seconds"], med["prof"], med["stages"], med["mfma_bound_ms"]
@@ -581,7 +582,7 @@ def main(argv=None):
                               "frames_per_s": [frames_total / r["seconds"] for r in regions],
                               "min": frames_total / max(r["seconds"] for r in regions), "max": frames_total / min(r["seconds"] for r in regions)},
             "calibration": {"mfma_loop_tflops": calib_tf, "shader_clock_mhz_in_that_loop": calib_mhz, "samples": [list(c) for c in cal],
-                            "what": "rcv_mfma_calibrate: bare v_mfma_f32_16x16x32_f16 loop on every SIMD, 0.25 s, before and after the timed regions "
+                            "what": "rcv_mfma_calibrate: bare v_mfma_f32_16x16x32_f16 loop on every SIMD, 0.25 s, twice, after the timed regions "
                                     "(rank 0's device): the dense fp16 rate THIS box holds; boxes differ by several per cent",
                             "reference_tflops": CALIB_REF_TFLOPS,
                             "mfma_bound_ms_per_step": mfma_bound_ms,

@@ -44,7 +44,15 @@ typedef enum rcv_status {
 } rcv_status;
 
 const char *rcv_strerror(int status);
+/* ABI version of this header: bumped whenever a struct layout, an entry point's signature or a documented behaviour changes
+ * (600 = round 6: rcv_op grew wq_off (88 bytes), rcv_fcn_range_status takes a stream, rcv_abi_check, RCV_SEAM_COUNT_NONFINITE).
+ * rcv_version() returns the library's value; a binding compiled against another header must refuse to run (an ops array with
+ * the wrong stride would be read as a garbage program): call rcv_abi_check once after loading the library. */
+#define RCV_ABI_VERSION 600
 int rcv_version(void);
+/* RCV_OK iff the caller's header matches the library: version == rcv_version() and the struct sizes the caller compiled
+ * (sizeof(rcv_op), sizeof(rcv_acc_result), sizeof(rcv_strided), sizeof(rcv_icp_result)) equal the library's; RCV_E_INVALID otherwise. */
+int rcv_abi_check(int version, size_t sizeof_op, size_t sizeof_acc_result, size_t sizeof_strided, size_t sizeof_icp_result);
 /* Text of the last failing HIP call in this process (for RCV_E_HIP). */
 const char *rcv_last_hip_error(void);
 /* Measurement aid (bench.py; no reference counterpart): runs a bare v_mfma_f32_16x16x32_f16 loop on every SIMD of the device for
@@ -76,6 +84,11 @@ typedef struct rcv_acc_result {
 } rcv_acc_result;
 
 #define RCV_SEAM_RADIAL_F16 256
+/* rcv_seam_compact[_batch] mode bit: `counts` has room for FOUR int32 per item and the seam also writes counts[2] = the number of
+ * pixels whose segmentation or radial value is not finite (NaN / Inf -- the mask comparisons silently drop such pixels, here as in
+ * the reference, AccumulatorSpace.py:603-610; a caller that wants to refuse such maps reads the count with its results).  counts[3]
+ * is written as 0. */
+#define RCV_SEAM_COUNT_NONFINITE 512
 
 /* Bytes of workspace for rcv_seam_compact / rcv_accumulate_3d for clouds of up to max_points points (and radii).
  * rcv_acc_workspace_bytes_min is what every call needs (~45 MB at 640x480); rcv_acc_workspace_bytes adds the replica area
@@ -296,8 +309,10 @@ typedef struct rcv_op {
     int32_t relu;
     int64_t w_off;           /* element offset of this op's weights [G][cout][k][k][c0+c1] in the weight blob */
     int64_t b_off;           /* element offset of this op's fp32 bias [G][cout] in the bias blob */
-    int64_t wq_off;          /* RCV_F16X3: element offset of a second copy of this op's weights in the q6 row layout (engine
-                              * option 11, below), or 0 = none */
+    int64_t wq_off;          /* RCV_F16X3: element offset of a SECOND copy of this op's weights, or 0 = none.  For a 3x3 / stride-1 op:
+                              * the q6 row layout (engine option 11, below).  For the conv7 op of the tail (the 3x3 behind the last
+                              * upsampling): the parity-composed weights [G][4 * cout][3][3][cin] of engine option 13, whose
+                              * [bias x 4 | scale] records sit behind the first copy's in the bias blob */
 } rcv_op;
 
 typedef struct rcv_fcn rcv_fcn; /* opaque engine handle */
@@ -373,9 +388,13 @@ int rcv_fcn_set_profiling(rcv_fcn *h, int enable);
  * rewritten in place (k_q6_pack) into rows [32 hi halves | 4 x (16 e2m3 codes in 12 bytes, e8m0 block scale in byte 12, 3 zero
  * bytes)] for the blocks hi[0:16], hi[16:32], lo[0:16], lo[16:32] of each 32-channel group; the q6 weight rows are
  * [32 hi halves | lo[0:16], lo[16:32], hi[0:16], hi[16:32]] with the scale in byte 14 of each 16-byte chunk; block scale
- * 2^(floor(log2 max|block|) - 2), codes rounded to nearest even, saturating at 7.5.  rcvpose_amd/fcn_engine.py requests it for
- * the 3x3 convolutions of layer 3 only (measured map error 1-2e-5 instead of 0.4-0.8e-5; every 3x3 layer: 6-7e-5,
- * tools/probe/fp8_cross_probe.py).  0: three half-precision MFMAs everywhere (the bit-identical family of kernels).
+ * 2^(floor(log2 max|block|) - 2), codes rounded to nearest even, saturating at 7.5.  The key only ENABLES the form: an op takes it
+ * when its wq_off names a q6 copy, so the feature is opt-in per op through the program.  rcvpose_amd/fcn_engine.py packs q6 copies
+ * only on request (FcnEngine(q6=True) / a regular expression over op names; its Q6_DEFAULT = the 44 stride-1 3x3 convolutions of
+ * layers 2-4, `block[234].N.conv2`): measured map error against the fp32 engine 2-8e-5 on the bench networks (3.4e-5 -> 7.8e-5 on the
+ * worst one; layers 2 + 4 alone: unchanged; every 3x3 layer incl. the decoder: 6e-5 and more per layer group, tools/q6_precision.py,
+ * profiles/r05_q6_precision.txt) -- most of the 1e-4 tolerance, which is why the Python default is off.  0: three half-precision
+ * MFMAs everywhere (the bit-identical family of kernels).
  * key 12 (default 0, 16-bit and split engines): latency option for one or a few frames in flight (the reference calls the model
  * frame by frame, AccumulatorSpace.py:596).  Launches of k_conv_lat with far fewer tiles than the chip has CUs deal their K steps
  * over S workgroups per tile (S depends on the layer's shape only) and a second kernel adds the S partial sums in a fixed order

@@ -37,6 +37,14 @@ add_threshold = {
     'phone': .02543407135792}
 
 DEFAULT_FRAMES_PER_STEP = 53  # frames per device batch of the evaluation drivers (bench.py's optimum for the f16x3 forward)
+
+
+def default_eval_threads():
+    """Host threads for the per-frame Horn / ADD(-S) / ICP evaluation: 16 overlap a batch's chains of small launches on a GPU box
+    (128 hardware threads there); never more than the host has."""
+    import os
+
+    return max(1, min(16, os.cpu_count() or 1))
 ACC_UNIT_MM = 5.0  # reference AccumulatorSpace.py:374 hard-codes 5 mm voxels
 SEG_THRESHOLD = 0.8  # reference AccumulatorSpace.py:603
 
@@ -507,15 +515,33 @@ def estimate_6d_pose_lm(opts, return_details=False):
             # 31 padded frames of wasted work
             # (the default of 53 is tuned for one MI355X with 288 GB: on a smaller or shared device the workspaces of a batch may not
             # fit -- halve the batch until they do; results do not depend on it)
-            while True:
+            # The engine is built ONCE; the batch is then sized from the free device memory and the byte counts of a batch's
+            # workspaces (nothing is allocated to find out), and an allocation that fails all the same -- another process took the
+            # memory in between -- is retried with half the batch OUTSIDE the except block (inside it the traceback still holds the
+            # failed pipeline's tensors, so nothing could be released), whether torch's allocator or a hipMalloc of the library refused.
+            from .fcn_engine import FcnEngine
+            import gc
+
+            dtype_ = getattr(opts, 'dtype', 'f16x3')
+            fcn = FcnEngine(sds, H, W, dtype=dtype_)
+            pipe = None
+            while pipe is None:
                 n_batches = (len(todo) + n_step - 1) // n_step
                 n_step = (len(todo) + n_batches - 1) // n_batches
-                try:
-                    pipe = FramePipeline(sds, H, W, dtype=getattr(opts, 'dtype', 'f16x3'), frames_per_step=n_step)
-                    break
-                except _torch().cuda.OutOfMemoryError:
+                free_b = _torch().cuda.mem_get_info()[0] + _torch().cuda.memory_reserved() - _torch().cuda.memory_allocated()
+                need_b = FramePipeline.device_bytes(fcn, n_step, H, W, len(sds))
+                failed = need_b > 0.95 * free_b
+                if not failed:
+                    try:
+                        pipe = FramePipeline(sds, H, W, dtype=dtype_, frames_per_step=n_step, fcn=fcn)
+                    except (_torch().cuda.OutOfMemoryError, _hip.HipLibraryError) as e:
+                        if isinstance(e, _hip.HipLibraryError) and 'memory' not in str(e).lower():
+                            raise
+                        failed = True
+                if failed:
                     if n_step == 1:
-                        raise
+                        raise MemoryError('the workspaces of one frame (%.1f GB) do not fit the device (%.1f GB free)' % (need_b / 1e9, free_b / 1e9))
+                    gc.collect()
                     _torch().cuda.empty_cache()
                     n_step = max(1, n_step // 2)
                     print('frames_per_step reduced to %d (device memory)' % n_step)
@@ -545,7 +571,7 @@ def estimate_6d_pose_lm(opts, return_details=False):
             kpts_model = keypoints[1:4, :] * 1000
             import threading
 
-            n_eval = max(1, int(getattr(opts, 'eval_threads', 16)))  # (main.py's default)
+            n_eval = max(1, int(getattr(opts, 'eval_threads', default_eval_threads())))  # (main.py's default)
             tls = threading.local()
 
             def worker_stream():

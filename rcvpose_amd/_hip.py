@@ -21,6 +21,8 @@ RCV_E_UNSUPPORTED = -8
 RCV_E_RANGE = -9
 
 RCV_SEAM_RADIAL_F16 = 256
+RCV_SEAM_COUNT_NONFINITE = 512  # counts then holds four int32 per item: [points, radii, non-finite pixels, 0]
+ABI_VERSION = 600  # RCV_ABI_VERSION of include/rcvpose_hip.h
 RCV_VOTE_AUTO, RCV_VOTE_RASTER = 0, 1
 VOTE_ENGINES = {"auto": RCV_VOTE_AUTO, "full": RCV_VOTE_RASTER}
 
@@ -91,6 +93,7 @@ _vp, _i, _d, _f, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_double, ctypes.c_
 SYMBOLS = {
     "rcv_strerror": (ctypes.c_char_p, [_i]),
     "rcv_version": (_i, []),
+    "rcv_abi_check": (_i, [_i, _sz, _sz, _sz, _sz]),
     "rcv_last_hip_error": (ctypes.c_char_p, []),
     "rcv_init": (_i, []),
     "rcv_mfma_calibrate": (_i, [_d, ctypes.POINTER(_d), ctypes.POINTER(_d), _vp]),
@@ -162,6 +165,11 @@ def load_library():
         fn.argtypes = args
     if missing:  # header and library out of sync: refuse to run anything
         raise HipLibraryError("librcvpose_hip.so lacks symbols declared in include/rcvpose_hip.h: " + ", ".join(missing))
+    # same header on both sides: version and the struct layouts this binding declares (an ops array with another stride would be
+    # read as a garbage program)
+    if lib.rcv_abi_check(ABI_VERSION, ctypes.sizeof(Op), ctypes.sizeof(AccResult), ctypes.sizeof(Strided), ctypes.sizeof(IcpResult)) != 0:
+        raise HipLibraryError("librcvpose_hip.so (ABI %d) does not match this binding (ABI %d, sizeof rcv_op %d): rebuild with "
+                              "`python -m rcvpose_amd.build --force`" % (lib.rcv_version(), ABI_VERSION, ctypes.sizeof(Op)))
     _lib = lib
     return lib
 

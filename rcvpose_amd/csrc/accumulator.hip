@@ -291,9 +291,9 @@ template <typename RT>
 __device__ __forceinline__ void d_seam_count(const float *seg, const RT *rad, const uint16_t *depth, int HW,
                                                     float thr, double rmax, int mode, int2 *blk_counts)
 {
-    __shared__ int sp[4], sr[4];
+    __shared__ int sp[4], sr[4], sn[4];
     const int base = blockIdx.x * SEAM_PIX_PER_BLOCK;
-    int cp = 0, cr = 0;
+    int cp = 0, cr = 0, cn = 0;
     for (int j = 0; j < 4; j++) {
         int p = base + j * 256 + threadIdx.x;
         if (p < HW) {
@@ -301,27 +301,39 @@ __device__ __forceinline__ void d_seam_count(const float *seg, const RT *rad, co
             seam_flags(seg, rad, depth, p, thr, rmax, mode, mr, mp);
             cp += mp;
             cr += mr;
+            // RCV_SEAM_COUNT_NONFINITE: NaN / Inf in the maps (the comparisons above drop such pixels without a trace)
+            cn += ((mode == 0 || mode == 3) && !isfinite(seg[p])) || ((mode == 0 || mode == 1) && !isfinite((float)rad[p]));
         }
     }
     cp = wave_sum_i32(cp);
     cr = wave_sum_i32(cr);
-    if (lane_id() == 0) { sp[wave_id()] = cp; sr[wave_id()] = cr; }
+    cn = wave_sum_i32(cn);
+    if (lane_id() == 0) { sp[wave_id()] = cp; sr[wave_id()] = cr; sn[wave_id()] = cn; }
     __syncthreads();
-    if (threadIdx.x == 0) blk_counts[blockIdx.x] = make_int2(sp[0] + sp[1] + sp[2] + sp[3], sr[0] + sr[1] + sr[2] + sr[3]);
+    // a block holds SEAM_PIX_PER_BLOCK = 1024 pixels: the radii count in bits 0..15 of .y, the non-finite count in bits 16..31
+    if (threadIdx.x == 0)
+        blk_counts[blockIdx.x] = make_int2(sp[0] + sp[1] + sp[2] + sp[3], (sr[0] + sr[1] + sr[2] + sr[3]) | ((sn[0] + sn[1] + sn[2] + sn[3]) << 16));
 }
 
-__device__ __forceinline__ void d_seam_scan(const int2 *blk_counts, int nb, int2 *blk_offsets, int32_t *counts_out)
+__device__ __forceinline__ void d_seam_scan(const int2 *blk_counts, int nb, int2 *blk_offsets, int32_t *counts_out, int want_nonfinite)
 {
     __shared__ int2 s[1024];
+    __shared__ int s_nf;
     const int t = threadIdx.x;
+    if (t == 0) s_nf = 0;
+    __syncthreads();
     int2 loc[4];
     int2 sum = make_int2(0, 0);
+    int nf = 0;
     for (int j = 0; j < 4; j++) {
         int b = t * 4 + j;
         loc[j] = b < nb ? blk_counts[b] : make_int2(0, 0);
+        nf += (int)((unsigned)loc[j].y >> 16);
+        loc[j].y &= 0xFFFF;
         sum.x += loc[j].x;
         sum.y += loc[j].y;
     }
+    if (nf) atomicAdd(&s_nf, nf);
     s[t] = sum;
     __syncthreads();
     for (int off = 1; off < 1024; off <<= 1) {
@@ -339,7 +351,11 @@ __device__ __forceinline__ void d_seam_scan(const int2 *blk_counts, int nb, int2
         run.x += loc[j].x;
         run.y += loc[j].y;
     }
-    if (t == 1023) { counts_out[0] = s[t].x; counts_out[1] = s[t].y; }
+    if (t == 1023) {
+        counts_out[0] = s[t].x;
+        counts_out[1] = s[t].y;
+        if (want_nonfinite) { counts_out[2] = s_nf; counts_out[3] = 0; }  // (s_nf is complete: every add precedes the scan's barriers)
+    }
 }
 
 template <typename RT>
@@ -2190,10 +2206,10 @@ __global__ __launch_bounds__(256) void k_seam_count(SP<const float> seg, SP<cons
     d_seam_count<RT>(seg.get(), rad.get(), depth.get(), HW, thr, rmax.p ? *rmax.get() : rmax_scalar, mode,
                      (int2 *)(ws.get() + L.seam_counts));
 }
-__global__ __launch_bounds__(1024) void k_seam_scan(int nb, SP<int32_t> counts, SP<unsigned char> ws, Layout L)
+__global__ __launch_bounds__(1024) void k_seam_scan(int nb, SP<int32_t> counts, SP<unsigned char> ws, Layout L, int want_nonfinite)
 {
     unsigned char *w = ws.get();
-    d_seam_scan((const int2 *)(w + L.seam_counts), nb, (int2 *)(w + L.seam_offsets), counts.get());
+    d_seam_scan((const int2 *)(w + L.seam_counts), nb, (int2 *)(w + L.seam_offsets), counts.get(), want_nonfinite);
 }
 template <typename RT>
 __global__ __launch_bounds__(256) void k_seam_scatter(SP<const float> seg, SP<const RT> rad, SP<const uint16_t> depth, int HW,
@@ -2618,7 +2634,8 @@ static int seam_batch(rcv_strided seg, rcv_strided rad, rcv_strided depth, int H
 {
     if (!depth.ptr || !K || !xyz.ptr || !counts.ptr || !ws.ptr) return RCV_E_INVALID;
     const bool rad_f16 = (mode & RCV_SEAM_RADIAL_F16) != 0;
-    mode &= ~RCV_SEAM_RADIAL_F16;
+    const int want_nonfinite = (mode & RCV_SEAM_COUNT_NONFINITE) != 0;
+    mode &= ~(RCV_SEAM_RADIAL_F16 | RCV_SEAM_COUNT_NONFINITE);
     if (mode < 0 || mode > 3) return RCV_E_INVALID;
     if (mode != 2 && (!rad.ptr || !rlist.ptr)) return RCV_E_INVALID;
     if ((mode == 0 || mode == 3) && !seg.ptr) return RCV_E_INVALID;
@@ -2644,7 +2661,7 @@ static int seam_batch(rcv_strided seg, rcv_strided rad, rcv_strided depth, int H
                            rmax_scalar, mode, sws, L);
     RCV_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_seam_scan, dim3(1, n_frames, n_kp), dim3(1024), 0, st, nb,
-                       SP<int32_t>{(int32_t *)counts.ptr, counts.stride_frame, counts.stride_kp}, sws, L);
+                       SP<int32_t>{(int32_t *)counts.ptr, counts.stride_frame, counts.stride_kp}, sws, L, want_nonfinite);
     RCV_LAUNCH_CHECK();
     const SP<double> sxyz{(double *)xyz.ptr, xyz.stride_frame, xyz.stride_kp};
     const SP<float> srl{(float *)rlist.ptr, rlist.stride_frame, rlist.stride_kp};

@@ -64,35 +64,53 @@ __global__ __launch_bounds__(256) void k_mfma_calibrate(float *sink, unsigned lo
 
 extern "C" {
 
+namespace {
+// frees what rcv_mfma_calibrate allocated on every way out (the checks below return early)
+struct CalBuffers {
+    float *sink = nullptr;
+    unsigned long long *ticks = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    ~CalBuffers()
+    {
+        if (e0) (void)hipEventDestroy(e0);
+        if (e1) (void)hipEventDestroy(e1);
+        if (sink) (void)hipFree(sink);
+        if (ticks) (void)hipFree(ticks);
+    }
+};
+}  // namespace
+
 int rcv_mfma_calibrate(double seconds, double *tflops_out, double *clock_mhz_out, void *stream)
 {
     if (!(seconds > 0) || seconds > 10 || !tflops_out) return RCV_E_INVALID;
     hipStream_t st = (hipStream_t)stream;
-    const int blocks = 256 * 4;  // four workgroups of four waves per CU, taken one after the other per SIMD
-    float *sink = nullptr;
-    unsigned long long *ticks = nullptr;
-    RCV_HIP_CHECK(hipMalloc((void **)&sink, (size_t)blocks * 256 * sizeof(float)));
-    RCV_HIP_CHECK(hipMalloc((void **)&ticks, (size_t)blocks * 2 * sizeof(unsigned long long)));
-    hipEvent_t e0, e1;
-    RCV_HIP_CHECK(hipEventCreate(&e0));
-    RCV_HIP_CHECK(hipEventCreate(&e1));
+    int dev = 0;
+    hipDeviceProp_t prop;
+    RCV_HIP_CHECK(hipGetDevice(&dev));
+    RCV_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
+    const int blocks = std::max(1, prop.multiProcessorCount) * 4;  // four workgroups of four waves per CU, taken one after the other per SIMD
+    CalBuffers B;
+    RCV_HIP_CHECK(hipMalloc((void **)&B.sink, (size_t)blocks * 256 * sizeof(float)));
+    RCV_HIP_CHECK(hipMalloc((void **)&B.ticks, (size_t)blocks * 2 * sizeof(unsigned long long)));
+    RCV_HIP_CHECK(hipEventCreate(&B.e0));
+    RCV_HIP_CHECK(hipEventCreate(&B.e1));
     int iters = 20000;  // 16 MFMAs per iteration
     double tf = 0, mhz = 0;
     for (int pass = 0; pass < 3; pass++) {  // pass 0 sizes the loop (and warms the clock governor), the last one is reported
-        RCV_HIP_CHECK(hipEventRecord(e0, st));
-        hipLaunchKernelGGL(rcv::k_mfma_calibrate, dim3(blocks), dim3(256), 0, st, sink, ticks, iters);
+        RCV_HIP_CHECK(hipEventRecord(B.e0, st));
+        hipLaunchKernelGGL(rcv::k_mfma_calibrate, dim3(blocks), dim3(256), 0, st, B.sink, B.ticks, iters);
         RCV_LAUNCH_CHECK();
-        RCV_HIP_CHECK(hipEventRecord(e1, st));
-        RCV_HIP_CHECK(hipEventSynchronize(e1));
+        RCV_HIP_CHECK(hipEventRecord(B.e1, st));
+        RCV_HIP_CHECK(hipEventSynchronize(B.e1));
         float ms = 0.f;
-        RCV_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+        RCV_HIP_CHECK(hipEventElapsedTime(&ms, B.e0, B.e1));
         const double flop = (double)blocks * 4 * iters * 16.0 * (2.0 * 16 * 16 * 32);
         tf = flop / (ms * 1e-3) / 1e12;
         if (pass == 0) iters = (int)std::min(4.0e6, std::max(1000.0, iters * seconds * 1e3 / std::max(ms, 1e-3f)));
     }
     if (clock_mhz_out) {
         std::vector<unsigned long long> h((size_t)blocks * 2);
-        RCV_HIP_CHECK(hipMemcpy(h.data(), ticks, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        RCV_HIP_CHECK(hipMemcpy(h.data(), B.ticks, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
         std::vector<double> f;
         for (int i = 0; i < blocks; i++)
             if (h[2 * i + 1]) f.push_back((double)h[2 * i] / (double)h[2 * i + 1] * 100.0);  // s_memrealtime ticks at 100 MHz
@@ -101,10 +119,6 @@ int rcv_mfma_calibrate(double seconds, double *tflops_out, double *clock_mhz_out
         *clock_mhz_out = mhz;
     }
     *tflops_out = tf;
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
-    (void)hipFree(sink);
-    (void)hipFree(ticks);
     return RCV_OK;
 }
 
@@ -125,7 +139,15 @@ const char *rcv_strerror(int status)
     }
 }
 
-int rcv_version(void) { return 100; }
+int rcv_version(void) { return RCV_ABI_VERSION; }
+
+int rcv_abi_check(int version, size_t sizeof_op, size_t sizeof_acc_result, size_t sizeof_strided, size_t sizeof_icp_result)
+{
+    return (version == RCV_ABI_VERSION && sizeof_op == sizeof(rcv_op) && sizeof_acc_result == sizeof(rcv_acc_result) &&
+            sizeof_strided == sizeof(rcv_strided) && sizeof_icp_result == sizeof(rcv_icp_result))
+               ? RCV_OK
+               : RCV_E_INVALID;
+}
 
 const char *rcv_last_hip_error(void)
 {

@@ -505,6 +505,10 @@ class FcnEngine:
         except Exception:
             pass
 
+    def workspace_bytes(self, B):
+        """Device bytes of the activation workspace for a batch of B images (nothing is allocated)."""
+        return int(self.lib.rcv_fcn_workspace_bytes(self.handle, B))
+
     def workspace(self, B):
         import torch
 

@@ -4,6 +4,7 @@ Same flags as the reference plus `--using_ckpts` (which the reference's test pat
 but main.py forgot to define) and `--dtype`."""
 import argparse
 
+from .AccumulatorSpace import default_eval_threads
 from .train import Trainer
 from .utils import get_config, str2bool
 
@@ -30,7 +31,7 @@ def build_parser():
     p.add_argument('--frames_per_step', type=int, default=53,
                    help="frames of a class that travel through the device pipeline together (LINEMOD loop with checkpoints; default: "
                         "bench.py's batch); results do not depend on it")
-    p.add_argument('--eval_threads', type=int, default=16,
+    p.add_argument('--eval_threads', type=int, default=default_eval_threads(),
                    help="host threads (one HIP stream each) for the per-frame Horn / ADD(-S) / ICP evaluation of a batch")
     return p
 

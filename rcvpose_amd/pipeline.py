@@ -16,11 +16,12 @@ from . import _hip, fcn_engine
 
 class FramePipeline:
     def __init__(self, state_dicts, H=480, W=640, dtype="f16x3", frames_per_step=1, K=A.linemod_K, acc_unit=A.ACC_UNIT_MM,
-                 device="cuda", overlap=False, radial_f16=False, engine="auto", q6=False):
+                 device="cuda", overlap=False, radial_f16=False, engine="auto", q6=False, fcn=None):
         """acc_unit: voxel edge in mm (the reference hard-codes 5, AccumulatorSpace.py:374).  radial_f16: the FCN head
         writes the radial maps as float16 and the seam reads them as such (the stress configuration of BASELINE.json).
         engine: 'auto' / 'full', the arg-max engine of rcv_accumulate_3d (identical results).  q6: FcnEngine's q6 (fp6 cross
-        terms in the stride-1 3x3 convolutions of layers 2-4; default off)."""
+        terms in the stride-1 3x3 convolutions of layers 2-4; default off).  fcn: an FcnEngine already built for these networks and this
+        input size (BN folding, weight packing and upload take seconds: a caller that sizes its batch first builds the engine once)."""
         import torch
 
         assert len(state_dicts) >= 1
@@ -34,7 +35,7 @@ class FramePipeline:
         self.vote_engine = _hip.VOTE_ENGINES[engine]
         self.seg_threshold = float(A.SEG_THRESHOLD)  # reference :603 (LINEMOD); the LM-O driver uses >= 0.5 (:836)
         self.device = device
-        self.engine = fcn_engine.FcnEngine(state_dicts, H, W, dtype=dtype, device=device, q6=q6)
+        self.engine = fcn if fcn is not None else fcn_engine.FcnEngine(state_dicts, H, W, dtype=dtype, device=device, q6=q6)
         self.engine.workspace(self.B)
         if self.radial_f16:
             self.engine.set_option(8, 1)
@@ -53,8 +54,9 @@ class FramePipeline:
         self.ws = torch.empty((n_items, ws_bytes), dtype=torch.uint8, device=device)
         self.xyz = torch.empty((n_items, cap, 3), dtype=torch.float64, device=device)
         self.rlist = torch.empty((n_items, cap), dtype=torch.float32, device=device)
-        self.counts = torch.zeros((n_items, 2), dtype=torch.int32, device=device)
+        self.counts = torch.zeros((n_items, 4), dtype=torch.int32, device=device)  # [points, radii, non-finite pixels of the maps, 0]
         self.results = torch.zeros((n_items, ctypes.sizeof(_hip.AccResult)), dtype=torch.uint8, device=device)
+        self._nonfinite = torch.zeros((), dtype=torch.int32, device=device)  # largest counts[:, 2] of any batch since the last read_results
         self.k4 = (ctypes.c_double * 4)(self.K[0, 0], self.K[1, 1], self.K[0, 2], self.K[1, 2])
         # overlapped mode (enqueue_step): FCN on one stream, seam + voting + result copy on another
         # overlap=False: one stream for both (kernel timings free of cross-stream time slicing)
@@ -65,6 +67,15 @@ class FramePipeline:
         self._step = 0
         self._timing = False
         self._marks = []
+
+    @staticmethod
+    def device_bytes(fcn, frames_per_step, H, W, G, radial_f16=False):
+        """Device bytes a FramePipeline of `frames_per_step` frames allocates around the engine `fcn` (its activation workspace, the
+        double-buffered output planes, and per (frame, keypoint) item the voting workspace, point and radius lists)."""
+        B, HW = int(frames_per_step), H * W
+        per_item = int(_hip.lib().rcv_acc_workspace_bytes_min(HW)) + HW * (24 + 4) + 16 + ctypes.sizeof(_hip.AccResult)
+        planes = 2 * G * B * HW * (4 + (2 if radial_f16 else 4))
+        return fcn.workspace_bytes(B) + B * 3 * HW * 4 + planes + B * G * per_item
 
     # -- stages ----------------------------------------------------------------------------
     def forward_fcn(self, rgb_u8):
@@ -118,16 +129,17 @@ class FramePipeline:
         seg = S(self.seg, HW * 4, B * HW * 4)
         rb = self.radial.element_size()
         rad = S(self.radial, HW * rb, B * HW * rb)
-        seam_mode = _hip.RCV_SEAM_RADIAL_F16 if self.radial_f16 else 0
+        seam_mode = (_hip.RCV_SEAM_RADIAL_F16 if self.radial_f16 else 0) | _hip.RCV_SEAM_COUNT_NONFINITE
         dep = S(depth_u16, HW * 2, 0)
         rmx = S(self._rmax, 8 * G if self._rmax.dim() == 2 else 0, 8)
         xyz = item(self.xyz, self.cap * 24)
         rl = item(self.rlist, self.cap * 4)
-        cnt = item(self.counts, 8)
+        cnt = item(self.counts, 16)
         ws = item(self.ws, self.ws_bytes)
         res = item(self.results, ctypes.sizeof(_hip.AccResult))
         _hip.check(L.rcv_seam_compact_batch(seg, rad, dep, self.H, self.W, self.k4, float(self.seg_threshold), rmx, seam_mode, xyz, rl, cnt,
                                             self.cap, ws, self.ws_bytes, B, G, st), "rcv_seam_compact_batch")
+        torch.maximum(self._nonfinite, self.counts[:, 2].amax(), out=self._nonfinite)  # (stream-ordered; sticky until read_results)
         self._mark("seam")
         _hip.check(L.rcv_accumulate_3d_batch(xyz, rl, 0, cnt, self.cap, self.acc_unit, self.vote_engine, res, ws, self.ws_bytes, B, G, st),
                    "rcv_accumulate_3d_batch")
@@ -137,12 +149,16 @@ class FramePipeline:
         """One D2H copy -> (estimated_kpts float64 [B,G,3] mm, list of AccResult).  Raises _hip.HalfRangeError when a forward
         since the last call stored an activation beyond the half-precision range (f16x3 / fp16 engines: clipped maps)."""
         raw = self.results.cpu().numpy()
+        nonfinite = int(self._nonfinite.item())
+        self._nonfinite.zero_()
         self.finish()
         self.engine.range_status(clear=True, raise_on_flag=True)
-        # the range guard sees magnitudes, not NaNs (v_max drops them, and so does the next ReLU): the maps the votes were cast on are
-        # checked themselves -- one reduction over the current output planes per call
-        if not (bool(self.torch.isfinite(self.seg).all()) and bool(self.torch.isfinite(self.radial).all())):
-            raise FloatingPointError("non-finite FCN output in %s mode (NaN weights or input?)" % self.engine.dtype_name)
+        # the range guard sees magnitudes, not NaNs (v_max drops them, and so does the next ReLU), and the mask comparisons drop a NaN
+        # pixel without a trace: the seam counts the non-finite values of the very maps the votes are cast on (counts[:, 2]), and vote()
+        # keeps the largest count of every batch enqueued since the last call -- whichever output buffer a later forward has taken since
+        if nonfinite != 0:
+            raise FloatingPointError("non-finite FCN output in %s mode (NaN weights or input?): up to %d pixels of a map"
+                                     % (self.engine.dtype_name, nonfinite))
         res = [_hip.AccResult.from_buffer_copy(raw[i].tobytes()) for i in range(raw.shape[0])]
         kpts = np.array([[r.center_mm[0], r.center_mm[1], r.center_mm[2]] for r in res]).reshape(self.B, self.G, 3)
         return kpts, res

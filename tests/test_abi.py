@@ -28,7 +28,8 @@ def test_header_binding_and_library_agree():
     for name in declared:
         assert hasattr(lib, name), name
     L = _hip.load_library()
-    assert L.rcv_version() >= 100
+    header = open(os.path.join(ROOT, "include", "rcvpose_hip.h")).read()
+    assert L.rcv_version() == _hip.ABI_VERSION == int(re.search(r"#define RCV_ABI_VERSION (\d+)", header).group(1))
     assert L.rcv_strerror(0) == b"ok" and b"empty" in L.rcv_strerror(_hip.RCV_E_EMPTY)
     assert L.rcv_acc_workspace_bytes(15000) > 15000 * 28
 
@@ -40,6 +41,19 @@ def test_struct_layouts_match_header():
     assert ctypes.sizeof(_hip.Op) == 16 * 4 + 3 * 8
     assert ctypes.sizeof(_hip.IcpResult) == 16 * 8 + 2 * 8 + 4 * 4  # rcv_icp_result
     assert _hip.AccResult.status.offset == 92
+
+
+def test_abi_check_refuses_another_header():
+    """A binding compiled against another header (older version, or an rcv_op without wq_off: 80 instead of 88 bytes) would hand
+    rcv_fcn_create an ops array with the wrong stride: rcv_abi_check tells, and _hip.load_library calls it."""
+    from rcvpose_amd import _hip
+
+    L = _hip.load_library()
+    sizes = (ctypes.sizeof(_hip.Op), ctypes.sizeof(_hip.AccResult), ctypes.sizeof(_hip.Strided), ctypes.sizeof(_hip.IcpResult))
+    assert L.rcv_abi_check(_hip.ABI_VERSION, *sizes) == 0
+    assert L.rcv_abi_check(100, *sizes) == _hip.RCV_E_INVALID
+    assert L.rcv_abi_check(_hip.ABI_VERSION, 80, *sizes[1:]) == _hip.RCV_E_INVALID
+    assert L.rcv_abi_check(_hip.ABI_VERSION, sizes[0], 88, *sizes[2:]) == _hip.RCV_E_INVALID
 
 
 def test_product_path_fails_loudly_without_gpu():

@@ -260,6 +260,25 @@ def test_read_results_refuses_non_finite_maps(golden_dir):
     pipe.process(rgb, depth, [1.0], inject=(seg, rad))
     with pytest.raises(FloatingPointError):
         pipe.read_results()
+    pipe.process(rgb, depth, [1.0], inject=(seg, torch.full_like(rad, 0.5)))
+    pipe.read_results()                       # the flag was consumed with the batch it belonged to
+    # double-buffered stream of batches: the NaN batch is followed by two clean ones, which take both output buffers before the
+    # results are read -- the seam counted the non-finite pixels of the maps ITS votes were cast on, so the batch is still refused
+    over = FramePipeline(_state_dicts(golden_dir, 1), H, W, frames_per_step=1, overlap=True)
+    clean = torch.full_like(rad, 0.5)
+    for r in (rad, clean, clean):
+        over.enqueue_step(rgb, depth, [1.0], inject=(seg, r))
+    with pytest.raises(FloatingPointError):
+        over.read_results()
+    for r in (clean, clean, clean):
+        over.enqueue_step(rgb, depth, [1.0], inject=(seg, r))
+    over.read_results()
+    # a NaN in the segmentation plane is dropped by `seg > 0.8` without a trace: counted as well
+    seg_bad = seg.clone()
+    seg_bad[0, 0, 0, 7, 9] = float("inf")
+    pipe.process(rgb, depth, [1.0], inject=(seg_bad, clean))
+    with pytest.raises(FloatingPointError):
+        pipe.read_results()
 
 
 def test_mfma_calibration_returns_a_plausible_rate():
