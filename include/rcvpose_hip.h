@@ -86,8 +86,9 @@ typedef struct rcv_acc_result {
 #define RCV_SEAM_RADIAL_F16 256
 /* rcv_seam_compact[_batch] mode bit: `counts` has room for FOUR int32 per item and the seam also writes counts[2] = the number of
  * pixels whose segmentation or radial value is not finite (NaN / Inf -- the mask comparisons silently drop such pixels, here as in
- * the reference, AccumulatorSpace.py:603-610; a caller that wants to refuse such maps reads the count with its results).  counts[3]
- * is written as 0. */
+ * the reference, AccumulatorSpace.py:603-610; a caller that wants to refuse such maps reads the count with its results) and
+ * counts[3] = max(counts[3], counts[2]): the largest such count of any call since the caller last zeroed it (a stream of batches
+ * that reuses the buffer is checked once, at the end). */
 #define RCV_SEAM_COUNT_NONFINITE 512
 
 /* Bytes of workspace for rcv_seam_compact / rcv_accumulate_3d for clouds of up to max_points points (and radii).
@@ -401,14 +402,17 @@ int rcv_fcn_set_profiling(rcv_fcn *h, int enable);
  * and applies the epilogue: run-to-run identical results, within the engine's tolerance of -- but not bit-identical to -- the
  * unsplit kernels, so a frame's maps then depend on the batch size it travels in.  Switching it on allocates a 48 MB buffer
  * owned by the handle.
- * key 13 (default 0 -- a measured experiment: 6.5 ms against k_tail_x3's 6.1; RCV_F16X3): the tail (x2 bilinear upsampling ->
- * conv7 3x3 -> head; reference models/fcnresnet.py:177-191) as ONE
- * 3x3 convolution on the low-resolution tensor: both maps are linear, so conv7 on the upsampled image equals a convolution with 4 x 32
+ * key 13 (default 1, RCV_F16X3): the tail (x2 bilinear upsampling -> conv7 3x3 -> head; reference models/fcnresnet.py:177-191) as ONE 3x3
+ * convolution on the low-resolution tensor: both maps are linear, so conv7 on the upsampled image equals a convolution with 4 x 32
  * parity-stacked output channels whose weights the host composes (rcv_op::wq_off of the conv7 op: [G][128][3][3][cin] behind the first
  * copy, its [bias x 4 | scale] records behind the first copy's; rcvpose_amd/fcn_engine.py::compose_upsample_conv3).  k_conv_halo reads
- * the low-resolution tensor with replicate padding and applies ReLU + the head in its epilogue; the outermost ring of output pixels
- * (where the upsampling's clamp and the convolution's zero padding meet) is recomputed by k_tail_ring.  Same function, another
- * summation: within ~2e-6 of k_tail_x3 (0: that kernel), not its bits. */
+ * the low-resolution tensor with replicate padding and applies ReLU + the head in a register-only epilogue (no upsampled tensor, no
+ * conv7 activation ever exists in memory); the tiles that touch the image border -- the outermost ring of output pixels is where the
+ * upsampling's clamp and the convolution's zero padding meet, which the composed form cannot express -- are recomputed by k_tail_x3
+ * (ring_only).  Same function, another summation: within ~3e-6 of k_tail_x3, not its bits, and 4.9 ms against 6.2 per forward of
+ * 53 x 3 (r06).  1: on images with at least 64 rectangles of 320 low-resolution pixels (a rule of the image size alone: a frame's maps
+ * do not depend on the batch it travels in -- beyond ~109 frames per batch at 480x640 the 32-bit DMA offsets send the tail back to
+ * k_tail_x3); 2: wherever the halo tiling applies (tests); 0: k_tail_x3 everywhere (member of the bit-identical family). */
 int rcv_fcn_set_option(rcv_fcn *h, int key, int value);
 int rcv_fcn_get_profile(rcv_fcn *h, double *conv_ms, double *other_ms, double *conv_flop);
 /* Per-op device times (ms) of the last profiled forward; ms_out has room for n_ops doubles. */

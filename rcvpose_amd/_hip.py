@@ -21,7 +21,7 @@ RCV_E_UNSUPPORTED = -8
 RCV_E_RANGE = -9
 
 RCV_SEAM_RADIAL_F16 = 256
-RCV_SEAM_COUNT_NONFINITE = 512  # counts then holds four int32 per item: [points, radii, non-finite pixels, 0]
+RCV_SEAM_COUNT_NONFINITE = 512  # counts then holds four int32 per item: [points, radii, non-finite pixels, running maximum of those]
 ABI_VERSION = 600  # RCV_ABI_VERSION of include/rcvpose_hip.h
 RCV_VOTE_AUTO, RCV_VOTE_RASTER = 0, 1
 VOTE_ENGINES = {"auto": RCV_VOTE_AUTO, "full": RCV_VOTE_RASTER}

@@ -354,7 +354,10 @@ __device__ __forceinline__ void d_seam_scan(const int2 *blk_counts, int nb, int2
     if (t == 1023) {
         counts_out[0] = s[t].x;
         counts_out[1] = s[t].y;
-        if (want_nonfinite) { counts_out[2] = s_nf; counts_out[3] = 0; }  // (s_nf is complete: every add precedes the scan's barriers)
+        if (want_nonfinite) {  // (s_nf is complete: every add precedes the scan's barriers)
+            counts_out[2] = s_nf;
+            counts_out[3] = max(counts_out[3], s_nf);  // sticky: the largest count since the caller last zeroed it
+        }
     }
 }
 

@@ -1507,6 +1507,9 @@ __global__ __launch_bounds__(512) void k_conv_halo(const HaloParams p)
 #else
 #define RCV_HSTAMP_X(TAP, idx)
 #endif
+// (TAILC: operands swapped -- a lane then holds four consecutive CHANNELS of one pixel instead of four pixels of one channel,
+// which is what the register-only head epilogue wants; the same products in the same K order)
+#define RCV_HALO_MM(a_, b_, c_) (TAILC ? RCV_MFMA16(b_, a_, c_, 0, 0, 0) : RCV_MFMA16(a_, b_, c_, 0, 0, 0))
 #define RCV_HALO_STEP_X3(TAP)                                                                                  \
     {                                                                                                          \
         constexpr int T2_ = ((TAP) + 2) % 9, S2_ = ((TAP) + 2) / 9;                                            \
@@ -1529,9 +1532,9 @@ __global__ __launch_bounds__(512) void k_conv_halo(const HaloParams p)
         RCV_HSTAMP_X(TAP, 2);                                                                                  \
         __builtin_amdgcn_s_setprio(1);                                                                         \
         _Pragma("unroll") for (int i = 0; i < MT; i++)                                                         \
-            _Pragma("unroll") for (int j = 0; j < NT; j++) acc[i][j] = RCV_MFMA16(ah[i], bh[j], acc[i][j], 0, 0, 0); \
+            _Pragma("unroll") for (int j = 0; j < NT; j++) acc[i][j] = RCV_HALO_MM(ah[i], bh[j], acc[i][j]); \
         _Pragma("unroll") for (int i = 0; i < MT; i++)                                                         \
-            _Pragma("unroll") for (int j = 0; j < NT / 2; j++) acc[i][j] = RCV_MFMA16(ah[i], bl[j], acc[i][j], 0, 0, 0); \
+            _Pragma("unroll") for (int j = 0; j < NT / 2; j++) acc[i][j] = RCV_HALO_MM(ah[i], bl[j], acc[i][j]); \
         __builtin_amdgcn_s_setprio(0);                                                                         \
         RCV_HSTAMP_X(TAP, 3);                                                                                  \
         __builtin_amdgcn_s_barrier();                                                                          \
@@ -1552,9 +1555,9 @@ __global__ __launch_bounds__(512) void k_conv_halo(const HaloParams p)
         RCV_HSTAMP_X(TAP, 6);                                                                                  \
         __builtin_amdgcn_s_setprio(1);                                                                         \
         _Pragma("unroll") for (int i = 0; i < MT; i++)                                                         \
-            _Pragma("unroll") for (int j = NT / 2; j < NT; j++) acc[i][j] = RCV_MFMA16(ah[i], bl[j], acc[i][j], 0, 0, 0); \
+            _Pragma("unroll") for (int j = NT / 2; j < NT; j++) acc[i][j] = RCV_HALO_MM(ah[i], bl[j], acc[i][j]); \
         _Pragma("unroll") for (int i = 0; i < MT; i++)                                                         \
-            _Pragma("unroll") for (int j = 0; j < NT; j++) acc[i][j] = RCV_MFMA16(al[i], bh[j], acc[i][j], 0, 0, 0); \
+            _Pragma("unroll") for (int j = 0; j < NT; j++) acc[i][j] = RCV_HALO_MM(al[i], bh[j], acc[i][j]); \
         __builtin_amdgcn_s_setprio(0);                                                                         \
         RCV_HSTAMP_X(TAP, 7);                                                                                  \
         __builtin_amdgcn_s_barrier();                                                                          \
@@ -1774,12 +1777,76 @@ __global__ __launch_bounds__(512) void k_conv_halo(const HaloParams p)
 #undef RCV_HALO_STEP
 #undef RCV_HALO_STEP2
 #undef RCV_HALO_STEP_X3
+#undef RCV_HALO_MM
 #undef RCV_HALO_STEP_X3Q
 #undef RCV_HALO_STEP2_X3Q
 #undef RCV_HALO_STEP2_X3
 #undef RCV_HALO_B
 #undef RCV_HALO_PATCH
 
+    if constexpr (TAILC && kX3) {
+        // ---- parity-composed tail: ReLU + the head straight from the accumulators, no LDS, no barrier.  With the operands swapped
+        // (RCV_HALO_MM) lane (r16, kq) holds, of pixel r16 of tile i, the channels n = wn*64 + j*16 + kq*4 + e -- conv7's channel
+        // c = (j & 1)*16 + kq*4 + e at the high-resolution pixel of parity 2*ppy + ppx = wn*2 + (j >> 1).  The head's two dot products
+        // over the 32 channels are 8 FMAs per lane and (pixel, parity, plane) and a sum over the four kq: v_permlane16_swap on the
+        // (seg, radial) pair + add, then v_permlane32_swap on the (ppx = 0, ppx = 1) pair + add -- a reduce-scatter that leaves lane
+        // (r16, kq) with plane kq & 1 of column parity kq >> 1: the 32 lanes of a plane store 16 pixels x 2 columns = 128 contiguous bytes.
+        static_assert(!TAILC || (BN == 128 && NT == 4), "four parities x 32 channels");
+        const float *bias = p.bias + (long long)g * p.bias_gs;
+        const H16 *w8 = (const H16 *)p.w8 + (long long)g * p.w8_gs;
+        float part[MT][2][2];
+#pragma unroll
+        for (int i = 0; i < MT; i++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) part[i][q >> 1][q & 1] = 0.f;
+        float rmax = 0.f;
+#pragma unroll
+        for (int j = 0; j < NT; j++) {
+            const int nl = n0 + wn * (BN / 2) + j * 16 + kq * 4, c = (j & 1) * 16 + kq * 4;
+            const float4 bv = *(const float4 *)(bias + nl), sc = *(const float4 *)(bias + p.Cout + nl);
+            const float bva[4] = {bv.x, bv.y, bv.z, bv.w}, sca[4] = {sc.x, sc.y, sc.z, sc.w};
+            float h0[4], h1[4];
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                h0[e] = (float)w8[c + e] + (float)w8[64 + c + e];
+                h1[e] = (float)w8[32 + c + e] + (float)w8[96 + c + e];
+            }
+#pragma unroll
+            for (int i = 0; i < MT; i++)
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const float v = fmaxf(__fmaf_rn(acc[i][j][e], sca[e], bva[e]), 0.f);
+                    rmax = fmaxf(rmax, v);
+                    part[i][j >> 1][0] = fmaf(v, h0[e], part[i][j >> 1][0]);
+                    part[i][j >> 1][1] = fmaf(v, h1[e], part[i][j >> 1][1]);
+                }
+        }
+        const float hb = p.b8[(long long)g * p.b8_gs + (kq & 1)], hs = p.b8[(long long)g * p.b8_gs + 2 + (kq & 1)];
+        const int Ho = 2 * p.H, Wo = 2 * p.W;
+#pragma unroll
+        for (int i = 0; i < MT; i++) {
+            float s2[2];
+#pragma unroll
+            for (int pp = 0; pp < 2; pp++) {  // even rows of lanes: seg summed over a kq pair; odd rows: radial
+                const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(part[i][pp][0]), __float_as_uint(part[i][pp][1]), false, false);
+                s2[pp] = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+            }
+            // lanes 0..31: column parity 0 summed over all four kq; lanes 32..63: column parity 1
+            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(s2[0]), __float_as_uint(s2[1]), false, false);
+            const float outv = __fmaf_rn(__uint_as_float(sw[0]) + __uint_as_float(sw[1]), hs, hb);
+            const int r = wm * RW + i * 16 + r16;
+            const int py = (int)(((float)r + 0.5f) * rT), px = r - py * p.tw;
+            const int y = y0 + py, x = x0 + px;
+            if (r < npx && y < p.H && x < p.W) {
+                const long long o = ((long long)(g * p.n_img + img) * Ho + (2 * y + wn)) * Wo + (2 * x + (kq >> 1));
+                if ((kq & 1) == 0) p.seg[o] = outv;
+                else if (p.rad_f16) ((_Float16 *)p.radial)[o] = (_Float16)outv;
+                else p.radial[o] = outv;
+            }
+        }
+        rng_flush(p.range, rmax);
+        return;
+    }
     // epilogue: k_conv_dma's (fp32 tile staged in LDS, 16-byte vectors of contiguous channels), in two halves of 2 * RW rows
     // (the 320-row tile would not fit at once); tile row -> image pixel
     T *dst = (T *)p.dst + (long long)g * p.dst_gs;
@@ -1804,49 +1871,6 @@ __global__ __launch_bounds__(512) void k_conv_halo(const HaloParams p)
             }
         }
         __syncthreads();
-        if constexpr (TAILC) {
-            // The 128 staged values of a low-resolution pixel are conv7's 32 channels at its four high-resolution pixels (2y + py,
-            // 2x + px), channel (2 py + px) * 32 + c.  Task = (py, row, px), consecutive lanes = consecutive (row, px): a wave's two
-            // stores (seg, radial) are 256 contiguous bytes of one output row each.  ReLU and the head's two FMA chains over the 32
-            // channels in fp32 (the activation is not rounded to a stored pair here: it is never stored).
-            static_assert(!TAILC || BN == 128, "four parities x 32 channels");
-            float hw0[32], hw1[32];
-            {
-                const H16 *w8 = (const H16 *)p.w8 + (long long)g * p.w8_gs;
-#pragma unroll
-                for (int c = 0; c < 32; c++) {
-                    hw0[c] = (float)w8[c] + (float)w8[64 + c];
-                    hw1[c] = (float)w8[32 + c] + (float)w8[96 + c];
-                }
-            }
-            const float hb0 = p.b8[(long long)g * p.b8_gs], hb1 = p.b8[(long long)g * p.b8_gs + 1];
-            const float hs0 = p.b8[(long long)g * p.b8_gs + 2], hs1 = p.b8[(long long)g * p.b8_gs + 3];
-            const int Ho = 2 * p.H, Wo = 2 * p.W;
-            for (int t = tid; t < 2 * (2 * RW) * 2; t += 512) {
-                const int ppx = t & 1, lr = (t >> 1) % (2 * RW), ppy = (t >> 1) / (2 * RW);
-                const int r = half * 2 * RW + lr;
-                const int py = (int)(((float)r + 0.5f) * rT), px = r - py * p.tw;
-                const int y = y0 + py, x = x0 + px;
-                if (r >= npx || y >= p.H || x >= p.W) continue;
-                const float4 *sp4 = (const float4 *)(stg + lr * SROW + (ppy * 2 + ppx) * 32);
-                float a0 = 0.f, a1 = 0.f;
-#pragma unroll
-                for (int c4 = 0; c4 < 8; c4++) {
-                    const float4 t4 = sp4[c4];
-                    const float v0 = fmaxf(t4.x, 0.f), v1 = fmaxf(t4.y, 0.f), v2 = fmaxf(t4.z, 0.f), v3 = fmaxf(t4.w, 0.f);
-                    rmax = fmaxf(fmaxf(rmax, fmaxf(v0, v1)), fmaxf(v2, v3));
-                    a0 = fmaf(v0, hw0[c4 * 4], a0); a1 = fmaf(v0, hw1[c4 * 4], a1);
-                    a0 = fmaf(v1, hw0[c4 * 4 + 1], a0); a1 = fmaf(v1, hw1[c4 * 4 + 1], a1);
-                    a0 = fmaf(v2, hw0[c4 * 4 + 2], a0); a1 = fmaf(v2, hw1[c4 * 4 + 2], a1);
-                    a0 = fmaf(v3, hw0[c4 * 4 + 3], a0); a1 = fmaf(v3, hw1[c4 * 4 + 3], a1);
-                }
-                const long long o = ((long long)(g * p.n_img + img) * Ho + (2 * y + ppy)) * Wo + (2 * x + ppx);
-                p.seg[o] = __fmaf_rn(a0, hs0, hb0);
-                const float o1 = __fmaf_rn(a1, hs1, hb1);
-                if (p.rad_f16) ((_Float16 *)p.radial)[o] = (_Float16)o1;
-                else p.radial[o] = o1;
-            }
-        } else
 #pragma unroll
         for (int pass = 0; pass < (2 * RW + RPR - 1) / RPR; pass++) {
             const int lr = pass * RPR + tid / CPR, cc = tid % CPR;  // row within the half, 16-byte chunk
@@ -1883,99 +1907,6 @@ __global__ __launch_bounds__(512) void k_conv_halo(const HaloParams p)
         if (half == 0) __syncthreads();
     }
     rng_flush(p.range, rmax);
-}
-
-// ---------------------------------------------------------------------------------------------
-// k_tail_ring (engine option 13): the outermost ring of high-resolution pixels of the parity-composed tail, recomputed directly.
-// There the upsampling clamps and conv7 pads with zeros, which the composed low-resolution convolution (replicate padding) cannot
-// express: rows 0 and Ho - 1, columns 0 and Wo - 1 -- 0.7 % of the pixels.  A workgroup keeps conv7's weights as fp32 in LDS and walks
-// 64 ring pixels four at a time: thread = (pixel, channel) builds the 3 x 3 x 64 upsampled patches (zero outside the image), thread =
-// (pixel, tap parity, output channel) multiplies, then the tap sums, scale / bias, ReLU and the head.  fp32 VALU arithmetic.
-// ---------------------------------------------------------------------------------------------
-constexpr int RING_PX = 64;                                  // ring pixels per workgroup
-constexpr int RING_LDS = (9 * 64 * 33 + 4 * 9 * 64 + 4 * 32 * 9) * 4;  // conv7 weights [tap][ci][co + pad], four patches, partial sums
-__global__ __launch_bounds__(256) void k_tail_ring(const H16 *src, const H16 *w7, const float *b7, const H16 *w8, const float *b8, float *seg,
-                                                    float *radial, int B, int Hin, int Win, long long src_gs, long long w7_gs, int b7_gs,
-                                                    long long w8_gs, int b8_gs, int rad_f16)
-{
-    using T = H16;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    float *sw = (float *)smem;               // [9 * 64][33]: conv7 weights as fp32 (hi + lo), row = tap * 64 + ci, column = co
-    float *su = sw + 9 * 64 * 33;            // [4 pixels][9 * 64]: upsampled patches (zero outside the image)
-    float *sp = su + 4 * 9 * 64;             // [4 pixels][32 co][9 taps]: partial sums
-    const int Ho = 2 * Hin, Wo = 2 * Win, ring = 2 * Wo + 2 * (Ho - 2);
-    const int g = blockIdx.z, img = blockIdx.y, tid = threadIdx.x;
-    {   // weights [co][tap][2 groups][32 hi | 32 lo] -> fp32 [tap * 64 + ci][co]
-        const T *w = w7 + (long long)g * w7_gs;
-        for (int e = tid; e < 32 * 9 * 64; e += 256) {
-            const int ci = e & 63, t = (e >> 6) % 9, co = e / 576;
-            const T *q = w + ((long long)co * 9 + t) * 128 + ((ci >> 5) << 6) + (ci & 31);
-            sw[(t * 64 + ci) * 33 + co] = (float)q[0] + (float)q[32];
-        }
-    }
-    const T *z = src + (long long)g * src_gs + (long long)img * Hin * Win * 128;  // 64 channels = two groups of [32 hi | 32 lo]
-    const float *bb = b7 + (long long)g * b7_gs;
-    const int pix = tid >> 6, c = tid & 63, coff = ((c >> 5) << 6) + (c & 31);   // patch build: thread = (pixel of four, channel)
-    const int co = tid & 31, tp = (tid >> 5) & 1, pq = tid >> 6;                 // multiply: thread = (pixel of four, tap parity, channel)
-    for (int p0 = blockIdx.x * RING_PX; p0 < min(ring, (int)(blockIdx.x + 1) * RING_PX); p0 += 4) {
-        __syncthreads();
-        {
-            const int idx = min(p0 + pix, ring - 1);
-            int Y, X;
-            if (idx < Wo) { Y = 0; X = idx; }
-            else if (idx < 2 * Wo) { Y = Ho - 1; X = idx - Wo; }
-            else { const int k = idx - 2 * Wo; Y = 1 + (k >> 1); X = (k & 1) ? Wo - 1 : 0; }
-            for (int t = 0; t < 9; t++) {
-                const int yy = Y + t / 3 - 1, xx = X + t % 3 - 1;
-                float u = 0.f;
-                if (yy >= 0 && yy < Ho && xx >= 0 && xx < Wo) {
-                    // align_corners = False: source coordinate (p + 0.5) / 2 - 0.5, clamped at 0 (PyTorch's area_pixel_compute_source_index)
-                    const float fy = fmaxf((yy + 0.5f) * 0.5f - 0.5f, 0.f), fx = fmaxf((xx + 0.5f) * 0.5f - 0.5f, 0.f);
-                    const int y0 = (int)fy, x0 = (int)fx, y1 = min(y0 + 1, Hin - 1), x1 = min(x0 + 1, Win - 1);
-                    const float ly = fy - (float)y0, lx = fx - (float)x0;
-                    auto at = [&](int yq, int xq) {
-                        const T *q = z + ((long long)yq * Win + xq) * 128 + coff;
-                        return (float)q[0] + (float)q[32];
-                    };
-                    u = (1.f - ly) * ((1.f - lx) * at(y0, x0) + lx * at(y0, x1)) + ly * ((1.f - lx) * at(y1, x0) + lx * at(y1, x1));
-                }
-                su[pix * 576 + t * 64 + c] = u;
-            }
-        }
-        __syncthreads();
-        {   // taps of this thread's parity (0: 0, 2, 4, 6, 8; 1: 1, 3, 5, 7), 64 channels each
-            const float *up = su + pq * 576;
-            for (int t = tp; t < 9; t += 2) {
-                float a = 0.f;
-#pragma unroll 16
-                for (int ci = 0; ci < 64; ci++) a = fmaf(up[t * 64 + ci], sw[(t * 64 + ci) * 33 + co], a);
-                sp[(pq * 32 + co) * 9 + t] = a;
-            }
-        }
-        __syncthreads();
-        if (tid < 128) {  // thread = (pixel, channel): the nine tap sums in order, scale / bias, ReLU -> su (reused: 32 floats per pixel)
-            const int q4 = tid >> 5, ch = tid & 31;
-            float a = 0.f;
-            for (int t = 0; t < 9; t++) a += sp[(q4 * 32 + ch) * 9 + t];
-            sp[(q4 * 32 + ch) * 9] = fmaxf(__fmaf_rn(a, bb[32 + ch], bb[ch]), 0.f);
-        }
-        __syncthreads();
-        if (tid < 8 && p0 + (tid >> 1) < min(ring, (int)(blockIdx.x + 1) * RING_PX)) {
-            const int q4 = tid >> 1, oc = tid & 1, idx = p0 + q4;
-            int Y, X;
-            if (idx < Wo) { Y = 0; X = idx; }
-            else if (idx < 2 * Wo) { Y = Ho - 1; X = idx - Wo; }
-            else { const int k = idx - 2 * Wo; Y = 1 + (k >> 1); X = (k & 1) ? Wo - 1 : 0; }
-            const T *h8 = w8 + (long long)g * w8_gs + oc * 32;
-            float a = 0.f;
-            for (int ci = 0; ci < 32; ci++) a = fmaf(sp[(q4 * 32 + ci) * 9], (float)h8[ci] + (float)h8[64 + ci], a);
-            const float outv = __fmaf_rn(a, b8[(long long)g * b8_gs + 2 + oc], b8[(long long)g * b8_gs + oc]);
-            const long long o = ((long long)(g * B + img) * Ho + Y) * Wo + X;
-            if (oc == 0) seg[o] = outv;
-            else if (rad_f16) ((_Float16 *)radial)[o] = (_Float16)outv;
-            else radial[o] = outv;
-        }
-    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -4454,10 +4385,11 @@ constexpr int TX_LDS = TX_LDS_MAIN + 64 * 4;
 static_assert(TX_NPX == 128, "the head maps thread -> (pixel, plane) with 128 pixels per tile");
 static_assert(TX_NPX * TX_HP <= TX_UH * TX_UW * TX_UP, "the conv7 rows reuse the upsampled patch's LDS");
 static_assert(2 * TX_LDS <= 160 * 1024, "two workgroups per CU");
+constexpr int TX_RING_ROWS = 10;                             // interior tile rows per workgroup of the ring pass (two tiles each)
 
 __global__ __launch_bounds__(256, 2) void k_tail_x3(const H16 *src, const H16 *w7, const float *b7, const H16 *w8, const float *b8,
                                                  float *seg, float *radial, int B, int Hin, int Win, long long src_gs, long long w7_gs,
-                                                 int b7_gs, long long w8_gs, int b8_gs, int rad_f16, unsigned *range)
+                                                 int b7_gs, long long w8_gs, int b8_gs, int rad_f16, unsigned *range, int ring_only)
 {
     RCV_X3_MODE();
     using T = H16;
@@ -4468,8 +4400,7 @@ __global__ __launch_bounds__(256, 2) void k_tail_x3(const H16 *src, const H16 *w
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r16 = lane & 15, kq = lane >> 4;
     const int Ho = Hin * 2, Wo = Win * 2;
-    const int ty = blockIdx.x, img = blockIdx.y, g = blockIdx.z;
-    const int ho0 = ty * TX_TH;
+    const int img = blockIdx.y, g = blockIdx.z;
     const T *sg = src + (long long)g * src_gs + (long long)img * Hin * Win * 128;
     const int pq = wave & 1, nt = wave >> 1;
     float rmax = 0.f;  // range guard: the largest conv7 activation stored as hi + lo
@@ -4500,23 +4431,25 @@ __global__ __launch_bounds__(256, 2) void k_tail_x3(const H16 *src, const H16 *w
         const int m = pq * 64 + i * 16 + r16;
         ubase[i] = (m >> 5) * TX_UW + (m & 31);
     }
-    const int sy0 = ho0 / 2 - 1;
     const int src_bytes = Hin * Win * 256;
     const int wv = __builtin_amdgcn_readfirstlane(wave);
     constexpr int SPW = (TX_SPIECES + 3) / 4;  // pieces per wave
-    int s_row[SPW], s_col[SPW];  // byte offset of the patch row (+ the lane's 16-byte chunk); patch column, or -1
+    int s_a[SPW], s_col[SPW];  // patch row and patch column (or -1) of this lane's pixel of piece k
 #pragma unroll
     for (int k = 0; k < SPW; k++) {
         const int pp = (k * 4 + wv) * 4 + (lane >> 4);
         const int a = pp / TX_SW, b = pp - a * TX_SW;
-        s_row[k] = min(max(sy0 + a, 0), Hin - 1) * Win * 256 + (lane & 15) * 16;
+        s_a[k] = a;
         s_col[k] = (k * 4 + wv < TX_SPIECES && pp < TX_SPIX) ? b : -1;
     }
-#define RCV_TX_SOURCE(sx0_)                                                                                    \
+// source patch of the tile whose first output row / column is ho0_ / wo0_: rows ho0_ / 2 - 1 .., columns wo0_ / 2 - 1 .., clamped
+#define RCV_TX_SOURCE(ho0_, wo0_)                                                                              \
     _Pragma("unroll") for (int k = 0; k < SPW; k++)                                                            \
         if (k * 4 + wv < TX_SPIECES)                                                                           \
             tail_dma16(sg, src_bytes, sS + (k * 4 + wv) * 1024,                                                \
-                       s_col[k] >= 0 ? s_row[k] + min(max((sx0_) + s_col[k], 0), Win - 1) * 256 : (int)0x80000000);
+                       s_col[k] >= 0 ? min(max((ho0_) / 2 - 1 + s_a[k], 0), Hin - 1) * Win * 256 + (lane & 15) * 16 + \
+                                           min(max((wo0_) / 2 - 1 + s_col[k], 0), Win - 1) * 256                \
+                                     : (int)0x80000000);
 #if defined(RCV_HALO_STAMPS) && defined(RCV_TAIL_STAMPS)
     unsigned hst[16];
     for (int k = 0; k < 16; k++) hst[k] = 0u;
@@ -4526,11 +4459,24 @@ __global__ __launch_bounds__(256, 2) void k_tail_x3(const H16 *src, const H16 *w
 #else
 #define RCV_TSTAMP(idx)
 #endif
-    RCV_TX_SOURCE(-1);
-    for (int tx = 0; tx * TX_TW < Wo; tx++) {
-        const int wo0 = tx * TX_TW;
+    // The workgroup's tiles.  Normally tile row blockIdx.x, left to right.  ring_only (engine option 13): only the tiles that touch
+    // the image border -- the parity-composed tail (k_conv_halo<.., TAILC>) cannot express the outermost ring of output pixels,
+    // where the upsampling clamps and conv7 pads with zeros; this pass, launched after it, recomputes the border tiles with the
+    // exact three-layer arithmetic (11.5 % of the tiles at 480 x 640).  Workgroup 0 takes the first tile row, 1 the last, and
+    // workgroup 2 + j the first and the last tile of TX_RING_ROWS interior rows (a workgroup's start-up -- conv7's weights into
+    // registers -- costs about as much as two tiles: one workgroup per interior row made the pass 1.3 instead of 0.7 ms).
+    const int ntx = (Wo + TX_TW - 1) / TX_TW, nty = (Ho + TX_TH - 1) / TX_TH;
+    const int wgx = blockIdx.x;
+    const bool sparse = ring_only && wgx >= 2;
+    const int row0 = !ring_only ? wgx : wgx == 0 ? 0 : wgx == 1 ? nty - 1 : 1 + (wgx - 2) * TX_RING_ROWS;
+    const int ntile = !sparse ? ntx : 2 * max(0, min(TX_RING_ROWS, nty - 1 - row0));
+    auto tile_ho0 = [&](int q_) { return (sparse ? row0 + (q_ >> 1) : row0) * TX_TH; };
+    auto tile_wo0 = [&](int q_) { return (sparse ? ((q_ & 1) ? ntx - 1 : 0) : q_) * TX_TW; };
+    if (ntile > 0) RCV_TX_SOURCE(tile_ho0(0), tile_wo0(0));
+    for (int tq = 0; tq < ntile; tq++) {
+        const int ho0 = tile_ho0(tq), wo0 = tile_wo0(tq);
 #if defined(RCV_HALO_STAMPS) && defined(RCV_TAIL_STAMPS)
-        stamp_on = stamp_blk && tx == 10;
+        stamp_on = stamp_blk && tq == 10;
 #endif
         RCV_TSTAMP(0)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -4580,7 +4526,7 @@ __global__ __launch_bounds__(256, 2) void k_tail_x3(const H16 *src, const H16 *w
         RCV_TSTAMP(3)
         __syncthreads();  // U is complete, sS is free
         RCV_TSTAMP(4)
-        if ((tx + 1) * TX_TW < Wo) RCV_TX_SOURCE((wo0 + TX_TW) / 2 - 1);
+        if (tq + 1 < ntile) RCV_TX_SOURCE(tile_ho0(tq + 1), tile_wo0(tq + 1));
         // ---- conv7: K = 2 channel slices x 9 taps x [32 hi | 32 lo]
         f32x4 acc[4];
 #pragma unroll
@@ -4713,8 +4659,10 @@ struct rcv_fcn {
     bool radial_f16 = false;  // the radial plane leaves the head as float16 (BASELINE.json stress configuration)
     bool use_lat = true;      // latency kernel (k_conv_lat) for launches with few tiles (small batches)
     int use_chain2 = 1;       // split engine: 1 = k_chain2_x3 (r04), 0 = k_chain_x3, 2 = k_chain3_x3 for the 256-wide block
-    int use_tailc = 0;        // split engine (13, measured experiment, off): (upsampling, conv7, head) as one parity-composed 3x3 on the low-resolution
-                              // tensor (+ k_tail_ring): 4.5 + 2.0 ms per forward of 53 x 3 against k_tail_x3's 6.1 (r05)
+    int use_tailc = 1;        // split engine (13): (upsampling, conv7, head) as one parity-composed 3x3 on the low-resolution tensor with the head in
+                              // its register-only epilogue (+ the border tiles by k_tail_x3): r06 4.2 + 0.75 ms per forward of 53 x 3 against
+                              // k_tail_x3's 6.2.  1: where an image has >= 64 rectangles (a rule of the image size alone: a frame's maps do not
+                              // depend on the batch it travels in); 2: wherever the halo tiling applies (tests); 0: k_tail_x3
     int use_splitk = 0;       // latency option (12): split-K in k_conv_lat + k_splitk_finish for launches with few tiles (one or a few frames)
     float *splitk_ws = nullptr;  // ... its partial sums (allocated when the option is switched on, never on the hot path)
     size_t splitk_bytes = 0;
@@ -5031,7 +4979,6 @@ int register_kernel_attributes()
     RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_conv_halo<64, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, halo_lds(64)));
     RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_conv_halo<128, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, halo_lds(128)));
     RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_conv_halo<128, 5, true>, hipFuncAttributeMaxDynamicSharedMemorySize, halo_lds(128)));
-    RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_tail_ring, hipFuncAttributeMaxDynamicSharedMemorySize, RING_LDS));
     RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_conv_halo<128, 4, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, halo_lds(128)));
     RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_conv_halo<128, 5, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, halo_lds(128)));
     RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_stem_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, STEM_LDS));
@@ -5205,12 +5152,12 @@ int forward_impl(rcv_fcn *h, const float *x, int B, float *seg, float *radial, c
                     const bool tailc = kX3 && h->use_tailc && c.wq_off > 0 && u.c0 == 64 && h->use_halo &&
                                        (long long)h->slot_elems[u.src0] * B * 4 < 0x7fffffffLL &&
                                        halo_tile(u.hin, u.win, h->use_halo, 128, (long long)B * h->groups, tth, ttw) &&
-                                       (long long)B * ((u.hin + tth - 1) / tth) * ((u.win + ttw - 1) / ttw) * h->groups >= 192;
+                                       (h->use_tailc == 2 || (long long)u.hin * u.win >= 64 * 320);  // (>= 64 rectangles of 320 pixels per image)
                     if (tailc) {
                         // (r05, option 13) conv7 on the x2 upsampling == a 3x3 convolution on the LOW-resolution tensor with 4 x 32
                         // parity-stacked output channels (fcn_engine.compose_upsample_conv3): the halo kernel with replicate padding
                         // and the head in its epilogue; the outermost ring of output pixels, where clamp and zero padding differ
-                        // from that, is recomputed by k_tail_ring.  No upsampled tensor, no VALU patch build.
+                        // from that, is recomputed by k_tail_x3 on the border tiles.  No upsampled tensor, no VALU patch build in the interior.
                         HaloParams q;
                         memset(&q, 0, sizeof(q));
                         q.th = tth; q.tw = ttw;
@@ -5226,17 +5173,18 @@ int forward_impl(rcv_fcn *h, const float *x, int B, float *seg, float *radial, c
                         if (q.th * q.tw > 256) hipLaunchKernelGGL((k_conv_halo<128, 5, false, true>), hgrid, dim3(512), halo_lds(128), st, q);
                         else hipLaunchKernelGGL((k_conv_halo<128, 4, false, true>), hgrid, dim3(512), halo_lds(128), st, q);
                         RCV_LAUNCH_CHECK();
-                        const int ring = 2 * (2 * u.win) + 2 * (2 * u.hin - 2);
-                        hipLaunchKernelGGL(k_tail_ring, dim3((ring + RING_PX - 1) / RING_PX, B, h->groups), dim3(256), RING_LDS, st, (const H16 *)(ws + off[u.src0]),
+                        // the border tiles again, with the three-layer arithmetic (k_tail_x3, ring_only)
+                        const int nty = (u.hout + TX_TH - 1) / TX_TH, ring_wgs = nty < 2 ? 1 : 2 + (nty - 2 + TX_RING_ROWS - 1) / TX_RING_ROWS;
+                        hipLaunchKernelGGL(k_tail_x3, dim3(ring_wgs, B, h->groups), dim3(256), TX_LDS, st, (const H16 *)(ws + off[u.src0]),
                                            (const H16 *)h->weights + c.w_off, h->bias + c.b_off, (const H16 *)h->weights + d.w_off,
                                            h->bias + d.b_off, seg, radial, B, u.hin, u.win, (long long)h->slot_elems[u.src0] * B * 2,
-                                           (long long)32 * 576 * 2, 64, (long long)128, 4, h->radial_f16 ? 1 : 0);
+                                           (long long)32 * 576 * 2, 64, (long long)128, 4, h->radial_f16 ? 1 : 0, h->range_dev, 1);
                         RCV_LAUNCH_CHECK();
                     } else if constexpr (kX3)
                         hipLaunchKernelGGL(k_tail_x3, dim3((u.hout + TX_TH - 1) / TX_TH, B, h->groups), dim3(256), TX_LDS, st, (const H16 *)(ws + off[u.src0]),
                                            (const H16 *)h->weights + c.w_off, h->bias + c.b_off, (const H16 *)h->weights + d.w_off,
                                            h->bias + d.b_off, seg, radial, B, u.hin, u.win, (long long)h->slot_elems[u.src0] * B * 2,
-                                           (long long)32 * 576 * 2, 64, (long long)128, 4, h->radial_f16 ? 1 : 0, h->range_dev);
+                                           (long long)32 * 576 * 2, 64, (long long)128, 4, h->radial_f16 ? 1 : 0, h->range_dev, 0);
                     else
                         hipLaunchKernelGGL(k_tail, grid, dim3(256), TAIL_LDS, st, (const H16 *)(ws + off[u.src0]),
                                            (const H16 *)h->weights + c.w_off, h->bias + c.b_off, (const H16 *)h->weights + d.w_off,

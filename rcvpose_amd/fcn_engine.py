@@ -354,7 +354,7 @@ def compose_upsample_conv3(w):
     [4 * cout, 3, 3, cin] of the equivalent 3x3 convolution on the LOW-resolution tensor whose output channel (2 py + px) * cout + co
     is channel co of the high-resolution pixel (2 i + py, 2 j + px) -- both maps are linear, the composition is exact.  (Away from
     the image border: the upsampling clamps there and the convolution pads with zeros, so the outermost ring of high-resolution
-    pixels is recomputed separately: k_tail_ring.)"""
+    pixels is recomputed separately: k_tail_x3 on the border tiles.)"""
     import torch
 
     cout = w.shape[0]

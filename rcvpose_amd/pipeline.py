@@ -54,9 +54,8 @@ class FramePipeline:
         self.ws = torch.empty((n_items, ws_bytes), dtype=torch.uint8, device=device)
         self.xyz = torch.empty((n_items, cap, 3), dtype=torch.float64, device=device)
         self.rlist = torch.empty((n_items, cap), dtype=torch.float32, device=device)
-        self.counts = torch.zeros((n_items, 4), dtype=torch.int32, device=device)  # [points, radii, non-finite pixels of the maps, 0]
+        self.counts = torch.zeros((n_items, 4), dtype=torch.int32, device=device)  # [points, radii, non-finite pixels of the maps, their running maximum]
         self.results = torch.zeros((n_items, ctypes.sizeof(_hip.AccResult)), dtype=torch.uint8, device=device)
-        self._nonfinite = torch.zeros((), dtype=torch.int32, device=device)  # largest counts[:, 2] of any batch since the last read_results
         self.k4 = (ctypes.c_double * 4)(self.K[0, 0], self.K[1, 1], self.K[0, 2], self.K[1, 2])
         # overlapped mode (enqueue_step): FCN on one stream, seam + voting + result copy on another
         # overlap=False: one stream for both (kernel timings free of cross-stream time slicing)
@@ -139,7 +138,6 @@ class FramePipeline:
         res = item(self.results, ctypes.sizeof(_hip.AccResult))
         _hip.check(L.rcv_seam_compact_batch(seg, rad, dep, self.H, self.W, self.k4, float(self.seg_threshold), rmx, seam_mode, xyz, rl, cnt,
                                             self.cap, ws, self.ws_bytes, B, G, st), "rcv_seam_compact_batch")
-        torch.maximum(self._nonfinite, self.counts[:, 2].amax(), out=self._nonfinite)  # (stream-ordered; sticky until read_results)
         self._mark("seam")
         _hip.check(L.rcv_accumulate_3d_batch(xyz, rl, 0, cnt, self.cap, self.acc_unit, self.vote_engine, res, ws, self.ws_bytes, B, G, st),
                    "rcv_accumulate_3d_batch")
@@ -148,14 +146,14 @@ class FramePipeline:
     def read_results(self):
         """One D2H copy -> (estimated_kpts float64 [B,G,3] mm, list of AccResult).  Raises _hip.HalfRangeError when a forward
         since the last call stored an activation beyond the half-precision range (f16x3 / fp16 engines: clipped maps)."""
+        self.finish()  # (first: the copies below run on the caller's stream, the votes of enqueue_step on the pipeline's own)
         raw = self.results.cpu().numpy()
-        nonfinite = int(self._nonfinite.item())
-        self._nonfinite.zero_()
-        self.finish()
+        nonfinite = int(self.counts[:, 3].max().item())
+        self.counts[:, 3].zero_()
         self.engine.range_status(clear=True, raise_on_flag=True)
         # the range guard sees magnitudes, not NaNs (v_max drops them, and so does the next ReLU), and the mask comparisons drop a NaN
-        # pixel without a trace: the seam counts the non-finite values of the very maps the votes are cast on (counts[:, 2]), and vote()
-        # keeps the largest count of every batch enqueued since the last call -- whichever output buffer a later forward has taken since
+        # pixel without a trace: the seam counts the non-finite values of the very maps the votes are cast on (counts[:, 2]) and keeps
+        # the largest count of every batch enqueued since the last call (counts[:, 3]) -- whichever output buffer a later forward has taken since
         if nonfinite != 0:
             raise FloatingPointError("non-finite FCN output in %s mode (NaN weights or input?): up to %d pixels of a map"
                                      % (self.engine.dtype_name, nonfinite))
