@@ -1293,6 +1293,7 @@ struct HaloParams {
     int bias_gs;
     int C0, C1, Cout, H, W, n_img, relu, K;
     int th, tw, tiles_y, tiles_x;
+    int c1_shift;     // log2(C1 / C0) (signed) when a second source has another channel count: its patch offsets are the first source's, rescaled
     unsigned *range;  // sticky range-flag word (ConvParams::range)
     // parity-composed tail (template parameter TAILC, engine option 13): the head's weights / [bias | scale] record and the output planes
     const void *w8;
@@ -1301,6 +1302,16 @@ struct HaloParams {
     int b8_gs, rad_f16;
     float *seg, *radial;
 };
+// log2(c1 / c0) if the ratio is a power of two (0 without a second source), else INT_MIN: k_conv_halo rescales its patch offsets by shifts
+inline int halo_c1_shift(int c0, int c1)
+{
+    if (c1 <= 0 || c1 == c0) return 0;
+    for (int s = 1; s < 16; s++) {
+        if (c0 << s == c1) return s;
+        if (c1 << s == c0) return -s;
+    }
+    return (int)0x80000000;
+}
 // patch pieces (8 rows x 128 B) per wave and slice, one per tap 0 .. PPW - 1.  BN = 128: 7 -> 448 patch rows, a 320-pixel rectangle
 // with its halo (10 x 42); BN = 64 (half the weight stages): 8 -> 512 rows, a 384-pixel rectangle (14 x 34)
 constexpr int halo_ppw(int bn) { return bn == 64 ? 8 : 7; }
@@ -1323,7 +1334,7 @@ __global__ __launch_bounds__(512) void k_conv_halo(const HaloParams p)
     using T = H16;
     constexpr int EPV = 8, NT = BN / 32, RW = 16 * MT;   // 8 waves = 4 x 2 of RW pixels x BN / 2 channels (tile: 4 * RW rows)
     constexpr int BPW = BN / 64;                             // weight pieces per wave and K step
-    constexpr int OOB = (int)0x80000000;
+    constexpr int HALO_SKIP = -128;  // byte offset of a patch row outside the image: beyond any tensor, and still negative after the rescaling shifts
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int HALO_PPW = halo_ppw(BN), HALO_PATCH = halo_patch(BN);
     unsigned char *sP = smem;                    // [2][HALO_PATCH]
@@ -1353,8 +1364,12 @@ __global__ __launch_bounds__(512) void k_conv_halo(const HaloParams p)
         const int pr = (k * 8 + wave) * 8 + lrow;
         const int py = (int)(((float)pr + 0.5f) * rP), px = pr - py * pitch;
         const int y = y0 - 1 + py, x = x0 - 1 + px;
-        // The patch is swizzled with chunk ^= key(patch position), key = (px + tw * py) & 7, kept in bits 28..30 of lin[k] (a pixel
-        // index is < 2^24: 32-bit byte offsets).  The taps read the patch rows of 16 CONSECUTIVE PIXELS of the rectangle from any
+        // r06: lin[k] is the piece's BYTE OFFSET in the first source, pixel * (C0 * 2) + its swizzled 16-byte chunk (HALO_SKIP = -128 for
+        // rows outside the image: out of range for the buffer load, zeros in LDS).  It is the same for every channel slice -- the slice
+        // moves the descriptor's base -- so a patch piece costs the load phase NO vector instruction (r02-r05: unpack, multiply, swizzle,
+        // a compare and an exec-mask round trip, ~10 instructions per piece in the phase the partner wave's MFMAs wait for); slices of a
+        // second source with another channel count rescale it by the power of two C1 / C0 (arithmetic shifts: the sentinel stays negative).
+        // The patch is swizzled with chunk ^= key(patch position), key = (px + tw * py) & 7.  The taps read the patch rows of 16 CONSECUTIVE PIXELS of the rectangle from any
         // start; along the rectangle's pixel order this key counts on across the end of a rectangle row, where the patch row
         // jumps by the two halo columns -- with the r02/r03 key (patch row & 7, continuous only inside a row) every 16-pixel tile
         // that wraps (three of four in the 15 x 20 rectangles of layer 3) read with 2-way bank conflicts: rocprofv3 counted
@@ -1362,9 +1377,9 @@ __global__ __launch_bounds__(512) void k_conv_halo(const HaloParams p)
         const int key = (px + p.tw * py) & 7;
         if constexpr (TAILC) {  // the composed tail reads the low-resolution tensor with REPLICATE padding (the upsampling's clamp)
             const int yc = min(max(y, 0), p.H - 1), xc = min(max(x, 0), p.W - 1);
-            lin[k] = pr < prows ? ((img * p.H + yc) * p.W + xc) | (key << 28) : -1;
+            lin[k] = pr < prows ? ((img * p.H + yc) * p.W + xc) * (p.C0 * 2) + ((lpos ^ key) << 4) : HALO_SKIP;
         } else
-            lin[k] = (pr < prows && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W) ? ((img * p.H + y) * p.W + x) | (key << 28) : -1;
+            lin[k] = (pr < prows && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W) ? ((img * p.H + y) * p.W + x) * (p.C0 * 2) + ((lpos ^ key) << 4) : HALO_SKIP;
     }
     int b_off[BPW];
 #pragma unroll
@@ -1376,6 +1391,7 @@ __global__ __launch_bounds__(512) void k_conv_halo(const HaloParams p)
     const int a_bytes0 = (int)((long long)p.C0 * p.H * p.W * p.n_img * 2), a_bytes1 = (int)((long long)p.C1 * p.H * p.W * p.n_img * 2);
     const int b_bytes = BN * p.K * 2;
     const int nsl = Ctot >> 6;
+    const int c1_shift = p.c1_shift;
 
     // fragment rows: tile row r = wm * RW + i * 16 + r16 -> patch row of its pixel (centre tap); rows beyond the rectangle
     // read pixel 0's (their results are never stored)
@@ -1393,18 +1409,20 @@ __global__ __launch_bounds__(512) void k_conv_halo(const HaloParams p)
     {                                                                                                          \
         const int cgp_ = (sl_) << 6;                                                                           \
         const bool first_ = cgp_ < p.C0, live_ = (sl_) < nsl;                                                  \
-        const int Cs_ = first_ ? p.C0 : p.C1;                                                                  \
         const char *ab_ = (const char *)(first_ ? src0 : src1) + (long long)(first_ ? cgp_ : cgp_ - p.C0) * 2; \
-        int lk_ = lin[k];                                                                                      \
-        asm volatile("" : "+v"(lk_)); /* unpack here, every time: hoisted out of the K loop the two halves cost 7 registers and spill */ \
-        const int off_ = (live_ && lk_ >= 0) ? (lk_ & 0x0FFFFFFF) * (Cs_ * 2) + ((lpos ^ (lk_ >> 28)) << 4) : OOB; \
-        halo_dma16(ab_, first_ ? a_bytes0 : a_bytes1, sP + ((sl_) & 1) * HALO_PATCH + ((k) * 8 + wave) * 1024, off_); \
+        int off_ = lin[k];                                                                                     \
+        if (!first_ && c1_shift != 0) { /* (wave-uniform branch) */                                            \
+            asm volatile("" : "+v"(off_)); /* (here, every time: hoisted, the second source's offsets cost HALO_PPW registers) */ \
+            const int hi_ = off_ & ~127;                                                                       \
+            off_ = (c1_shift > 0 ? hi_ << c1_shift : hi_ >> -c1_shift) | (off_ & 127);                         \
+        }                                                                                                      \
+        halo_dma16(ab_, live_ ? (first_ ? a_bytes0 : a_bytes1) : 0, sP + ((sl_) & 1) * HALO_PATCH + ((k) * 8 + wave) * 1024, off_); \
     }
 // weight piece c of K step (slice sl_, tap t_) into ring stage st_; steps beyond the last one: zeros
 #define RCV_HALO_B(sl_, t_, st_, c)                                                                            \
     {                                                                                                          \
-        halo_dma16(b_base + (long long)((t_) * Ctot + ((sl_) << 6)) * 2, b_bytes, sB + (st_) * (BN * 128) + (wave * (8 * BPW) + (c) * 8) * 128, \
-                   (sl_) < nsl ? b_off[c] : OOB);                                                              \
+        halo_dma16(b_base + (long long)((t_) * Ctot + ((sl_) << 6)) * 2, (sl_) < nsl ? b_bytes : 0, sB + (st_) * (BN * 128) + (wave * (8 * BPW) + (c) * 8) * 128, \
+                   b_off[c]);                                                                                  \
     }
 
     f32x4 acc[MT][NT];
@@ -4754,6 +4772,8 @@ int launch_conv_halo(const ConvParams &p, int B, int groups, int mode, hipStream
     q.C0 = p.C0; q.C1 = p.C1; q.Cout = p.Cout; q.H = p.Hout; q.W = p.Wout; q.n_img = B; q.relu = p.relu; q.K = p.K;
     q.tiles_y = (q.H + q.th - 1) / q.th; q.tiles_x = (q.W + q.tw - 1) / q.tw;
     q.range = p.range;
+    q.c1_shift = halo_c1_shift(p.C0, p.C1);
+    if (q.c1_shift == (int)0x80000000) return RCV_E_UNSUPPORTED;
     dim3 grid(p.Cout / bn, (unsigned)(B * q.tiles_y * q.tiles_x), groups);
     if (p.q6) {  // fp6 cross terms (option 11): source and weights in the q6 row layout
         if (q.th * q.tw > 256) hipLaunchKernelGGL((k_conv_halo<128, 5, true>), grid, dim3(512), halo_lds(128), st, q);
@@ -4933,7 +4953,7 @@ int run_op(rcv_fcn *h, const rcv_op &op, const float *x, int B, float *seg, floa
             int th, tw;
             const int hbn = p.Cout % 128 == 0 ? 128 : 64;
             if (h->use_halo && dma_ok && op.ksize == 3 && op.stride == 1 && op.pad == 1 && op.res < 0 && p.Cout % 64 == 0 &&
-                p.C0 % 64 == 0 && p.C1 % 64 == 0 && op.hin == op.hout && op.win == op.wout &&
+                p.C0 % 64 == 0 && p.C1 % 64 == 0 && op.hin == op.hout && op.win == op.wout && halo_c1_shift(p.C0, p.C1) != (int)0x80000000 &&
                 halo_tile(op.hout, op.wout, h->use_halo, hbn, (long long)B * G * (p.Cout / hbn), th, tw) &&
                 (long long)B * ((op.hout + th - 1) / th) * ((op.wout + tw - 1) / tw) * (p.Cout / hbn) * G >= 192)
                 return launch_conv_halo(p, B, G, h->use_halo, st);
