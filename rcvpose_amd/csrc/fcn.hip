@@ -1327,6 +1327,12 @@ __device__ __forceinline__ void halo_dma16(const void *base, int num_bytes, unsi
     __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void *)lds_wave_base, 16, voffset, 0, 0, 0);
 }
 
+// ... through a descriptor built once per workgroup, the wave-uniform part of the address in the instruction's scalar offset
+__device__ __forceinline__ void halo_dma16r(__amdgpu_buffer_rsrc_t r, unsigned char *lds_wave_base, int voffset, int soffset)
+{
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void *)lds_wave_base, 16, voffset, soffset, 0, 0);
+}
+
 template <int BN, int MT, bool Q6 = false, bool TAILC = false>
 __global__ __launch_bounds__(512) void k_conv_halo(const HaloParams p)
 {
@@ -1405,24 +1411,42 @@ __global__ __launch_bounds__(512) void k_conv_halo(const HaloParams p)
     }
 
 // patch piece k of channel slice sl_ into patch buffer (sl_ & 1); slices beyond the last one: zeros
+// r06: the load phases are what the partner wave's MFMA phase waits for at the barrier, and a scalar instruction costs them an issue
+// slot like any other.  The three operand tensors get ONE descriptor each per workgroup; what changes per step is a scalar byte
+// offset (the instruction's soffset): (tap * Ctot + slice * 64) * 2 for the weights, the slice's channel offset for a patch -- ~30
+// scalar instructions per step less than building a descriptor (64-bit base, selects between the two sources) per piece.  Pieces past
+// the end (the weights of steps nsteps, nsteps + 1; the patch of slice nsl) re-read offset 0: nobody consumes them.
+    const __amdgpu_buffer_rsrc_t rA0 = __builtin_amdgcn_make_buffer_rsrc((void *)src0, 0, a_bytes0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rA1 = __builtin_amdgcn_make_buffer_rsrc((void *)(src1 ? src1 : src0), 0, src1 ? a_bytes1 : a_bytes0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void *)b_base, 0, b_bytes, 0x00020000);
+    // the patch source of the NEXT slice (set at the top of every slice): descriptor, channel offset, rescaling of the offsets
+    __amdgpu_buffer_rsrc_t rAn = rA0;
+    int soffA = 0;
+    bool xfn = false;
+#define RCV_HALO_NEXT_SLICE(sl_)                                                                               \
+    {                                                                                                          \
+        const int sn_ = (sl_) + 1 < nsl ? (sl_) + 1 : 0, cgn_ = sn_ << 6;                                      \
+        const bool firstn_ = cgn_ < p.C0;                                                                      \
+        rAn = firstn_ ? rA0 : rA1;                                                                             \
+        soffA = (firstn_ ? cgn_ : cgn_ - p.C0) * 2;                                                            \
+        xfn = !firstn_ && c1_shift != 0;                                                                       \
+    }
+// patch piece k of the next slice into patch buffer ((sl_) & 1); sl_ = 0: the prologue's (first source, channel offset 0)
 #define RCV_HALO_PATCH(sl_, k)                                                                                 \
     {                                                                                                          \
-        const int cgp_ = (sl_) << 6;                                                                           \
-        const bool first_ = cgp_ < p.C0, live_ = (sl_) < nsl;                                                  \
-        const char *ab_ = (const char *)(first_ ? src0 : src1) + (long long)(first_ ? cgp_ : cgp_ - p.C0) * 2; \
         int off_ = lin[k];                                                                                     \
-        if (!first_ && c1_shift != 0) { /* (wave-uniform branch) */                                            \
+        if (xfn) { /* (wave-uniform branch) */                                                                 \
             asm volatile("" : "+v"(off_)); /* (here, every time: hoisted, the second source's offsets cost HALO_PPW registers) */ \
             const int hi_ = off_ & ~127;                                                                       \
             off_ = (c1_shift > 0 ? hi_ << c1_shift : hi_ >> -c1_shift) | (off_ & 127);                         \
         }                                                                                                      \
-        halo_dma16(ab_, live_ ? (first_ ? a_bytes0 : a_bytes1) : 0, sP + ((sl_) & 1) * HALO_PATCH + ((k) * 8 + wave) * 1024, off_); \
+        halo_dma16r(rAn, sP + ((sl_) & 1) * HALO_PATCH + ((k) * 8 + wave) * 1024, off_, soffA);                \
     }
-// weight piece c of K step (slice sl_, tap t_) into ring stage st_; steps beyond the last one: zeros
+// weight piece c of K step (slice sl_, tap t_) into ring stage st_
 #define RCV_HALO_B(sl_, t_, st_, c)                                                                            \
     {                                                                                                          \
-        halo_dma16(b_base + (long long)((t_) * Ctot + ((sl_) << 6)) * 2, (sl_) < nsl ? b_bytes : 0, sB + (st_) * (BN * 128) + (wave * (8 * BPW) + (c) * 8) * 128, \
-                   b_off[c]);                                                                                  \
+        halo_dma16r(rB, sB + (st_) * (BN * 128) + (wave * (8 * BPW) + (c) * 8) * 128, b_off[c],                \
+                    (sl_) < nsl ? ((t_) * Ctot + ((sl_) << 6)) * 2 : 0);                                       \
     }
 
     f32x4 acc[MT][NT];
@@ -1748,6 +1772,7 @@ __global__ __launch_bounds__(512) void k_conv_halo(const HaloParams p)
 #define RCV_Q6_TWO_PHASE 0  // 1: one load phase + one MFMA phase per step (below).  Measured r05: 17.9 ms per 35 layer-3 launches against 12.3 in the four-phase form -- its 72 fragment registers beside the 6-wide operand tuples spill 22 registers, the reloads sit in the K loop and every scratch load joins the vmcnt queue of the DMA pieces
 #endif
         for (int sl = 0; sl < nsl; sl++) {
+            RCV_HALO_NEXT_SLICE(sl);
 #if RCV_Q6_TWO_PHASE
             RCV_HALO_STEP2_X3Q(0); RCV_HALO_STEP2_X3Q(1); RCV_HALO_STEP2_X3Q(2);
             RCV_HALO_STEP2_X3Q(3); RCV_HALO_STEP2_X3Q(4); RCV_HALO_STEP2_X3Q(5);
@@ -1760,6 +1785,7 @@ __global__ __launch_bounds__(512) void k_conv_halo(const HaloParams p)
         }
     } else if constexpr (BPW == 2 && kX3 && (!RCV_X3_HALO_TWO_PHASE || MT == 5)) {  // (the 320-row tile would spill in the two-phase form)
         for (int sl = 0; sl < nsl; sl++) {
+            RCV_HALO_NEXT_SLICE(sl);
 #ifdef RCV_HALO_STAMPS
             stamp_on = stamp_blk && sl == 2;
 #endif
@@ -1769,18 +1795,21 @@ __global__ __launch_bounds__(512) void k_conv_halo(const HaloParams p)
         }
     } else if constexpr (kX3) {
         for (int sl = 0; sl < nsl; sl++) {
+            RCV_HALO_NEXT_SLICE(sl);
             RCV_HALO_STEP2_X3(0); RCV_HALO_STEP2_X3(1); RCV_HALO_STEP2_X3(2);
             RCV_HALO_STEP2_X3(3); RCV_HALO_STEP2_X3(4); RCV_HALO_STEP2_X3(5);
             RCV_HALO_STEP2_X3(6); RCV_HALO_STEP2_X3(7); RCV_HALO_STEP2_X3(8);
         }
     } else if constexpr (BPW == 2) {
         for (int sl = 0; sl < nsl; sl++) {
+            RCV_HALO_NEXT_SLICE(sl);
             RCV_HALO_STEP(0); RCV_HALO_STEP(1); RCV_HALO_STEP(2);
             RCV_HALO_STEP(3); RCV_HALO_STEP(4); RCV_HALO_STEP(5);
             RCV_HALO_STEP(6); RCV_HALO_STEP(7); RCV_HALO_STEP(8);
         }
     } else {
         for (int sl = 0; sl < nsl; sl++) {
+            RCV_HALO_NEXT_SLICE(sl);
             RCV_HALO_STEP2(0); RCV_HALO_STEP2(1); RCV_HALO_STEP2(2);
             RCV_HALO_STEP2(3); RCV_HALO_STEP2(4); RCV_HALO_STEP2(5);
             RCV_HALO_STEP2(6); RCV_HALO_STEP2(7); RCV_HALO_STEP2(8);
@@ -1801,6 +1830,7 @@ __global__ __launch_bounds__(512) void k_conv_halo(const HaloParams p)
 #undef RCV_HALO_STEP2_X3
 #undef RCV_HALO_B
 #undef RCV_HALO_PATCH
+#undef RCV_HALO_NEXT_SLICE
 
     if constexpr (TAILC && kX3) {
         // ---- parity-composed tail: ReLU + the head straight from the accumulators, no LDS, no barrier.  With the operands swapped
