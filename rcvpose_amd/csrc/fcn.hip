@@ -853,11 +853,11 @@ __global__ __launch_bounds__(512) void k_conv_dma(const ConvParams p)
 // 32 x 32), the operands by LDS-DMA into a ring of LAT_STAGES 16 KB stages, LAT_STAGES - 1 steps in flight, all eight
 // waves issuing (one A and one B piece each per step), ONE barrier per step, counted vmcnt.  Same K order and
 // the same MFMA sequence per output element as k_conv / k_conv_dma: bit-identical results (tests/test_gpu_fcn.py), which
-// is what keeps a frame's maps independent of the batch it travels in.  No split-K: a different summation order would
-// break exactly that.
+// is what keeps a frame's maps independent of the batch it travels in.  No split-K by default: a different summation order would
+// break exactly that (engine option 12 is the opt-in).  r06: the step's instruction stream cut to a third (see RCV_LAT_ISSUE_NOW).
 // ---------------------------------------------------------------------------------------------
 #ifndef RCV_LAT_AHEAD
-#define RCV_LAT_AHEAD 0  // 1: fragment reads one K step ahead of the MFMAs (bit-identical; measured r04: 4.41 vs 4.30 ms per batch-1 f16x3 forward -- slower, off)
+#define RCV_LAT_AHEAD 1  // 1: fragment reads one K step ahead of the MFMAs (bit-identical).  r04, heavy issue path: 4.41 vs 4.30 ms per batch-1 f16x3 forward (slower); r06, lean issue path: see DESIGN.md
 #endif
 constexpr int LAT_BM = 64, LAT_BN = 64, LAT_STAGES = 8;
 constexpr int LAT_STAGE_BYTES = (LAT_BM + LAT_BN) * 128;
@@ -939,27 +939,50 @@ __global__ __launch_bounds__(512) void k_conv_lat(const ConvParams p)
     const int taps = p.KS * p.KS, tap0 = kt0 % taps;
     int tap_r = tap0 / p.KS, tap_s = tap0 - (tap0 / p.KS) * p.KS, cg = (kt0 / taps) * KE, issued = 0;
 
-// the two pieces of the next K step (if there is one) into stage `st_`
-#define RCV_LAT_ISSUE(st_)                                                                                     \
-    if (issued < nk) {                                                                                         \
+// The two pieces of the next K step into stage `st_`.  r06: a step of this kernel is a chain of barrier -> issue -> fragment reads ->
+// MFMAs walked 36 ... 864 times by a launch with few tiles, and at 8 (bf16) / 24 (split) MFMAs per step it is the INSTRUCTION STREAM
+// that sets its length: ~100 scalar instructions per step went into 64-bit operand bases, per-piece descriptors, selects between the
+// two sources and a compare-and-branch ladder for the counted wait.  Now: one descriptor per operand tensor and workgroup; the weights'
+// step offset is the DMA's scalar offset; the patch displacement of a tap is a 32-bit scalar added to the lane's pixel offset; the
+// source (descriptor, channel count, pixel offsets) changes only where the channel slice crosses into the second tensor; and the
+// steady-state loop waits with a constant count (the tail of the K range drains through the ladder).
+    const __amdgpu_buffer_rsrc_t rA0 = __builtin_amdgcn_make_buffer_rsrc((void *)src0, 0, a_bytes0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rA1 = __builtin_amdgcn_make_buffer_rsrc((void *)(src1 ? src1 : src0), 0, src1 ? a_bytes1 : a_bytes0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void *)b_base, 0, b_bytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t rA = rA0;   // source of the slice being issued
+    int Cs = p.C0, c_in = cg, a_off = a_off0;
+    auto lat_source = [&]() {          // (after cg moved)
+        const bool first_ = cg < p.C0;
+        rA = first_ ? rA0 : rA1;
+        Cs = first_ ? p.C0 : p.C1;
+        c_in = first_ ? cg : cg - p.C0;
+        a_off = first_ ? a_off0 : a_off1;
+    };
+    lat_source();
+#define RCV_LAT_ISSUE_NOW(st_)                                                                                 \
+    {                                                                                                          \
         unsigned char *As_ = smem + (st_) * LAT_STAGE_BYTES;                                                   \
         unsigned char *Bs_ = As_ + BM * 128;                                                                   \
-        const bool first_ = cg < p.C0;                                                                         \
-        const int Cs_ = first_ ? p.C0 : p.C1, c_ = first_ ? cg : cg - p.C0;                                    \
         const int tap_ = tap_r * p.KS + tap_s;                                                                 \
-        const long long disp_ = ((long long)((tap_r - p.pad) * p.Win + (tap_s - p.pad)) * Cs_ + c_) * 2;      \
-        lat_dma16((const char *)(first_ ? src0 : src1) + disp_, first_ ? a_bytes0 : a_bytes1, As_ + wave * 8 * 128,  \
-                  ((a_ok >> tap_) & 1u) ? (first_ ? a_off0 : a_off1) : OOB);                                  \
-        lat_dma16(b_base + (long long)(tap_ * Ctot + cg) * 2, b_bytes, Bs_ + wave * 8 * 128, b_off);           \
+        const int disp_ = (((tap_r - p.pad) * p.Win + (tap_s - p.pad)) * Cs + c_in) * 2;                       \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (__attribute__((address_space(3))) void *)(As_ + wave * 8 * 128), 16, \
+                                                 ((a_ok >> tap_) & 1u) ? a_off + disp_ : OOB, 0, 0, 0);        \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (__attribute__((address_space(3))) void *)(Bs_ + wave * 8 * 128), 16, \
+                                                 b_off, (tap_ * Ctot + cg) * 2, 0, 0);                         \
         issued++;                                                                                              \
         tap_s += 1;                                                                                            \
-        const bool wrap_ = tap_s == p.KS;                                                                      \
-        tap_s = wrap_ ? 0 : tap_s;                                                                             \
-        tap_r += wrap_ ? 1 : 0;                                                                                \
-        const bool wrap2_ = tap_r == p.KS;                                                                     \
-        tap_r = wrap2_ ? 0 : tap_r;                                                                            \
-        cg += wrap2_ ? KE : 0;                                                                                 \
+        if (tap_s == p.KS) {                                                                                   \
+            tap_s = 0;                                                                                         \
+            tap_r += 1;                                                                                        \
+            if (tap_r == p.KS) {                                                                               \
+                tap_r = 0;                                                                                     \
+                cg += KE;                                                                                      \
+                lat_source();                                                                                  \
+            }                                                                                                  \
+        }                                                                                                      \
     }
+#define RCV_LAT_ISSUE(st_)                                                                                     \
+    if (issued < nk) RCV_LAT_ISSUE_NOW(st_)
 
     f32x4 acc[MT][NT];
 #pragma unroll
@@ -1007,44 +1030,64 @@ __global__ __launch_bounds__(512) void k_conv_lat(const ConvParams p)
     };
     static_assert(NS == 8, "the counted waits are written for 8 stages");
 #if RCV_LAT_AHEAD
-    // r04 experiment (off): the fragment reads run ONE STEP AHEAD of the MFMAs.  A step is barrier -> DMA issue -> eight fragment reads ->
-    // their LDS latency -> the MFMAs, a dependent chain of ~750 cycles walked 36 ... 864 times by a launch with few tiles.  Now the
-    // barrier of step kt certifies step kt + 1 (all eight stages are issued up front and the counted wait looks one step further),
-    // the multiplying waves request the fragments of step kt + 1 into a second register set and multiply step kt's, which they
-    // have held since the previous step: the LDS round trip leaves the chain.  The stage of step kt is free as soon as that
-    // barrier is passed (its fragments are in registers) and takes step kt + 8.  Same products in the same order.
+    // The fragment reads run ONE STEP AHEAD of the MFMAs.  A step is barrier -> issue -> eight fragment reads -> their LDS latency ->
+    // the MFMAs, a dependent chain walked 36 ... 864 times by a launch with few tiles.  Here the barrier of step kt certifies step
+    // kt + 1 (all eight stages are issued up front and the counted wait looks one step further), the multiplying waves request the
+    // fragments of step kt + 1 into a second register set and multiply step kt's, which they have held since the previous step: the
+    // LDS round trip leaves the chain.  The stage of step kt is free as soon as that barrier is passed (its fragments are in
+    // registers) and takes step kt + 8.  Same products in the same order.  (r04, with the heavy issue path: 4.41 against 4.30 ms per
+    // batch-1 f16x3 forward -- slower; r06, lean issue path: see RCV_LAT_AHEAD.)
 #pragma unroll
     for (int s_ = 0; s_ < NS; s_++) RCV_LAT_ISSUE(s_);
-    wait_steps(min(NS - 1, nk - 1));
+    wait_steps(min(NS - 1, nk - 1));  // step 0 has landed (this wave's pieces)
     __builtin_amdgcn_s_barrier();
     if (mma) read_frags(0, 0);
-    int stage = 0;
-    for (int kt = 0; kt < nk; kt += 2) {
-#pragma unroll
-        for (int par = 0; par < 2; par++) {  // (two steps per trip: the register set of a step is a compile-time index)
-            const int k_ = kt + par;
-            if (k_ < nk) {
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's reads of stage `stage` are complete: it may be refilled
-                if (k_ + 1 < nk) wait_steps(min(NS - 2, nk - 2 - k_));  // step k_ + 1 has landed (this wave's pieces)
-                __builtin_amdgcn_s_barrier();                        // ... and everybody's; everybody holds step k_ in registers
-                const int nxt = stage + 1 == NS ? 0 : stage + 1;
-                if (mma && k_ + 1 < nk) read_frags(par ^ 1, nxt);
-                RCV_LAT_ISSUE(stage);
-                if (mma) multiply(par);
-                stage = nxt;
-            }
-        }
+    int stage = 0, kt = 0;
+#define RCV_LAT_STEP(par_, WAIT_, ISSUE_)                                                                      \
+    {                                                                                                          \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); /* this wave's reads of `stage` are complete: it may be refilled */ \
+        WAIT_;                                             /* step kt + 1 has landed (this wave's pieces) */     \
+        __builtin_amdgcn_s_barrier();                      /* ... and everybody's; everybody holds step kt in registers */ \
+        const int nxt_ = stage + 1 == NS ? 0 : stage + 1;                                                      \
+        if (mma && kt + 1 < nk) read_frags((par_) ^ 1, nxt_);                                                  \
+        ISSUE_;                                                                                                \
+        if (mma) multiply(par_);                                                                               \
+        stage = nxt_;                                                                                          \
+        kt++;                                                                                                  \
     }
+    // steady state, two steps per trip (the register set of a step is a compile-time index): step kt + NS exists and takes the
+    // stage of step kt; NS - 2 steps younger than step kt + 1 are in flight
+    while (kt + NS + 1 < nk) {
+        RCV_LAT_STEP(0, asm volatile("s_waitcnt vmcnt(12)" ::: "memory"), RCV_LAT_ISSUE_NOW(stage));
+        RCV_LAT_STEP(1, asm volatile("s_waitcnt vmcnt(12)" ::: "memory"), RCV_LAT_ISSUE_NOW(stage));
+    }
+    // tail: the last steps to issue (if any), then the drain
+    while (kt < nk) {
+        RCV_LAT_STEP(0, if (kt + 1 < nk) wait_steps(min(NS - 2, min(issued, nk) - 2 - kt)), RCV_LAT_ISSUE(stage));
+        if (kt < nk) RCV_LAT_STEP(1, if (kt + 1 < nk) wait_steps(min(NS - 2, min(issued, nk) - 2 - kt)), RCV_LAT_ISSUE(stage));
+    }
+#undef RCV_LAT_STEP
 #else
 #pragma unroll
     for (int s_ = 0; s_ < NS - 1; s_++) RCV_LAT_ISSUE(s_);
     int stage = 0;
-    for (int kt = 0; kt < nk; kt++) {
-        // steps issued after step kt: min(NS - 2, nk - 1 - kt), two pieces each (wave-uniform)
-        wait_steps(min(NS - 2, nk - 1 - kt));
+    int kt = 0;
+    // steady state: step kt + NS - 1 exists and is issued into the stage step kt - 1 was read from; NS - 2 younger steps in flight
+    for (; kt + NS - 1 < nk; kt++) {
+        asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
         __builtin_amdgcn_s_barrier();  // step kt has landed for every wave; every wave is done reading step kt - 1
-        const int free_ = stage == 0 ? NS - 1 : stage - 1;  // the stage step kt - 1 was read from
-        RCV_LAT_ISSUE(free_);
+        const int free_ = stage == 0 ? NS - 1 : stage - 1;
+        RCV_LAT_ISSUE_NOW(free_);
+        if (mma) {
+            read_frags(0, stage);
+            multiply(0);
+        }
+        stage = stage + 1 == NS ? 0 : stage + 1;
+    }
+    // tail: nothing left to issue; steps issued after step kt: nk - 1 - kt (<= NS - 2), two pieces each (wave-uniform)
+    for (; kt < nk; kt++) {
+        wait_steps(min(NS - 2, nk - 1 - kt));
+        __builtin_amdgcn_s_barrier();
         if (mma) {
             read_frags(0, stage);
             multiply(0);
@@ -1053,6 +1096,7 @@ __global__ __launch_bounds__(512) void k_conv_lat(const ConvParams p)
     }
 #endif
 #undef RCV_LAT_ISSUE
+#undef RCV_LAT_ISSUE_NOW
     // epilogue: fp32 tile through LDS, 16-byte vectors of contiguous channels (bias + residual + ReLU fused)
     T *dst = (T *)p.dst + (long long)g * p.dst_gs;
     const float *bias = p.bias + (long long)g * p.bias_gs;
