@@ -189,6 +189,28 @@ __device__ __forceinline__ void x3_join8(const uint4 &hi, const uint4 &lo, float
 }
 #endif
 
+// ---- t3: the 3-byte form of a split-precision tensor (r06, engine option 14).  A bottleneck stage's trunk -- the 4*CMID-channel block
+// output -- is written once and read once, by the next block's chain kernel as its RESIDUAL: a VALU path (every other consumer takes its
+// operand by LDS-DMA straight into the MFMA layout and needs the [32 hi | 32 lo] rows).  Between two chain kernels the tensor therefore
+// travels as sign / 5-bit exponent / 18-bit mantissa: per 32-channel group 64 bytes of top halves (an IEEE half, truncated) + 32 bytes
+// of the next eight mantissa bits = 96 instead of 128 bytes per group and pixel, rounded to nearest even from the fp32 value (19
+// significant bits; the [hi | lo] pair carries 22).  The chains of layers 1-2 are HBM-bound: -20 % of their bytes.  Emulated on the
+// CPU (tools/probe/storage_bits_probe.py --stages): maps 3.8-7.8e-6 from the fp32 forward against 3.4-7.3e-6 without.
+__device__ __forceinline__ float t3_decode(unsigned top16, unsigned low8)
+{
+    const unsigned bits = ((top16 & 0x8000u) << 16) | ((top16 & 0x7fffu) << 13) | (low8 << 5);
+    return __uint_as_float(bits) * 0x1p112f;  // (the half's exponent field sits in the float's: rebias; subnormal halves come out exact)
+}
+__device__ __forceinline__ void t3_encode(float v, unsigned &top16, unsigned &low8)
+{
+    const unsigned b = __float_as_uint(v * 0x1p-112f);
+    unsigned m = b & 0x7fffffffu;
+    m = m + 0xFu + ((m >> 5) & 1u);      // nearest even at bit 5
+    m = min(m, 0x0F7FFFE0u);             // the format's largest finite value (65535.875): saturate like the [hi | lo] split does
+    top16 = ((b >> 16) & 0x8000u) | (m >> 13);
+    low8 = (m >> 5) & 0xffu;
+}
+
 // ---- range guard of the half-precision stores (RCV_F16X3 and RCV_F16).  A magnitude beyond 65504 is clamped by x3_split (the
 // stored pair is finite and wrong) or becomes an infinity in RCV_F16: every epilogue that rounds to halves keeps the largest
 // magnitude it stored in one register (v_max3_f32 with |.| modifiers: four instructions per eight values) and ORs a bit into the
@@ -2316,6 +2338,7 @@ struct BlockParams {
     int b3_gs;
     unsigned *range;  // sticky range-flag word (ConvParams::range)
     int q6_dst3;      // k_chain2_x3: dst3 feeds a q6 op only (engine option 11) -- write q6 rows instead of [hi | lo] rows
+    int t3_res, t3_dst;  // k_chain2_x3 (engine option 14): the residual arrives / the block output leaves in the 3-byte form (t3_decode / t3_encode)
 };
 constexpr int BLK_BM = 128;
 constexpr int BLK_RING = 3, BLK_SLOT = 128 * 128;  // expand-weight ring: 16 KB slots (128 out channels x 64 K)
@@ -3828,22 +3851,26 @@ __device__ __forceinline__ void lds_arrive4(f32x4 &a, f32x4 &b, f32x4 &c, f32x4 
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
 }
 
-template <int CMID>
-__global__ __launch_bounds__(512) void k_chain2_x3(const BlockParams p)
+// NW (r06): waves per workgroup.  8 = 128 pixels per workgroup.  4 (64 pixels): the 128-wide form's 54 KB of LDS and 162 registers let THREE
+// four-wave workgroups share a CU (12 waves) where one eight-wave workgroup ran alone -- each brings its own weight ring (twice the L2 ->
+// LDS weight traffic per pixel), a wave issues twice the DMA pieces per step
+template <int CMID, bool T3 = false, int NW = 8>
+__global__ __launch_bounds__(64 * NW, (NW == 4 ? 3 : (CMID == 64 && !T3) ? 4 : 2)) void k_chain2_x3(const BlockParams p)  // (CMID = 64: two workgroups per CU = 128 registers -- the HBM-bound form lives on its occupancy)
 {
     RCV_X3_MODE();
     using T = H16;
     constexpr int COUT = 4 * CMID, HC = COUT / 64, KE = CMID / 32;  // half chunks of 64 output channels; K slices of the expand
+    static_assert(!T3 || CMID <= 128, "the 3-byte trunk exists where the kernel is HBM-bound (layers 1-2); the 256-wide form has no VALU slot to spare");
     constexpr int SE = c2_se(CMID);                                 // K slices of the expand per step
     constexpr int ES = KE / SE, SPC = ES + 2;                       // expand steps + two reduce steps per half chunk
     constexpr int NTR = CMID / 16;                                  // 16-channel tiles of the reduce's output
-    constexpr int PE = SE, PR = CMID / 64;                          // DMA pieces (8 rows x 128 B) per wave: expand step, reduce step
+    constexpr int PE = SE * 8 / NW, PR = CMID / 64 * 8 / NW;        // DMA pieces (8 rows x 128 B) per wave: expand step, reduce step
     constexpr int SLOT = c2_slot(CMID);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r16 = lane & 15, kq = lane >> 4, lrow = lane >> 3, lpos = lane & 7;
     const int g = blockIdx.z;
-    const int m0 = blockIdx.x * CH_BM;
+    const int m0 = blockIdx.x * (16 * NW);
     if constexpr (RCV_C2_DEPHASE > 0) {
         // Workgroups that start together run their half chunks in step: every CU stores, then every CU loads, and the memory
         // system sees bursts it takes microseconds to drain -- which the in-order vmcnt then charges to the weight stream.  A start-up
@@ -3861,8 +3888,8 @@ __global__ __launch_bounds__(512) void k_chain2_x3(const BlockParams p)
     const float *b2 = p.b2 + (long long)g * p.b2_gs, *b3 = p.b3 + (long long)g * p.b3_gs;  // [bias | scale]
     const int w2_bytes = COUT * CMID * 4, w3_bytes = CMID * COUT * 4;
     float *sB2 = (float *)(smem + C2_RING * SLOT), *sB3 = sB2 + 2 * COUT;
-    for (int i = tid; i < 2 * COUT; i += 512) sB2[i] = b2[i];
-    for (int i = tid; i < 2 * CMID; i += 512) sB3[i] = b3[i];
+    for (int i = tid; i < 2 * COUT; i += 64 * NW) sB2[i] = b2[i];
+    for (int i = tid; i < 2 * CMID; i += 64 * NW) sB3[i] = b3[i];
     const unsigned aB2 = (unsigned)(C2_RING * SLOT) + kq * 32, aB3 = (unsigned)(C2_RING * SLOT + 2 * COUT * 4) + kq * 32;  // this lane's 8 channels
 
     const int m = m0 + wave * 16 + r16;
@@ -3947,9 +3974,15 @@ __global__ __launch_bounds__(512) void k_chain2_x3(const BlockParams p)
             const int b = (k - 2) * 2;
 #pragma unroll
             for (int e = 0; e < 2; e++) {
-                const f32x2 s2 = x3_join2<true>(rh[b + e], rl[b + e]);
-                erv[2 * (b + e)] = s2[0];
-                erv[2 * (b + e) + 1] = s2[1];
+                if (T3 && p.t3_res) {  // words b + e of the top halves; bytes 2 (b + e), 2 (b + e) + 1 of the low bytes
+                    const unsigned lo2 = rl[(b + e) >> 1] >> (16 * ((b + e) & 1));
+                    erv[2 * (b + e)] = t3_decode(rh[b + e] & 0xffffu, lo2 & 0xffu);
+                    erv[2 * (b + e) + 1] = t3_decode(rh[b + e] >> 16, (lo2 >> 8) & 0xffu);
+                } else {
+                    const f32x2 s2 = x3_join2<true>(rh[b + e], rl[b + e]);
+                    erv[2 * (b + e)] = s2[0];
+                    erv[2 * (b + e) + 1] = s2[1];
+                }
             }
             break;
         }
@@ -3966,9 +3999,27 @@ __global__ __launch_bounds__(512) void k_chain2_x3(const BlockParams p)
             break;
         }
         default: {  // 11: the block output (full 128-byte lines per pixel over the wave's two stores)
-            T *op = dst + mrow * (2 * COUT) + ((RCV_C2_DIAG == 1 || RCV_C2_DIAG == 4 ? 0 : h) * 2 + t) * 64 + kq * 8;
-            *(uint4 *)op = eoh;
-            *(uint4 *)(op + 32) = eol;
+            if (T3 && p.t3_dst) {  // the slice's eight values (still in ev) in the 3-byte form, encoded where they are stored: nothing of it
+                                   // stays live across the MFMA phases (the [hi | lo] words above remain the reduce's operand)
+                unsigned e3h[4], e3l[2];
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    unsigned t0, l0, t1, l1;
+                    t3_encode(ev[2 * e], t0, l0);
+                    t3_encode(ev[2 * e + 1], t1, l1);
+                    e3h[e] = t0 | (t1 << 16);
+                    const unsigned two = l0 | (l1 << 8);
+                    if ((e & 1) == 0) e3l[e >> 1] = two;
+                    else e3l[e >> 1] |= two << 16;
+                }
+                char *op = (char *)dst + mrow * (3 * COUT) + (h * 2 + t) * 96;
+                *(uint4 *)(op + kq * 16) = make_uint4(e3h[0], e3h[1], e3h[2], e3h[3]);
+                *(uint2 *)(op + 64 + kq * 8) = make_uint2(e3l[0], e3l[1]);
+            } else {
+                T *op = dst + mrow * (2 * COUT) + ((RCV_C2_DIAG == 1 || RCV_C2_DIAG == 4 ? 0 : h) * 2 + t) * 64 + kq * 8;
+                *(uint4 *)op = eoh;
+                *(uint4 *)(op + 32) = eol;
+            }
             break;
         }
         }
@@ -4019,9 +4070,16 @@ __global__ __launch_bounds__(512) void k_chain2_x3(const BlockParams p)
                 if (q == 0) {  // this half chunk's residual: channels kq*8 .. +7 of the slices h*2 + t (hi, lo)
 #pragma unroll
                     for (int t2 = 0; t2 < 2; t2++) {
-                        const T *rp = res + mrow * (2 * COUT) + ((RCV_C2_DIAG == 1 || RCV_C2_DIAG == 4 ? 0 : h) * 2 + t2) * 64 + kq * 8;  // (diag 1: one hot line)
-                        rres[t2][0] = *(const uint4 *)rp;
-                        rres[t2][1] = *(const uint4 *)(rp + 32);
+                        if (T3 && p.t3_res) {  // 96 bytes per group: [32 top halves | 32 low bytes] (two loads, like the [hi | lo] row)
+                            const char *rp = (const char *)res + mrow * (3 * COUT) + (h * 2 + t2) * 96;
+                            rres[t2][0] = *(const uint4 *)(rp + kq * 16);
+                            const uint2 lo8 = *(const uint2 *)(rp + 64 + kq * 8);
+                            rres[t2][1] = make_uint4(lo8.x, lo8.y, 0u, 0u);
+                        } else {
+                            const T *rp = res + mrow * (2 * COUT) + ((RCV_C2_DIAG == 1 || RCV_C2_DIAG == 4 ? 0 : h) * 2 + t2) * 64 + kq * 8;  // (diag 1: one hot line)
+                            rres[t2][0] = *(const uint4 *)rp;
+                            rres[t2][1] = *(const uint4 *)(rp + 32);
+                        }
                     }
                 }
             }
@@ -4751,6 +4809,12 @@ struct rcv_fcn {
     bool radial_f16 = false;  // the radial plane leaves the head as float16 (BASELINE.json stress configuration)
     bool use_lat = true;      // latency kernel (k_conv_lat) for launches with few tiles (small batches)
     int use_chain2 = 1;       // split engine: 1 = k_chain2_x3 (r04), 0 = k_chain_x3, 2 = k_chain3_x3 for the 256-wide block
+    int use_c2w4 = 0;         // split engine (15, measured experiment, off): k_chain2_x3<128> as four-wave workgroups of 64 pixels, three to a CU instead of
+                              // one eight-wave workgroup: bit-identical, 7.94 against 7.26 ms per 8 launches (twice the DMA issue per wave)
+    int use_t3 = 0;           // split engine (14, measured experiment, off): the trunk of a bottleneck stage travels between the chain kernels of layer 2
+                              // in the 3-byte form (sign / 5-bit exponent / 18-bit mantissa; t3_encode): -20 % of those kernels' bytes, maps 5.8e-6 away
+                              // -- and 9.5 against 7.2 ms per 8 launches: the ~140 VALU instructions per slice of encode + decode cost the chain
+                              // kernel more than the bytes give back (2: also layer 1, whose 128-register budget the form does not fit)
     int use_tailc = 1;        // split engine (13): (upsampling, conv7, head) as one parity-composed 3x3 on the low-resolution tensor with the head in
                               // its register-only epilogue (+ the border tiles by k_tail_x3): r06 4.2 + 0.75 ms per forward of 53 x 3 against
                               // k_tail_x3's 6.2.  1: where an image has >= 64 rectangles (a rule of the image size alone: a frame's maps do not
@@ -5088,6 +5152,9 @@ int register_kernel_attributes()
     RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_chain_x3<256>, hipFuncAttributeMaxDynamicSharedMemorySize, CH_LDS));
     RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_chain2_x3<64>, hipFuncAttributeMaxDynamicSharedMemorySize, c2_lds(64)));
     RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_chain2_x3<128>, hipFuncAttributeMaxDynamicSharedMemorySize, c2_lds(128)));
+    RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_chain2_x3<128, false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, c2_lds(128)));
+    RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_chain2_x3<64, true>, hipFuncAttributeMaxDynamicSharedMemorySize, c2_lds(64)));
+    RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_chain2_x3<128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, c2_lds(128)));
     RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_chain2_x3<256>, hipFuncAttributeMaxDynamicSharedMemorySize, c2_lds(256)));
     RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_chain3_x3<256>, hipFuncAttributeMaxDynamicSharedMemorySize, c2_lds(256)));
     RCV_HIP_CHECK(hipFuncSetAttribute((const void *)k_conv_block<64, false>, hipFuncAttributeMaxDynamicSharedMemorySize, blk_lds(64)));
@@ -5113,6 +5180,38 @@ int forward_impl(rcv_fcn *h, const float *x, int B, float *seg, float *radial, c
         for (auto &e : h->events) RCV_HIP_CHECK(hipEventCreate(&e));
     }
     std::vector<char> src_q6(h->ops.size() + 3, 0);  // per op: its source was written as q6 rows by its (fused) producer
+    std::vector<char> res_t3(h->ops.size() + 3, 0);  // per op: its residual was written in the 3-byte form by the chain kernel before it
+    // split engine: ops i, i + 1 = a 1x1 expand (+ residual, ReLU) and the next block's 1x1 reduce (ReLU) that run as ONE chain kernel
+    // (option 4) -- when the launch has enough 128-pixel tiles to fill the chip (bit-identical to the two kernels, so the choice is free)
+    auto chain_at = [&](size_t i) -> bool {
+        if (!(kX3 && sizeof(T) == 2 && h->use_block && i + 1 < h->ops.size() && h->ops[i].kind == RCV_OP_CONV && h->ops[i + 1].kind == RCV_OP_CONV))
+            return false;
+        const rcv_op &a = h->ops[i], &b = h->ops[i + 1];
+        const int cmid = a.c0;
+        const long long M = (long long)B * a.hout * a.wout;
+        return a.ksize == 1 && a.stride == 1 && a.pad == 0 && a.src1 < 0 && a.res >= 0 && a.relu && a.cout == 4 * cmid &&
+               (cmid == 64 || cmid == 128 || cmid == 256) && b.ksize == 1 && b.stride == 1 && b.pad == 0 && b.src0 == a.dst &&
+               b.src1 < 0 && b.res < 0 && b.relu && b.c0 == 4 * cmid && b.cout == cmid && b.hout == a.hout && b.wout == a.wout &&
+               b.dst != a.src0 && b.dst != a.res && b.dst != a.dst && a.dst != a.src0 && a.dst != a.res &&
+               (M + CH_BM - 1) / CH_BM * h->groups >= 192 && M * 4 * cmid * 4 < 0x7fffffffLL;
+    };
+    // The block output of chain launch i (ops i, i + 1) may travel in the 3-byte form (option 14) iff the only other reader of that
+    // tensor is the RESIDUAL of a later chain launch of the same width (CMID <= 128: the HBM-bound forms): -> that launch's index, or 0
+    auto t3_reader = [&](size_t i) -> size_t {
+        if (!(h->use_t3 && h->use_chain2 == 1 && (h->ops[i].c0 == 128 || (h->use_t3 == 2 && h->ops[i].c0 == 64)))) return 0;  // (64: A-B only, see use_t3)
+        const int s = h->ops[i].dst;
+        size_t reader = 0;
+        for (size_t j = i + 2; j < h->ops.size(); j++) {
+            const rcv_op &o = h->ops[j];
+            const bool reads = o.src0 == s || o.src1 == s || o.res == s;
+            if (reads) {
+                if (reader || o.res != s || o.src0 == s || o.src1 == s || !chain_at(j) || o.c0 != h->ops[i].c0) return 0;
+                reader = j;
+            }
+            if (o.dst == s) break;  // (the slot takes another tensor from here on)
+        }
+        return reader;
+    };
     for (size_t i = 0; i < h->ops.size(); i++) {
         if constexpr (sizeof(T) == 2) {
             // 3x3 (-> 256 channels, ReLU) followed by the 1x1 expand to 1024 channels with residual and ReLU: the second
@@ -5182,15 +5281,11 @@ int forward_impl(rcv_fcn *h, const float *x, int B, float *seg, float *radial, c
             }
             // split engine: 1x1 expand (+ residual, ReLU) followed by the next block's 1x1 reduce (ReLU): one kernel (option 4) when
             // the launch has enough 128-pixel tiles to fill the chip (bit-identical to the two kernels, so the choice is free)
-            if (kX3 && h->use_block && i + 1 < h->ops.size() && h->ops[i].kind == RCV_OP_CONV && h->ops[i + 1].kind == RCV_OP_CONV) {
+            if (chain_at(i)) {
                 const rcv_op &a = h->ops[i], &b = h->ops[i + 1];
                 const int cmid = a.c0;
                 const long long M = (long long)B * a.hout * a.wout;
-                if (a.ksize == 1 && a.stride == 1 && a.pad == 0 && a.src1 < 0 && a.res >= 0 && a.relu && a.cout == 4 * cmid &&
-                    (cmid == 64 || cmid == 128 || cmid == 256) && b.ksize == 1 && b.stride == 1 && b.pad == 0 && b.src0 == a.dst &&
-                    b.src1 < 0 && b.res < 0 && b.relu && b.c0 == 4 * cmid && b.cout == cmid && b.hout == a.hout && b.wout == a.wout &&
-                    b.dst != a.src0 && b.dst != a.res && b.dst != a.dst && a.dst != a.src0 && a.dst != a.res &&
-                    (M + CH_BM - 1) / CH_BM * h->groups >= 192 && M * 4 * cmid * 4 < 0x7fffffffLL) {
+                {
                     auto gs = [&](int s) -> long long { return (long long)h->slot_elems[s] * B * 2; };
                     BlockParams q;
                     memset(&q, 0, sizeof(q));
@@ -5207,13 +5302,24 @@ int forward_impl(rcv_fcn *h, const float *x, int B, float *seg, float *radial, c
                         q.q6_dst3 = 1;
                         src_q6[i + 2] = 1;
                     }
+                    // the trunk between two chain kernels of layers 1-2 in the 3-byte form (option 14)
+                    q.t3_res = res_t3[i];
+                    if (const size_t rd = t3_reader(i)) {
+                        q.t3_dst = 1;
+                        res_t3[rd] = 1;
+                    }
                     if (h->profiling) RCV_HIP_CHECK(hipEventRecord(h->events[2 * i], st));  // time booked on the expand
                     const dim3 grid((unsigned)((M + CH_BM - 1) / CH_BM), 1, h->groups);
                     if (h->use_chain2 == 2 && cmid == 256) {  // (option 10 = 2: four waves x 32 pixels, one wave per SIMD)
                         hipLaunchKernelGGL((k_chain3_x3<256>), grid, dim3(256), c2_lds(256), st, q);
                     } else if (h->use_chain2) {  // (option 10: the r04 form; 0: k_chain_x3, bit-identical output)
+                        const bool t3 = q.t3_res || q.t3_dst;  // (a separate instantiation: the [hi | lo] form keeps its registers and its occupancy)
                         if (cmid == 256) hipLaunchKernelGGL((k_chain2_x3<256>), grid, dim3(512), c2_lds(256), st, q);
+                        else if (cmid == 128 && t3) hipLaunchKernelGGL((k_chain2_x3<128, true>), grid, dim3(512), c2_lds(128), st, q);
+                        else if (cmid == 128 && h->use_c2w4)  // (option 15: three four-wave workgroups per CU instead of one eight-wave one)
+                            hipLaunchKernelGGL((k_chain2_x3<128, false, 4>), dim3((unsigned)((M + 63) / 64), 1, h->groups), dim3(256), c2_lds(128), st, q);
                         else if (cmid == 128) hipLaunchKernelGGL((k_chain2_x3<128>), grid, dim3(512), c2_lds(128), st, q);
+                        else if (t3) hipLaunchKernelGGL((k_chain2_x3<64, true>), grid, dim3(512), c2_lds(64), st, q);
                         else hipLaunchKernelGGL((k_chain2_x3<64>), grid, dim3(512), c2_lds(64), st, q);
                     } else if (cmid == 256) hipLaunchKernelGGL((k_chain_x3<256>), grid, dim3(512), CH_LDS, st, q);
                     else if (cmid == 128) hipLaunchKernelGGL((k_chain_x3<128>), grid, dim3(512), CH_LDS, st, q);
@@ -5549,6 +5655,8 @@ int rcv_fcn_set_option(rcv_fcn *h, int key, int value)
     if (key == 10) { h->use_chain2 = value; return RCV_OK; }
     if (key == 11) { h->use_q6 = value; return RCV_OK; }
     if (key == 13) { h->use_tailc = value; return RCV_OK; }
+    if (key == 14) { h->use_t3 = value; return RCV_OK; }
+    if (key == 15) { h->use_c2w4 = value; return RCV_OK; }
     if (key == 12) {
         if (value && !h->splitk_ws) {
             const size_t bytes = (size_t)48 << 20;  // the largest split launch of the FCN programs at up to 3 networks x 1 frame needs 11 MB

@@ -111,6 +111,35 @@ def test_x3_kernel_variants_identical(shapes):
         assert eng.range_status() == 0
 
 
+def test_x3_trunk_experiments_of_round_6(shapes):
+    """Two measured experiments that stay in the tree switched off.  Engine option 15 (the 128-wide chain kernel as four-wave
+    workgroups, three per CU): the same arithmetic, bit-identical maps.  Engine option 14 (the trunk between two chain kernels of layer 2
+    in a 3-byte form: 19 instead of 22 significant bits): another function -- maps within 2e-5 of the default path and within 1e-4 of
+    the fp32 engine."""
+    from rcvpose_amd.fcn_engine import FcnEngine
+
+    sds = [_sd(shapes, s) for s in range(3)]
+    H, W, B = 480, 640, 7
+    eng = FcnEngine(sds, H, W, dtype="f16x3")
+    x = torch.from_numpy(fcn_weights.make_input(53, (B, 3, H, W))).cuda()
+    seg0, rad0 = [t.clone() for t in eng.forward(x)]
+    eng.set_option(15, 1)
+    seg1, rad1 = [t.clone() for t in eng.forward(x)]
+    assert torch.equal(seg0, seg1) and torch.equal(rad0, rad1)
+    eng.set_option(15, 0)
+    eng.set_option(14, 1)
+    seg2, rad2 = [t.clone() for t in eng.forward(x)]
+    d = float((rad2 - rad0).abs().max() / rad0.abs().max())
+    print("3-byte trunk in layer 2: radial maps %.2e from the default path" % d)
+    assert 0.0 < d <= 2e-5 and eng.range_status() == 0
+    seg_f, rad_f = FcnEngine(sds, H, W, dtype="fp32").forward(x[:2])
+    for g in range(3):
+        assert float((rad2[g, :2] - rad_f[g]).abs().max() / rad_f[g].abs().max()) <= REL_TIGHT
+    eng.set_option(14, 0)
+    seg3, rad3 = eng.forward(x)
+    assert torch.equal(rad3, rad0) and torch.equal(seg3, seg0)
+
+
 def test_x3_mfma_stem_against_direct_stem(shapes):
     """The MFMA stem (image split into half hi / lo pairs, three MFMAs per product) against the direct fp32 stem kernel, at the
     stem's own output and at the network output: both are fp32-grade, not bit-identical (different summation)."""
