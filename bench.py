@@ -530,7 +530,7 @@ def main(argv=None):
         # HBM bytes of the conv family: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the FCN of this mode
         # (gfx950 correction applied), committed under profiles/ with the batch they were taken at -- NOT counters of this run
         traffic, traffic_src = None, None
-        for name, modes in (("r05_conv_hbm_traffic_%s.json" % args.dtype, (args.dtype,)), ("r04_conv_hbm_traffic_%s.json" % args.dtype, (args.dtype,)),
+        for name, modes in (("r06_conv_hbm_traffic_%s.json" % args.dtype, (args.dtype,)), ("r05_conv_hbm_traffic_%s.json" % args.dtype, (args.dtype,)), ("r04_conv_hbm_traffic_%s.json" % args.dtype, (args.dtype,)),
                             ("r03_conv_hbm_traffic_%s.json" % args.dtype, (args.dtype,)),
                             ("r02_conv_hbm_traffic.json", ("bf16", "fp16"))):
             tpath = os.path.join(ROOT, "profiles", name)
@@ -563,7 +563,7 @@ def main(argv=None):
             "equivalent_votes_note": "sum of 5.44 r^2 shell voxels per point / stage time: the votes a rasteriser would cast; the timed "
                                      "engine (exact branch-and-bound peak search) never casts them",
         }
-        vp = next((q for q in (os.path.join(ROOT, "profiles", n) for n in ("r05_vote_pmc.json", "r04_vote_pmc.json", "r03_vote_pmc.json", "r02_vote_pmc.json")) if os.path.exists(q)), None)
+        vp = next((q for q in (os.path.join(ROOT, "profiles", n) for n in ("r06_vote_pmc.json", "r05_vote_pmc.json", "r04_vote_pmc.json", "r03_vote_pmc.json", "r02_vote_pmc.json")) if os.path.exists(q)), None)
         if vp:  # separate rocprofv3 --pmc passes of the voting stage (tools/collect_profiles.sh; r04: at the bench batch)
             pj = json.load(open(vp))
             roof_vote["pmc"] = {"source": "profiles/%s: " % os.path.basename(vp) + pj["source"], "definitions": pj["definitions"],

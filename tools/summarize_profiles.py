@@ -31,7 +31,7 @@ def short(n):
     mm = re.search(r'k_convI(\w+?)Li(\d+)ELi(\d+)', n)
     if mm:
         return 'k_conv<%s,%s,%s>' % ("16-bit" if ("16b" in mm.group(1) or "DF16" in mm.group(1)) else "f32", mm.group(2), mm.group(3))
-    mc2 = re.search(r'k_chain2_x3<(\d+)>', n) or re.search(r'k_chain2_x3ILi(\d+)', n)
+    mc2 = re.search(r'k_chain2_x3<(\d+)', n) or re.search(r'k_chain2_x3ILi(\d+)', n)
     if mc2:
         return 'k_chain2_x3<%s>' % mc2.group(1)
     mc = re.search(r'k_chain_x3<(\d+)>', n) or re.search(r'k_chain_x3ILi(\d+)', n)
@@ -40,9 +40,9 @@ def short(n):
     mb = re.search(r'k_conv_block<(\d+), (\w+), (\w+)>', n)
     if mb:
         return 'k_conv_block<%s,%s,%s>' % mb.groups()
-    mh = re.search(r'k_conv_halo<(\d+), (\d+)>', n)
+    mh = re.search(r'k_conv_halo<(\d+), (\d+)(?:, (\w+))?(?:, (\w+))?>', n)
     if mh:
-        return 'k_conv_halo<%s,%s>' % mh.groups()
+        return 'k_conv_halo<%s,%s>%s' % (mh.group(1), mh.group(2), ' tail' if mh.group(4) == 'true' else ' q6' if mh.group(3) == 'true' else '')
     ml = re.search(r'k_bb_level<(\w+), (\w+), (\d+)>', n)
     if ml:
         return 'k_bb_level<%s,%s>' % ml.groups()[:2]
