@@ -294,6 +294,26 @@ __device__ __forceinline__ void d_seam_count(const float *seg, const RT *rad, co
     __shared__ int sp[4], sr[4], sn[4];
     const int base = blockIdx.x * SEAM_PIX_PER_BLOCK;
     int cp = 0, cr = 0, cn = 0;
+    if (mode == 0) {  // the hot path (LINEMOD seam), straight-line: both maps of all four pixels requested up front
+        float sv[4], rv[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int p = min(base + j * 256 + (int)threadIdx.x, HW - 1);
+            sv[j] = seg[p];
+            rv[j] = (float)rad[p];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int p = base + j * 256 + threadIdx.x;
+            if (p < HW) {
+                const bool mr = (sv[j] > thr) && ((double)rv[j] <= rmax);  // (seam_flags, mode 0)
+                cr += mr;
+                if (mr) cp += depth[p] != 0;
+                // RCV_SEAM_COUNT_NONFINITE: NaN / Inf in the maps (the comparisons above drop such pixels without a trace)
+                cn += !(fabsf(sv[j]) <= 3.402823466e38f) || !(fabsf(rv[j]) <= 3.402823466e38f);
+            }
+        }
+    } else
     for (int j = 0; j < 4; j++) {
         int p = base + j * 256 + threadIdx.x;
         if (p < HW) {
@@ -301,8 +321,7 @@ __device__ __forceinline__ void d_seam_count(const float *seg, const RT *rad, co
             seam_flags(seg, rad, depth, p, thr, rmax, mode, mr, mp);
             cp += mp;
             cr += mr;
-            // RCV_SEAM_COUNT_NONFINITE: NaN / Inf in the maps (the comparisons above drop such pixels without a trace)
-            cn += ((mode == 0 || mode == 3) && !isfinite(seg[p])) || ((mode == 0 || mode == 1) && !isfinite((float)rad[p]));
+            cn += (mode == 3 && !isfinite(seg[p])) || (mode == 1 && !isfinite((float)rad[p]));
         }
     }
     cp = wave_sum_i32(cp);
