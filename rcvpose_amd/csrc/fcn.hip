@@ -1360,6 +1360,7 @@ struct HaloParams {
     int C0, C1, Cout, H, W, n_img, relu, K;
     int th, tw, tiles_y, tiles_x;
     int c1_shift;     // log2(C1 / C0) (signed) when a second source has another channel count: its patch offsets are the first source's, rescaled
+    int groups;       // composed tail (persistent workgroups): the work items are (group, rectangle), dealt by the kernel itself
     unsigned *range;  // sticky range-flag word (ConvParams::range)
     // parity-composed tail (template parameter TAILC, engine option 13): the head's weights / [bias | scale] record and the output planes
     const void *w8;
@@ -1413,13 +1414,35 @@ __global__ __launch_bounds__(512) void k_conv_halo(const HaloParams p)
     unsigned char *sB = smem + 2 * HALO_PATCH;   // [3][BN][128 B]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
-    int mt_, nt_;
-    tile_of_block(p.Cout / BN, mt_, nt_);
-    const int g = blockIdx.z, n0 = nt_ * BN;
+    // The composed tail (TAILC) runs with PERSISTENT workgroups, one per CU, each walking its (group, rectangle) items itself: a
+    // workgroup of that launch lives 18 K steps, so dispatch, index arithmetic and the first operands' latency were a fifth of its
+    // life -- and its epilogue needs no LDS, so the next item's patch and first weights are requested BEFORE the epilogue of this one
+    // runs.  The items of an XCD are a contiguous range (its workgroups take them round-robin: neighbours meet in its L2).  Every
+    // other form: one item per workgroup, numbered by tile_of_block (a restructuring of all forms cost the long-K launches more in
+    // lost hoisting than it gave: DESIGN.md 8).
+    constexpr bool PERSIST = TAILC && kX3;
     const int tpi = p.tiles_y * p.tiles_x;
-    const int img = mt_ / tpi, trem = mt_ - img * tpi;
-    const int ty = trem / p.tiles_x, tx = trem - ty * p.tiles_x;
-    const int y0 = ty * p.th, x0 = tx * p.tw;
+    int item = 0, item_step = 0, item_end = 0;
+    int mt_, nt_, g;
+    if constexpr (PERSIST) {
+        const unsigned total = (unsigned)(p.n_img * tpi) * (unsigned)p.groups;
+        const unsigned xcd = blockIdx.x % 8u, slot = blockIdx.x / 8u, q8 = total / 8u, r8 = total % 8u;
+        const unsigned lo = xcd < r8 ? xcd * (q8 + 1u) : r8 * (q8 + 1u) + (xcd - r8) * q8;
+        item = (int)(lo + slot);
+        item_end = (int)(lo + q8 + (xcd < r8 ? 1u : 0u));
+        item_step = (int)((gridDim.x - xcd + 7u) / 8u);  // workgroups of this XCD
+        if (item >= item_end) return;
+        nt_ = 0;
+        mt_ = item % (p.n_img * tpi);
+        g = item / (p.n_img * tpi);
+    } else {
+        tile_of_block(p.Cout / BN, mt_, nt_);
+        g = blockIdx.z;
+    }
+    const int n0 = nt_ * BN;
+    int img = mt_ / tpi, trem = mt_ - img * tpi;
+    int ty = trem / p.tiles_x, tx = trem - ty * p.tiles_x;
+    int y0 = ty * p.th, x0 = tx * p.tw;
     const int pitch = p.tw + 2, prows = (p.th + 2) * pitch, npx = p.th * p.tw;
     const int Ctot = p.C0 + p.C1;
     const T *src0 = (const T *)p.src0 + (long long)g * p.src0_gs;
@@ -1431,9 +1454,18 @@ __global__ __launch_bounds__(512) void k_conv_halo(const HaloParams p)
 
     // loader: patch piece k of this wave = patch rows (k * 8 + wave) * 8 + lrow; pixel index in the image or -1
     int lin[HALO_PPW];
+    auto fill_lin = [&]() {
 #pragma unroll
     for (int k = 0; k < HALO_PPW; k++) {
-        const int pr = (k * 8 + wave) * 8 + lrow;
+        int lrow_ = lrow, lpos_ = lpos;
+        if constexpr (PERSIST) {  // (the lane's part comes from the exec mask, not from registers that would have to live across the K loop -- and
+                                  // nothing of this arithmetic may be hoisted out of the item loop)
+            const int lane_ = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+            lrow_ = lane_ >> 3;
+            lpos_ = lane_ & 7;
+            asm volatile("" : "+v"(lrow_), "+v"(lpos_));
+        }
+        const int pr = (k * 8 + wave) * 8 + lrow_;
         const int py = (int)(((float)pr + 0.5f) * rP), px = pr - py * pitch;
         const int y = y0 - 1 + py, x = x0 - 1 + px;
         // r06: lin[k] is the piece's BYTE OFFSET in the first source, pixel * (C0 * 2) + its swizzled 16-byte chunk (HALO_SKIP = -128 for
@@ -1449,10 +1481,12 @@ __global__ __launch_bounds__(512) void k_conv_halo(const HaloParams p)
         const int key = (px + p.tw * py) & 7;
         if constexpr (TAILC) {  // the composed tail reads the low-resolution tensor with REPLICATE padding (the upsampling's clamp)
             const int yc = min(max(y, 0), p.H - 1), xc = min(max(x, 0), p.W - 1);
-            lin[k] = pr < prows ? ((img * p.H + yc) * p.W + xc) * (p.C0 * 2) + ((lpos ^ key) << 4) : HALO_SKIP;
+            lin[k] = pr < prows ? ((img * p.H + yc) * p.W + xc) * (p.C0 * 2) + ((lpos_ ^ key) << 4) : HALO_SKIP;
         } else
-            lin[k] = (pr < prows && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W) ? ((img * p.H + y) * p.W + x) * (p.C0 * 2) + ((lpos ^ key) << 4) : HALO_SKIP;
+            lin[k] = (pr < prows && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W) ? ((img * p.H + y) * p.W + x) * (p.C0 * 2) + ((lpos_ ^ key) << 4) : HALO_SKIP;
     }
+    };
+    fill_lin();
     int b_off[BPW];
 #pragma unroll
     for (int c = 0; c < BPW; c++) {
@@ -1482,9 +1516,9 @@ __global__ __launch_bounds__(512) void k_conv_halo(const HaloParams p)
 // offset (the instruction's soffset): (tap * Ctot + slice * 64) * 2 for the weights, the slice's channel offset for a patch -- ~30
 // scalar instructions per step less than building a descriptor (64-bit base, selects between the two sources) per piece.  Pieces past
 // the end (the weights of steps nsteps, nsteps + 1; the patch of slice nsl) re-read offset 0: nobody consumes them.
-    const __amdgpu_buffer_rsrc_t rA0 = __builtin_amdgcn_make_buffer_rsrc((void *)src0, 0, a_bytes0, 0x00020000);
+    __amdgpu_buffer_rsrc_t rA0 = __builtin_amdgcn_make_buffer_rsrc((void *)src0, 0, a_bytes0, 0x00020000);
     const __amdgpu_buffer_rsrc_t rA1 = __builtin_amdgcn_make_buffer_rsrc((void *)(src1 ? src1 : src0), 0, src1 ? a_bytes1 : a_bytes0, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void *)b_base, 0, b_bytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void *)b_base, 0, b_bytes, 0x00020000);
     // the patch source of the NEXT slice (set at the top of every slice): descriptor, channel offset, rescaling of the offsets
     __amdgpu_buffer_rsrc_t rAn = rA0;
     int soffA = 0;
@@ -1516,10 +1550,6 @@ __global__ __launch_bounds__(512) void k_conv_halo(const HaloParams p)
     }
 
     f32x4 acc[MT][NT];
-#pragma unroll
-    for (int i = 0; i < MT; i++)
-#pragma unroll
-        for (int j = 0; j < NT; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int ch0 = ((0 * 4 + kq) ^ ((r16 >> 1) & 7)) << 4, ch1 = ((1 * 4 + kq) ^ ((r16 >> 1) & 7)) << 4;
 
 // One K step = (slice sl, tap TAP), four phases as in k_conv_dma.  Pieces issued: first load phase the first weight piece
@@ -1818,14 +1848,27 @@ __global__ __launch_bounds__(512) void k_conv_halo(const HaloParams p)
     const bool stamp_blk = blockIdx.x + gridDim.x * blockIdx.y == (gridDim.x * gridDim.y) / 2 && blockIdx.z == 0 && (wave & 3) == 0;
     bool stamp_on = false;
 #endif
+// the first operands of the current item: its whole first patch and the weights of steps 0 and 1
+#define RCV_HALO_PROLOGUE()                                                                                    \
+    {                                                                                                          \
+        _Pragma("unroll") for (int k = 0; k < HALO_PPW; k++) RCV_HALO_PATCH(0, k);                             \
+        RCV_HALO_B(0, 0, 0, 0);                                                                                \
+        if constexpr (BPW == 2) RCV_HALO_B(0, 0, 0, 1);                                                        \
+        RCV_HALO_B(0, 1, 1, 0);                                                                                \
+        if constexpr (BPW == 2) RCV_HALO_B(0, 1, 1, 1);                                                        \
+    }
+    RCV_HALO_PROLOGUE();
+    bool first_item = true;
+next_item_top:
 #pragma unroll
-    for (int k = 0; k < HALO_PPW; k++) RCV_HALO_PATCH(0, k);
-    RCV_HALO_B(0, 0, 0, 0);
-    if constexpr (BPW == 2) RCV_HALO_B(0, 0, 0, 1);
-    RCV_HALO_B(0, 1, 1, 0);
-    if constexpr (BPW == 2) RCV_HALO_B(0, 1, 1, 1);
-    if constexpr (BPW == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    for (int i = 0; i < MT; i++)
+#pragma unroll
+        for (int j = 0; j < NT; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (!PERSIST || first_item) {
+        if constexpr (BPW == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    } else  // (younger than the prologue's pieces: the previous item's stores)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if (grp == 1) __builtin_amdgcn_s_barrier();
     int stage = 0;
@@ -1894,9 +1937,6 @@ __global__ __launch_bounds__(512) void k_conv_halo(const HaloParams p)
 #undef RCV_HALO_STEP_X3Q
 #undef RCV_HALO_STEP2_X3Q
 #undef RCV_HALO_STEP2_X3
-#undef RCV_HALO_B
-#undef RCV_HALO_PATCH
-#undef RCV_HALO_NEXT_SLICE
 
     if constexpr (TAILC && kX3) {
         // ---- parity-composed tail: ReLU + the head straight from the accumulators, no LDS, no barrier.  With the operands swapped
@@ -1906,8 +1946,53 @@ __global__ __launch_bounds__(512) void k_conv_halo(const HaloParams p)
         // (seg, radial) pair + add, then v_permlane32_swap on the (ppx = 0, ppx = 1) pair + add -- a reduce-scatter that leaves lane
         // (r16, kq) with plane kq & 1 of column parity kq >> 1: the 32 lanes of a plane store 16 pixels x 2 columns = 128 contiguous bytes.
         static_assert(!TAILC || (BN == 128 && NT == 4), "four parities x 32 channels");
-        const float *bias = p.bias + (long long)g * p.bias_gs;
-        const H16 *w8 = (const H16 *)p.w8 + (long long)g * p.w8_gs;
+        const int e_g = g, e_img = img, e_y0 = y0, e_x0 = x0;  // this item's identity: the variables move on to the next item below
+        int r16_ = r16, kq_ = kq;  // (as in fill_lin: nothing of the epilogue's index arithmetic may be hoisted across the K loop)
+        asm volatile("" : "+v"(r16_), "+v"(kq_));
+        // what the epilogue reads from memory is requested BEFORE the next item's DMA pieces (vector-memory results return in
+        // order: behind them, the epilogue's first instruction would wait for the whole patch)
+        const float *bias = p.bias + (long long)e_g * p.bias_gs;
+        const H16 *w8 = (const H16 *)p.w8 + (long long)e_g * p.w8_gs;
+        float4 bvr[NT], scr[NT];
+#pragma unroll
+        for (int j = 0; j < NT; j++) {
+            const int nl = n0 + wn * (BN / 2) + j * 16 + kq_ * 4;
+            bvr[j] = *(const float4 *)(bias + nl);
+            scr[j] = *(const float4 *)(bias + p.Cout + nl);
+        }
+        float h0[2][4], h1[2][4];
+#pragma unroll
+        for (int jj = 0; jj < 2; jj++)
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const int c = jj * 16 + kq_ * 4 + e;
+                h0[jj][e] = (float)w8[c] + (float)w8[64 + c];
+                h1[jj][e] = (float)w8[32 + c] + (float)w8[96 + c];
+            }
+        float hb = p.b8[(long long)e_g * p.b8_gs + (kq_ & 1)], hs = p.b8[(long long)e_g * p.b8_gs + 2 + (kq_ & 1)];
+        asm volatile("" : "+v"(hb), "+v"(hs), "+v"(h0[0][0]), "+v"(h1[1][3]), "+v"(bvr[0].x), "+v"(scr[NT - 1].w));  // (issued here, not sunk below the DMA)
+        const int next_item = item + item_step;
+        const bool has_next = PERSIST && next_item < item_end;
+        if (has_next) {  // the next item's first operands: LDS is free (every wave has passed its last barrier; this wave's own pieces have landed)
+            item = next_item;
+            mt_ = item % (p.n_img * tpi);
+            g = item / (p.n_img * tpi);
+            img = mt_ / tpi;
+            trem = mt_ - img * tpi;
+            ty = trem / p.tiles_x;
+            tx = trem - ty * p.tiles_x;
+            y0 = ty * p.th;
+            x0 = tx * p.tw;
+            src0 = (const T *)p.src0 + (long long)g * p.src0_gs;
+            b_base = (const char *)((const T *)p.w + (long long)g * p.w_gs + (long long)n0 * p.K);
+            rA0 = __builtin_amdgcn_make_buffer_rsrc((void *)src0, 0, a_bytes0, 0x00020000);
+            rB = __builtin_amdgcn_make_buffer_rsrc((void *)b_base, 0, b_bytes, 0x00020000);
+            rAn = rA0;
+            soffA = 0;
+            xfn = false;
+            fill_lin();
+            RCV_HALO_PROLOGUE();
+        }
         float part[MT][2][2];
 #pragma unroll
         for (int i = 0; i < MT; i++)
@@ -1916,26 +2001,17 @@ __global__ __launch_bounds__(512) void k_conv_halo(const HaloParams p)
         float rmax = 0.f;
 #pragma unroll
         for (int j = 0; j < NT; j++) {
-            const int nl = n0 + wn * (BN / 2) + j * 16 + kq * 4, c = (j & 1) * 16 + kq * 4;
-            const float4 bv = *(const float4 *)(bias + nl), sc = *(const float4 *)(bias + p.Cout + nl);
-            const float bva[4] = {bv.x, bv.y, bv.z, bv.w}, sca[4] = {sc.x, sc.y, sc.z, sc.w};
-            float h0[4], h1[4];
-#pragma unroll
-            for (int e = 0; e < 4; e++) {
-                h0[e] = (float)w8[c + e] + (float)w8[64 + c + e];
-                h1[e] = (float)w8[32 + c + e] + (float)w8[96 + c + e];
-            }
+            const float bva[4] = {bvr[j].x, bvr[j].y, bvr[j].z, bvr[j].w}, sca[4] = {scr[j].x, scr[j].y, scr[j].z, scr[j].w};
 #pragma unroll
             for (int i = 0; i < MT; i++)
 #pragma unroll
                 for (int e = 0; e < 4; e++) {
                     const float v = fmaxf(__fmaf_rn(acc[i][j][e], sca[e], bva[e]), 0.f);
                     rmax = fmaxf(rmax, v);
-                    part[i][j >> 1][0] = fmaf(v, h0[e], part[i][j >> 1][0]);
-                    part[i][j >> 1][1] = fmaf(v, h1[e], part[i][j >> 1][1]);
+                    part[i][j >> 1][0] = fmaf(v, h0[j & 1][e], part[i][j >> 1][0]);
+                    part[i][j >> 1][1] = fmaf(v, h1[j & 1][e], part[i][j >> 1][1]);
                 }
         }
-        const float hb = p.b8[(long long)g * p.b8_gs + (kq & 1)], hs = p.b8[(long long)g * p.b8_gs + 2 + (kq & 1)];
         const int Ho = 2 * p.H, Wo = 2 * p.W;
 #pragma unroll
         for (int i = 0; i < MT; i++) {
@@ -1948,17 +2024,21 @@ __global__ __launch_bounds__(512) void k_conv_halo(const HaloParams p)
             // lanes 0..31: column parity 0 summed over all four kq; lanes 32..63: column parity 1
             const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(s2[0]), __float_as_uint(s2[1]), false, false);
             const float outv = __fmaf_rn(__uint_as_float(sw[0]) + __uint_as_float(sw[1]), hs, hb);
-            const int r = wm * RW + i * 16 + r16;
+            const int r = wm * RW + i * 16 + r16_;
             const int py = (int)(((float)r + 0.5f) * rT), px = r - py * p.tw;
-            const int y = y0 + py, x = x0 + px;
+            const int y = e_y0 + py, x = e_x0 + px;
             if (r < npx && y < p.H && x < p.W) {
-                const long long o = ((long long)(g * p.n_img + img) * Ho + (2 * y + wn)) * Wo + (2 * x + (kq >> 1));
-                if ((kq & 1) == 0) p.seg[o] = outv;
+                const long long o = ((long long)(e_g * p.n_img + e_img) * Ho + (2 * y + wn)) * Wo + (2 * x + (kq_ >> 1));
+                if ((kq_ & 1) == 0) p.seg[o] = outv;
                 else if (p.rad_f16) ((_Float16 *)p.radial)[o] = (_Float16)outv;
                 else p.radial[o] = outv;
             }
         }
         rng_flush(p.range, rmax);
+        if (has_next) {
+            first_item = false;
+            goto next_item_top;
+        }
         return;
     }
     // epilogue: k_conv_dma's (fp32 tile staged in LDS, 16-byte vectors of contiguous channels), in two halves of 2 * RW rows
@@ -2021,6 +2101,10 @@ __global__ __launch_bounds__(512) void k_conv_halo(const HaloParams p)
         if (half == 0) __syncthreads();
     }
     rng_flush(p.range, rmax);
+#undef RCV_HALO_B
+#undef RCV_HALO_PATCH
+#undef RCV_HALO_PROLOGUE
+#undef RCV_HALO_NEXT_SLICE
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -4898,6 +4982,21 @@ bool halo_tile(int H, int W, int mode, int bn, long long units, int &th, int &tw
     return found;
 }
 
+// the composed tail's workgroups are persistent -- one per CU (160 KB of LDS each), or one per work item when there are fewer
+dim3 halo_persistent_grid(long long items)
+{
+    static int n_cu = 0;
+    if (n_cu == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+                   ? prop.multiProcessorCount : 256;
+        n_cu -= n_cu % 8;  // (the item ranges are dealt per XCD)
+        if (n_cu < 8) n_cu = 8;
+    }
+    return dim3((unsigned)(items < n_cu ? items : n_cu), 1, 1);
+}
+
 int launch_conv_halo(const ConvParams &p, int B, int groups, int mode, hipStream_t st)
 {
     HaloParams q;
@@ -5369,7 +5468,8 @@ int forward_impl(rcv_fcn *h, const float *x, int B, float *seg, float *radial, c
                         q.range = h->range_dev;
                         q.w8 = (const H16 *)h->weights + d.w_off; q.w8_gs = 128; q.b8 = h->bias + d.b_off; q.b8_gs = 4;
                         q.seg = seg; q.radial = radial; q.rad_f16 = h->radial_f16 ? 1 : 0;
-                        const dim3 hgrid(1, (unsigned)(B * q.tiles_y * q.tiles_x), h->groups);
+                        q.groups = h->groups;
+                        const dim3 hgrid = halo_persistent_grid((long long)B * q.tiles_y * q.tiles_x * h->groups);  // one workgroup per CU
                         if (q.th * q.tw > 256) hipLaunchKernelGGL((k_conv_halo<128, 5, false, true>), hgrid, dim3(512), halo_lds(128), st, q);
                         else hipLaunchKernelGGL((k_conv_halo<128, 4, false, true>), hgrid, dim3(512), halo_lds(128), st, q);
                         RCV_LAUNCH_CHECK();
