@@ -1420,26 +1420,33 @@ __global__ __launch_bounds__(512) void k_conv_halo(const HaloParams p)
     // runs.  The items of an XCD are a contiguous range (its workgroups take them round-robin: neighbours meet in its L2).  Every
     // other form: one item per workgroup, numbered by tile_of_block (a restructuring of all forms cost the long-K launches more in
     // lost hoisting than it gave: DESIGN.md 8).
-    constexpr bool PERSIST = TAILC && kX3;
+#ifndef RCV_HALO_PERSIST_ALL
+#define RCV_HALO_PERSIST_ALL 0  // 1: every form of the split engine with persistent workgroups (A-B)
+#endif
+    constexpr bool PERSIST = kX3 && (TAILC || RCV_HALO_PERSIST_ALL);
+    // the epilogue from registers (no LDS: the next item's first operands go out BEFORE it runs) wants the MFMA operands swapped: a lane
+    // then holds four consecutive CHANNELS of one pixel instead of four pixels of one channel; the same products in the same K order
+    constexpr bool REGEPI = PERSIST && !Q6, HALO_SWAP = REGEPI;
     const int tpi = p.tiles_y * p.tiles_x;
+    const int n_nt = p.Cout / BN, n_mt = p.n_img * tpi;
     int item = 0, item_step = 0, item_end = 0;
     int mt_, nt_, g;
-    if constexpr (PERSIST) {
-        const unsigned total = (unsigned)(p.n_img * tpi) * (unsigned)p.groups;
+    if constexpr (PERSIST) {  // items = (group, rectangle, channel block), the channel blocks of a rectangle neighbours
+        const unsigned total = (unsigned)(n_nt * n_mt) * (unsigned)p.groups;
         const unsigned xcd = blockIdx.x % 8u, slot = blockIdx.x / 8u, q8 = total / 8u, r8 = total % 8u;
         const unsigned lo = xcd < r8 ? xcd * (q8 + 1u) : r8 * (q8 + 1u) + (xcd - r8) * q8;
         item = (int)(lo + slot);
         item_end = (int)(lo + q8 + (xcd < r8 ? 1u : 0u));
         item_step = (int)((gridDim.x - xcd + 7u) / 8u);  // workgroups of this XCD
         if (item >= item_end) return;
-        nt_ = 0;
-        mt_ = item % (p.n_img * tpi);
-        g = item / (p.n_img * tpi);
+        nt_ = item % n_nt;
+        mt_ = (item / n_nt) % n_mt;
+        g = item / (n_nt * n_mt);
     } else {
-        tile_of_block(p.Cout / BN, mt_, nt_);
+        tile_of_block(n_nt, mt_, nt_);
         g = blockIdx.z;
     }
-    const int n0 = nt_ * BN;
+    int n0 = nt_ * BN;
     int img = mt_ / tpi, trem = mt_ - img * tpi;
     int ty = trem / p.tiles_x, tx = trem - ty * p.tiles_x;
     int y0 = ty * p.th, x0 = tx * p.tw;
@@ -1448,6 +1455,22 @@ __global__ __launch_bounds__(512) void k_conv_halo(const HaloParams p)
     const T *src0 = (const T *)p.src0 + (long long)g * p.src0_gs;
     const T *src1 = p.src1 ? (const T *)p.src1 + (long long)g * p.src1_gs : nullptr;
     const T *wg = (const T *)p.w + (long long)g * p.w_gs;
+    // PERSIST: the current item moves on to the next one (decode, operand bases, descriptors, patch offsets) and its first operands go out
+    auto next_item_setup = [&](int it_) {
+        item = it_;
+        nt_ = item % n_nt;
+        mt_ = (item / n_nt) % n_mt;
+        g = item / (n_nt * n_mt);
+        n0 = nt_ * BN;
+        img = mt_ / tpi;
+        trem = mt_ - img * tpi;
+        ty = trem / p.tiles_x;
+        tx = trem - ty * p.tiles_x;
+        y0 = ty * p.th;
+        x0 = tx * p.tw;
+        src0 = (const T *)p.src0 + (long long)g * p.src0_gs;
+        src1 = p.src1 ? (const T *)p.src1 + (long long)g * p.src1_gs : nullptr;
+    };
     const int lrow = lane >> 3, lpos = lane & 7;
     const int r16 = lane & 15, kq = lane >> 4;
     const float rP = 1.0f / (float)pitch, rT = 1.0f / (float)p.tw;
@@ -1517,7 +1540,7 @@ __global__ __launch_bounds__(512) void k_conv_halo(const HaloParams p)
 // scalar instructions per step less than building a descriptor (64-bit base, selects between the two sources) per piece.  Pieces past
 // the end (the weights of steps nsteps, nsteps + 1; the patch of slice nsl) re-read offset 0: nobody consumes them.
     __amdgpu_buffer_rsrc_t rA0 = __builtin_amdgcn_make_buffer_rsrc((void *)src0, 0, a_bytes0, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rA1 = __builtin_amdgcn_make_buffer_rsrc((void *)(src1 ? src1 : src0), 0, src1 ? a_bytes1 : a_bytes0, 0x00020000);
+    __amdgpu_buffer_rsrc_t rA1 = __builtin_amdgcn_make_buffer_rsrc((void *)(src1 ? src1 : src0), 0, src1 ? a_bytes1 : a_bytes0, 0x00020000);
     __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void *)b_base, 0, b_bytes, 0x00020000);
     // the patch source of the NEXT slice (set at the top of every slice): descriptor, channel offset, rescaling of the offsets
     __amdgpu_buffer_rsrc_t rAn = rA0;
@@ -1647,7 +1670,13 @@ __global__ __launch_bounds__(512) void k_conv_halo(const HaloParams p)
 #endif
 // (TAILC: operands swapped -- a lane then holds four consecutive CHANNELS of one pixel instead of four pixels of one channel,
 // which is what the register-only head epilogue wants; the same products in the same K order)
-#define RCV_HALO_MM(a_, b_, c_) (TAILC ? RCV_MFMA16(b_, a_, c_, 0, 0, 0) : RCV_MFMA16(a_, b_, c_, 0, 0, 0))
+#define RCV_HALO_MM(a_, b_, c_) (HALO_SWAP ? RCV_MFMA16(b_, a_, c_, 0, 0, 0) : RCV_MFMA16(a_, b_, c_, 0, 0, 0))
+// all (tile row i, tile column j in [J0, J1)) products of one operand pair, tile row outermost.  (r06, measured with the operands
+// swapped: the column-outermost order, which keeps the MFMA's A operand across consecutive instructions, ran the K loop 26 % SLOWER;
+// the swap itself costs the row-outermost loop 5-8 % -- which is why only the composed tail, whose epilogue gains more, swaps)
+#define RCV_HALO_MMLOOP(A_, B_, J0, J1)                                                                        \
+    _Pragma("unroll") for (int i = 0; i < MT; i++)                                                             \
+        _Pragma("unroll") for (int j = (J0); j < (J1); j++) acc[i][j] = RCV_HALO_MM(A_[i], B_[j], acc[i][j]);
 #define RCV_HALO_STEP_X3(TAP)                                                                                  \
     {                                                                                                          \
         constexpr int T2_ = ((TAP) + 2) % 9, S2_ = ((TAP) + 2) / 9;                                            \
@@ -1669,10 +1698,8 @@ __global__ __launch_bounds__(512) void k_conv_halo(const HaloParams p)
         __builtin_amdgcn_s_barrier();                                                                          \
         RCV_HSTAMP_X(TAP, 2);                                                                                  \
         __builtin_amdgcn_s_setprio(1);                                                                         \
-        _Pragma("unroll") for (int i = 0; i < MT; i++)                                                         \
-            _Pragma("unroll") for (int j = 0; j < NT; j++) acc[i][j] = RCV_HALO_MM(ah[i], bh[j], acc[i][j]); \
-        _Pragma("unroll") for (int i = 0; i < MT; i++)                                                         \
-            _Pragma("unroll") for (int j = 0; j < NT / 2; j++) acc[i][j] = RCV_HALO_MM(ah[i], bl[j], acc[i][j]); \
+        RCV_HALO_MMLOOP(ah, bh, 0, NT);                                                                        \
+        RCV_HALO_MMLOOP(ah, bl, 0, NT / 2);                                                                    \
         __builtin_amdgcn_s_setprio(0);                                                                         \
         RCV_HSTAMP_X(TAP, 3);                                                                                  \
         __builtin_amdgcn_s_barrier();                                                                          \
@@ -1692,10 +1719,8 @@ __global__ __launch_bounds__(512) void k_conv_halo(const HaloParams p)
         __builtin_amdgcn_s_barrier();                                                                          \
         RCV_HSTAMP_X(TAP, 6);                                                                                  \
         __builtin_amdgcn_s_setprio(1);                                                                         \
-        _Pragma("unroll") for (int i = 0; i < MT; i++)                                                         \
-            _Pragma("unroll") for (int j = NT / 2; j < NT; j++) acc[i][j] = RCV_HALO_MM(ah[i], bl[j], acc[i][j]); \
-        _Pragma("unroll") for (int i = 0; i < MT; i++)                                                         \
-            _Pragma("unroll") for (int j = 0; j < NT; j++) acc[i][j] = RCV_HALO_MM(al[i], bh[j], acc[i][j]); \
+        RCV_HALO_MMLOOP(ah, bl, NT / 2, NT);                                                                   \
+        RCV_HALO_MMLOOP(al, bh, 0, NT);                                                                        \
         __builtin_amdgcn_s_setprio(0);                                                                         \
         RCV_HSTAMP_X(TAP, 7);                                                                                  \
         __builtin_amdgcn_s_barrier();                                                                          \
@@ -1831,11 +1856,11 @@ __global__ __launch_bounds__(512) void k_conv_halo(const HaloParams p)
         __builtin_amdgcn_s_barrier();                                                                          \
         __builtin_amdgcn_s_setprio(1);                                                                         \
         _Pragma("unroll") for (int i = 0; i < MT; i++)                                                         \
-            _Pragma("unroll") for (int j = 0; j < NT; j++) acc[i][j] = RCV_MFMA16(af[0][i], bfr[0][j], acc[i][j], 0, 0, 0); \
+            _Pragma("unroll") for (int j = 0; j < NT; j++) acc[i][j] = RCV_HALO_MM(af[0][i], bfr[0][j], acc[i][j]); \
         _Pragma("unroll") for (int i = 0; i < MT; i++)                                                         \
-            _Pragma("unroll") for (int j = 0; j < NT; j++) acc[i][j] = RCV_MFMA16(af[0][i], bfr[1][j], acc[i][j], 0, 0, 0); \
+            _Pragma("unroll") for (int j = 0; j < NT; j++) acc[i][j] = RCV_HALO_MM(af[0][i], bfr[1][j], acc[i][j]); \
         _Pragma("unroll") for (int i = 0; i < MT; i++)                                                         \
-            _Pragma("unroll") for (int j = 0; j < NT; j++) acc[i][j] = RCV_MFMA16(af[1][i], bfr[0][j], acc[i][j], 0, 0, 0); \
+            _Pragma("unroll") for (int j = 0; j < NT; j++) acc[i][j] = RCV_HALO_MM(af[1][i], bfr[0][j], acc[i][j]); \
         __builtin_amdgcn_s_setprio(0);                                                                         \
         __builtin_amdgcn_s_barrier();                                                                          \
         stage = stage + 1 == 3 ? 0 : stage + 1;                                                                \
@@ -1856,6 +1881,20 @@ __global__ __launch_bounds__(512) void k_conv_halo(const HaloParams p)
         if constexpr (BPW == 2) RCV_HALO_B(0, 0, 0, 1);                                                        \
         RCV_HALO_B(0, 1, 1, 0);                                                                                \
         if constexpr (BPW == 2) RCV_HALO_B(0, 1, 1, 1);                                                        \
+    }
+// PERSIST: on to item it_ and out with its first operands (LDS must be free: every wave past its last barrier / staging read)
+#define RCV_HALO_NEXT_ITEM(it_)                                                                                \
+    {                                                                                                          \
+        next_item_setup(it_);                                                                                  \
+        b_base = (const char *)((const T *)p.w + (long long)g * p.w_gs + (long long)n0 * p.K);                 \
+        rA0 = __builtin_amdgcn_make_buffer_rsrc((void *)src0, 0, a_bytes0, 0x00020000);                        \
+        rA1 = __builtin_amdgcn_make_buffer_rsrc((void *)(src1 ? src1 : src0), 0, src1 ? a_bytes1 : a_bytes0, 0x00020000); \
+        rB = __builtin_amdgcn_make_buffer_rsrc((void *)b_base, 0, b_bytes, 0x00020000);                        \
+        rAn = rA0;                                                                                             \
+        soffA = 0;                                                                                             \
+        xfn = false;                                                                                           \
+        fill_lin();                                                                                            \
+        RCV_HALO_PROLOGUE();                                                                                   \
     }
     RCV_HALO_PROLOGUE();
     bool first_item = true;
@@ -1933,7 +1972,6 @@ next_item_top:
 #undef RCV_HALO_STEP
 #undef RCV_HALO_STEP2
 #undef RCV_HALO_STEP_X3
-#undef RCV_HALO_MM
 #undef RCV_HALO_STEP_X3Q
 #undef RCV_HALO_STEP2_X3Q
 #undef RCV_HALO_STEP2_X3
@@ -1974,24 +2012,7 @@ next_item_top:
         const int next_item = item + item_step;
         const bool has_next = PERSIST && next_item < item_end;
         if (has_next) {  // the next item's first operands: LDS is free (every wave has passed its last barrier; this wave's own pieces have landed)
-            item = next_item;
-            mt_ = item % (p.n_img * tpi);
-            g = item / (p.n_img * tpi);
-            img = mt_ / tpi;
-            trem = mt_ - img * tpi;
-            ty = trem / p.tiles_x;
-            tx = trem - ty * p.tiles_x;
-            y0 = ty * p.th;
-            x0 = tx * p.tw;
-            src0 = (const T *)p.src0 + (long long)g * p.src0_gs;
-            b_base = (const char *)((const T *)p.w + (long long)g * p.w_gs + (long long)n0 * p.K);
-            rA0 = __builtin_amdgcn_make_buffer_rsrc((void *)src0, 0, a_bytes0, 0x00020000);
-            rB = __builtin_amdgcn_make_buffer_rsrc((void *)b_base, 0, b_bytes, 0x00020000);
-            rAn = rA0;
-            soffA = 0;
-            xfn = false;
-            fill_lin();
-            RCV_HALO_PROLOGUE();
+            RCV_HALO_NEXT_ITEM(next_item);
         }
         float part[MT][2][2];
 #pragma unroll
@@ -2041,6 +2062,74 @@ next_item_top:
         }
         return;
     }
+    if constexpr (REGEPI && !TAILC) {
+        // ---- scale, bias, ReLU, range guard, split, store -- from registers: lane (r16, kq) holds channels nl .. nl + 3 of pixel r16 of
+        // tile i (8 bytes of hi halves, 8 bytes of lo halves per tile; a pixel's 128-byte row fills over two tiles).  Element for
+        // element the operations of the LDS-staged epilogue below: bit-identical tensors.
+        const int e_g = g, e_n0 = n0, e_img = img, e_y0 = y0, e_x0 = x0;
+        const int lane_ = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+        int r16_ = lane_ & 15, kq_ = lane_ >> 4;  // (from the exec mask and opaque: nothing of the index arithmetic may be hoisted across the K loop)
+        asm volatile("" : "+v"(r16_), "+v"(kq_));
+        const float *bias = p.bias + (long long)e_g * p.bias_gs;
+        float4 bvr[NT], scr[NT];  // requested BEFORE the next item's DMA pieces: vector-memory results return in order
+#pragma unroll
+        for (int j = 0; j < NT; j++) {
+            const int nl = e_n0 + wn * (BN / 2) + j * 16 + kq_ * 4;
+            bvr[j] = *(const float4 *)(bias + nl);
+            scr[j] = *(const float4 *)(bias + p.Cout + nl);
+        }
+        asm volatile("" : "+v"(bvr[0].x), "+v"(scr[NT - 1].w));
+        const int next_item = item + item_step;
+        const bool has_next = next_item < item_end;
+        if (has_next) RCV_HALO_NEXT_ITEM(next_item);
+        T *dst = (T *)p.dst + (long long)e_g * p.dst_gs;
+        float rmax = 0.f;
+#pragma unroll
+        for (int i = 0; i < MT; i++) {
+            const int r = wm * RW + i * 16 + r16_;
+            const int py = (int)(((float)r + 0.5f) * rT), px = r - py * p.tw;
+            const int y = e_y0 + py, x = e_x0 + px;
+            const bool ok = r < npx && y < p.H && x < p.W;
+            const long long m = (long long)(e_img * p.H + y) * p.W + x;
+#pragma unroll
+            for (int j = 0; j < NT; j++) {
+                const int nl = e_n0 + wn * (BN / 2) + j * 16 + kq_ * 4;
+                const float bva[4] = {bvr[j].x, bvr[j].y, bvr[j].z, bvr[j].w}, sca[4] = {scr[j].x, scr[j].y, scr[j].z, scr[j].w};
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    v[e] = __fmaf_rn(acc[i][j][e], sca[e], bva[e]);
+                    if (p.relu) v[e] = fmaxf(v[e], 0.f);
+                }
+                rmax = rng_see<4>(rmax, v);
+                uint2 oh, ol;
+                x3_split2(v[0], v[1], oh.x, ol.x);
+                x3_split2(v[2], v[3], oh.y, ol.y);
+                if (ok) {
+                    T *op = dst + nhwc_off<T>(m, p.Cout, nl);
+                    *(uint2 *)op = oh;
+                    *(uint2 *)(op + 32) = ol;
+                }
+            }
+        }
+        rng_flush(p.range, rmax);
+        if (has_next) {
+            first_item = false;
+            goto next_item_top;
+        }
+        return;
+    }
+    // (persistent form: the epilogue's per-thread index arithmetic is the same for every item -- hidden from the optimiser, or it is
+    // hoisted out of the item loop and its ~25 registers live, and spill, across the K loop: that, not the loop's own code, is what
+    // made the first persistent attempt of this round 4-8 % slower)
+    int tid_e = tid, r16_e = r16, kq_e = kq;
+    if constexpr (PERSIST) {
+        const int lane_ = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+        tid_e = wave * 64 + lane_;
+        r16_e = lane_ & 15;
+        kq_e = lane_ >> 4;
+        asm volatile("" : "+v"(tid_e), "+v"(r16_e), "+v"(kq_e));
+    }
     // epilogue: k_conv_dma's (fp32 tile staged in LDS, 16-byte vectors of contiguous channels), in two halves of 2 * RW rows
     // (the 320-row tile would not fit at once); tile row -> image pixel
     T *dst = (T *)p.dst + (long long)g * p.dst_gs;
@@ -2054,20 +2143,20 @@ next_item_top:
         if ((wm >> 1) == half) {
 #pragma unroll
             for (int j = 0; j < NT; j++) {
-                const int nl = wn * (BN / 2) + j * 16 + r16;
+                const int nl = wn * (BN / 2) + j * 16 + r16_e;
                 const float bv = bias[n0 + nl];
                 const float sc = kX3 ? bias[p.Cout + n0 + nl] : 1.f;  // (split mode: the weights' power-of-two scale, undone here)
 #pragma unroll
                 for (int i = 0; i < MT; i++)
 #pragma unroll
                     for (int e = 0; e < 4; e++)
-                        stg[((wm & 1) * RW + i * 16 + kq * 4 + e) * SROW + nl] = kX3 ? __fmaf_rn(acc[i][j][e], sc, bv) : acc[i][j][e] + bv;
+                        stg[((wm & 1) * RW + i * 16 + kq_e * 4 + e) * SROW + nl] = kX3 ? __fmaf_rn(acc[i][j][e], sc, bv) : acc[i][j][e] + bv;
             }
         }
         __syncthreads();
 #pragma unroll
         for (int pass = 0; pass < (2 * RW + RPR - 1) / RPR; pass++) {
-            const int lr = pass * RPR + tid / CPR, cc = tid % CPR;  // row within the half, 16-byte chunk
+            const int lr = pass * RPR + tid_e / CPR, cc = tid_e % CPR;  // row within the half, 16-byte chunk
             const int r = half * 2 * RW + lr;
             const int py = (int)(((float)r + 0.5f) * rT), px = r - py * p.tw;
             const int y = y0 + py, x = x0 + px;
@@ -2101,10 +2190,21 @@ next_item_top:
         if (half == 0) __syncthreads();
     }
     rng_flush(p.range, rmax);
+    if constexpr (PERSIST) {
+        if (item + item_step < item_end) {
+            __syncthreads();  // every thread is done reading the staging tile: the next item's patch may land on it
+            RCV_HALO_NEXT_ITEM(item + item_step);
+            first_item = false;
+            goto next_item_top;
+        }
+    }
 #undef RCV_HALO_B
 #undef RCV_HALO_PATCH
 #undef RCV_HALO_PROLOGUE
 #undef RCV_HALO_NEXT_SLICE
+#undef RCV_HALO_NEXT_ITEM
+#undef RCV_HALO_MM
+#undef RCV_HALO_MMLOOP
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -5011,7 +5111,11 @@ int launch_conv_halo(const ConvParams &p, int B, int groups, int mode, hipStream
     q.range = p.range;
     q.c1_shift = halo_c1_shift(p.C0, p.C1);
     if (q.c1_shift == (int)0x80000000) return RCV_E_UNSUPPORTED;
+    q.groups = groups;
     dim3 grid(p.Cout / bn, (unsigned)(B * q.tiles_y * q.tiles_x), groups);
+#if defined(RCV_HALO_PERSIST_ALL) && RCV_HALO_PERSIST_ALL
+    if constexpr (kX3) grid = halo_persistent_grid((long long)(p.Cout / bn) * B * q.tiles_y * q.tiles_x * groups);
+#endif
     if (p.q6) {  // fp6 cross terms (option 11): source and weights in the q6 row layout
         if (q.th * q.tw > 256) hipLaunchKernelGGL((k_conv_halo<128, 5, true>), grid, dim3(512), halo_lds(128), st, q);
         else hipLaunchKernelGGL((k_conv_halo<128, 4, true>), grid, dim3(512), halo_lds(128), st, q);
