@@ -1423,10 +1423,13 @@ __global__ __launch_bounds__(512) void k_conv_halo(const HaloParams p)
 #ifndef RCV_HALO_PERSIST_ALL
 #define RCV_HALO_PERSIST_ALL 0  // 1: every form of the split engine with persistent workgroups (A-B)
 #endif
-    constexpr bool PERSIST = kX3 && (TAILC || RCV_HALO_PERSIST_ALL);
+    constexpr bool PERSIST = kX3 && (TAILC || BN == 64 || RCV_HALO_PERSIST_ALL);  // (BN = 64: the 18- and 27-step launches of layer 1 and conv_up1, -2 ... -4 %)
     // the epilogue from registers (no LDS: the next item's first operands go out BEFORE it runs) wants the MFMA operands swapped: a lane
     // then holds four consecutive CHANNELS of one pixel instead of four pixels of one channel; the same products in the same K order
-    constexpr bool REGEPI = PERSIST && !Q6, HALO_SWAP = REGEPI;
+#ifndef RCV_HALO_REGEPI_ALL
+#define RCV_HALO_REGEPI_ALL 0  // 1 (with RCV_HALO_PERSIST_ALL): the plain forms too store from registers with swapped operands (A-B: K loop +5-8 %)
+#endif
+    constexpr bool REGEPI = PERSIST && !Q6 && (TAILC || RCV_HALO_REGEPI_ALL), HALO_SWAP = REGEPI;
     const int tpi = p.tiles_y * p.tiles_x;
     const int n_nt = p.Cout / BN, n_mt = p.n_img * tpi;
     int item = 0, item_step = 0, item_end = 0;
@@ -5113,9 +5116,7 @@ int launch_conv_halo(const ConvParams &p, int B, int groups, int mode, hipStream
     if (q.c1_shift == (int)0x80000000) return RCV_E_UNSUPPORTED;
     q.groups = groups;
     dim3 grid(p.Cout / bn, (unsigned)(B * q.tiles_y * q.tiles_x), groups);
-#if defined(RCV_HALO_PERSIST_ALL) && RCV_HALO_PERSIST_ALL
-    if constexpr (kX3) grid = halo_persistent_grid((long long)(p.Cout / bn) * B * q.tiles_y * q.tiles_x * groups);
-#endif
+    if (kX3 && (bn == 64 || RCV_HALO_PERSIST_ALL)) grid = halo_persistent_grid((long long)(p.Cout / bn) * B * q.tiles_y * q.tiles_x * groups);
     if (p.q6) {  // fp6 cross terms (option 11): source and weights in the q6 row layout
         if (q.th * q.tw > 256) hipLaunchKernelGGL((k_conv_halo<128, 5, true>), grid, dim3(512), halo_lds(128), st, q);
         else hipLaunchKernelGGL((k_conv_halo<128, 4, true>), grid, dim3(512), halo_lds(128), st, q);
