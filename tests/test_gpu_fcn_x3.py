@@ -355,7 +355,9 @@ def test_x3_composed_tail_against_the_three_kernel_tail(shapes):
     from rcvpose_amd.fcn_engine import FcnEngine
 
     sds = [_sd(shapes, s) for s in range(3)]
-    for (H, W, B) in ((480, 640, 2), (96, 160, 5)):
+    # (at 480 x 640 with two frames the persistent workgroups of the composed kernel walk five or six items each; the small sizes run one item
+    # per workgroup)
+    for (H, W, B) in ((480, 640, 2), (96, 160, 5), (160, 288, 3)):
         eng = FcnEngine(sds, H, W, dtype="f16x3")
         assert any(o["wq_off"] for o in eng.ops if o["cout"] == 32)
         x = torch.from_numpy(fcn_weights.make_input(41, (B, 3, H, W))).cuda()
