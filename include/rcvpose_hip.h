@@ -411,8 +411,8 @@ int rcv_fcn_set_profiling(rcv_fcn *h, int enable);
  * upsampling's clamp and the convolution's zero padding meet, which the composed form cannot express -- are recomputed by k_tail_x3
  * (ring_only).  Same function, another summation: within ~3e-6 of k_tail_x3, not its bits, and 4.9 ms against 6.2 per forward of
  * 53 x 3 (r06).  1: on images with at least 64 rectangles of 320 low-resolution pixels (a rule of the image size alone: a frame's maps
- * do not depend on the batch it travels in -- beyond ~109 frames per batch at 480x640 the 32-bit DMA offsets send the tail back to
- * k_tail_x3); 2: wherever the halo tiling applies (tests); 0: k_tail_x3 everywhere (member of the bit-identical family).
+ * do not depend on the batch it travels in -- a batch beyond the 32-bit DMA range, ~108 frames at 480x640, runs in slices of images);
+ * 2: wherever the halo tiling applies (tests); 0: k_tail_x3 everywhere (member of the bit-identical family).
  * key 14 (default 0 -- a measured experiment, r06; RCV_F16X3): the 4*CMID-channel trunk tensor between two chain kernels of layer 2 (written once, read
  * once, as a residual) in a 3-byte form (sign / 5-bit exponent / 18-bit mantissa, 96 instead of 128 bytes per 32-channel group): maps within
  * 6e-6 of the [hi | lo] form, 20 % fewer bytes, and SLOWER (9.5 against 7.2 ms per forward of 53 x 3: the encode / decode instructions).

@@ -1361,6 +1361,7 @@ struct HaloParams {
     int th, tw, tiles_y, tiles_x;
     int c1_shift;     // log2(C1 / C0) (signed) when a second source has another channel count: its patch offsets are the first source's, rescaled
     int groups;       // composed tail (persistent workgroups): the work items are (group, rectangle), dealt by the kernel itself
+    int out_b, out_img0;  // composed tail: images per group of the output planes, and the first image of this launch (batches beyond the 32-bit DMA range run in slices)
     unsigned *range;  // sticky range-flag word (ConvParams::range)
     // parity-composed tail (template parameter TAILC, engine option 13): the head's weights / [bias | scale] record and the output planes
     const void *w8;
@@ -2052,7 +2053,7 @@ next_item_top:
             const int py = (int)(((float)r + 0.5f) * rT), px = r - py * p.tw;
             const int y = e_y0 + py, x = e_x0 + px;
             if (r < npx && y < p.H && x < p.W) {
-                const long long o = ((long long)(e_g * p.n_img + e_img) * Ho + (2 * y + wn)) * Wo + (2 * x + (kq_ >> 1));
+                const long long o = ((long long)(e_g * p.out_b + p.out_img0 + e_img) * Ho + (2 * y + wn)) * Wo + (2 * x + (kq_ >> 1));
                 if ((kq_ & 1) == 0) p.seg[o] = outv;
                 else if (p.rad_f16) ((_Float16 *)p.radial)[o] = (_Float16)outv;
                 else p.radial[o] = outv;
@@ -5554,7 +5555,6 @@ int forward_impl(rcv_fcn *h, const float *x, int B, float *seg, float *radial, c
                     dim3 grid((u.hout + TAIL_TH - 1) / TAIL_TH, B, h->groups);
                     int tth = 0, ttw = 0;
                     const bool tailc = kX3 && h->use_tailc && c.wq_off > 0 && u.c0 == 64 && h->use_halo &&
-                                       (long long)h->slot_elems[u.src0] * B * 4 < 0x7fffffffLL &&
                                        halo_tile(u.hin, u.win, h->use_halo, 128, (long long)B * h->groups, tth, ttw) &&
                                        (h->use_tailc == 2 || (long long)u.hin * u.win >= 64 * 320);  // (>= 64 rectangles of 320 pixels per image)
                     if (tailc) {
@@ -5562,22 +5562,30 @@ int forward_impl(rcv_fcn *h, const float *x, int B, float *seg, float *radial, c
                         // parity-stacked output channels (fcn_engine.compose_upsample_conv3): the halo kernel with replicate padding
                         // and the head in its epilogue; the outermost ring of output pixels, where clamp and zero padding differ
                         // from that, is recomputed by k_tail_x3 on the border tiles.  No upsampled tensor, no VALU patch build in the interior.
-                        HaloParams q;
-                        memset(&q, 0, sizeof(q));
-                        q.th = tth; q.tw = ttw;
-                        q.src0 = ws + off[u.src0]; q.src0_gs = (long long)h->slot_elems[u.src0] * B * 2;
-                        q.w = (const H16 *)h->weights + c.wq_off; q.w_gs = (long long)128 * 9 * 128;
-                        q.bias = h->bias + c.b_off + (long long)h->groups * 64; q.bias_gs = 256;
-                        q.C0 = 128; q.C1 = 0; q.Cout = 128; q.H = u.hin; q.W = u.win; q.n_img = B; q.relu = 1; q.K = 9 * 128;
-                        q.tiles_y = (q.H + q.th - 1) / q.th; q.tiles_x = (q.W + q.tw - 1) / q.tw;
-                        q.range = h->range_dev;
-                        q.w8 = (const H16 *)h->weights + d.w_off; q.w8_gs = 128; q.b8 = h->bias + d.b_off; q.b8_gs = 4;
-                        q.seg = seg; q.radial = radial; q.rad_f16 = h->radial_f16 ? 1 : 0;
-                        q.groups = h->groups;
-                        const dim3 hgrid = halo_persistent_grid((long long)B * q.tiles_y * q.tiles_x * h->groups);  // one workgroup per CU
-                        if (q.th * q.tw > 256) hipLaunchKernelGGL((k_conv_halo<128, 5, false, true>), hgrid, dim3(512), halo_lds(128), st, q);
-                        else hipLaunchKernelGGL((k_conv_halo<128, 4, false, true>), hgrid, dim3(512), halo_lds(128), st, q);
-                        RCV_LAUNCH_CHECK();
+                        // The DMA addresses a group's tensor with 32-bit byte offsets: a batch beyond that range (> ~109 frames at 480 x 640)
+                        // runs in slices of images, so that the form -- and with it a frame's bits -- does not depend on the batch size.
+                        const long long img_elems = h->slot_elems[u.src0];  // elements of one image's tensor per group (16-bit units: x2 for the hi / lo pair)
+                        int max_imgs = (int)std::max<long long>(1, 0x7fffffffLL / (img_elems * 4) - 1);
+                        if (const char *e = getenv("RCV_TAILC_MAX_IMAGES")) max_imgs = std::max(1, std::min(max_imgs, atoi(e)));  // (test hook: small slices)
+                        for (int b0 = 0; b0 < B; b0 += max_imgs) {
+                            const int nb = std::min(max_imgs, B - b0);
+                            HaloParams q;
+                            memset(&q, 0, sizeof(q));
+                            q.th = tth; q.tw = ttw;
+                            q.src0 = ws + off[u.src0] + (size_t)b0 * img_elems * 4; q.src0_gs = img_elems * B * 2;
+                            q.w = (const H16 *)h->weights + c.wq_off; q.w_gs = (long long)128 * 9 * 128;
+                            q.bias = h->bias + c.b_off + (long long)h->groups * 64; q.bias_gs = 256;
+                            q.C0 = 128; q.C1 = 0; q.Cout = 128; q.H = u.hin; q.W = u.win; q.n_img = nb; q.relu = 1; q.K = 9 * 128;
+                            q.tiles_y = (q.H + q.th - 1) / q.th; q.tiles_x = (q.W + q.tw - 1) / q.tw;
+                            q.range = h->range_dev;
+                            q.w8 = (const H16 *)h->weights + d.w_off; q.w8_gs = 128; q.b8 = h->bias + d.b_off; q.b8_gs = 4;
+                            q.seg = seg; q.radial = radial; q.rad_f16 = h->radial_f16 ? 1 : 0;
+                            q.groups = h->groups; q.out_b = B; q.out_img0 = b0;
+                            const dim3 hgrid = halo_persistent_grid((long long)nb * q.tiles_y * q.tiles_x * h->groups);  // one workgroup per CU
+                            if (q.th * q.tw > 256) hipLaunchKernelGGL((k_conv_halo<128, 5, false, true>), hgrid, dim3(512), halo_lds(128), st, q);
+                            else hipLaunchKernelGGL((k_conv_halo<128, 4, false, true>), hgrid, dim3(512), halo_lds(128), st, q);
+                            RCV_LAUNCH_CHECK();
+                        }
                         // the border tiles again, with the three-layer arithmetic (k_tail_x3, ring_only)
                         const int nty = (u.hout + TX_TH - 1) / TX_TH, ring_wgs = nty < 2 ? 1 : 2 + (nty - 2 + TX_RING_ROWS - 1) / TX_RING_ROWS;
                         hipLaunchKernelGGL(k_tail_x3, dim3(ring_wgs, B, h->groups), dim3(256), TX_LDS, st, (const H16 *)(ws + off[u.src0]),

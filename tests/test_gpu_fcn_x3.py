@@ -111,6 +111,27 @@ def test_x3_kernel_variants_identical(shapes):
         assert eng.range_status() == 0
 
 
+def test_x3_composed_tail_in_image_slices(shapes, monkeypatch):
+    """The composed tail addresses a group's tensor with 32-bit DMA offsets; a batch beyond that range (> ~108 frames at 480x640) runs
+    in slices of images instead of falling back to another kernel, so a frame's bits do not depend on the batch.  The slice size is
+    forced down to two images here (RCV_TAILC_MAX_IMAGES): five frames = slices of 2 + 2 + 1, identical maps."""
+    from rcvpose_amd.fcn_engine import FcnEngine
+
+    sds = [_sd(shapes, s) for s in range(3)]
+    H, W, B = 96, 160, 5
+    eng = FcnEngine(sds, H, W, dtype="f16x3")
+    eng.set_option(13, 2)
+    x = torch.from_numpy(fcn_weights.make_input(43, (B, 3, H, W))).cuda()
+    seg0, rad0 = [t.clone() for t in eng.forward(x)]
+    monkeypatch.setenv("RCV_TAILC_MAX_IMAGES", "2")
+    seg1, rad1 = [t.clone() for t in eng.forward(x)]
+    monkeypatch.delenv("RCV_TAILC_MAX_IMAGES")
+    assert torch.equal(seg0, seg1) and torch.equal(rad0, rad1)
+    eng.set_option(13, 0)
+    seg2, rad2 = eng.forward(x)
+    assert not torch.equal(rad2, rad0)   # (the composed form was really the one that ran)
+
+
 def test_x3_trunk_experiments_of_round_6(shapes):
     """Two measured experiments that stay in the tree switched off.  Engine option 15 (the 128-wide chain kernel as four-wave
     workgroups, three per CU): the same arithmetic, bit-identical maps.  Engine option 14 (the trunk between two chain kernels of layer 2
