@@ -4042,12 +4042,16 @@ __device__ __forceinline__ void lds_arrive4(f32x4 &a, f32x4 &b, f32x4 &c, f32x4 
 // NW (r06): waves per workgroup.  8 = 128 pixels per workgroup.  4 (64 pixels): the 128-wide form's 54 KB of LDS and 162 registers let THREE
 // four-wave workgroups share a CU (12 waves) where one eight-wave workgroup ran alone -- each brings its own weight ring (twice the L2 ->
 // LDS weight traffic per pixel), a wave issues twice the DMA pieces per step
+#ifndef RCV_C2_FD
+#define RCV_C2_FD 2  // tiles of weight fragments in flight ahead of the MFMAs.  Measured r06 (same box, ms per 36 launches of the 256-wide form): 2: 22.96-23.05, 3: 23.02-23.04, 4: 23.03-23.08 -- the fragments' LDS latency is not what the kernel waits for
+#endif
 template <int CMID, bool T3 = false, int NW = 8>
 __global__ __launch_bounds__(64 * NW, (NW == 4 ? 3 : (CMID == 64 && !T3) ? 4 : 2)) void k_chain2_x3(const BlockParams p)  // (CMID = 64: two workgroups per CU = 128 registers -- the HBM-bound form lives on its occupancy)
 {
     RCV_X3_MODE();
     using T = H16;
     constexpr int COUT = 4 * CMID, HC = COUT / 64, KE = CMID / 32;  // half chunks of 64 output channels; K slices of the expand
+    constexpr int FD = RCV_C2_FD, NF = FD + 1;  // weight-fragment sets requested ahead of the tile being multiplied
     static_assert(!T3 || CMID <= 128, "the 3-byte trunk exists where the kernel is HBM-bound (layers 1-2); the 256-wide form has no VALU slot to spare");
     constexpr int SE = c2_se(CMID);                                 // K slices of the expand per step
     constexpr int ES = KE / SE, SPC = ES + 2;                       // expand steps + two reduce steps per half chunk
@@ -4150,7 +4154,9 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 ? 3 : (CMID == 64 && !T3) ? 4 : 2
         const unsigned *rh = (const unsigned *)&rres[t][0], *rl = (const unsigned *)&rres[t][1];
         switch (k) {
         case 0:  // (LDS reads complete in order: the fragment reads issued after the request have been consumed by now)
-            asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(ebi0), "+v"(ebi1), "+v"(esc0), "+v"(esc1));  // (at most two tiles' fragments are newer)
+            if constexpr (FD == 2) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(ebi0), "+v"(ebi1), "+v"(esc0), "+v"(esc1));  // (at most FD tiles' fragments are newer: two reads each)
+            else if constexpr (FD == 3) asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(ebi0), "+v"(ebi1), "+v"(esc0), "+v"(esc1));
+            else asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(ebi0), "+v"(ebi1), "+v"(esc0), "+v"(esc1));
 #pragma unroll
             for (int e = 0; e < 4; e++) ev[e] = __fmaf_rn(accE[2 * t][e], esc0[e], ebi0[e]);
             break;
@@ -4213,7 +4219,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 ? 3 : (CMID == 64 && !T3) ? 4 : 2
         }
     };
 
-    bf16x8 fwh[3], fwl[3];  // weight fragments (hi, lo) of three tiles: two in flight ahead of the one being multiplied
+    bf16x8 fwh[NF], fwl[NF];  // weight fragments (hi, lo) of FD + 1 tiles: FD in flight ahead of the one being multiplied
 #if defined(RCV_HALO_STAMPS) && defined(RCV_CHAIN2_STAMPS)
     // diagnostic build (tools/halo_stamps.py --chain2): four stamps per step over half chunks 6 and 7 of one workgroup in the
     // middle of the launch -- step top, after the counted vmcnt wait, after the barrier, after the issue (DMA pieces, residual)
@@ -4289,17 +4295,18 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 ? 3 : (CMID == 64 && !T3) ? 4 : 2
                 auto off = [&](int i) { return ((i >> 1) % SE) * 8192 + (i / (2 * SE)) * 4096 + (i & 1) * 512; };
                 if (q == ES - 1) ep_request(h, 0);
                 __builtin_amdgcn_sched_barrier(0);  // (the requests stay older than every fragment read of the step)
-                rd(0, off(0));
-                rd(1, off(1));
+#pragma unroll
+                for (int f = 0; f < FD; f++)
+                    if (f < NTE) rd(f, off(f));
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int i = 0; i < NTE; i++) {
-                    if (i + 2 < NTE) rd((i + 2) % 3, off(i + 2));
+                    if (i + FD < NTE) rd((i + FD) % NF, off(i + FD));
                     const int ks = (i >> 1) % SE;
                     f32x4 &a = accE[(i / (2 * SE)) * 2 + (i & 1)];
-                    a = RCV_MFMA16(fwh[i % 3], aE[SE * q + ks][0], a, 0, 0, 0);
-                    a = RCV_MFMA16(fwl[i % 3], aE[SE * q + ks][0], a, 0, 0, 0);
-                    a = RCV_MFMA16(fwh[i % 3], aE[SE * q + ks][1], a, 0, 0, 0);
+                    a = RCV_MFMA16(fwh[i % NF], aE[SE * q + ks][0], a, 0, 0, 0);
+                    a = RCV_MFMA16(fwl[i % NF], aE[SE * q + ks][0], a, 0, 0, 0);
+                    a = RCV_MFMA16(fwh[i % NF], aE[SE * q + ks][1], a, 0, 0, 0);
                     if (q == ES - 1 && i >= NTE / 2) {  // slice 0 is final: its epilogue rides on the second tile pair's MFMAs
                         constexpr int PPT = (EP_N + NTE / 2 - 1) / (NTE / 2);
 #pragma unroll
@@ -4318,15 +4325,16 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 ? 3 : (CMID == 64 && !T3) ? 4 : 2
                 auto off = [](int j) { return (j >> 1) * 4096 + (j & 1) * 512; };
                 if (t == 0) ep_request(h, 1);
                 __builtin_amdgcn_sched_barrier(0);
-                rd(0, off(0));
-                rd(1, off(1));
+#pragma unroll
+                for (int f = 0; f < FD; f++)
+                    if (f < NTR) rd(f, off(f));
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int j = 0; j < NTR; j++) {
-                    if (j + 2 < NTR) rd((j + 2) % 3, off(j + 2));
-                    accR[j] = RCV_MFMA16(fwh[j % 3], ah, accR[j], 0, 0, 0);
-                    accR[j] = RCV_MFMA16(fwl[j % 3], ah, accR[j], 0, 0, 0);
-                    accR[j] = RCV_MFMA16(fwh[j % 3], al, accR[j], 0, 0, 0);
+                    if (j + FD < NTR) rd((j + FD) % NF, off(j + FD));
+                    accR[j] = RCV_MFMA16(fwh[j % NF], ah, accR[j], 0, 0, 0);
+                    accR[j] = RCV_MFMA16(fwl[j % NF], ah, accR[j], 0, 0, 0);
+                    accR[j] = RCV_MFMA16(fwh[j % NF], al, accR[j], 0, 0, 0);
                     if (t == 0) {  // EP_N pieces over the tiles from the second on (the bias reads are older than tile 2's fragments)
                         constexpr int PPT = (EP_N + NTR - 2) / (NTR - 1);
 #pragma unroll
