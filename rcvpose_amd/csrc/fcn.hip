@@ -2562,6 +2562,17 @@ __device__ __forceinline__ void blk_dma16(const void *base, int num_bytes, unsig
     __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void *)lds_wave_base, 16, voffset, 0, 0, 0);
 }
 
+// (... through a descriptor built once per workgroup, the wave-uniform part of the address in the instruction's scalar offset.  A plain
+// function, like blk_dma16: a template kernel's body is instantiated for the host too, where the buffer builtins do not exist)
+__device__ __forceinline__ void blk_dma16r(__amdgpu_buffer_rsrc_t r, unsigned char *lds_wave_base, int voffset, int soffset)
+{
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void *)lds_wave_base, 16, voffset, soffset, 0, 0);
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t blk_rsrc(const void *base, int num_bytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, num_bytes, 0x00020000);
+}
+
 template <int CMID, bool CHAIN, bool STAG = false>
 __global__ __launch_bounds__(512, (CMID == 64 ? 4 : 2)) void k_conv_block(const BlockParams p)
 {
@@ -4019,7 +4030,7 @@ constexpr int c2_slot(int cmid) { return cmid * 128 > c2_se(cmid) * 8192 ? cmid 
 #define RCV_C2_DIST 2  // steps between the issue of a step's weights and their use (ring slots = RCV_C2_DIST + 1)
 #endif
 #ifndef RCV_C2_DIAG
-#define RCV_C2_DIAG 0  // timing diagnostics with WRONG outputs: 1 = residual loads / block-output stores always hit the same line (no HBM traffic), 2 = weights always of the first chunk (L2-hot), 3 = no weight DMA after the first half chunk, 4 = 1 + 3
+#define RCV_C2_DIAG 0  // timing diagnostics with WRONG outputs: 1 = residual loads / block-output stores always hit the same line (no HBM traffic), 2 = weights always of the first chunk (L2-hot), 3 = no weight DMA after the first half chunk, 4 = 1 + 3, 5 = no epilogue pieces (r06)
 #endif
 #ifndef RCV_C2_DEPHASE
 #define RCV_C2_DEPHASE 0  // cycles per phase unit of the start-up delay (blockIdx.x % 6 units): spreads the workgroups' store / load bursts
@@ -4087,23 +4098,33 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 ? 3 : (CMID == 64 && !T3) ? 4 : 2
     const int m = m0 + wave * 16 + r16;
     const long long mrow = m < p.M ? m : p.M - 1;  // (rows beyond M recompute and re-store row M - 1: equal VM operation counts)
 
-    // ---- weights of step (half chunk h, position q) into ring slot `slot`: lane -> (row of the piece, 16-byte column)
+    // ---- weights of step (half chunk h, position q) into ring slot `slot`: lane -> (row of the piece, 16-byte column).  r06: one
+    // descriptor per weight tensor, the lane's part of a piece's offset (row, swizzled column) precomputed, the step's part (half chunk,
+    // K slices) in the DMA's scalar offset: no vector instruction per piece (the epilogue's vector instructions are what this kernel
+    // waits for: without them it runs at the matrix pipe's rate, RCV_C2_DIAG = 5)
+    const __amdgpu_buffer_rsrc_t rW2 = blk_rsrc(w2, w2_bytes), rW3 = blk_rsrc(w3, w3_bytes);
+    int voffE[PE], voffR[PR];
+#pragma unroll
+    for (int c = 0; c < PE; c++) {
+        const int pid = wave * PE + c, ks = pid >> 3, row = (pid & 7) * 8 + lrow;
+        voffE[c] = (row * (2 * CMID) + ks * 64 + ((lpos ^ c2_key(row)) << 3)) * 2;
+    }
+#pragma unroll
+    for (int c = 0; c < PR; c++) {
+        const int row = (wave * PR + c) * 8 + lrow;
+        voffR[c] = (row * (2 * COUT) + ((lpos ^ c2_key(row)) << 3)) * 2;
+    }
     auto issue = [&](int h, int q, int slot) {
         unsigned char *sl = smem + slot * SLOT;
+        const int hh = RCV_C2_DIAG == 2 ? 0 : h;
         if (q < ES) {  // [SE K slices][64 out channels h*64 ..][32 ch (hi | lo)] of w2 [COUT][KE][64 halves]
 #pragma unroll
-            for (int c = 0; c < PE; c++) {
-                const int pid = wave * PE + c, ks = pid >> 3, row = (pid & 7) * 8 + lrow;
-                const int off = (((RCV_C2_DIAG == 2 ? 0 : h) * 64 + row) * (2 * CMID) + (SE * q + ks) * 64 + ((lpos ^ c2_key(row)) << 3)) * 2;
-                blk_dma16(w2, w2_bytes, sl + pid * 1024, off);
-            }
+            for (int c = 0; c < PE; c++)
+                blk_dma16r(rW2, sl + (wave * PE + c) * 1024, voffE[c], (hh * 64 * (2 * CMID) + SE * q * 64) * 2);
         } else {       // [CMID out channels][32 ch] of w3 [CMID][COUT / 32][64 halves], K slice h*2 + t
 #pragma unroll
-            for (int c = 0; c < PR; c++) {
-                const int pid = wave * PR + c, row = pid * 8 + lrow;
-                const int off = (row * (2 * COUT) + ((RCV_C2_DIAG == 2 ? 0 : h) * 2 + (q - ES)) * 64 + ((lpos ^ c2_key(row)) << 3)) * 2;
-                blk_dma16(w3, w3_bytes, sl + pid * 1024, off);
-            }
+            for (int c = 0; c < PR; c++)
+                blk_dma16r(rW3, sl + (wave * PR + c) * 1024, voffR[c], (hh * 2 + (q - ES)) * 128);
         }
     };
     // vector-memory operations a step issues besides the weights of the step two ahead: the half chunk's residual vectors
@@ -4142,7 +4163,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 ? 3 : (CMID == 64 && !T3) ? 4 : 2
     // closed by a scheduling fence: both waves of a SIMD then alternate matrix and vector work instead of doing ~90 VALU
     // instructions side by side while the matrix pipe idles.  Element for element the operations of k_chain_x3's epilogue.
     constexpr int EP_N = 12;
-    float ev[8], erv[8];
+    f32x2 evp[4], ervp[4];  // the slice's eight values / residuals as pairs
     f32x4 ebi0, ebi1, esc0, esc1;
     uint4 eoh, eol;
     auto ep_request = [&](int h, int t) {  // bias / scale of the slice's eight channels: LDS reads left in flight
@@ -4150,6 +4171,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 ? 3 : (CMID == 64 && !T3) ? 4 : 2
         lds_req128(a, ebi0); lds_req128(a + 16, ebi1); lds_req128(a + COUT * 4, esc0); lds_req128(a + COUT * 4 + 16, esc1);
     };
     auto ep_piece = [&](int h, int t, int k) {
+        if constexpr (RCV_C2_DIAG == 5) return;  // (timing only: no epilogue at all -- what the MFMAs, fragment reads, DMA and barriers take by themselves)
         unsigned *wh_ = (unsigned *)&eoh, *wl_ = (unsigned *)&eol;
         const unsigned *rh = (const unsigned *)&rres[t][0], *rl = (const unsigned *)&rres[t][1];
         switch (k) {
@@ -4157,12 +4179,14 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 ? 3 : (CMID == 64 && !T3) ? 4 : 2
             if constexpr (FD == 2) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(ebi0), "+v"(ebi1), "+v"(esc0), "+v"(esc1));  // (at most FD tiles' fragments are newer: two reads each)
             else if constexpr (FD == 3) asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(ebi0), "+v"(ebi1), "+v"(esc0), "+v"(esc1));
             else asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(ebi0), "+v"(ebi1), "+v"(esc0), "+v"(esc1));
-#pragma unroll
-            for (int e = 0; e < 4; e++) ev[e] = __fmaf_rn(accE[2 * t][e], esc0[e], ebi0[e]);
+            // (r06: pairs -- v_pk_fma_f32 / v_pk_add_f32 do two of the same IEEE operations per instruction, and this kernel waits for its
+            // epilogue's vector instructions: without them it runs at the matrix pipe's rate, RCV_C2_DIAG = 5)
+            evp[0] = __builtin_elementwise_fma(__builtin_shufflevector(accE[2 * t], accE[2 * t], 0, 1), __builtin_shufflevector(esc0, esc0, 0, 1), __builtin_shufflevector(ebi0, ebi0, 0, 1));
+            evp[1] = __builtin_elementwise_fma(__builtin_shufflevector(accE[2 * t], accE[2 * t], 2, 3), __builtin_shufflevector(esc0, esc0, 2, 3), __builtin_shufflevector(ebi0, ebi0, 2, 3));
             break;
         case 1:
-#pragma unroll
-            for (int e = 0; e < 4; e++) ev[4 + e] = __fmaf_rn(accE[2 * t + 1][e], esc1[e], ebi1[e]);
+            evp[2] = __builtin_elementwise_fma(__builtin_shufflevector(accE[2 * t + 1], accE[2 * t + 1], 0, 1), __builtin_shufflevector(esc1, esc1, 0, 1), __builtin_shufflevector(ebi1, ebi1, 0, 1));
+            evp[3] = __builtin_elementwise_fma(__builtin_shufflevector(accE[2 * t + 1], accE[2 * t + 1], 2, 3), __builtin_shufflevector(esc1, esc1, 2, 3), __builtin_shufflevector(ebi1, ebi1, 2, 3));
             break;
         case 2: case 3: {  // residual: hi + lo of channels 4(k-2) .. +3
             const int b = (k - 2) * 2;
@@ -4170,26 +4194,25 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 ? 3 : (CMID == 64 && !T3) ? 4 : 2
             for (int e = 0; e < 2; e++) {
                 if (T3 && p.t3_res) {  // words b + e of the top halves; bytes 2 (b + e), 2 (b + e) + 1 of the low bytes
                     const unsigned lo2 = rl[(b + e) >> 1] >> (16 * ((b + e) & 1));
-                    erv[2 * (b + e)] = t3_decode(rh[b + e] & 0xffffu, lo2 & 0xffu);
-                    erv[2 * (b + e) + 1] = t3_decode(rh[b + e] >> 16, (lo2 >> 8) & 0xffu);
-                } else {
-                    const f32x2 s2 = x3_join2<true>(rh[b + e], rl[b + e]);
-                    erv[2 * (b + e)] = s2[0];
-                    erv[2 * (b + e) + 1] = s2[1];
-                }
+                    ervp[b + e] = f32x2{t3_decode(rh[b + e] & 0xffffu, lo2 & 0xffu), t3_decode(rh[b + e] >> 16, (lo2 >> 8) & 0xffu)};
+                } else
+                    ervp[b + e] = x3_join2<true>(rh[b + e], rl[b + e]);
             }
             break;
         }
         case 4: case 5: {
-            const int b = (k - 4) * 4;
+            const int b = (k - 4) * 2;
 #pragma unroll
-            for (int e = 0; e < 4; e++) ev[b + e] = fmaxf(ev[b + e] + erv[b + e], 0.f);
+            for (int e = 0; e < 2; e++) {
+                const f32x2 s2 = evp[b + e] + ervp[b + e];
+                evp[b + e] = f32x2{fmaxf(s2.x, 0.f), fmaxf(s2.y, 0.f)};
+            }
             break;
         }
-        case 6: rmax = rng_see<8>(rmax, ev); break;
+        case 6: rmax = rng_see<8>(rmax, (const float *)evp); break;
         case 7: case 8: case 9: case 10: {  // split of elements 2(k-7), 2(k-7) + 1 (x3_split8's operations)
             const int e = k - 7;
-            x3_split2<true>(ev[2 * e], ev[2 * e + 1], wh_[e], wl_[e]);
+            x3_split2<true>(evp[e].x, evp[e].y, wh_[e], wl_[e]);
             break;
         }
         default: {  // 11: the block output (full 128-byte lines per pixel over the wave's two stores)
@@ -4199,8 +4222,8 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 ? 3 : (CMID == 64 && !T3) ? 4 : 2
 #pragma unroll
                 for (int e = 0; e < 4; e++) {
                     unsigned t0, l0, t1, l1;
-                    t3_encode(ev[2 * e], t0, l0);
-                    t3_encode(ev[2 * e + 1], t1, l1);
+                    t3_encode(evp[e].x, t0, l0);
+                    t3_encode(evp[e].y, t1, l1);
                     e3h[e] = t0 | (t1 << 16);
                     const unsigned two = l0 | (l1 << 8);
                     if ((e & 1) == 0) e3l[e >> 1] = two;
