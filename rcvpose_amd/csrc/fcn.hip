@@ -4030,7 +4030,7 @@ constexpr int c2_slot(int cmid) { return cmid * 128 > c2_se(cmid) * 8192 ? cmid 
 #define RCV_C2_DIST 2  // steps between the issue of a step's weights and their use (ring slots = RCV_C2_DIST + 1)
 #endif
 #ifndef RCV_C2_DIAG
-#define RCV_C2_DIAG 0  // timing diagnostics with WRONG outputs: 1 = residual loads / block-output stores always hit the same line (no HBM traffic), 2 = weights always of the first chunk (L2-hot), 3 = no weight DMA after the first half chunk, 4 = 1 + 3, 5 = no epilogue pieces (r06)
+#define RCV_C2_DIAG 0  // timing diagnostics with WRONG outputs: 1 = residual loads / block-output stores always hit the same line (no HBM traffic), 2 = weights always of the first chunk (L2-hot), 3 = no weight DMA after the first half chunk, 4 = 1 + 3, 5 = no epilogue pieces (r06; invalid: the expand's MFMAs are dead code then), 6 = no residual loads, 7 = no block-output stores, 8 = neither (the epilogue's arithmetic alone)
 #endif
 #ifndef RCV_C2_DEPHASE
 #define RCV_C2_DEPHASE 0  // cycles per phase unit of the start-up delay (blockIdx.x % 6 units): spreads the workgroups' store / load bursts
@@ -4053,6 +4053,15 @@ __device__ __forceinline__ void lds_arrive4(f32x4 &a, f32x4 &b, f32x4 &c, f32x4 
 // NW (r06): waves per workgroup.  8 = 128 pixels per workgroup.  4 (64 pixels): the 128-wide form's 54 KB of LDS and 162 registers let THREE
 // four-wave workgroups share a CU (12 waves) where one eight-wave workgroup ran alone -- each brings its own weight ring (twice the L2 ->
 // LDS weight traffic per pixel), a wave issues twice the DMA pieces per step
+#ifndef RCV_C2_SPREAD
+#define RCV_C2_SPREAD 0  // 1 = the weight pieces of a step are issued between its tiles instead of all at its top (needs RCV_C2_UNCOND)
+#endif
+#ifndef RCV_C2_NT
+#define RCV_C2_NT 0  // cache policy experiment: 1 = the block-output stores nontemporal, 2 = the residual loads, 3 = both
+#endif
+#ifndef RCV_C2_UNCOND
+#define RCV_C2_UNCOND 1  // 0 = the weight pieces past the last half chunk are branched around (r04-r05: see the issue in the step loop)
+#endif
 #ifndef RCV_C2_FD
 #define RCV_C2_FD 2  // tiles of weight fragments in flight ahead of the MFMAs.  Measured r06 (same box, ms per 36 launches of the 256-wide form): 2: 22.96-23.05, 3: 23.02-23.04, 4: 23.03-23.08 -- the fragments' LDS latency is not what the kernel waits for
 #endif
@@ -4069,6 +4078,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 ? 3 : (CMID == 64 && !T3) ? 4 : 2
     constexpr int NTR = CMID / 16;                                  // 16-channel tiles of the reduce's output
     constexpr int PE = SE * 8 / NW, PR = CMID / 64 * 8 / NW;        // DMA pieces (8 rows x 128 B) per wave: expand step, reduce step
     constexpr int SLOT = c2_slot(CMID);
+    constexpr bool C2_NOLOAD = RCV_C2_DIAG == 6 || RCV_C2_DIAG == 8, C2_NOSTORE = RCV_C2_DIAG == 7 || RCV_C2_DIAG == 8;  // (timing only)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r16 = lane & 15, kq = lane >> 4, lrow = lane >> 3, lpos = lane & 7;
@@ -4100,8 +4110,8 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 ? 3 : (CMID == 64 && !T3) ? 4 : 2
 
     // ---- weights of step (half chunk h, position q) into ring slot `slot`: lane -> (row of the piece, 16-byte column).  r06: one
     // descriptor per weight tensor, the lane's part of a piece's offset (row, swizzled column) precomputed, the step's part (half chunk,
-    // K slices) in the DMA's scalar offset: no vector instruction per piece (the epilogue's vector instructions are what this kernel
-    // waits for: without them it runs at the matrix pipe's rate, RCV_C2_DIAG = 5)
+    // K slices) in the DMA's scalar offset: no vector instruction per piece (bit-identical; 24.07 vs 24.10 ms per 36 launches of the
+    // 256-wide form on one box: this kernel does not wait for its instruction count)
     const __amdgpu_buffer_rsrc_t rW2 = blk_rsrc(w2, w2_bytes), rW3 = blk_rsrc(w3, w3_bytes);
     int voffE[PE], voffR[PR];
 #pragma unroll
@@ -4114,23 +4124,29 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 ? 3 : (CMID == 64 && !T3) ? 4 : 2
         const int row = (wave * PR + c) * 8 + lrow;
         voffR[c] = (row * (2 * COUT) + ((lpos ^ c2_key(row)) << 3)) * 2;
     }
-    auto issue = [&](int h, int q, int slot) {
+    auto issue_piece = [&](int h, int q, int slot, int c) {  // piece c of the step's pieces_for(q)
         unsigned char *sl = smem + slot * SLOT;
         const int hh = RCV_C2_DIAG == 2 ? 0 : h;
-        if (q < ES) {  // [SE K slices][64 out channels h*64 ..][32 ch (hi | lo)] of w2 [COUT][KE][64 halves]
+        if (q < ES)  // [SE K slices][64 out channels h*64 ..][32 ch (hi | lo)] of w2 [COUT][KE][64 halves]
+            blk_dma16r(rW2, sl + (wave * PE + c) * 1024, voffE[c], (hh * 64 * (2 * CMID) + SE * q * 64) * 2);
+        else         // [CMID out channels][32 ch] of w3 [CMID][COUT / 32][64 halves], K slice h*2 + t
+            blk_dma16r(rW3, sl + (wave * PR + c) * 1024, voffR[c], (hh * 2 + (q - ES)) * 128);
+    };
+    auto issue = [&](int h, int q, int slot) {
+        if (q < ES) {
 #pragma unroll
-            for (int c = 0; c < PE; c++)
-                blk_dma16r(rW2, sl + (wave * PE + c) * 1024, voffE[c], (hh * 64 * (2 * CMID) + SE * q * 64) * 2);
-        } else {       // [CMID out channels][32 ch] of w3 [CMID][COUT / 32][64 halves], K slice h*2 + t
+            for (int c = 0; c < PE; c++) issue_piece(h, q, slot, c);
+        } else {
 #pragma unroll
-            for (int c = 0; c < PR; c++)
-                blk_dma16r(rW3, sl + (wave * PR + c) * 1024, voffR[c], (hh * 2 + (q - ES)) * 128);
+            for (int c = 0; c < PR; c++) issue_piece(h, q, slot, c);
         }
     };
     // vector-memory operations a step issues besides the weights of the step two ahead: the half chunk's residual vectors
     // (2 slices x (hi, lo)) at its first step; the stores of slice 0 in the last expand step and of slice 1 in reduce step 0
     auto pieces_for = [&](int q2) { return q2 < ES ? PE : PR; };
-    auto extra_at = [&](int q_) { return (q_ == 0 ? 4 : 0) + (q_ == ES - 1 || q_ == ES ? 2 : 0); };
+    auto loads_at = [&](int q_) { return q_ == 0 && !C2_NOLOAD ? 4 : 0; };
+    auto stores_at = [&](int q_) { return (q_ == ES - 1 || q_ == ES) && !C2_NOSTORE ? 2 : 0; };
+    auto extra_at = [&](int q_) { return loads_at(q_) + stores_at(q_); };
 
     bf16x8 aE[KE][2];
     {
@@ -4155,6 +4171,12 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 ? 3 : (CMID == 64 && !T3) ? 4 : 2
     const unsigned frow = (unsigned)(((r16 >> 2) * 8 + (r16 & 3)) * 128);
     const unsigned fhi = frow + ((kq ^ fkey) << 4), flo = frow + (((4 + kq) ^ fkey) << 4);
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    // (r06) The compiler's wait-count pass does not read the wait above: to it the operand fragments loaded before the loop stay
+    // "in flight" at the loop's entry, and it guards their first uses in EVERY iteration with its own s_waitcnt vmcnt(23), (22), ...
+    // (4) ladder -- in-order counts that are tighter than the counted waits below and drain the weight stream a step early.  Using
+    // the registers here makes it place its wait where it costs nothing.
+#pragma unroll
+    for (int s_ = 0; s_ < KE; s_++) asm volatile("" : "+v"(aE[s_][0]), "+v"(aE[s_][1]));
     __builtin_amdgcn_s_barrier();
 
     // The epilogue of slice t of half chunk h (accumulators of tiles 2t, 2t + 1 -> eight consecutive channels of this lane's pixel:
@@ -4171,7 +4193,8 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 ? 3 : (CMID == 64 && !T3) ? 4 : 2
         lds_req128(a, ebi0); lds_req128(a + 16, ebi1); lds_req128(a + COUT * 4, esc0); lds_req128(a + COUT * 4 + 16, esc1);
     };
     auto ep_piece = [&](int h, int t, int k) {
-        if constexpr (RCV_C2_DIAG == 5) return;  // (timing only: no epilogue at all -- what the MFMAs, fragment reads, DMA and barriers take by themselves)
+        if constexpr (RCV_C2_DIAG == 5) return;  // (NOT a valid "no epilogue" timing: the expand's accumulators are dead then and the compiler drops its MFMAs -- the build
+                                                 // times the reduce alone, tools/halo_stamps.py --chain2 shows expand steps of ~100 cycles.  Use 8.)
         unsigned *wh_ = (unsigned *)&eoh, *wl_ = (unsigned *)&eol;
         const unsigned *rh = (const unsigned *)&rres[t][0], *rl = (const unsigned *)&rres[t][1];
         switch (k) {
@@ -4179,8 +4202,9 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 ? 3 : (CMID == 64 && !T3) ? 4 : 2
             if constexpr (FD == 2) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(ebi0), "+v"(ebi1), "+v"(esc0), "+v"(esc1));  // (at most FD tiles' fragments are newer: two reads each)
             else if constexpr (FD == 3) asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(ebi0), "+v"(ebi1), "+v"(esc0), "+v"(esc1));
             else asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(ebi0), "+v"(ebi1), "+v"(esc0), "+v"(esc1));
-            // (r06: pairs -- v_pk_fma_f32 / v_pk_add_f32 do two of the same IEEE operations per instruction, and this kernel waits for its
-            // epilogue's vector instructions: without them it runs at the matrix pipe's rate, RCV_C2_DIAG = 5)
+            // (r06: pairs -- v_pk_fma_f32 / v_pk_add_f32 do two of the same IEEE operations per instruction: 19 % fewer vector instructions,
+            // no time gained.  tools/probe/mfma_valu_coissue_probe.hip says why: beside a SIMD's MFMAs an ordinary vector instruction
+            // costs ~1.6 cycles (mostly hidden), a packed-fp32 one ~7.7: it issues at half rate and is not hidden.)
             evp[0] = __builtin_elementwise_fma(__builtin_shufflevector(accE[2 * t], accE[2 * t], 0, 1), __builtin_shufflevector(esc0, esc0, 0, 1), __builtin_shufflevector(ebi0, ebi0, 0, 1));
             evp[1] = __builtin_elementwise_fma(__builtin_shufflevector(accE[2 * t], accE[2 * t], 2, 3), __builtin_shufflevector(esc0, esc0, 2, 3), __builtin_shufflevector(ebi0, ebi0, 2, 3));
             break;
@@ -4234,8 +4258,15 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 ? 3 : (CMID == 64 && !T3) ? 4 : 2
                 *(uint2 *)(op + 64 + kq * 8) = make_uint2(e3l[0], e3l[1]);
             } else {
                 T *op = dst + mrow * (2 * COUT) + ((RCV_C2_DIAG == 1 || RCV_C2_DIAG == 4 ? 0 : h) * 2 + t) * 64 + kq * 8;
-                *(uint4 *)op = eoh;
-                *(uint4 *)(op + 32) = eol;
+                if constexpr (C2_NOSTORE) {
+                    asm volatile("" :: "v"(eoh.x), "v"(eoh.y), "v"(eoh.z), "v"(eoh.w), "v"(eol.x), "v"(eol.y), "v"(eol.z), "v"(eol.w));
+                } else if constexpr ((RCV_C2_NT & 1) != 0) {
+                    __builtin_nontemporal_store(*(const i32x4 *)&eoh, (i32x4 *)op);
+                    __builtin_nontemporal_store(*(const i32x4 *)&eol, (i32x4 *)(op + 32));
+                } else {
+                    *(uint4 *)op = eoh;
+                    *(uint4 *)(op + 32) = eol;
+                }
             }
             break;
         }
@@ -4256,7 +4287,6 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 ? 3 : (CMID == 64 && !T3) ? 4 : 2
 #endif
     int slot = 0;
     for (int h = 0; h < HC; h++) {
-        const bool last = h == HC - 1;
 #if defined(RCV_HALO_STAMPS) && defined(RCV_CHAIN2_STAMPS)
         stamp_on = stamp_blk && (h == 6 || h == 7);
 #endif
@@ -4268,10 +4298,11 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 ? 3 : (CMID == 64 && !T3) ? 4 : 2
                 if (h > 0 || q >= C2_DIST) {  // (the first C2_DIST steps: the prologue waited)
                     // younger than this step's weights (issued C2_DIST steps ago, first thing of that step): that step's loads and
                     // stores, then per step since: the pieces for the step C2_DIST ahead of it (if there is one) and its loads / stores
-                    int n = extra_at((q + 2 * SPC - C2_DIST) % SPC);
+                    // (RCV_C2_SPREAD: the pieces ride between the step's tiles, after its residual loads and before its stores)
+                    int n = RCV_C2_SPREAD ? stores_at((q + 2 * SPC - C2_DIST) % SPC) : extra_at((q + 2 * SPC - C2_DIST) % SPC);
 #pragma unroll
                     for (int k = 1; k < C2_DIST; k++) {
-                        const bool exists = h * SPC + q + k < HC * SPC;
+                        const bool exists = RCV_C2_UNCOND || h * SPC + q + k < HC * SPC;
                         n += (exists ? pieces_for((q + k) % SPC) : 0) + extra_at((q + 2 * SPC - C2_DIST + k) % SPC);
                     }
                     blk_vmwait(n);
@@ -4283,24 +4314,49 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 ? 3 : (CMID == 64 && !T3) ? 4 : 2
             __builtin_amdgcn_sched_barrier(0);
             {
                 const int q2 = (q + C2_DIST) % SPC, h2 = h + (q + C2_DIST) / SPC;
-                if (h2 < HC && !((RCV_C2_DIAG == 3 || RCV_C2_DIAG == 4) && h2 > 0)) issue(h2, q2, slot + C2_DIST >= C2_RING ? slot + C2_DIST - C2_RING : slot + C2_DIST);
+                // (r06: issued unconditionally -- past the last half chunk the pieces re-read its weights into the free slot, 2 steps of
+                // 96.  A branch around the issue makes the compiler's wait for the residual registers assume the path WITHOUT the
+                // pieces: s_waitcnt vmcnt(2) where 12 younger operations are in flight, i.e. the weight stream drained twice per half chunk.)
+                const int h2c = RCV_C2_UNCOND ? (h2 < HC ? h2 : HC - 1) : h2;
+                if (!RCV_C2_SPREAD && (RCV_C2_UNCOND || h2 < HC) && !((RCV_C2_DIAG == 3 || RCV_C2_DIAG == 4) && h2 > 0)) issue(h2c, q2, slot + C2_DIST >= C2_RING ? slot + C2_DIST - C2_RING : slot + C2_DIST);
                 if (q == 0) {  // this half chunk's residual: channels kq*8 .. +7 of the slices h*2 + t (hi, lo)
 #pragma unroll
                     for (int t2 = 0; t2 < 2; t2++) {
-                        if (T3 && p.t3_res) {  // 96 bytes per group: [32 top halves | 32 low bytes] (two loads, like the [hi | lo] row)
+                        if constexpr (C2_NOLOAD) {
+                            asm volatile("" : "=v"(rres[t2][0].x), "=v"(rres[t2][0].y), "=v"(rres[t2][0].z), "=v"(rres[t2][0].w), "=v"(rres[t2][1].x), "=v"(rres[t2][1].y), "=v"(rres[t2][1].z), "=v"(rres[t2][1].w));
+                        } else if (T3 && p.t3_res) {  // 96 bytes per group: [32 top halves | 32 low bytes] (two loads, like the [hi | lo] row)
                             const char *rp = (const char *)res + mrow * (3 * COUT) + (h * 2 + t2) * 96;
                             rres[t2][0] = *(const uint4 *)(rp + kq * 16);
                             const uint2 lo8 = *(const uint2 *)(rp + 64 + kq * 8);
                             rres[t2][1] = make_uint4(lo8.x, lo8.y, 0u, 0u);
                         } else {
                             const T *rp = res + mrow * (2 * COUT) + ((RCV_C2_DIAG == 1 || RCV_C2_DIAG == 4 ? 0 : h) * 2 + t2) * 64 + kq * 8;  // (diag 1: one hot line)
-                            rres[t2][0] = *(const uint4 *)rp;
-                            rres[t2][1] = *(const uint4 *)(rp + 32);
+                            if constexpr ((RCV_C2_NT & 2) != 0) {
+                                const i32x4 n0 = __builtin_nontemporal_load((const i32x4 *)rp), n1 = __builtin_nontemporal_load((const i32x4 *)(rp + 32));
+                                rres[t2][0] = *(const uint4 *)&n0;
+                                rres[t2][1] = *(const uint4 *)&n1;
+                            } else {
+                                rres[t2][0] = *(const uint4 *)rp;
+                                rres[t2][1] = *(const uint4 *)(rp + 32);
+                            }
                         }
                     }
                 }
             }
             RCV_C2STAMP(3)
+            // RCV_C2_SPREAD: the weights of the step C2_DIST ahead, one piece before every (tiles / pieces)-th tile of this step: the
+            // texture path takes a 1 KB piece per ~16 cycles and CU, and eight waves issuing 2-4 pieces each right behind the barrier
+            // queue there for 200-500 cycles with the matrix pipe idle (stamps: "issue")
+            auto spread_issue = [&](int tile, int ntiles) {
+                if constexpr (RCV_C2_SPREAD) {
+                    const int q2 = (q + C2_DIST) % SPC, h2 = h + (q + C2_DIST) / SPC;
+                    const int np = pieces_for(q2), every = ntiles / np;
+                    if (tile % every == 0 && tile / every < np) {
+                        const int h2c = h2 < HC ? h2 : HC - 1;
+                        issue_piece(h2c, q2, slot + C2_DIST >= C2_RING ? slot + C2_DIST - C2_RING : slot + C2_DIST, tile / every);
+                    }
+                }
+            };
             const unsigned sbase = (unsigned)(slot * SLOT);
             const unsigned char *slh = smem + sbase + fhi, *sll = smem + sbase + flo;
             auto rd = [&](int buf, int o) {
@@ -4324,6 +4380,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 ? 3 : (CMID == 64 && !T3) ? 4 : 2
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int i = 0; i < NTE; i++) {
+                    spread_issue(i, NTE);
                     if (i + FD < NTE) rd((i + FD) % NF, off(i + FD));
                     const int ks = (i >> 1) % SE;
                     f32x4 &a = accE[(i / (2 * SE)) * 2 + (i & 1)];
@@ -4354,6 +4411,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 ? 3 : (CMID == 64 && !T3) ? 4 : 2
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int j = 0; j < NTR; j++) {
+                    spread_issue(j, NTR);
                     if (j + FD < NTR) rd((j + FD) % NF, off(j + FD));
                     accR[j] = RCV_MFMA16(fwh[j % NF], ah, accR[j], 0, 0, 0);
                     accR[j] = RCV_MFMA16(fwl[j % NF], ah, accR[j], 0, 0, 0);
@@ -4580,7 +4638,6 @@ __global__ __launch_bounds__(256) void k_chain3_x3(const BlockParams p)
     bf16x8 fwh[3], fwl[3];
     int slot = 0;
     for (int h = 0; h < HC; h++) {
-        const bool last = h == HC - 1;
 #pragma unroll
         for (int q = 0; q < SPC; q++) {
             if (h > 0 || q >= 1) {
