@@ -4030,7 +4030,7 @@ constexpr int c2_slot(int cmid) { return cmid * 128 > c2_se(cmid) * 8192 ? cmid 
 #define RCV_C2_DIST 2  // steps between the issue of a step's weights and their use (ring slots = RCV_C2_DIST + 1)
 #endif
 #ifndef RCV_C2_DIAG
-#define RCV_C2_DIAG 0  // timing diagnostics with WRONG outputs: 1 = residual loads / block-output stores always hit the same line (no HBM traffic), 2 = weights always of the first chunk (L2-hot), 3 = no weight DMA after the first half chunk, 4 = 1 + 3, 5 = no epilogue pieces (r06; invalid: the expand's MFMAs are dead code then), 6 = no residual loads, 7 = no block-output stores, 8 = neither (the epilogue's arithmetic alone)
+#define RCV_C2_DIAG 0  // timing diagnostics with WRONG outputs: 1 = residual loads / block-output stores always hit the same line (no HBM traffic), 2 = weights always of the first chunk (L2-hot), 3 = no weight DMA after the first half chunk, 4 = 1 + 3, 5 = no epilogue pieces (r06; invalid: the expand's MFMAs are dead code then), 6 = no residual loads, 7 = no block-output stores, 8 = neither (the epilogue's arithmetic alone), 9 = residual / block output addressed slice-major ([slice][pixel][32 ch (hi | lo)]: 2 KB contiguous per wave and slice instead of 16 x 128 B at the row stride; same bytes)
 #endif
 #ifndef RCV_C2_DEPHASE
 #define RCV_C2_DEPHASE 0  // cycles per phase unit of the start-up delay (blockIdx.x % 6 units): spreads the workgroups' store / load bursts
@@ -4257,7 +4257,8 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 ? 3 : (CMID == 64 && !T3) ? 4 : 2
                 *(uint4 *)(op + kq * 16) = make_uint4(e3h[0], e3h[1], e3h[2], e3h[3]);
                 *(uint2 *)(op + 64 + kq * 8) = make_uint2(e3l[0], e3l[1]);
             } else {
-                T *op = dst + mrow * (2 * COUT) + ((RCV_C2_DIAG == 1 || RCV_C2_DIAG == 4 ? 0 : h) * 2 + t) * 64 + kq * 8;
+                T *op = RCV_C2_DIAG == 9 ? dst + ((long long)(h * 2 + t) * p.M + mrow) * 64 + kq * 8
+                                         : dst + mrow * (2 * COUT) + ((RCV_C2_DIAG == 1 || RCV_C2_DIAG == 4 ? 0 : h) * 2 + t) * 64 + kq * 8;
                 if constexpr (C2_NOSTORE) {
                     asm volatile("" :: "v"(eoh.x), "v"(eoh.y), "v"(eoh.z), "v"(eoh.w), "v"(eol.x), "v"(eol.y), "v"(eol.z), "v"(eol.w));
                 } else if constexpr ((RCV_C2_NT & 1) != 0) {
@@ -4330,7 +4331,8 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 ? 3 : (CMID == 64 && !T3) ? 4 : 2
                             const uint2 lo8 = *(const uint2 *)(rp + 64 + kq * 8);
                             rres[t2][1] = make_uint4(lo8.x, lo8.y, 0u, 0u);
                         } else {
-                            const T *rp = res + mrow * (2 * COUT) + ((RCV_C2_DIAG == 1 || RCV_C2_DIAG == 4 ? 0 : h) * 2 + t2) * 64 + kq * 8;  // (diag 1: one hot line)
+                            const T *rp = RCV_C2_DIAG == 9 ? res + ((long long)(h * 2 + t2) * p.M + mrow) * 64 + kq * 8  // (diag 9: slice-major addresses, same bytes)
+                                                           : res + mrow * (2 * COUT) + ((RCV_C2_DIAG == 1 || RCV_C2_DIAG == 4 ? 0 : h) * 2 + t2) * 64 + kq * 8;  // (diag 1: one hot line)
                             if constexpr ((RCV_C2_NT & 2) != 0) {
                                 const i32x4 n0 = __builtin_nontemporal_load((const i32x4 *)rp), n1 = __builtin_nontemporal_load((const i32x4 *)(rp + 32));
                                 rres[t2][0] = *(const uint4 *)&n0;
