@@ -4022,9 +4022,15 @@ __global__ __launch_bounds__(512) void k_chain_x3(const BlockParams p)
 //     instead of both waves of a SIMD doing VALU work while the matrix pipe idles; slice 0's sits in the last expand step.
 // ---------------------------------------------------------------------------------------------
 #ifndef RCV_C2_SE
-#define RCV_C2_SE 2  // K slices of the expand per step (2: 24 MFMAs per wave behind a barrier; 4: 48, two barriers less per half chunk)
+#define RCV_C2_SE 0  // K slices of the expand per step (2: 24 MFMAs per wave behind a barrier; 4: 48, two barriers less per half chunk).  0 = per
+                     // form (r06, same box, ms per forward): the 256-wide form 4 (with the spread issue below 22.75 against 23.55 at 2; 4 alone 23.0),
+                     // the 128-wide form 2 (7.23 against 7.51 at 4)
 #endif
-constexpr int c2_se(int cmid) { return RCV_C2_SE < cmid / 32 ? RCV_C2_SE : cmid / 32; }      // K slices of the expand per step
+constexpr int c2_se(int cmid)  // K slices of the expand per step
+{
+    const int want = RCV_C2_SE ? RCV_C2_SE : (cmid == 256 ? 4 : 2);
+    return want < cmid / 32 ? want : cmid / 32;
+}
 constexpr int c2_slot(int cmid) { return cmid * 128 > c2_se(cmid) * 8192 ? cmid * 128 : c2_se(cmid) * 8192; }  // ring slot: the larger of the two step images
 #ifndef RCV_C2_DIST
 #define RCV_C2_DIST 2  // steps between the issue of a step's weights and their use (ring slots = RCV_C2_DIST + 1)
@@ -4054,14 +4060,18 @@ __device__ __forceinline__ void lds_arrive4(f32x4 &a, f32x4 &b, f32x4 &c, f32x4 
 // four-wave workgroups share a CU (12 waves) where one eight-wave workgroup ran alone -- each brings its own weight ring (twice the L2 ->
 // LDS weight traffic per pixel), a wave issues twice the DMA pieces per step
 #ifndef RCV_C2_SPREAD
-#define RCV_C2_SPREAD 0  // 1 = the weight pieces of a step are issued between its tiles instead of all at its top (needs RCV_C2_UNCOND)
+#define RCV_C2_SPREAD -1  // 1 = the weight pieces of a step are issued between its tiles instead of all at its top (needs RCV_C2_UNCOND), 0 = at its top,
+                          // -1 = per form (r06): on for the 256-wide form with its four-slice expand steps (-0.3 ms on top of them; with two-slice steps
+                          // +0.4) and the 128-wide form (7.00-7.07 against 7.11-7.13), off for the 64-wide form (5.73-5.76 against 5.70-5.71)
 #endif
+constexpr bool c2_spread(int cmid) { return RCV_C2_SPREAD < 0 ? cmid >= 128 : RCV_C2_SPREAD != 0; }
 #ifndef RCV_C2_NT
 #define RCV_C2_NT 0  // cache policy experiment: 1 = the block-output stores nontemporal, 2 = the residual loads, 3 = both
 #endif
 #ifndef RCV_C2_UNCOND
 #define RCV_C2_UNCOND 1  // 0 = the weight pieces past the last half chunk are branched around (r04-r05: see the issue in the step loop)
 #endif
+static_assert(RCV_C2_UNCOND || RCV_C2_SPREAD == 0, "the spread issue counts on every step having its pieces");
 #ifndef RCV_C2_FD
 #define RCV_C2_FD 2  // tiles of weight fragments in flight ahead of the MFMAs.  Measured r06 (same box, ms per 36 launches of the 256-wide form): 2: 22.96-23.05, 3: 23.02-23.04, 4: 23.03-23.08 -- the fragments' LDS latency is not what the kernel waits for
 #endif
@@ -4078,6 +4088,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 ? 3 : (CMID == 64 && !T3) ? 4 : 2
     constexpr int NTR = CMID / 16;                                  // 16-channel tiles of the reduce's output
     constexpr int PE = SE * 8 / NW, PR = CMID / 64 * 8 / NW;        // DMA pieces (8 rows x 128 B) per wave: expand step, reduce step
     constexpr int SLOT = c2_slot(CMID);
+    constexpr bool SPREAD = c2_spread(CMID);
     constexpr bool C2_NOLOAD = RCV_C2_DIAG == 6 || RCV_C2_DIAG == 8, C2_NOSTORE = RCV_C2_DIAG == 7 || RCV_C2_DIAG == 8;  // (timing only)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -4300,7 +4311,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 ? 3 : (CMID == 64 && !T3) ? 4 : 2
                     // younger than this step's weights (issued C2_DIST steps ago, first thing of that step): that step's loads and
                     // stores, then per step since: the pieces for the step C2_DIST ahead of it (if there is one) and its loads / stores
                     // (RCV_C2_SPREAD: the pieces ride between the step's tiles, after its residual loads and before its stores)
-                    int n = RCV_C2_SPREAD ? stores_at((q + 2 * SPC - C2_DIST) % SPC) : extra_at((q + 2 * SPC - C2_DIST) % SPC);
+                    int n = SPREAD ? stores_at((q + 2 * SPC - C2_DIST) % SPC) : extra_at((q + 2 * SPC - C2_DIST) % SPC);
 #pragma unroll
                     for (int k = 1; k < C2_DIST; k++) {
                         const bool exists = RCV_C2_UNCOND || h * SPC + q + k < HC * SPC;
@@ -4319,7 +4330,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 ? 3 : (CMID == 64 && !T3) ? 4 : 2
                 // 96.  A branch around the issue makes the compiler's wait for the residual registers assume the path WITHOUT the
                 // pieces: s_waitcnt vmcnt(2) where 12 younger operations are in flight, i.e. the weight stream drained twice per half chunk.)
                 const int h2c = RCV_C2_UNCOND ? (h2 < HC ? h2 : HC - 1) : h2;
-                if (!RCV_C2_SPREAD && (RCV_C2_UNCOND || h2 < HC) && !((RCV_C2_DIAG == 3 || RCV_C2_DIAG == 4) && h2 > 0)) issue(h2c, q2, slot + C2_DIST >= C2_RING ? slot + C2_DIST - C2_RING : slot + C2_DIST);
+                if (!SPREAD && (RCV_C2_UNCOND || h2 < HC) && !((RCV_C2_DIAG == 3 || RCV_C2_DIAG == 4) && h2 > 0)) issue(h2c, q2, slot + C2_DIST >= C2_RING ? slot + C2_DIST - C2_RING : slot + C2_DIST);
                 if (q == 0) {  // this half chunk's residual: channels kq*8 .. +7 of the slices h*2 + t (hi, lo)
 #pragma unroll
                     for (int t2 = 0; t2 < 2; t2++) {
@@ -4350,7 +4361,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 ? 3 : (CMID == 64 && !T3) ? 4 : 2
             // texture path takes a 1 KB piece per ~16 cycles and CU, and eight waves issuing 2-4 pieces each right behind the barrier
             // queue there for 200-500 cycles with the matrix pipe idle (stamps: "issue")
             auto spread_issue = [&](int tile, int ntiles) {
-                if constexpr (RCV_C2_SPREAD) {
+                if constexpr (SPREAD) {
                     const int q2 = (q + C2_DIST) % SPC, h2 = h + (q + C2_DIST) / SPC;
                     const int np = pieces_for(q2), every = ntiles / np;
                     if (tile % every == 0 && tile / every < np) {
